@@ -1,0 +1,170 @@
+/*
+ * kvxhip.h -- C ABI of libkvxhip.so: MI355X (gfx950) implementation of the KKT
+ * factor/solve hot path of sanurielf/kvxopt.
+ *
+ * Every entry point is what the reference's Python/C extension layer would bind for
+ * this path; the reference interface each one replaces is cited as file:line relative
+ * to the reference tree.  Plain pointers and sizes only; indices are int64 (the
+ * reference's int_t = Py_ssize_t, src/C/kvxopt.h:46), values are IEEE double.
+ *
+ * Pointer kinds: *_host = host memory, *_dev = device (HBM) memory of the current
+ * HIP device.  Unless a name ends in _dev, pointers are host pointers.
+ *
+ * Return value: 0 = KVX_OK, otherwise one of the KVX_E* codes below.  The thin host
+ * layer maps codes to the exceptions the reference raises (see each function).
+ */
+#ifndef KVXHIP_H
+#define KVXHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KVX_OK            0
+#define KVX_EINVAL        1   /* bad argument            -> ValueError / TypeError          */
+#define KVX_ENOMEM        2   /* host or device OOM     -> MemoryError                      */
+#define KVX_ENOTPOSDEF    3   /* factor does not exist  -> ArithmeticError(minor)           */
+#define KVX_ESYMBOLIC     4   /* numeric op on a symbolic-only factor -> ValueError         */
+#define KVX_ESINGULAR     5   /* solve on a failed factor -> ArithmeticError("singular")    */
+#define KVX_EDEVICE       6   /* HIP runtime error / no GPU -> RuntimeError (never a CPU fallback) */
+#define KVX_EPERM         7   /* p is not a valid permutation -> ValueError                 */
+
+typedef struct kvx_chol kvx_chol;          /* opaque factor: replaces the cholmod_factor capsule (cholmod.c:287-290) */
+typedef struct kvx_atda kvx_atda;          /* opaque plan for S = G' D G on a fixed pattern (misc.py:1418-1462) */
+
+/* Options: replaces cholmod.options / set_options() (cholmod.c:87-129). */
+typedef struct {
+    int32_t supernodal;     /* 2 (default): supernodal LL'. Only 2 is implemented; others -> KVX_EINVAL */
+    int32_t ordering;       /* 0 = built-in nested-dissection/min-degree (when p == NULL); 1 = natural   */
+    int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
+    int32_t relax_small;    /* relaxed-amalgamation: always merge if merged width <= this (default 4)    */
+    double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .05)     */
+    double  relax_z2;
+    double  relax_z3;
+    double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off                     */
+    int32_t reserved[8];
+} kvx_chol_opts;
+
+void kvx_chol_default_opts(kvx_chol_opts *o);
+
+/* Library / device probes (host layer uses these to fail loudly when there is no GPU). */
+const char *kvx_version(void);
+int  kvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only box) */
+const char *kvx_last_error(void);       /* text of the last error on this thread               */
+
+/* ---- sparse Cholesky: replaces kvxopt.cholmod ------------------------------------------ */
+
+/* symbolic(A, p, uplo)  -- cholmod.c:244-291 (pack :132-181, analyze_p :274).
+ * A is n x n CCS (colptr[n+1], rowind[nnz], rows sorted within a column); only the `uplo`
+ * ('L' or 'U') triangle is read.  perm: NULL, or n int64 with P*A*P' = L*L',
+ * (PAP')(i,j) = A(perm[i],perm[j]).  Host-only work; no GPU needed. */
+int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
+                     const int64_t *perm, const kvx_chol_opts *opts, kvx_chol **out);
+
+/* numeric(A, F) -- cholmod.c:322-398.  values[nnz] are the entries of the matrix whose
+ * pattern was analysed (same order).  On KVX_ENOTPOSDEF, *minor = failing column (index in
+ * the permuted matrix, as CHOLMOD's L->minor, cholmod.c:376-379). */
+int kvx_chol_factorize(kvx_chol *F, const double *values, int64_t *minor);
+int kvx_chol_factorize_dev(kvx_chol *F, const double *values_dev, int64_t *minor);
+/* Asynchronous variant: enqueue only; status is read later by kvx_chol_status(). */
+int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev);
+int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the factor's stream */
+
+/* solve(F, B, sys, nrhs, ldB, offsetB) -- cholmod.c:429-499; sys 0..8 = A, LDL', LD, DL', L,
+ * L', D, P, P' (:437-439) with D = I.  B (n x nrhs, leading dimension ldB >= max(1,n)) is
+ * overwritten.  The caller applies offsetB to the pointer. */
+int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB);
+int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
+
+/* spsolve(F, B, sys) -- cholmod.c:524-587.  B is n x ncol CCS; the result is returned as a
+ * newly malloc'ed CCS triple the caller frees with kvx_free(). */
+int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi,
+                     const double *Bx, int64_t **Xp, int64_t **Xi, double **Xx);
+
+/* diag(F) -- cholmod.c:900-945: diagonal of L in permuted order, n doubles. */
+int kvx_chol_diag(kvx_chol *F, double *d);
+
+/* getfactor(F) -- cholmod.c:948-985: L as CCS (lower, sorted). Call with Lp=Li=Lx=NULL to
+ * query *lnz first. */
+int kvx_chol_get_factor(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx);
+
+/* Introspection used by bench/tests: the measure of SURVEY 8(d). */
+typedef struct {
+    int64_t n, nnz_a;        /* order, entries of the analysed triangle                      */
+    int64_t lnz;             /* sum_j c_j: nnz(L) for the permutation used (simplicial count)  */
+    double  flops;           /* sum_j c_j^2                                                   */
+    int64_t nsuper;          /* supernodes (fronts)                                           */
+    int64_t lsize;           /* doubles stored for L (dense panels, >= lnz)                   */
+    int64_t nlevels;         /* elimination-tree levels = dependent launch stages             */
+    int64_t max_front;       /* largest front order m                                         */
+    int64_t upd_size;        /* doubles in the update-matrix workspace                        */
+    int64_t is_numeric;      /* 1 after a successful factorize                                */
+    int64_t minor;
+    int64_t solve_rowidx;    /* sum_s m_s: index entries read per triangular sweep           */
+    int64_t reserved[5];
+} kvx_chol_info;
+int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info);
+int kvx_chol_get_perm(kvx_chol *F, int64_t *perm);     /* final permutation (ordering o postorder) */
+/* Supernode layout for tests: super[nsuper+1] column starts, nrows[nsuper] front orders,
+ * parent[nsuper], level[nsuper]. Any pointer may be NULL. */
+int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level);
+/* Dominant-kernel timing of the last factorize/solve, measured with HIP events on the
+ * factor's own stream (bench.py roofline leg). ms_factor / ms_solve may be NULL. */
+int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);
+void kvx_chol_free(kvx_chol *F);
+void kvx_free(void *p);
+
+/* ---- normal-equations assembly: replaces base.gemm(partial)+base.syrk(partial) ---------- */
+
+/* Plan S = G' diag(w) G (+ P) on a fixed lower-triangular CCS pattern (misc.py:1418-1426,
+ * 1451-1455 -> sparse.c:1260-1283, 2176-2256).  G is ml x n CCS.  The plan computes the
+ * pattern of tril(G'G) (union with the lower pattern of P when Pp != NULL) and returns it
+ * through kvx_atda_pattern(). */
+int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi,
+                  const int64_t *Pp, const int64_t *Pi, kvx_atda **out);
+int kvx_atda_pattern(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si);
+/* Sx[snz] = sum_k w[k] G[k,i] G[k,j] (+ P[i,j]); w = di.^2. Host and device variants. */
+int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx);
+int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx_dev, const double *w_dev,
+                          const double *Px_dev, double *Sx_dev);
+void kvx_atda_free(kvx_atda *T);
+
+/* ---- Nesterov-Todd scaling, orthant ('l') cone: replaces kvxopt.misc / misc_solvers ------ */
+/* All vectors are device pointers of length ml (x: ml x ncols with leading dimension ldx). */
+
+/* compute_scaling 'l' block (misc.py:284-287): d = sqrt(s./z), di = 1./d, lmbda = sqrt(s.*z) */
+int kvx_nt_compute_scaling_dev(int64_t ml, const double *s, const double *z,
+                               double *d, double *di, double *lmbda);
+/* update_scaling 'l' block (misc.py:444-464), in place: s:=sqrt(s), z:=sqrt(z),
+ * d:=d.*s./z, di:=1./d, lmbda:=s.*z */
+int kvx_nt_update_scaling_dev(int64_t ml, double *s, double *z, double *d, double *di, double *lmbda);
+/* scale 'l' block (misc_solvers.c:132-141): x := w .* x for each of ncols columns */
+int kvx_nt_scale_dev(int64_t ml, int64_t ncols, int64_t ldx, double *x, const double *w);
+/* scale2 (misc_solvers.c:287-298): inverse=0: x := x./lmbda ; inverse=1: x := x.*lmbda */
+int kvx_nt_scale2_dev(int64_t ml, const double *lmbda, double *x, int inverse);
+/* sprod (misc_solvers.c:662-669) x := x.*y ; sinv (:793-800) x := x./y ; ssqr (misc.py:951-952) x := y.*y */
+int kvx_nt_sprod_dev(int64_t ml, double *x, const double *y);
+int kvx_nt_sinv_dev(int64_t ml, double *x, const double *y);
+int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y);
+/* sdot (misc_solvers.c:1018) and max_step (misc_solvers.c:1065-1071: max_i -x_i) */
+int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host);
+int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host);
+
+/* ---- sparse mat-vec: replaces base.gemv on spmatrix (sparse.c:1073-1104) ----------------- */
+/* y := alpha*op(A)*x + beta*y, A m x n CCS with int64 indices on the device. trans 'N'/'T'. */
+int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap_dev, const int64_t *Ai_dev,
+                 const double *Ax_dev, double alpha, const double *x_dev, double beta, double *y_dev);
+
+/* ---- device memory plumbing for hosts without their own allocator ------------------------ */
+int kvx_dev_malloc(void **p, int64_t bytes);
+int kvx_dev_free(void *p);
+int kvx_dev_upload(void *dst_dev, const void *src_host, int64_t bytes);
+int kvx_dev_download(void *dst_host, const void *src_dev, int64_t bytes);
+int kvx_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,181 @@
+"""ctypes binding of libkvxhip.so (the C ABI declared in include/kvxhip.h).
+
+The library is the product: if it is missing or no HIP device is visible, numeric
+entry points raise -- there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvxhip.so")
+
+KVX_OK, KVX_EINVAL, KVX_ENOMEM, KVX_ENOTPOSDEF, KVX_ESYMBOLIC, KVX_ESINGULAR, KVX_EDEVICE, KVX_EPERM = range(8)
+
+i64 = ctypes.c_int64
+f64 = ctypes.c_double
+i64p = ctypes.POINTER(ctypes.c_int64)
+f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class CholOpts(ctypes.Structure):
+    _fields_ = [("supernodal", ctypes.c_int32), ("ordering", ctypes.c_int32), ("postorder", ctypes.c_int32),
+                ("relax_small", ctypes.c_int32), ("relax_z1", f64), ("relax_z2", f64), ("relax_z3", f64),
+                ("dbound", f64), ("reserved", ctypes.c_int32 * 8)]
+
+
+class CholInfo(ctypes.Structure):
+    _fields_ = [("n", i64), ("nnz_a", i64), ("lnz", i64), ("flops", f64), ("nsuper", i64), ("lsize", i64),
+                ("nlevels", i64), ("max_front", i64), ("upd_size", i64), ("is_numeric", i64), ("minor", i64),
+                ("solve_rowidx", i64), ("reserved", i64 * 5)]
+
+
+_SIGS = {
+    "kvx_version": (ctypes.c_char_p, []),
+    "kvx_device_count": (ctypes.c_int, []),
+    "kvx_last_error": (ctypes.c_char_p, []),
+    "kvx_chol_default_opts": (None, [ctypes.POINTER(CholOpts)]),
+    "kvx_chol_analyze": (ctypes.c_int, [i64, i64p, i64p, ctypes.c_int, i64p, ctypes.POINTER(CholOpts), ctypes.POINTER(vp)]),
+    "kvx_chol_factorize": (ctypes.c_int, [vp, f64p, i64p]),
+    "kvx_chol_factorize_dev": (ctypes.c_int, [vp, vp, i64p]),
+    "kvx_chol_factorize_async_dev": (ctypes.c_int, [vp, vp]),
+    "kvx_chol_status": (ctypes.c_int, [vp, i64p]),
+    "kvx_chol_solve": (ctypes.c_int, [vp, ctypes.c_int, f64p, i64, i64]),
+    "kvx_chol_solve_dev": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
+    "kvx_chol_spsolve": (ctypes.c_int, [vp, ctypes.c_int, i64, i64p, i64p, f64p,
+                                        ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p)]),
+    "kvx_chol_diag": (ctypes.c_int, [vp, f64p]),
+    "kvx_chol_get_factor": (ctypes.c_int, [vp, i64p, i64p, i64p, f64p]),
+    "kvx_chol_get_info": (ctypes.c_int, [vp, ctypes.POINTER(CholInfo)]),
+    "kvx_chol_get_perm": (ctypes.c_int, [vp, i64p]),
+    "kvx_chol_get_supernodes": (ctypes.c_int, [vp, i64p, i64p, i64p, i64p]),
+    "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
+    "kvx_chol_free": (None, [vp]),
+    "kvx_free": (None, [vp]),
+    "kvx_atda_plan": (ctypes.c_int, [i64, i64, i64p, i64p, i64p, i64p, ctypes.POINTER(vp)]),
+    "kvx_atda_pattern": (ctypes.c_int, [vp, i64p, i64p, i64p]),
+    "kvx_atda_assemble": (ctypes.c_int, [vp, f64p, f64p, f64p, f64p]),
+    "kvx_atda_assemble_dev": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    "kvx_atda_free": (None, [vp]),
+    "kvx_nt_compute_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
+    "kvx_nt_update_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
+    "kvx_nt_scale_dev": (ctypes.c_int, [i64, i64, i64, vp, vp]),
+    "kvx_nt_scale2_dev": (ctypes.c_int, [i64, vp, vp, ctypes.c_int]),
+    "kvx_nt_sprod_dev": (ctypes.c_int, [i64, vp, vp]),
+    "kvx_nt_sinv_dev": (ctypes.c_int, [i64, vp, vp]),
+    "kvx_nt_ssqr_dev": (ctypes.c_int, [i64, vp, vp]),
+    "kvx_nt_sdot_dev": (ctypes.c_int, [i64, vp, vp, f64p]),
+    "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),
+    "kvx_spmv_dev": (ctypes.c_int, [ctypes.c_int, i64, i64, vp, vp, vp, f64, vp, f64, vp]),
+    "kvx_dev_malloc": (ctypes.c_int, [ctypes.POINTER(vp), i64]),
+    "kvx_dev_free": (ctypes.c_int, [vp]),
+    "kvx_dev_upload": (ctypes.c_int, [vp, vp, i64]),
+    "kvx_dev_download": (ctypes.c_int, [vp, vp, i64]),
+    "kvx_dev_sync": (ctypes.c_int, []),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libkvxhip.so; raises if it was not built (run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not found: the HIP extension is not built; there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def last_error():
+    return lib().kvx_last_error().decode("utf-8", "replace")
+
+
+def pi(a):
+    return a.ctypes.data_as(i64p)
+
+
+def pd(a):
+    return a.ctypes.data_as(f64p)
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def require_device():
+    if lib().kvx_device_count() <= 0:
+        raise RuntimeError("kvxopt_amd: no HIP device visible; the numeric path has no CPU fallback")
+
+
+def raise_for(rc, what=""):
+    """Map a C-ABI status to the exception the reference raises (cholmod.c error macros)."""
+    if rc == KVX_OK:
+        return
+    msg = last_error() or what
+    if rc == KVX_EINVAL:
+        raise ValueError(msg or "invalid argument")
+    if rc == KVX_EPERM:
+        raise ValueError(msg or "p is not a valid permutation")
+    if rc == KVX_ENOMEM:
+        raise MemoryError(msg)
+    if rc == KVX_ESYMBOLIC:
+        raise ValueError(msg or "called with symbolic factor")
+    if rc == KVX_ESINGULAR:
+        raise ArithmeticError(msg or "singular matrix")
+    if rc == KVX_ENOTPOSDEF:
+        raise ArithmeticError(msg)
+    raise RuntimeError("kvxhip device error: %s" % (msg or rc))
+
+
+class DeviceBuffer:
+    """A plain HBM allocation owned through the C ABI (no torch dependency)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = vp()
+        raise_for(lib().kvx_dev_malloc(ctypes.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        b.upload(a)
+        return b
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        raise_for(lib().kvx_dev_upload(self.ptr, a.ctypes.data, a.nbytes))
+
+    def download(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        raise_for(lib().kvx_dev_download(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().kvx_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,580 @@
+// C-ABI of libkvxhip.so (include/kvxhip.h): host orchestration of the HIP path.
+// There is NO CPU fallback: every numeric entry point needs a HIP device and returns
+// KVX_EDEVICE otherwise.
+#include "../../include/kvxhip.h"
+#include "device.hpp"
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace kvx;
+
+static thread_local std::string g_err;
+static void set_err(const std::string &s) { g_err = s; }
+
+#define HIPCHK(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_err(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return KVX_EDEVICE;                                                          \
+        }                                                                                \
+    } while (0)
+
+struct LevelPlan {
+    // fronts of the level sorted by m descending: [big | cls3 | cls2 | cls1 | cls0]
+    int64_t off[5];      // offset into d_lists of class c (4 = big)
+    int cnt[5];
+    int maxm[5];
+    int big_maxk = 0;
+    int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
+    // solve groups: [m > 128], [33..128], [<= 32]
+    int64_t soff[3];
+    int scnt[3];
+    int smaxm[3];
+};
+
+struct kvx_chol {
+    Symbolic S;
+    kvx_chol_opts opts;
+    bool dev_ready = false;
+    bool numeric = false;
+    bool pending = false;     // a factorisation was enqueued and its status not yet read
+    int64_t minor = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_ftime = false, have_stime = false;
+    double ms_factor = 0, ms_solve = 0;
+
+    int32_t *d_k = nullptr, *d_m = nullptr, *d_first = nullptr, *d_rowidx = nullptr, *d_rel = nullptr,
+            *d_children = nullptr, *d_perm = nullptr, *d_lists = nullptr;
+    int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
+            *d_amap = nullptr;
+    double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
+    double *d_X = nullptr, *d_W[2] = {nullptr, nullptr};
+    int64_t x_cap = 0;        // right-hand sides the solve workspace holds
+    int *d_status = nullptr;
+    int *h_status = nullptr;  // pinned
+    DevSym ds{};
+    std::vector<LevelPlan> plan;
+};
+
+namespace {
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(hipMalloc((void **)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KVX_OK;
+}
+
+int cls_of(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 96 ? 2 : m <= KVX_SMALL_MAX ? 3 : 4; }
+
+int ensure_device(kvx_chol *F)
+{
+    if (F->dev_ready) return KVX_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_err("no HIP device visible: the kvxhip numeric path has no CPU fallback");
+        return KVX_EDEVICE;
+    }
+    Symbolic &S = F->S;
+    HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
+    int rc;
+    std::vector<int32_t> first((size_t)S.nsuper), perm32((size_t)S.n);
+    for (int64_t s = 0; s < S.nsuper; s++) first[s] = (int32_t)S.super[s];
+    for (int64_t i = 0; i < S.n; i++) perm32[i] = (int32_t)S.perm[i];
+    if ((rc = upload(&F->d_k, S.sn_k))) return rc;
+    if ((rc = upload(&F->d_m, S.sn_m))) return rc;
+    if ((rc = upload(&F->d_first, first))) return rc;
+    if ((rc = upload(&F->d_rowidx, S.rowidx))) return rc;
+    if ((rc = upload(&F->d_rel, S.rel))) return rc;
+    if ((rc = upload(&F->d_children, S.children))) return rc;
+    if ((rc = upload(&F->d_perm, perm32))) return rc;
+    if ((rc = upload(&F->d_lists, S.levellist))) return rc;
+    std::vector<int64_t> px(S.px.begin(), S.px.end());
+    if ((rc = upload(&F->d_px, px))) return rc;
+    if ((rc = upload(&F->d_rowptr, S.rowptr))) return rc;
+    if ((rc = upload(&F->d_ux, S.ux))) return rc;
+    if ((rc = upload(&F->d_wx, S.wx))) return rc;
+    if ((rc = upload(&F->d_childptr, S.childptr))) return rc;
+    if ((rc = upload(&F->d_amap, S.amap))) return rc;
+    HIPCHK(hipMalloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
+    for (int p = 0; p < 2; p++)
+        HIPCHK(hipMalloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&F->d_status, sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
+    F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
+                   F->d_ux, F->d_wx, F->d_childptr, F->d_children};
+    // per-level launch plan
+    F->plan.assign((size_t)S.nlevels, LevelPlan());
+    for (int l = 0; l < S.nlevels; l++) {
+        LevelPlan &P = F->plan[l];
+        for (int c = 0; c < 5; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; }
+        for (int g = 0; g < 3; g++) { P.soff[g] = 0; P.scnt[g] = 0; P.smaxm[g] = 0; }
+        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
+            int s = S.levellist[q];
+            int m = S.sn_m[s], k = S.sn_k[s];
+            int c = cls_of(m);
+            if (P.cnt[c] == 0) P.off[c] = q;
+            P.cnt[c]++;
+            P.maxm[c] = std::max(P.maxm[c], m);
+            if (c == 4) {
+                P.big_maxk = std::max(P.big_maxk, k);
+                P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
+            }
+            int g = m > KVX_SMALL_MAX ? 0 : m > 32 ? 1 : 2;
+            if (P.scnt[g] == 0) P.soff[g] = q;
+            P.scnt[g]++;
+            P.smaxm[g] = std::max(P.smaxm[g], m);
+        }
+    }
+    F->dev_ready = true;
+    return KVX_OK;
+}
+
+int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
+{
+    if (nrhs <= F->x_cap) return KVX_OK;
+    Symbolic &S = F->S;
+    if (F->d_X) { (void)hipFree(F->d_X); F->d_X = nullptr; }
+    for (int p = 0; p < 2; p++)
+        if (F->d_W[p]) { (void)hipFree(F->d_W[p]); F->d_W[p] = nullptr; }
+    F->x_cap = 0;
+    HIPCHK(hipMalloc((void **)&F->d_X, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    const int64_t wmax = std::max(S.wrk_size[0], S.wrk_size[1]);   // common per-rhs stride of both parity buffers
+    for (int p = 0; p < 2; p++)
+        HIPCHK(hipMalloc((void **)&F->d_W[p], std::max<int64_t>(wmax * nrhs, 1) * sizeof(double)));
+    F->x_cap = nrhs;
+    return KVX_OK;
+}
+
+// enqueue the numeric factorisation; d_Ax already holds the values
+int enqueue_factor(kvx_chol *F)
+{
+    Symbolic &S = F->S;
+    hipStream_t st = F->stream;
+    HIPCHK(hipEventRecord(F->ev[0], st));
+    HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
+    HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+    launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx);
+    for (int l = S.nlevels - 1; l >= 0; l--) {
+        const LevelPlan &P = F->plan[l];
+        double *Uout = F->d_U[l & 1];
+        const double *Uch = F->d_U[(l + 1) & 1];
+        if (P.cnt[4] > 0) {
+            const int32_t *list = F->d_lists + P.off[4];
+            if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
+            launch_assemble_big(st, F->ds, list, P.cnt[4], P.maxm[4], F->d_Lx, Uch, Uout);
+            for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
+                launch_potrf_diag(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_status);
+                launch_trsm_panel(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx);
+                launch_syrk_trailing(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, Uout);
+            }
+        }
+        for (int c = 3; c >= 0; c--)
+            if (P.cnt[c] > 0)
+                launch_front_small(st, c, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
+    }
+    HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(F->ev[1], st));
+    HIPCHK(hipGetLastError());
+    F->pending = true;
+    F->have_ftime = false;
+    return KVX_OK;
+}
+
+int finish_factor(kvx_chol *F, int64_t *minor)
+{
+    if (F->pending) {
+        HIPCHK(hipStreamSynchronize(F->stream));
+        F->pending = false;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, F->ev[0], F->ev[1]) == hipSuccess) { F->ms_factor = ms; F->have_ftime = true; }
+        int st = *F->h_status;
+        F->numeric = true;
+        F->minor = (st >= 0x7f7f7f7f) ? F->S.n : (int64_t)st;
+    }
+    if (minor) *minor = F->minor;
+    if (!F->numeric) return KVX_ESYMBOLIC;
+    return F->minor < F->S.n ? KVX_ENOTPOSDEF : KVX_OK;
+}
+
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
+{
+    Symbolic &S = F->S;
+    for (int l = S.nlevels - 1; l >= 0; l--) {
+        const LevelPlan &P = F->plan[l];
+        for (int g = 0; g < 3; g++)
+            if (P.scnt[g] > 0)
+                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
+                                 F->d_Lx, X, ldx, nrhs, F->d_W[(l + 1) & 1], F->d_W[l & 1], S.wrk_size[0] > S.wrk_size[1] ? S.wrk_size[0] : S.wrk_size[1]);
+    }
+}
+
+void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
+{
+    Symbolic &S = F->S;
+    for (int l = 0; l < S.nlevels; l++) {
+        const LevelPlan &P = F->plan[l];
+        for (int g = 0; g < 3; g++)
+            if (P.scnt[g] > 0)
+                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
+                                 F->d_Lx, X, ldx, nrhs);
+    }
+}
+
+// B_dev: n x nrhs, leading dimension ldB, device memory.
+int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
+{
+    Symbolic &S = F->S;
+    const int64_t n = S.n;
+    if (sys < 0 || sys > 8) { set_err("invalid value for sys"); return KVX_EINVAL; }
+    int rc = finish_factor(F, nullptr);
+    if (rc == KVX_ESYMBOLIC) { set_err("called with symbolic factor"); return rc; }
+    if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
+    if (rc) return rc;
+    if (n == 0 || nrhs == 0) return KVX_OK;
+    if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
+    if ((int64_t)S.max_m * 8 + 64 * 65 * 8 > 160 * 1024) { set_err("front too large for the LDS-resident solve"); return KVX_EINVAL; }
+    if (sys == 6) return KVX_OK;   // D = I for an LL' factor
+    hipStream_t st = F->stream;
+    // wstride: both parity buffers are allocated with wrk_size[p]*x_cap; use a common stride
+    const int chunk_max = 65535;
+    for (int64_t r0 = 0; r0 < nrhs; r0 += chunk_max) {
+        int nr = (int)std::min<int64_t>(chunk_max, nrhs - r0);
+        double *Bc = B + r0 * ldB;
+        if ((rc = ensure_solve_ws(F, nr))) return rc;
+        HIPCHK(hipEventRecord(F->ev[2], st));
+        switch (sys) {
+        case 0:
+            launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
+            enqueue_fwd(F, F->d_X, n, nr);
+            enqueue_bwd(F, F->d_X, n, nr);
+            launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, Bc, ldB);
+            break;
+        case 1: enqueue_fwd(F, Bc, ldB, nr); enqueue_bwd(F, Bc, ldB, nr); break;
+        case 2: case 4: enqueue_fwd(F, Bc, ldB, nr); break;
+        case 3: case 5: enqueue_bwd(F, Bc, ldB, nr); break;
+        case 7:
+            launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
+            HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
+            break;
+        case 8:
+            launch_perm_scatter(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
+            HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
+            break;
+        }
+        HIPCHK(hipEventRecord(F->ev[3], st));
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, F->ev[2], F->ev[3]) == hipSuccess) { F->ms_solve = ms; F->have_stime = true; }
+    return KVX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *kvx_version(void) { return "kvxhip 0.1 (gfx950)"; }
+const char *kvx_last_error(void) { return g_err.c_str(); }
+int kvx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void kvx_chol_default_opts(kvx_chol_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->supernodal = 2;
+    o->ordering = 0;
+    o->postorder = 1;
+    o->relax_small = 4;
+    o->relax_z1 = 0.8;
+    o->relax_z2 = 0.1;
+    o->relax_z3 = 0.05;
+    o->dbound = 0.0;
+}
+
+int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo, const int64_t *perm,
+                     const kvx_chol_opts *opts, kvx_chol **out)
+{
+    if (!out || n < 0 || (n > 0 && (!colptr || (!rowind && colptr[n] > 0)))) { set_err("bad arguments"); return KVX_EINVAL; }
+    kvx_chol_opts o;
+    if (opts) o = *opts; else kvx_chol_default_opts(&o);
+    if (o.supernodal != 2) { set_err("only options['supernodal'] = 2 (supernodal LL') is implemented"); return KVX_EINVAL; }
+    kvx_chol *F = nullptr;
+    try {
+        F = new kvx_chol();
+        F->opts = o;
+        SymOpts so;
+        so.ordering = o.ordering;
+        so.postorder = o.postorder;
+        so.relax_small = o.relax_small;
+        so.relax_z1 = o.relax_z1; so.relax_z2 = o.relax_z2; so.relax_z3 = o.relax_z3;
+        if (o.reserved[0] > 0) so.nd_leaf = o.reserved[0];
+        static const int64_t zero = 0;
+        analyze(n, n ? colptr : &zero, rowind, uplo, perm, so, F->S);
+        F->minor = n;
+    } catch (const std::invalid_argument &e) {
+        delete F; set_err(e.what()); return KVX_EPERM;
+    } catch (const std::bad_alloc &) {
+        delete F; set_err("out of host memory"); return KVX_ENOMEM;
+    } catch (const std::exception &e) {
+        delete F; set_err(e.what()); return KVX_EINVAL;
+    }
+    *out = F;
+    return KVX_OK;
+}
+
+int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev)
+{
+    if (!F) return KVX_EINVAL;
+    int rc = ensure_device(F);
+    if (rc) return rc;
+    if (F->S.nnzA > 0)
+        HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, F->S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
+    return enqueue_factor(F);
+}
+
+int kvx_chol_status(kvx_chol *F, int64_t *minor)
+{
+    if (!F) return KVX_EINVAL;
+    return finish_factor(F, minor);
+}
+
+int kvx_chol_factorize_dev(kvx_chol *F, const double *values_dev, int64_t *minor)
+{
+    int rc = kvx_chol_factorize_async_dev(F, values_dev);
+    if (rc) return rc;
+    return finish_factor(F, minor);
+}
+
+int kvx_chol_factorize(kvx_chol *F, const double *values, int64_t *minor)
+{
+    if (!F) return KVX_EINVAL;
+    int rc = ensure_device(F);
+    if (rc) return rc;
+    if (F->S.nnzA > 0)
+        HIPCHK(hipMemcpyAsync(F->d_Ax, values, F->S.nnzA * sizeof(double), hipMemcpyHostToDevice, F->stream));
+    rc = enqueue_factor(F);
+    if (rc) return rc;
+    return finish_factor(F, minor);
+}
+
+int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    if (!F) return KVX_EINVAL;
+    if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    return solve_dev(F, sys, B_dev, nrhs, ldB);
+}
+
+int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
+{
+    if (!F) return KVX_EINVAL;
+    if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    const int64_t n = F->S.n;
+    if (sys < 0 || sys > 8) { set_err("invalid value for sys"); return KVX_EINVAL; }
+    int rc = finish_factor(F, nullptr);
+    if (rc == KVX_ESYMBOLIC) { set_err("called with symbolic factor"); return rc; }
+    if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
+    if (n == 0 || nrhs == 0) return KVX_OK;
+    if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
+    double *d_B = nullptr;
+    HIPCHK(hipMalloc((void **)&d_B, n * nrhs * sizeof(double)));
+    hipError_t e = hipMemcpy2D(d_B, n * sizeof(double), B, ldB * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = solve_dev(F, sys, d_B, nrhs, n);
+        if (rc == KVX_OK)
+            e = hipMemcpy2D(B, ldB * sizeof(double), d_B, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_B);
+    if (e != hipSuccess) { set_err(hipGetErrorString(e)); return KVX_EDEVICE; }
+    return rc;
+}
+
+int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
+                     int64_t **Xp, int64_t **Xi, double **Xx)
+{
+    if (!F || !Xp || !Xi || !Xx || ncol < 0) return KVX_EINVAL;
+    const int64_t n = F->S.n;
+    if (sys < 0 || sys > 8) { set_err("invalid value for sys"); return KVX_EINVAL; }
+    if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    int rc = finish_factor(F, nullptr);
+    if (rc == KVX_ESYMBOLIC) { set_err("called with symbolic factor"); return rc; }
+    if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
+    std::vector<int64_t> xp((size_t)ncol + 1, 0), xi;
+    std::vector<double> xx;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(ncol, (int64_t)(1 << 26) / std::max<int64_t>(n, 1)));
+    std::vector<double> dense;
+    for (int64_t c0 = 0; c0 < ncol && n > 0; c0 += chunk) {
+        int64_t nc = std::min(chunk, ncol - c0);
+        dense.assign((size_t)(n * nc), 0.0);
+        for (int64_t j = 0; j < nc; j++)
+            for (int64_t p = Bp[c0 + j]; p < Bp[c0 + j + 1]; p++) {
+                if (Bi[p] < 0 || Bi[p] >= n) { set_err("row index out of range in B"); return KVX_EINVAL; }
+                dense[(size_t)(Bi[p] + j * n)] += Bx[p];
+            }
+        rc = kvx_chol_solve(F, sys, dense.data(), nc, n);
+        if (rc) return rc;
+        for (int64_t j = 0; j < nc; j++) {
+            for (int64_t i = 0; i < n; i++) {
+                double v = dense[(size_t)(i + j * n)];
+                if (v != 0.0) { xi.push_back(i); xx.push_back(v); }
+            }
+            xp[(size_t)(c0 + j + 1)] = (int64_t)xi.size();
+        }
+    }
+    for (int64_t j = 0; j < ncol; j++) xp[j + 1] = std::max(xp[j + 1], xp[j]);
+    *Xp = (int64_t *)malloc(sizeof(int64_t) * (ncol + 1));
+    *Xi = (int64_t *)malloc(sizeof(int64_t) * std::max<size_t>(xi.size(), 1));
+    *Xx = (double *)malloc(sizeof(double) * std::max<size_t>(xx.size(), 1));
+    if (!*Xp || !*Xi || !*Xx) { free(*Xp); free(*Xi); free(*Xx); return KVX_ENOMEM; }
+    memcpy(*Xp, xp.data(), sizeof(int64_t) * (ncol + 1));
+    if (!xi.empty()) { memcpy(*Xi, xi.data(), sizeof(int64_t) * xi.size()); memcpy(*Xx, xx.data(), sizeof(double) * xx.size()); }
+    return KVX_OK;
+}
+
+int kvx_chol_diag(kvx_chol *F, double *d)
+{
+    if (!F || !d) return KVX_EINVAL;
+    if (!F->dev_ready) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESYMBOLIC; }
+    int rc = finish_factor(F, nullptr);
+    if (rc == KVX_ENOTPOSDEF) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESINGULAR; }
+    if (rc) return rc;
+    if (F->S.n == 0) return KVX_OK;
+    double *dd = nullptr;
+    HIPCHK(hipMalloc((void **)&dd, F->S.n * sizeof(double)));
+    launch_extract_diag(F->stream, F->ds, F->S.nsuper, F->d_Lx, dd);
+    hipError_t e = hipStreamSynchronize(F->stream);
+    if (e == hipSuccess) e = hipMemcpy(d, dd, F->S.n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dd);
+    if (e != hipSuccess) { set_err(hipGetErrorString(e)); return KVX_EDEVICE; }
+    return KVX_OK;
+}
+
+int kvx_chol_get_factor(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx)
+{
+    if (!F) return KVX_EINVAL;
+    Symbolic &S = F->S;
+    // structural entries of the supernodal factor: lower trapezoid of every panel
+    int64_t cnt = 0;
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        int64_t k = S.sn_k[s], m = S.sn_m[s];
+        cnt += k * m - k * (k - 1) / 2;
+    }
+    if (lnz) *lnz = cnt;
+    if (!Lp && !Li && !Lx) return KVX_OK;
+    if (!F->dev_ready) { set_err("F must be a numeric Cholesky factor"); return KVX_ESYMBOLIC; }
+    int rc = finish_factor(F, nullptr);
+    if (rc == KVX_ESYMBOLIC) { set_err("F must be a numeric Cholesky factor"); return rc; }
+    std::vector<double> host((size_t)std::max<int64_t>(S.lsize, 1));
+    if (S.lsize > 0) HIPCHK(hipMemcpy(host.data(), F->d_Lx, S.lsize * sizeof(double), hipMemcpyDeviceToHost));
+    int64_t q = 0;
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        int64_t k = S.sn_k[s], m = S.sn_m[s], f = S.super[s];
+        const int32_t *rows = S.rowidx.data() + S.rowptr[s];
+        for (int64_t j = 0; j < k; j++) {
+            if (Lp) Lp[f + j] = q;
+            for (int64_t i = j; i < m; i++) {
+                if (Li) Li[q] = rows[i];
+                if (Lx) Lx[q] = host[(size_t)(S.px[s] + i + j * m)];
+                q++;
+            }
+        }
+    }
+    if (Lp) Lp[S.n] = q;
+    return KVX_OK;
+}
+
+int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info)
+{
+    if (!F || !info) return KVX_EINVAL;
+    memset(info, 0, sizeof(*info));
+    Symbolic &S = F->S;
+    info->n = S.n;
+    info->nnz_a = S.nnzTri;
+    info->lnz = S.lnz;
+    info->flops = S.flops;
+    info->nsuper = S.nsuper;
+    info->lsize = S.lsize;
+    info->nlevels = S.nlevels;
+    info->max_front = S.max_m;
+    info->upd_size = S.upd_size[0] + S.upd_size[1];
+    info->is_numeric = (F->numeric && !F->pending) ? 1 : 0;
+    info->minor = F->minor;
+    info->solve_rowidx = S.sum_m;
+    return KVX_OK;
+}
+
+int kvx_chol_get_perm(kvx_chol *F, int64_t *perm)
+{
+    if (!F || (!perm && F->S.n > 0)) return KVX_EINVAL;
+    if (F->S.n > 0) memcpy(perm, F->S.perm.data(), sizeof(int64_t) * F->S.n);
+    return KVX_OK;
+}
+
+int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level)
+{
+    if (!F) return KVX_EINVAL;
+    Symbolic &S = F->S;
+    if (super) memcpy(super, S.super.data(), sizeof(int64_t) * (S.nsuper + 1));
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        if (nrows) nrows[s] = S.sn_m[s];
+        if (parent) parent[s] = S.sparent[s];
+        if (level) level[s] = S.depth[s];
+    }
+    return KVX_OK;
+}
+
+int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)
+{
+    if (!F) return KVX_EINVAL;
+    if (F->pending) finish_factor(F, nullptr);
+    if (ms_factor) *ms_factor = F->have_ftime ? F->ms_factor : -1.0;
+    if (ms_solve) *ms_solve = F->have_stime ? F->ms_solve : -1.0;
+    return KVX_OK;
+}
+
+void kvx_chol_free(kvx_chol *F)
+{
+    if (!F) return;
+    if (F->dev_ready) {
+        (void)hipStreamSynchronize(F->stream);
+        void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
+                        F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
+                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status};
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+        if (F->h_status) (void)hipHostFree(F->h_status);
+        for (int i = 0; i < 4; i++)
+            if (F->ev[i]) (void)hipEventDestroy(F->ev[i]);
+        if (F->stream) (void)hipStreamDestroy(F->stream);
+    }
+    delete F;
+}
+
+void kvx_free(void *p) { free(p); }
+
+int kvx_dev_malloc(void **p, int64_t bytes) { HIPCHK(hipMalloc(p, (size_t)std::max<int64_t>(bytes, 1))); return KVX_OK; }
+int kvx_dev_free(void *p) { HIPCHK(hipFree(p)); return KVX_OK; }
+int kvx_dev_upload(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); return KVX_OK; }
+int kvx_dev_download(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return KVX_OK; }
+int kvx_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return KVX_OK; }
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Device-side view of the symbolic analysis + launch helpers shared by the HIP sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace kvx {
+
+// Structure-of-arrays view of the fronts (all device pointers).  See symbolic.hpp.
+struct DevSym {
+    const int32_t *k;         // pivot columns per front
+    const int32_t *m;         // front order
+    const int32_t *first;     // first (permuted) column of the front
+    const int64_t *px;        // panel offset in Lx
+    const int64_t *rowptr;    // offset into rowidx / rel
+    const int32_t *rowidx;    // global row index of each front row
+    const int32_t *rel;       // position of each update row in the parent front
+    const int64_t *ux;        // update-matrix offset in its parity buffer
+    const int64_t *wx;        // solve update-vector offset in its parity buffer
+    const int64_t *childptr;
+    const int32_t *children;
+};
+
+constexpr int KVX_NB = 32;           // panel width of the blocked big-front factorisation
+constexpr int KVX_SMALL_MAX = 128;   // fronts up to this order are factored inside LDS
+constexpr int KVX_TILE = 64;         // trailing-update tile
+
+// ---- launchers (kernels.hip) ---------------------------------------------------------------
+void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx);
+// cls: 0: m<=32 (1 wave), 1: m<=64, 2: m<=96, 3: m<=128
+void launch_front_small(hipStream_t st, int cls, const DevSym &ds, const int32_t *list, int count,
+                        double *Lx, const double *Uchild, double *Uout, int *status);
+void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                         double *Lx, const double *Uchild, double *Uout);
+void launch_potrf_diag(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
+                       double *Lx, int *status);
+void launch_trsm_panel(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                       double *Lx);
+void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                          double *Lx, double *Uout);
+
+// solves: X is n x nrhs (ld = ldx) in PERMUTED order; W* are parity workspaces, each rhs
+// column uses a slice of wstride doubles.
+void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                      const double *Lx, double *X, int64_t ldx, int nrhs,
+                      const double *Wchild, double *Wout, int64_t wstride);
+void launch_bwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                      const double *Lx, double *X, int64_t ldx, int nrhs);
+// out[k + r*ldo] = in[perm[k] + r*ldi]  (gather)   /   out[perm[k] + r*ldo] = in[k + r*ldi]  (scatter)
+void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
+                        double *out, int64_t ldo);
+void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
+                         double *out, int64_t ldo);
+void launch_extract_diag(hipStream_t st, const DevSym &ds, int64_t nsuper, const double *Lx, double *d);
+
+}  // namespace kvx

@@ -1,0 +1,537 @@
+// HIP kernels (gfx950 / CDNA4) for the supernodal multifrontal Cholesky factorisation and the
+// level-scheduled triangular solves.
+//
+// Replaces the arithmetic the reference obtains from cholmod_l_factorize / cholmod_l_solve
+// (reference call sites src/C/cholmod.c:362, :483, :677, :735).  Design (own, MI355X-first):
+//   * fronts (supernodes) of one elimination-tree level are independent -> one launch per
+//     level and size class, one workgroup per front;
+//   * a front of order m <= 128 lives entirely in LDS: panel load, extend-add of the
+//     children's update matrices, partial Cholesky, Schur complement, write-back -- every
+//     HBM byte of the front is touched once;
+//   * larger fronts run a blocked right-looking factorisation in HBM/L2 whose trailing
+//     update is FP64 MFMA (v_mfma_f64_16x16x4_f64), 64-wide wavefronts, 64x64 tiles;
+//   * extend-add is parent-pull (each workgroup owns target columns), so there are no
+//     atomics and the result is bitwise reproducible.
+#include "device.hpp"
+
+namespace kvx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define KVX_LAUNCH_CHECK() (void)0
+
+// ------------------------------------------------------------------------------------------
+// scatter the caller's values into the (zeroed) panels
+__global__ void k_scatter_a(const double *__restrict__ Ax, const int64_t *__restrict__ amap, int64_t nnz,
+                            double *__restrict__ Lx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nnz; i += stride) {
+        int64_t d = amap[i];
+        if (d >= 0) Lx[d] = Ax[i];
+    }
+}
+
+void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx)
+{
+    if (nnz <= 0) return;
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_scatter_a, dim3((unsigned)blocks), dim3(256), 0, st, Ax, amap, nnz, Lx);
+}
+
+// ------------------------------------------------------------------------------------------
+// Small fronts: the whole m x m front in LDS (column-major, ld = m).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_front_small(DevSym ds, const int32_t *__restrict__ list,
+                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                    double *__restrict__ Uo, int *status)
+{
+    extern __shared__ double F[];
+    const int s = list[blockIdx.x];
+    const int k = ds.k[s], m = ds.m[s], u = m - k, tid = threadIdx.x;
+    double *P = Lx + ds.px[s];
+    const int mk = m * k, mm = m * m;
+    for (int i = tid; i < mk; i += NT) F[i] = P[i];
+    for (int i = mk + tid; i < mm; i += NT) F[i] = 0.0;
+    __syncthreads();
+    // extend-add of the children's update matrices (children one after another: deterministic)
+    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
+        const int ch = ds.children[c];
+        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
+        if (uc == 0) continue;
+        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
+        const double *U = Uc + ds.ux[ch];
+        if (NT == 64) {
+            for (int j = 0; j < uc; j++) {
+                const int tj = rl[j] * m;
+                for (int i = j + tid; i < uc; i += 64) F[rl[i] + tj] += U[i + (int64_t)j * uc];
+            }
+        } else {
+            const int wv = tid >> 6, ln = tid & 63;
+            for (int j = wv; j < uc; j += NT / 64) {
+                const int tj = rl[j] * m;
+                for (int i = j + ln; i < uc; i += 64) F[rl[i] + tj] += U[i + (int64_t)j * uc];
+            }
+        }
+        __syncthreads();
+    }
+    // right-looking Cholesky of the k pivot columns (updates confined to the panel columns)
+    for (int j = 0; j < k; j++) {
+        double d = F[j + j * m];
+        if (!(d > 0.0)) {
+            if (tid == 0) atomicMin(status, ds.first[s] + j);
+            d = 1.0;
+        }
+        const double ljj = sqrt(d);
+        const double inv = 1.0 / ljj;
+        __syncthreads();
+        for (int i = j + 1 + tid; i < m; i += NT) F[i + j * m] *= inv;
+        if (tid == 0) F[j + j * m] = ljj;
+        __syncthreads();
+        const int nc = k - j - 1;      // remaining panel columns
+        const int nr = m - j - 1;
+        for (int idx = tid; idx < nc * nr; idx += NT) {
+            const int c = j + 1 + idx / nr, i = j + 1 + idx % nr;
+            if (i >= c) F[i + c * m] -= F[i + j * m] * F[c + j * m];
+        }
+        __syncthreads();
+    }
+    // Schur complement of the update rows straight to HBM: U = F22 - L21 L21'
+    if (u > 0) {
+        double *Uout = Uo + ds.ux[s];
+        for (int idx = tid; idx < u * u; idx += NT) {
+            const int l = idx / u, i = idx - l * u;
+            if (i >= l) {
+                double acc = F[(k + i) + (k + l) * m];
+                for (int jj = 0; jj < k; jj++) acc -= F[(k + i) + jj * m] * F[(k + l) + jj * m];
+                Uout[idx] = acc;
+            }
+        }
+    }
+    for (int i = tid; i < mk; i += NT) P[i] = F[i];
+}
+
+void launch_front_small(hipStream_t st, int cls, const DevSym &ds, const int32_t *list, int count,
+                        double *Lx, const double *Uchild, double *Uout, int *status)
+{
+    if (count <= 0) return;
+    static const int cap[4] = {32, 64, 96, 128};
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8);
+        attr_set = true;
+    }
+    size_t lds = (size_t)cap[cls] * cap[cls] * sizeof(double);
+    if (cls == 0)
+        hipLaunchKernelGGL(k_front_small<64>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status);
+    else
+        hipLaunchKernelGGL(k_front_small<256>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status);
+}
+
+// ------------------------------------------------------------------------------------------
+// Big fronts: extend-add in HBM.  Workgroup (x, front) owns target columns [32x, 32x+32) of the
+// parent front and pulls the matching columns of every child, children in sequence.
+constexpr int ASM_TC = 32;
+
+__global__ __launch_bounds__(256) void k_assemble_big(DevSym ds, const int32_t *__restrict__ list,
+                                                      double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                      double *__restrict__ Uo)
+{
+    const int s = list[blockIdx.y];
+    const int k = ds.k[s], m = ds.m[s], u = m - k;
+    const int c0 = blockIdx.x * ASM_TC;
+    if (c0 >= m) return;
+    const int c1 = min(c0 + ASM_TC, m);
+    double *P = Lx + ds.px[s];
+    double *U = Uo + ds.ux[s];
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
+        const int ch = ds.children[c];
+        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
+        if (uc == 0) continue;
+        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
+        // child columns whose target column falls in [c0, c1): rl is increasing
+        int lo = 0, hi = uc;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c0) lo = mid + 1; else hi = mid; }
+        const int jlo = lo;
+        hi = uc;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c1) lo = mid + 1; else hi = mid; }
+        const int jhi = lo;
+        const double *Uch = Uc + ds.ux[ch];
+        for (int j = jlo + wv; j < jhi; j += 4) {
+            const int tc = rl[j];
+            const double *src = Uch + (int64_t)j * uc;
+            if (tc < k) {
+                double *dst = P + (int64_t)tc * m;
+                for (int i = j + ln; i < uc; i += 64) dst[rl[i]] += src[i];
+            } else {
+                double *dst = U + (int64_t)(tc - k) * u - k;
+                for (int i = j + ln; i < uc; i += 64) dst[rl[i]] += src[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                         double *Lx, const double *Uchild, double *Uout)
+{
+    if (count <= 0) return;
+    dim3 grid((unsigned)((max_m + ASM_TC - 1) / ASM_TC), (unsigned)count);
+    hipLaunchKernelGGL(k_assemble_big, grid, dim3(256), 0, st, ds, list, Lx, Uchild, Uout);
+}
+
+// ------------------------------------------------------------------------------------------
+// Big fronts, step jb of the blocked factorisation: (1) Cholesky of the NB x NB diagonal block
+__global__ __launch_bounds__(256) void k_potrf_diag(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                    double *__restrict__ Lx, int *status)
+{
+    constexpr int NB = KVX_NB, LD = NB + 1;
+    __shared__ double D[NB * LD];
+    const int s = list[blockIdx.x];
+    const int k = ds.k[s], m = ds.m[s], tid = threadIdx.x;
+    if (jb >= k) return;
+    const int nbk = min(NB, k - jb);
+    double *P = Lx + ds.px[s];
+    for (int idx = tid; idx < nbk * nbk; idx += 256) {
+        const int j = idx / nbk, i = idx - j * nbk;
+        D[i * LD + j] = (i >= j) ? P[(jb + i) + (int64_t)(jb + j) * m] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nbk; j++) {
+        double d = D[j * LD + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) atomicMin(status, ds.first[s] + jb + j);
+            d = 1.0;
+        }
+        const double ljj = sqrt(d), inv = 1.0 / ljj;
+        __syncthreads();
+        if (tid > j && tid < nbk) D[tid * LD + j] *= inv;
+        if (tid == j) D[j * LD + j] = ljj;
+        __syncthreads();
+        const int r = nbk - j - 1;
+        for (int idx = tid; idx < r * r; idx += 256) {
+            const int c = j + 1 + idx / r, i = j + 1 + idx % r;
+            if (i >= c) D[i * LD + c] -= D[i * LD + j] * D[c * LD + j];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < nbk * nbk; idx += 256) {
+        const int j = idx / nbk, i = idx - j * nbk;
+        if (i >= j) P[(jb + i) + (int64_t)(jb + j) * m] = D[i * LD + j];
+    }
+}
+
+void launch_potrf_diag(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
+                       double *Lx, int *status)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_potrf_diag, dim3((unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, status);
+}
+
+// (2) rows below the diagonal block: X := X * L11^{-T}, one row per thread
+__global__ __launch_bounds__(256) void k_trsm_panel(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                    double *__restrict__ Lx)
+{
+    constexpr int NB = KVX_NB, LD = NB + 1;
+    __shared__ double D[NB * LD];
+    const int s = list[blockIdx.y];
+    const int k = ds.k[s], m = ds.m[s], tid = threadIdx.x;
+    if (jb >= k) return;
+    const int nbk = min(NB, k - jb);
+    const int rbase = jb + nbk + blockIdx.x * 256;
+    if (rbase >= m) return;
+    double *P = Lx + ds.px[s];
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, i = idx - j * NB;
+        double v;
+        if (i < nbk && j < nbk) {
+            v = (i >= j) ? P[(jb + i) + (int64_t)(jb + j) * m] : 0.0;
+            if (i == j) v = 1.0 / v;
+        } else v = (i == j) ? 1.0 : 0.0;
+        D[i * LD + j] = v;
+    }
+    __syncthreads();
+    const int r = rbase + tid;
+    if (r < m) {
+        double x[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) x[j] = (j < nbk) ? P[r + (int64_t)(jb + j) * m] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            double acc = x[j];
+#pragma unroll
+            for (int l = 0; l < j; l++) acc -= x[l] * D[j * LD + l];
+            x[j] = acc * D[j * LD + j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+            if (j < nbk) P[r + (int64_t)(jb + j) * m] = x[j];
+    }
+}
+
+void launch_trsm_panel(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                       double *Lx)
+{
+    if (count <= 0) return;
+    int rows = max_m - jb - 1;
+    if (rows <= 0) return;
+    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(k_trsm_panel, grid, dim3(256), 0, st, ds, list, jb, Lx);
+}
+
+// (3) trailing update C -= L21 L21' on 64x64 tiles with FP64 MFMA.  The trailing matrix spans
+// the rest of the panel (columns < k, stored in Lx with ld = m) and the update matrix
+// (columns >= k, stored with ld = u).  Operand roles are swapped (A-operand <- tile columns,
+// B-operand <- tile rows) so that the 16 lanes sharing an accumulator register address
+// consecutive ROWS of C: column-major stores stay coalesced.
+__global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                       double *__restrict__ Lx, double *__restrict__ Uo)
+{
+    constexpr int NB = KVX_NB;
+    const int s = list[blockIdx.z];
+    const int k = ds.k[s], m = ds.m[s], u = m - k;
+    if (jb >= k) return;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const int nbk = min(NB, k - jb);
+    const int t0 = jb + nbk;
+    const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
+    if (r0 >= m) return;
+    double *P = Lx + ds.px[s];
+    double *U = Uo + ds.ux[s];
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int rr = r0 + 16 * w + lr;
+    for (int ks = 0; ks < nbk; ks += 4) {
+        const int kc = ks + lk;
+        const bool kin = kc < nbk;
+        const int64_t coff = (int64_t)(jb + kc) * m;
+        const double b = (kin && rr < m) ? P[rr + coff] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int cc = c0 + 16 * t + lr;
+            const double a = (kin && cc < m) ? P[cc + coff] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row
+    const int r = r0 + 16 * w + lr;
+    if (r < m) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = c0 + 16 * t + lk + 4 * q;
+                if (c <= r) {
+                    if (c < k) P[r + (int64_t)c * m] -= acc[t][q];
+                    else U[(r - k) + (int64_t)(c - k) * u] -= acc[t][q];
+                }
+            }
+    }
+}
+
+void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                          double *Lx, double *Uout)
+{
+    if (count <= 0) return;
+    int rows = max_m - jb - 1;   // upper bound of the trailing order (nbk >= 1)
+    if (rows <= 0) return;
+    unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
+    dim3 grid(T, T, (unsigned)count);
+    hipLaunchKernelGGL(k_syrk_trailing, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout);
+}
+
+// ------------------------------------------------------------------------------------------
+// Triangular solves, one workgroup per front and right-hand side.
+constexpr int SOLVE_B = 64, SOLVE_LD = 65;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_level(DevSym ds, const int32_t *__restrict__ list,
+                                                  const double *__restrict__ Lx, double *__restrict__ X,
+                                                  int64_t ldx, const double *__restrict__ Wc,
+                                                  double *__restrict__ Wo, int64_t wstride, int wcap)
+{
+    extern __shared__ double sm[];
+    double *w = sm, *D = sm + wcap;
+    const int s = list[blockIdx.x];
+    const int k = ds.k[s], m = ds.m[s], u = m - k, f = ds.first[s], tid = threadIdx.x;
+    double *x = X + (int64_t)blockIdx.y * ldx;
+    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
+    double *wo = Wo + (int64_t)blockIdx.y * wstride;
+    const double *P = Lx + ds.px[s];
+    for (int i = tid; i < m; i += NT) w[i] = (i < k) ? x[f + i] : 0.0;
+    __syncthreads();
+    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
+        const int ch = ds.children[c];
+        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
+        if (uc == 0) continue;
+        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
+        const double *src = wc + ds.wx[ch];
+        for (int i = tid; i < uc; i += NT) w[rl[i]] += src[i];
+        __syncthreads();
+    }
+    for (int jb = 0; jb < k; jb += SOLVE_B) {
+        const int nbk = min(SOLVE_B, k - jb);
+        for (int idx = tid; idx < nbk * nbk; idx += NT) {
+            const int j = idx / nbk, i = idx - j * nbk;
+            D[i * SOLVE_LD + j] = P[(jb + i) + (int64_t)(jb + j) * m];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int l = tid;
+            double wl = (l < nbk) ? w[jb + l] : 0.0;
+            for (int j = 0; j < nbk; j++) {
+                const double yj = __shfl(wl, j) / D[j * SOLVE_LD + j];
+                if (l == j) wl = yj;
+                else if (l > j && l < nbk) wl -= D[l * SOLVE_LD + j] * yj;
+            }
+            if (l < nbk) w[jb + l] = wl;
+        }
+        __syncthreads();
+        for (int i = jb + nbk + tid; i < m; i += NT) {
+            const double *Pi = P + i + (int64_t)jb * m;
+            double acc = 0.0;
+            for (int j = 0; j < nbk; j++) acc += Pi[(int64_t)j * m] * w[jb + j];
+            w[i] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < k; i += NT) x[f + i] = w[i];
+    if (u > 0) {
+        double *dst = wo + ds.wx[s];
+        for (int i = tid; i < u; i += NT) dst[i] = w[k + i];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_level(DevSym ds, const int32_t *__restrict__ list,
+                                                  const double *__restrict__ Lx, double *__restrict__ X,
+                                                  int64_t ldx, int wcap)
+{
+    extern __shared__ double sm[];
+    double *xf = sm, *D = sm + wcap;
+    const int s = list[blockIdx.x];
+    const int k = ds.k[s], m = ds.m[s], f = ds.first[s], tid = threadIdx.x;
+    double *x = X + (int64_t)blockIdx.y * ldx;
+    const double *P = Lx + ds.px[s];
+    const int32_t *rows = ds.rowidx + ds.rowptr[s];
+    for (int i = tid; i < m; i += NT) xf[i] = (i < k) ? x[f + i] : x[rows[i]];
+    __syncthreads();
+    const int nblk = (k + SOLVE_B - 1) / SOLVE_B;
+    const int wv = tid >> 6, ln = tid & 63;
+    for (int b = nblk - 1; b >= 0; b--) {
+        const int jb = b * SOLVE_B;
+        const int nbk = min(SOLVE_B, k - jb);
+        for (int idx = tid; idx < nbk * nbk; idx += NT) {
+            const int j = idx / nbk, i = idx - j * nbk;
+            D[i * SOLVE_LD + j] = P[(jb + i) + (int64_t)(jb + j) * m];
+        }
+        for (int j = wv; j < nbk; j += NT / 64) {
+            const double *Pc = P + (int64_t)(jb + j) * m;
+            double acc = 0.0;
+            for (int i = jb + nbk + ln; i < m; i += 64) acc += Pc[i] * xf[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (ln == 0) xf[jb + j] -= acc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int l = tid;
+            double tl = (l < nbk) ? xf[jb + l] : 0.0;
+            for (int j = nbk - 1; j >= 0; j--) {
+                const double xj = __shfl(tl, j) / D[j * SOLVE_LD + j];
+                if (l == j) tl = xj;
+                else if (l < j) tl -= D[j * SOLVE_LD + l] * xj;
+            }
+            if (l < nbk) xf[jb + l] = tl;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < k; i += NT) x[f + i] = xf[i];
+}
+
+static size_t solve_lds(int wcap) { return ((size_t)wcap + SOLVE_B * SOLVE_LD) * sizeof(double); }
+
+void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                      const double *Lx, double *X, int64_t ldx, int nrhs,
+                      const double *Wchild, double *Wout, int64_t wstride)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_fwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_bwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    if (max_m <= 32)
+        hipLaunchKernelGGL(k_fwd_level<64>, grid, dim3(64), solve_lds(32), st, ds, list, Lx, X, ldx, Wchild, Wout, wstride, 32);
+    else
+        hipLaunchKernelGGL(k_fwd_level<256>, grid, dim3(256), solve_lds(max_m), st, ds, list, Lx, X, ldx, Wchild, Wout, wstride, max_m);
+}
+
+void launch_bwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                      const double *Lx, double *X, int64_t ldx, int nrhs)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_fwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_bwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    if (max_m <= 32)
+        hipLaunchKernelGGL(k_bwd_level<64>, grid, dim3(64), solve_lds(32), st, ds, list, Lx, X, ldx, 32);
+    else
+        hipLaunchKernelGGL(k_bwd_level<256>, grid, dim3(256), solve_lds(max_m), st, ds, list, Lx, X, ldx, max_m);
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_perm_gather(const int32_t *__restrict__ perm, int64_t n, const double *__restrict__ in,
+                              int64_t ldi, double *__restrict__ out, int64_t ldo)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i + blockIdx.y * ldo] = in[perm[i] + blockIdx.y * ldi];
+}
+__global__ void k_perm_scatter(const int32_t *__restrict__ perm, int64_t n, const double *__restrict__ in,
+                               int64_t ldi, double *__restrict__ out, int64_t ldo)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[perm[i] + blockIdx.y * ldo] = in[i + blockIdx.y * ldi];
+}
+void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
+                        double *out, int64_t ldo)
+{
+    if (n <= 0 || nrhs <= 0) return;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)nrhs);
+    hipLaunchKernelGGL(k_perm_gather, grid, dim3(256), 0, st, perm, n, in, ldi, out, ldo);
+}
+void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
+                         double *out, int64_t ldo)
+{
+    if (n <= 0 || nrhs <= 0) return;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)nrhs);
+    hipLaunchKernelGGL(k_perm_scatter, grid, dim3(256), 0, st, perm, n, in, ldi, out, ldo);
+}
+
+__global__ void k_extract_diag(DevSym ds, int64_t nsuper, const double *__restrict__ Lx, double *__restrict__ d)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsuper) return;
+    const int k = ds.k[s], m = ds.m[s], f = ds.first[s];
+    const double *P = Lx + ds.px[s];
+    for (int j = 0; j < k; j++) d[f + j] = P[j + (int64_t)j * m];
+}
+void launch_extract_diag(hipStream_t st, const DevSym &ds, int64_t nsuper, const double *Lx, double *d)
+{
+    if (nsuper <= 0) return;
+    hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((nsuper + 255) / 256)), dim3(256), 0, st, ds, nsuper, Lx, d);
+}
+
+}  // namespace kvx

@@ -1,0 +1,196 @@
+// HIP kernels for the parts of the KKT step outside the Cholesky factorisation:
+//  * Nesterov-Todd scaling on the orthant ('l') cone -- reference src/python/misc.py:284-287,
+//    444-464, 951-952 and src/C/misc_solvers.c:132-141, 287-298, 662-669, 793-800, 1018, 1065-1071;
+//  * S = G' diag(w) G (+P) on a fixed pattern -- misc.py:1418-1426,1451-1455 -> src/C/sparse.c:
+//    1260-1283, 2176-2256, restated as a precomputed product list (one gather-multiply-reduce per
+//    stored entry of S instead of the reference's sparse-accumulator scatter per column);
+//  * CCS sparse mat-vec -- src/C/sparse.c:1073-1104.
+// All of it is HBM/latency-bound streaming work: coalesced grid-stride loops, wavefront (64-lane)
+// shuffles for the reductions, no MFMA.
+#include "kkt.hpp"
+
+namespace kvx {
+
+static inline unsigned grid_for(int64_t n, int bs = 256)
+{
+    int64_t b = (n + bs - 1) / bs;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+#define GS_LOOP(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void k_compute_scaling(int64_t n, const double *__restrict__ s, const double *__restrict__ z,
+                                  double *__restrict__ d, double *__restrict__ di, double *__restrict__ lm)
+{
+    GS_LOOP(i, n) {
+        const double si = s[i], zi = z[i];
+        const double dd = sqrt(si / zi);
+        d[i] = dd;
+        di[i] = 1.0 / dd;
+        lm[i] = sqrt(si * zi);
+    }
+}
+__global__ void k_update_scaling(int64_t n, double *__restrict__ s, double *__restrict__ z, double *__restrict__ d,
+                                 double *__restrict__ di, double *__restrict__ lm)
+{
+    GS_LOOP(i, n) {
+        const double ss = sqrt(s[i]), zz = sqrt(z[i]);
+        s[i] = ss;
+        z[i] = zz;
+        const double dd = (d[i] * ss) / zz;
+        d[i] = dd;
+        di[i] = 1.0 / dd;
+        lm[i] = ss * zz;
+    }
+}
+__global__ void k_scale(int64_t n, int64_t ldx, double *__restrict__ x, const double *__restrict__ w)
+{
+    double *xc = x + (int64_t)blockIdx.y * ldx;
+    GS_LOOP(i, n) xc[i] *= w[i];
+}
+__global__ void k_div(int64_t n, double *__restrict__ x, const double *__restrict__ y) { GS_LOOP(i, n) x[i] /= y[i]; }
+__global__ void k_mul(int64_t n, double *__restrict__ x, const double *__restrict__ y) { GS_LOOP(i, n) x[i] *= y[i]; }
+__global__ void k_sqr(int64_t n, double *__restrict__ x, const double *__restrict__ y) { GS_LOOP(i, n) { const double v = y[i]; x[i] = v * v; } }
+
+void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const double *z, double *d, double *di, double *lm)
+{ if (n > 0) hipLaunchKernelGGL(k_compute_scaling, dim3(grid_for(n)), dim3(256), 0, st, n, s, z, d, di, lm); }
+void launch_update_scaling(hipStream_t st, int64_t n, double *s, double *z, double *d, double *di, double *lm)
+{ if (n > 0) hipLaunchKernelGGL(k_update_scaling, dim3(grid_for(n)), dim3(256), 0, st, n, s, z, d, di, lm); }
+void launch_scale(hipStream_t st, int64_t n, int64_t ncols, int64_t ldx, double *x, const double *w)
+{ if (n > 0 && ncols > 0) hipLaunchKernelGGL(k_scale, dim3(grid_for(n), (unsigned)ncols), dim3(256), 0, st, n, ldx, x, w); }
+void launch_div(hipStream_t st, int64_t n, double *x, const double *y)
+{ if (n > 0) hipLaunchKernelGGL(k_div, dim3(grid_for(n)), dim3(256), 0, st, n, x, y); }
+void launch_mul(hipStream_t st, int64_t n, double *x, const double *y)
+{ if (n > 0) hipLaunchKernelGGL(k_mul, dim3(grid_for(n)), dim3(256), 0, st, n, x, y); }
+void launch_sqr(hipStream_t st, int64_t n, double *x, const double *y)
+{ if (n > 0) hipLaunchKernelGGL(k_sqr, dim3(grid_for(n)), dim3(256), 0, st, n, x, y); }
+
+// ---- reductions: fixed partial-sum tree (bitwise reproducible) -------------------------------
+constexpr int RED_BLOCKS = 256;
+
+template <bool MAXNEG>
+__device__ inline double wave_red(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = __shfl_xor(v, o);
+        v = MAXNEG ? fmax(v, t) : v + t;
+    }
+    return v;
+}
+
+template <bool MAXNEG>
+__global__ __launch_bounds__(256) void k_reduce1(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                 double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    double acc = MAXNEG ? -1.7976931348623157e308 : 0.0;
+    // contiguous chunk per block keeps the summation order independent of the grid-stride
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = per * blockIdx.x, b1 = min(n, b0 + per);
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) {
+        if (MAXNEG) acc = fmax(acc, -x[i]);
+        else acc += x[i] * y[i];
+    }
+    acc = wave_red<MAXNEG>(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sh[0];
+        for (int w = 1; w < 4; w++) r = MAXNEG ? fmax(r, sh[w]) : r + sh[w];
+        part[blockIdx.x] = r;
+    }
+}
+template <bool MAXNEG>
+__global__ __launch_bounds__(64) void k_reduce2(int nb, const double *__restrict__ part, double *__restrict__ out)
+{
+    double acc = MAXNEG ? -1.7976931348623157e308 : 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) acc = MAXNEG ? fmax(acc, part[i]) : acc + part[i];
+    acc = wave_red<MAXNEG>(acc);
+    if (threadIdx.x == 0) *out = acc;
+}
+
+void launch_dot(hipStream_t st, int64_t n, const double *x, const double *y, double *part, double *out)
+{
+    hipLaunchKernelGGL(k_reduce1<false>, dim3(RED_BLOCKS), dim3(256), 0, st, n, x, y, part);
+    hipLaunchKernelGGL(k_reduce2<false>, dim3(1), dim3(64), 0, st, RED_BLOCKS, part, out);
+}
+void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, double *out)
+{
+    hipLaunchKernelGGL(k_reduce1<true>, dim3(RED_BLOCKS), dim3(256), 0, st, n, x, x, part);
+    hipLaunchKernelGGL(k_reduce2<true>, dim3(1), dim3(64), 0, st, RED_BLOCKS, part, out);
+}
+int reduce_scratch_doubles() { return RED_BLOCKS + 1; }
+
+// ---- S = G' diag(w) G (+ P) on a fixed pattern ----------------------------------------------------
+// One thread per stored S entry e: sum over its product list [pp[e], pp[e+1]) of
+// w[Gi[pa]] * Gx[pa] * Gx[pb].  Lists are short (sum_r nnz_r(nnz_r+1)/2 products in total).
+__global__ void k_atda(int64_t snz, const int64_t *__restrict__ pp, const int32_t *__restrict__ pa,
+                       const int32_t *__restrict__ pb, const int32_t *__restrict__ gi, const double *__restrict__ gx,
+                       const double *__restrict__ w, double *__restrict__ sx)
+{
+    GS_LOOP(e, snz) {
+        double acc = 0.0;
+        for (int64_t q = pp[e]; q < pp[e + 1]; q++) {
+            const int32_t a = pa[q];
+            acc += (w[gi[a]] * gx[a]) * gx[pb[q]];
+        }
+        sx[e] = acc;
+    }
+}
+__global__ void k_add_at(int64_t pnz, const int64_t *__restrict__ slot, const double *__restrict__ px, double *__restrict__ sx)
+{
+    GS_LOOP(q, pnz) sx[slot[q]] += px[q];
+}
+void launch_atda(hipStream_t st, int64_t snz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
+                 const int32_t *gi, const double *gx, const double *w, double *sx)
+{ if (snz > 0) hipLaunchKernelGGL(k_atda, dim3(grid_for(snz)), dim3(256), 0, st, snz, pp, pa, pb, gi, gx, w, sx); }
+void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx)
+{ if (pnz > 0) hipLaunchKernelGGL(k_add_at, dim3(grid_for(pnz)), dim3(256), 0, st, pnz, slot, px, sx); }
+
+// ---- CCS mat-vec -------------------------------------------------------------------------------------
+// 'T': y_j = beta*y_j + alpha * <A(:,j), x>  -- one 16-lane group per column (columns are short).
+__global__ __launch_bounds__(256) void k_spmv_t(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                                                const double *__restrict__ Ax, double alpha, const double *__restrict__ x,
+                                                double beta, double *__restrict__ y)
+{
+    const int sub = threadIdx.x & 15;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (; j < n; j += stride) {
+        double acc = 0.0;
+        for (int64_t p = Ap[j] + sub; p < Ap[j + 1]; p += 16) acc += Ax[p] * x[Ai[p]];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) y[j] = (beta == 0.0 ? 0.0 : beta * y[j]) + alpha * acc;
+    }
+}
+__global__ void k_scal(int64_t n, double beta, double *__restrict__ y)
+{
+    GS_LOOP(i, n) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
+}
+// 'N': y += alpha * A x by column scatter with hardware FP64 atomics (order-dependent rounding;
+// the kvx_spmat handle offers the reproducible row-gather form).
+__global__ void k_spmv_n(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                         const double *__restrict__ Ax, double alpha, const double *__restrict__ x, double *__restrict__ y)
+{
+    GS_LOOP(j, n) {
+        const double xj = alpha * x[j];
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) unsafeAtomicAdd(&y[Ai[p]], Ax[p] * xj);
+    }
+}
+void launch_spmv(hipStream_t st, int trans, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                 double alpha, const double *x, double beta, double *y)
+{
+    if (trans == 'T') {
+        if (n > 0) hipLaunchKernelGGL(k_spmv_t, dim3(grid_for(n * 16)), dim3(256), 0, st, n, Ap, Ai, Ax, alpha, x, beta, y);
+    } else {
+        if (m > 0 && beta != 1.0) hipLaunchKernelGGL(k_scal, dim3(grid_for(m)), dim3(256), 0, st, m, beta, y);
+        if (n > 0) hipLaunchKernelGGL(k_spmv_n, dim3(grid_for(n)), dim3(256), 0, st, n, Ap, Ai, Ax, alpha, x, y);
+    }
+}
+
+}  // namespace kvx

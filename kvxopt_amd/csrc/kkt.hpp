@@ -1,0 +1,21 @@
+// Launchers of kkt.hip (NT scaling, normal-equations assembly, sparse mat-vec).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace kvx {
+void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const double *z, double *d, double *di, double *lm);
+void launch_update_scaling(hipStream_t st, int64_t n, double *s, double *z, double *d, double *di, double *lm);
+void launch_scale(hipStream_t st, int64_t n, int64_t ncols, int64_t ldx, double *x, const double *w);
+void launch_div(hipStream_t st, int64_t n, double *x, const double *y);
+void launch_mul(hipStream_t st, int64_t n, double *x, const double *y);
+void launch_sqr(hipStream_t st, int64_t n, double *x, const double *y);
+void launch_dot(hipStream_t st, int64_t n, const double *x, const double *y, double *part, double *out);
+void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, double *out);
+int reduce_scratch_doubles();
+void launch_atda(hipStream_t st, int64_t snz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
+                 const int32_t *gi, const double *gx, const double *w, double *sx);
+void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx);
+void launch_spmv(hipStream_t st, int trans, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
+                 double alpha, const double *x, double beta, double *y);
+}  // namespace kvx

@@ -1,0 +1,277 @@
+// C-ABI entry points for the NT scaling, normal-equations assembly and sparse mat-vec
+// (include/kvxhip.h).  Device-only: no CPU fallback.
+#include "../../include/kvxhip.h"
+#include "kkt.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace kvx;
+
+static thread_local std::string g_err2;
+extern "C" const char *kvx_last_error(void);
+
+#define HIPCHK(call)                                                             \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return KVX_EDEVICE;                                \
+    } while (0)
+
+struct kvx_atda {
+    int64_t ml = 0, n = 0, gnz = 0, snz = 0, pnz = 0;
+    std::vector<int64_t> Sp, Si;
+    std::vector<int64_t> pp;        // [snz+1]
+    std::vector<int32_t> pa, pb;    // product list: indices into Gx
+    std::vector<int64_t> pslot;     // per entry of the caller's P arrays: slot in S (or -1)
+    bool dev = false;
+    int64_t *d_pp = nullptr, *d_pslot = nullptr;
+    int32_t *d_pa = nullptr, *d_pb = nullptr, *d_gi = nullptr;
+    std::vector<int32_t> gi32;
+    double *d_gx = nullptr, *d_w = nullptr, *d_px = nullptr, *d_sx = nullptr;   // staging for the host variant
+};
+
+namespace {
+
+struct Scratch {
+    double *part = nullptr;
+    double *host = nullptr;
+};
+Scratch &scratch()
+{
+    static thread_local Scratch s;
+    return s;
+}
+int ensure_scratch()
+{
+    Scratch &s = scratch();
+    if (s.part) return KVX_OK;
+    HIPCHK(hipMalloc((void **)&s.part, reduce_scratch_doubles() * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&s.host, sizeof(double), hipHostMallocDefault));
+    return KVX_OK;
+}
+
+template <class T>
+int up(T **dst, const std::vector<T> &src)
+{
+    HIPCHK(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KVX_OK;
+}
+
+int atda_device(kvx_atda *T)
+{
+    if (T->dev) return KVX_OK;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return KVX_EDEVICE;
+    int rc;
+    if ((rc = up(&T->d_pp, T->pp))) return rc;
+    if ((rc = up(&T->d_pa, T->pa))) return rc;
+    if ((rc = up(&T->d_pb, T->pb))) return rc;
+    if ((rc = up(&T->d_gi, T->gi32))) return rc;
+    if ((rc = up(&T->d_pslot, T->pslot))) return rc;
+    T->dev = true;
+    return KVX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const int64_t *Pp, const int64_t *Pi,
+                  kvx_atda **out)
+{
+    if (!out || ml < 0 || n < 0 || (n > 0 && !Gp)) return KVX_EINVAL;
+    kvx_atda *T = new kvx_atda();
+    T->ml = ml; T->n = n;
+    const int64_t gnz = n ? Gp[n] : 0;
+    if (gnz >= ((int64_t)1 << 31)) { delete T; return KVX_EINVAL; }
+    T->gnz = gnz;
+    T->gi32.resize((size_t)gnz);
+    for (int64_t p = 0; p < gnz; p++) {
+        if (Gi[p] < 0 || Gi[p] >= ml) { delete T; return KVX_EINVAL; }
+        T->gi32[p] = (int32_t)Gi[p];
+    }
+    // CSR view of G: for every row the (column, CCS position) pairs, columns ascending
+    std::vector<int64_t> rptr((size_t)ml + 1, 0);
+    for (int64_t p = 0; p < gnz; p++) rptr[Gi[p] + 1]++;
+    for (int64_t r = 0; r < ml; r++) rptr[r + 1] += rptr[r];
+    std::vector<int32_t> rcol((size_t)gnz), rpos((size_t)gnz);
+    {
+        std::vector<int64_t> cur(rptr.begin(), rptr.end() - 1);
+        for (int64_t j = 0; j < n; j++)
+            for (int64_t p = Gp[j]; p < Gp[j + 1]; p++) {
+                int64_t q = cur[Gi[p]]++;
+                rcol[q] = (int32_t)j;
+                rpos[q] = (int32_t)p;
+            }
+    }
+    // pattern of tril(G'G) U tril(P), column by column
+    std::vector<int64_t> mark((size_t)n, -1);
+    std::vector<int64_t> col;
+    T->Sp.assign((size_t)n + 1, 0);
+    for (int64_t j = 0; j < n; j++) {
+        col.clear();
+        for (int64_t p = Gp[j]; p < Gp[j + 1]; p++) {
+            int64_t r = Gi[p];
+            for (int64_t q = rptr[r]; q < rptr[r + 1]; q++) {
+                int64_t i = rcol[q];
+                if (i >= j && mark[i] != j) { mark[i] = j; col.push_back(i); }
+            }
+        }
+        if (Pp)
+            for (int64_t p = Pp[j]; p < Pp[j + 1]; p++) {
+                int64_t i = Pi[p];
+                if (i < 0 || i >= n) { delete T; return KVX_EINVAL; }
+                if (i >= j && mark[i] != j) { mark[i] = j; col.push_back(i); }
+            }
+        std::sort(col.begin(), col.end());
+        T->Si.insert(T->Si.end(), col.begin(), col.end());
+        T->Sp[j + 1] = (int64_t)T->Si.size();
+    }
+    T->snz = (int64_t)T->Si.size();
+    // product lists
+    T->pp.assign((size_t)T->snz + 1, 0);
+    std::vector<int64_t> slot((size_t)n, -1);
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<int64_t> cur;
+        if (pass == 1) {
+            for (int64_t e = 0; e < T->snz; e++) T->pp[e + 1] += T->pp[e];
+            if (T->pp[T->snz] >= ((int64_t)1 << 40)) { delete T; return KVX_ENOMEM; }
+            T->pa.resize((size_t)T->pp[T->snz]);
+            T->pb.resize((size_t)T->pp[T->snz]);
+            cur.assign(T->pp.begin(), T->pp.end() - 1);
+        }
+        for (int64_t j = 0; j < n; j++) {
+            for (int64_t e = T->Sp[j]; e < T->Sp[j + 1]; e++) slot[T->Si[e]] = e;
+            for (int64_t p = Gp[j]; p < Gp[j + 1]; p++) {
+                int64_t r = Gi[p];
+                for (int64_t q = rptr[r]; q < rptr[r + 1]; q++) {
+                    int64_t i = rcol[q];
+                    if (i < j) continue;
+                    int64_t e = slot[i];
+                    if (pass == 0) T->pp[e + 1]++;
+                    else { int64_t t = cur[e]++; T->pa[t] = rpos[q]; T->pb[t] = (int32_t)p; }
+                }
+            }
+        }
+    }
+    if (Pp) {
+        T->pnz = Pp[n];
+        T->pslot.assign((size_t)T->pnz, -1);
+        for (int64_t j = 0; j < n; j++) {
+            for (int64_t e = T->Sp[j]; e < T->Sp[j + 1]; e++) slot[T->Si[e]] = e;
+            for (int64_t p = Pp[j]; p < Pp[j + 1]; p++)
+                if (Pi[p] >= j) T->pslot[p] = slot[Pi[p]];
+        }
+        // entries of P above the diagonal are ignored (lower triangle is read, as for 'L' storage)
+        for (int64_t p = 0; p < T->pnz; p++)
+            if (T->pslot[p] < 0) T->pslot[p] = 0;   // neutralised below by a zero value
+    }
+    *out = T;
+    return KVX_OK;
+}
+
+int kvx_atda_pattern(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si)
+{
+    if (!T) return KVX_EINVAL;
+    if (snz) *snz = T->snz;
+    if (Sp) memcpy(Sp, T->Sp.data(), sizeof(int64_t) * (T->n + 1));
+    if (Si && T->snz) memcpy(Si, T->Si.data(), sizeof(int64_t) * T->snz);
+    return KVX_OK;
+}
+
+int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
+{
+    if (!T) return KVX_EINVAL;
+    int rc = atda_device(T);
+    if (rc) return rc;
+    launch_atda(nullptr, T->snz, T->d_pp, T->d_pa, T->d_pb, T->d_gi, Gx, w, Sx);
+    if (Px && T->pnz > 0) launch_add_at(nullptr, T->pnz, T->d_pslot, Px, Sx);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
+{
+    if (!T) return KVX_EINVAL;
+    int rc = atda_device(T);
+    if (rc) return rc;
+    if (!T->d_gx) {
+        HIPCHK(hipMalloc((void **)&T->d_gx, std::max<int64_t>(T->gnz, 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&T->d_w, std::max<int64_t>(T->ml, 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&T->d_px, std::max<int64_t>(T->pnz, 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&T->d_sx, std::max<int64_t>(T->snz, 1) * sizeof(double)));
+    }
+    if (T->gnz) HIPCHK(hipMemcpy(T->d_gx, Gx, T->gnz * sizeof(double), hipMemcpyHostToDevice));
+    if (T->ml) HIPCHK(hipMemcpy(T->d_w, w, T->ml * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> ptmp;
+    if (Px && T->pnz) {
+        HIPCHK(hipMemcpy(T->d_px, Px, T->pnz * sizeof(double), hipMemcpyHostToDevice));
+    }
+    rc = kvx_atda_assemble_dev(T, T->d_gx, T->d_w, (Px && T->pnz) ? T->d_px : nullptr, T->d_sx);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (T->snz) HIPCHK(hipMemcpy(Sx, T->d_sx, T->snz * sizeof(double), hipMemcpyDeviceToHost));
+    return KVX_OK;
+}
+
+void kvx_atda_free(kvx_atda *T)
+{
+    if (!T) return;
+    void *ptrs[] = {T->d_pp, T->d_pslot, T->d_pa, T->d_pb, T->d_gi, T->d_gx, T->d_w, T->d_px, T->d_sx};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete T;
+}
+
+// ---- NT scaling ------------------------------------------------------------------------------------
+int kvx_nt_compute_scaling_dev(int64_t ml, const double *s, const double *z, double *d, double *di, double *lmbda)
+{ launch_compute_scaling(nullptr, ml, s, z, d, di, lmbda); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_update_scaling_dev(int64_t ml, double *s, double *z, double *d, double *di, double *lmbda)
+{ launch_update_scaling(nullptr, ml, s, z, d, di, lmbda); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_scale_dev(int64_t ml, int64_t ncols, int64_t ldx, double *x, const double *w)
+{ launch_scale(nullptr, ml, ncols, ldx, x, w); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_scale2_dev(int64_t ml, const double *lmbda, double *x, int inverse)
+{ if (inverse) launch_mul(nullptr, ml, x, lmbda); else launch_div(nullptr, ml, x, lmbda); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_sprod_dev(int64_t ml, double *x, const double *y)
+{ launch_mul(nullptr, ml, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_sinv_dev(int64_t ml, double *x, const double *y)
+{ launch_div(nullptr, ml, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y)
+{ launch_sqr(nullptr, ml, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+
+int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host)
+{
+    if (!result_host) return KVX_EINVAL;
+    int rc = ensure_scratch();
+    if (rc) return rc;
+    Scratch &s = scratch();
+    launch_dot(nullptr, ml, x, y, s.part, s.part + reduce_scratch_doubles() - 1);
+    HIPCHK(hipMemcpy(s.host, s.part + reduce_scratch_doubles() - 1, sizeof(double), hipMemcpyDeviceToHost));
+    *result_host = *s.host;
+    return KVX_OK;
+}
+int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host)
+{
+    if (!result_host) return KVX_EINVAL;
+    int rc = ensure_scratch();
+    if (rc) return rc;
+    Scratch &s = scratch();
+    launch_maxneg(nullptr, ml, x, s.part, s.part + reduce_scratch_doubles() - 1);
+    HIPCHK(hipMemcpy(s.host, s.part + reduce_scratch_doubles() - 1, sizeof(double), hipMemcpyDeviceToHost));
+    *result_host = *s.host;
+    return KVX_OK;
+}
+
+int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double alpha,
+                 const double *x, double beta, double *y)
+{
+    if (trans != 'N' && trans != 'T') return KVX_EINVAL;
+    launch_spmv(nullptr, trans, m, n, Ap, Ai, Ax, alpha, x, beta, y);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,437 @@
+// Symbolic analysis (host): see symbolic.hpp.  Reference role: cholmod_l_analyze_p as
+// called from src/C/cholmod.c:274 after pack() (:132-181).
+#include "symbolic.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+
+namespace kvx {
+namespace {
+
+// Pattern of the strictly-lower part of C = P A P' by column (rows sorted), built from
+// the caller's `uplo` triangle.  Also returns, for every caller entry, (row, col) of the
+// permuted lower-triangular position (or col = -1 when the entry is not read).
+struct LowerPattern {
+    std::vector<int64_t> ptr;
+    std::vector<int32_t> idx;
+};
+
+void build_lower(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo,
+                 const std::vector<int64_t> &iperm, LowerPattern &Lo)
+{
+    Lo.ptr.assign((size_t)n + 1, 0);
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            int64_t i = Ai[p];
+            if (i == j) continue;
+            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+            int64_t a = iperm[i], b = iperm[j];
+            Lo.ptr[(size_t)std::min(a, b) + 1]++;
+        }
+    for (int64_t j = 0; j < n; j++) Lo.ptr[j + 1] += Lo.ptr[j];
+    Lo.idx.resize((size_t)Lo.ptr[n]);
+    std::vector<int64_t> cur(Lo.ptr.begin(), Lo.ptr.end() - 1);
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            int64_t i = Ai[p];
+            if (i == j) continue;
+            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+            int64_t a = iperm[i], b = iperm[j];
+            Lo.idx[(size_t)cur[std::min(a, b)]++] = (int32_t)std::max(a, b);
+        }
+    for (int64_t j = 0; j < n; j++) std::sort(Lo.idx.begin() + Lo.ptr[j], Lo.idx.begin() + Lo.ptr[j + 1]);
+}
+
+// Elimination tree from the strictly-lower pattern by column.  Liu's algorithm needs,
+// for each k, the entries (k, i) with i < k, i.e. rows of the lower pattern: process
+// column-by-column through a transposed sweep.
+void etree_from_lower(int64_t n, const LowerPattern &Lo, std::vector<int32_t> &parent)
+{
+    // build row lists: for row k, the columns i < k with C(k,i) != 0
+    std::vector<int64_t> rptr((size_t)n + 1, 0);
+    for (int64_t p = 0; p < (int64_t)Lo.idx.size(); p++) rptr[(size_t)Lo.idx[p] + 1]++;
+    for (int64_t k = 0; k < n; k++) rptr[k + 1] += rptr[k];
+    std::vector<int32_t> ridx(Lo.idx.size());
+    std::vector<int64_t> cur(rptr.begin(), rptr.end() - 1);
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Lo.ptr[j]; p < Lo.ptr[j + 1]; p++) ridx[(size_t)cur[Lo.idx[p]]++] = (int32_t)j;
+    parent.assign((size_t)n, -1);
+    std::vector<int32_t> anc((size_t)n, -1);
+    for (int64_t k = 0; k < n; k++)
+        for (int64_t p = rptr[k]; p < rptr[k + 1]; p++) {
+            int32_t i = ridx[p];
+            while (i != -1 && i < k) {
+                int32_t nxt = anc[i];
+                anc[i] = (int32_t)k;
+                if (nxt == -1) parent[i] = (int32_t)k;
+                i = nxt;
+            }
+        }
+}
+
+// Postorder of a forest given by parent[] (parent[j] > j or -1).  Children are visited
+// in increasing subtree size so that the heaviest child ends adjacent to its parent
+// (it is the amalgamation candidate).
+void postorder(int64_t n, const std::vector<int32_t> &parent, std::vector<int32_t> &post)
+{
+    std::vector<int64_t> size((size_t)n, 1);
+    for (int64_t j = 0; j < n; j++)
+        if (parent[j] >= 0) size[parent[j]] += size[j];
+    // child lists sorted by (size, index): bucket via sort of indices
+    std::vector<int32_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return size[a] > size[b]; });
+    // push in decreasing size so that list heads are the smallest
+    std::vector<int32_t> head((size_t)n, -1), next((size_t)n, -1), roots_head(1, -1);
+    int32_t root_list = -1;
+    for (int32_t j : order) {
+        if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
+        else { next[j] = root_list; root_list = j; }
+    }
+    post.resize((size_t)n);
+    int64_t k = 0;
+    std::vector<int32_t> stack;
+    for (int32_t r = root_list; r != -1; r = next[r]) {
+        stack.push_back(r);
+        while (!stack.empty()) {
+            int32_t v = stack.back();
+            int32_t c = head[v];
+            if (c == -1) { post[(size_t)k++] = v; stack.pop_back(); }
+            else { head[v] = next[c]; stack.push_back(c); }
+        }
+    }
+}
+
+// Column counts of L (Gilbert, Ng, Peyton 1994: skeleton-matrix / least-common-ancestor
+// algorithm) for a matrix whose elimination tree is already postordered (parent[j] > j,
+// subtrees contiguous).
+void column_counts(int64_t n, const LowerPattern &Lo, const std::vector<int32_t> &parent,
+                   std::vector<int32_t> &cc)
+{
+    std::vector<int64_t> delta((size_t)n, 0);
+    std::vector<int32_t> first((size_t)n), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
+    std::vector<int64_t> size((size_t)n, 1);
+    std::vector<char> haschild((size_t)n, 0);
+    for (int64_t j = 0; j < n; j++)
+        if (parent[j] >= 0) { size[parent[j]] += size[j]; haschild[parent[j]] = 1; }
+    for (int64_t j = 0; j < n; j++) {
+        first[j] = (int32_t)(j - size[j] + 1);
+        delta[j] = haschild[j] ? 0 : 1;
+        anc[j] = (int32_t)j;
+    }
+    for (int64_t j = 0; j < n; j++) {
+        if (parent[j] >= 0) delta[parent[j]]--;
+        for (int64_t p = Lo.ptr[j]; p < Lo.ptr[j + 1]; p++) {
+            int32_t i = Lo.idx[p];
+            if (first[j] <= maxfirst[i]) continue;   // j is not a leaf of row subtree i
+            maxfirst[i] = first[j];
+            int32_t jprev = prevleaf[i];
+            prevleaf[i] = (int32_t)j;
+            delta[j]++;
+            if (jprev != -1) {
+                int32_t q = jprev;
+                while (q != anc[q]) q = anc[q];
+                for (int32_t s = jprev; s != q;) { int32_t sp = anc[s]; anc[s] = q; s = sp; }
+                delta[q]--;
+            }
+        }
+        if (parent[j] >= 0) anc[j] = parent[j];
+    }
+    cc.resize((size_t)n);
+    for (int64_t j = 0; j < n; j++)
+        if (parent[j] >= 0) delta[parent[j]] += delta[j];
+    for (int64_t j = 0; j < n; j++) cc[j] = (int32_t)delta[j];
+}
+
+}  // namespace
+
+void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const int64_t *user_perm,
+             const SymOpts &opts, Symbolic &S)
+{
+    if (n < 0) throw std::runtime_error("negative dimension");
+    if (n >= (int64_t)1 << 31) throw std::runtime_error("order exceeds 2^31-1");
+    if (uplo != 'L' && uplo != 'U') throw std::runtime_error("uplo must be 'L' or 'U'");
+    S = Symbolic();
+    S.n = n;
+    S.nnzA = n ? Ap[n] : 0;
+    for (int64_t j = 0; j < n; j++) {
+        if (Ap[j + 1] < Ap[j]) throw std::runtime_error("colptr not monotone");
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++)
+            if (Ai[p] < 0 || Ai[p] >= n) throw std::runtime_error("row index out of range");
+    }
+
+    // ---- 1. initial permutation -------------------------------------------------------
+    std::vector<int64_t> perm0((size_t)n), iperm0((size_t)n, -1);
+    if (user_perm) {
+        for (int64_t k = 0; k < n; k++) {
+            int64_t q = user_perm[k];
+            if (q < 0 || q >= n || iperm0[q] != -1) throw std::invalid_argument("p is not a valid permutation");
+            perm0[k] = q;
+            iperm0[q] = k;
+        }
+    } else if (opts.ordering == 1) {
+        std::iota(perm0.begin(), perm0.end(), 0);
+        iperm0 = perm0;
+    } else {
+        // full symmetric adjacency of the analysed triangle
+        std::vector<int64_t> aptr((size_t)n + 1, 0);
+        for (int64_t j = 0; j < n; j++)
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                int64_t i = Ai[p];
+                if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                aptr[i + 1]++;
+                aptr[j + 1]++;
+            }
+        for (int64_t j = 0; j < n; j++) aptr[j + 1] += aptr[j];
+        std::vector<int32_t> adj((size_t)aptr[n]);
+        std::vector<int64_t> cur(aptr.begin(), aptr.end() - 1);
+        for (int64_t j = 0; j < n; j++)
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                int64_t i = Ai[p];
+                if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                adj[(size_t)cur[i]++] = (int32_t)j;
+                adj[(size_t)cur[j]++] = (int32_t)i;
+            }
+        order_nd(n, aptr, adj, opts.nd_leaf, perm0);
+        for (int64_t k = 0; k < n; k++) iperm0[perm0[k]] = k;
+    }
+
+    // ---- 2. etree + postorder, fold the postorder into the permutation ---------------------
+    LowerPattern Lo;
+    std::vector<int32_t> parent;
+    build_lower(n, Ap, Ai, uplo, iperm0, Lo);
+    etree_from_lower(n, Lo, parent);
+    bool need_post = false;
+    {
+        // a tree is already postordered when every subtree is a contiguous index range
+        std::vector<int64_t> size((size_t)n, 1);
+        for (int64_t j = 0; j < n; j++)
+            if (parent[j] >= 0) size[parent[j]] += size[j];
+        // children of p must tile [p - size[p] + 1, p - 1]; check via first-descendant
+        std::vector<int64_t> fd((size_t)n);
+        for (int64_t j = 0; j < n; j++) fd[j] = j;
+        for (int64_t j = 0; j < n; j++)
+            if (parent[j] >= 0) fd[parent[j]] = std::min(fd[parent[j]], fd[j]);
+        for (int64_t j = 0; j < n && !need_post; j++) need_post = (fd[j] != j - size[j] + 1);
+    }
+    S.perm = perm0;
+    S.iperm = iperm0;
+    // Supernodes need contiguous subtrees, so the postorder is always applied (CHOLMOD's
+    // supernodal analysis does the same whatever options['postorder'] says).
+    (void)need_post;
+    {
+        std::vector<int32_t> post;
+        postorder(n, parent, post);
+        bool identity = true;
+        for (int64_t k = 0; k < n && identity; k++) identity = (post[k] == k);
+        if (!identity) {
+            for (int64_t k = 0; k < n; k++) S.perm[k] = perm0[post[k]];
+            for (int64_t k = 0; k < n; k++) S.iperm[S.perm[k]] = k;
+            build_lower(n, Ap, Ai, uplo, S.iperm, Lo);
+            etree_from_lower(n, Lo, parent);
+        }
+    }
+
+    // ---- 3. column counts ---------------------------------------------------------------
+    column_counts(n, Lo, parent, S.colcount);
+    S.lnz = 0;
+    S.flops = 0;
+    for (int64_t j = 0; j < n; j++) {
+        S.lnz += S.colcount[j];
+        S.flops += (double)S.colcount[j] * (double)S.colcount[j];
+    }
+
+    // ---- 4. supernodes: maximal zero-fill chains, then relaxed amalgamation ----------------
+    std::vector<int64_t> sstart;           // first column of each supernode
+    for (int64_t j = 0; j < n; j++) {
+        bool join = j > 0 && parent[j - 1] == j && S.colcount[j - 1] == S.colcount[j] + 1;
+        if (!join) sstart.push_back(j);
+    }
+    int64_t ns0 = (int64_t)sstart.size();
+    sstart.push_back(n);
+    std::vector<int32_t> col2s((size_t)n);
+    for (int64_t s = 0; s < ns0; s++)
+        for (int64_t j = sstart[s]; j < sstart[s + 1]; j++) col2s[j] = (int32_t)s;
+    std::vector<int32_t> sp0((size_t)ns0, -1);
+    for (int64_t s = 0; s < ns0; s++) {
+        int64_t last = sstart[s + 1] - 1;
+        if (parent[last] >= 0) sp0[s] = col2s[parent[last]];
+    }
+    // relaxed amalgamation: merge s into its parent when s is the parent's last child
+    // (adjacent columns) and the explicit zeros introduced stay below the bounds.
+    std::vector<int64_t> ncol((size_t)ns0), nrow((size_t)ns0);
+    std::vector<double> zeros((size_t)ns0, 0.0);
+    std::vector<char> dead((size_t)ns0, 0);
+    for (int64_t s = 0; s < ns0; s++) {
+        ncol[s] = sstart[s + 1] - sstart[s];
+        nrow[s] = S.colcount[sstart[s]];
+    }
+    std::vector<int64_t> mstart(sstart.begin(), sstart.end() - 1);  // merged first column
+    for (int64_t s = 0; s + 1 < ns0; s++) {
+        int64_t p = sp0[s];
+        if (p != s + 1) continue;
+        double nsc = (double)ncol[s], npc = (double)ncol[p];
+        double mp = (double)nrow[p], ms = (double)nrow[s];
+        double newz = nsc * (nsc + mp - ms);
+        double z = zeros[s] + zeros[p] + newz;
+        double tot = nsc + npc, mm = nsc + mp;
+        double lsz = tot * mm - tot * (tot - 1) / 2;
+        bool merge;
+        if (tot <= opts.relax_small) merge = true;
+        else {
+            double frac = z / lsz;
+            merge = (tot <= 16 && frac < opts.relax_z1) || (tot <= 48 && frac < opts.relax_z2) || frac < opts.relax_z3;
+            if (newz == 0) merge = true;
+        }
+        if (!merge) continue;
+        dead[s] = 1;
+        ncol[p] += ncol[s];
+        nrow[p] = (int64_t)mm;
+        zeros[p] = z;
+        mstart[p] = mstart[s];
+    }
+    S.super.clear();
+    std::vector<int32_t> old2new((size_t)ns0, -1);
+    for (int64_t s = 0; s < ns0; s++)
+        if (!dead[s]) { old2new[s] = (int32_t)S.super.size(); S.super.push_back(mstart[s]); }
+    S.nsuper = (int64_t)S.super.size();
+    S.super.push_back(n);
+    for (int64_t s = ns0 - 1; s >= 0; s--)      // dead supernodes map to the survivor above them
+        if (dead[s]) old2new[s] = old2new[s + 1];
+    for (int64_t j = 0; j < n; j++) col2s[j] = old2new[col2s[j]];
+    const int64_t ns = S.nsuper;
+    S.sn_k.resize((size_t)ns);
+    S.sparent.assign((size_t)ns, -1);
+    for (int64_t s = 0; s < ns; s++) {
+        S.sn_k[s] = (int32_t)(S.super[s + 1] - S.super[s]);
+        int64_t last = S.super[s + 1] - 1;
+        if (parent[last] >= 0) S.sparent[s] = col2s[parent[last]];
+    }
+    // children lists
+    S.childptr.assign((size_t)ns + 1, 0);
+    for (int64_t s = 0; s < ns; s++)
+        if (S.sparent[s] >= 0) S.childptr[S.sparent[s] + 1]++;
+    for (int64_t s = 0; s < ns; s++) S.childptr[s + 1] += S.childptr[s];
+    S.children.resize((size_t)S.childptr[ns]);
+    {
+        std::vector<int64_t> cur(S.childptr.begin(), S.childptr.end() - 1);
+        for (int64_t s = 0; s < ns; s++)
+            if (S.sparent[s] >= 0) S.children[(size_t)cur[S.sparent[s]]++] = (int32_t)s;
+    }
+
+    // ---- 5. front row structures (supernodal symbolic factorisation) -------------------------
+    S.rowptr.assign((size_t)ns + 1, 0);
+    S.sn_m.resize((size_t)ns);
+    S.rowidx.clear();
+    S.rowidx.reserve((size_t)(4 * n));
+    {
+        std::vector<int32_t> mark((size_t)n, -1);
+        std::vector<int32_t> tail;
+        for (int64_t s = 0; s < ns; s++) {
+            int64_t f = S.super[s], e = S.super[s + 1];
+            tail.clear();
+            for (int64_t j = f; j < e; j++) {
+                for (int64_t p = Lo.ptr[j]; p < Lo.ptr[j + 1]; p++) {
+                    int32_t i = Lo.idx[p];
+                    if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
+                }
+            }
+            for (int64_t c = S.childptr[s]; c < S.childptr[s + 1]; c++) {
+                int32_t ch = S.children[c];
+                for (int64_t p = S.rowptr[ch] + S.sn_k[ch]; p < S.rowptr[ch + 1]; p++) {
+                    int32_t i = S.rowidx[p];
+                    if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
+                }
+            }
+            std::sort(tail.begin(), tail.end());
+            for (int64_t j = f; j < e; j++) S.rowidx.push_back((int32_t)j);
+            S.rowidx.insert(S.rowidx.end(), tail.begin(), tail.end());
+            S.rowptr[s + 1] = (int64_t)S.rowidx.size();
+            S.sn_m[s] = (int32_t)(e - f + (int64_t)tail.size());
+        }
+    }
+    // ---- 6. relative indices child -> parent --------------------------------------------------
+    S.rel.assign(S.rowidx.size(), -1);
+    for (int64_t s = 0; s < ns; s++) {
+        int32_t p = S.sparent[s];
+        if (p < 0) {
+            if (S.sn_m[s] != S.sn_k[s]) throw std::runtime_error("internal: root front has update rows");
+            continue;
+        }
+        int64_t a = S.rowptr[s] + S.sn_k[s], ae = S.rowptr[s + 1];
+        int64_t b = S.rowptr[p], be = S.rowptr[p + 1];
+        for (; a < ae; a++) {
+            while (b < be && S.rowidx[b] < S.rowidx[a]) b++;
+            if (b >= be || S.rowidx[b] != S.rowidx[a]) throw std::runtime_error("internal: child row missing in parent front");
+            S.rel[a] = (int32_t)(b - S.rowptr[p]);
+        }
+    }
+    // ---- 7. storage offsets, levels ---------------------------------------------------------------
+    S.px.assign((size_t)ns + 1, 0);
+    S.max_m = 0; S.max_k = 0; S.sum_m = 0;
+    for (int64_t s = 0; s < ns; s++) {
+        S.px[s + 1] = S.px[s] + (int64_t)S.sn_m[s] * S.sn_k[s];
+        S.max_m = std::max(S.max_m, S.sn_m[s]);
+        S.max_k = std::max(S.max_k, S.sn_k[s]);
+        S.sum_m += S.sn_m[s];
+    }
+    S.lsize = S.px[ns];
+    S.depth.assign((size_t)ns, 0);
+    int32_t maxd = -1;
+    for (int64_t s = ns - 1; s >= 0; s--) {
+        S.depth[s] = S.sparent[s] >= 0 ? S.depth[S.sparent[s]] + 1 : 0;
+        maxd = std::max(maxd, S.depth[s]);
+    }
+    S.nlevels = maxd + 1;
+    S.levelptr.assign((size_t)S.nlevels + 1, 0);
+    for (int64_t s = 0; s < ns; s++) S.levelptr[S.depth[s] + 1]++;
+    for (int32_t l = 0; l < S.nlevels; l++) S.levelptr[l + 1] += S.levelptr[l];
+    S.levellist.resize((size_t)ns);
+    {
+        std::vector<int64_t> cur(S.levelptr.begin(), S.levelptr.end() - 1);
+        for (int64_t s = 0; s < ns; s++) S.levellist[(size_t)cur[S.depth[s]]++] = (int32_t)s;
+    }
+    // within a level: largest fronts first (big fronts get a contiguous head of the update
+    // buffer, long-running workgroups are dispatched first)
+    for (int32_t l = 0; l < S.nlevels; l++)
+        std::stable_sort(S.levellist.begin() + S.levelptr[l], S.levellist.begin() + S.levelptr[l + 1],
+                         [&](int32_t a, int32_t b) { return S.sn_m[a] > S.sn_m[b]; });
+    S.ux.assign((size_t)ns, 0);
+    S.wx.assign((size_t)ns, 0);
+    S.upd_size[0] = S.upd_size[1] = 0;
+    S.wrk_size[0] = S.wrk_size[1] = 0;
+    for (int32_t l = 0; l < S.nlevels; l++) {
+        int64_t off = 0, woff = 0;
+        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
+            int32_t s = S.levellist[q];
+            int64_t u = S.sn_m[s] - S.sn_k[s];
+            S.ux[s] = off;
+            S.wx[s] = woff;
+            off += u * u;
+            woff += u;
+        }
+        S.upd_size[l & 1] = std::max(S.upd_size[l & 1], off);
+        S.wrk_size[l & 1] = std::max(S.wrk_size[l & 1], woff);
+    }
+    // ---- 8. scatter map caller entries -> panels ------------------------------------------------
+    S.amap.assign((size_t)S.nnzA, -1);
+    S.nnzTri = 0;
+    for (int64_t j = 0; j < n; j++)
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            int64_t i = Ai[p];
+            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+            S.nnzTri++;
+            int64_t a = S.iperm[i], b = S.iperm[j];
+            int64_t r = std::max(a, b), c = std::min(a, b);
+            int32_t s = col2s[c];
+            const int32_t *rb = S.rowidx.data() + S.rowptr[s];
+            const int32_t *re = S.rowidx.data() + S.rowptr[s + 1];
+            const int32_t *it = std::lower_bound(rb, re, (int32_t)r);
+            if (it == re || *it != r) throw std::runtime_error("internal: entry outside the front structure");
+            S.amap[p] = S.px[s] + (it - rb) + (c - S.super[s]) * (int64_t)S.sn_m[s];
+        }
+}
+
+}  // namespace kvx

@@ -1,0 +1,70 @@
+// Host-side symbolic analysis for the supernodal multifrontal Cholesky factorisation.
+//
+// Replaces what the reference obtains from cholmod_l_analyze_p (reference call site
+// src/C/cholmod.c:274): fill-reducing ordering, elimination tree, postorder, column
+// counts, supernodes with relaxed amalgamation -- plus what the GPU schedule needs on
+// top: front row structures, child->parent relative indices, A->panel scatter map and
+// the elimination-tree level schedule.  Own design; no SuiteSparse code.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace kvx {
+
+struct SymOpts {
+    int ordering = 0;        // 0 = built-in ND + minimum degree, 1 = natural
+    int postorder = 1;
+    int relax_small = 4;
+    double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
+    int nd_leaf = 96;        // nested-dissection leaf size
+};
+
+struct Symbolic {
+    int64_t n = 0;
+    int64_t nnzA = 0;                 // entries in the caller's CCS arrays (both triangles)
+    int64_t nnzTri = 0;               // entries in the analysed triangle
+    std::vector<int64_t> perm, iperm; // final permutation: C = P A P', C(i,j) = A(perm[i],perm[j])
+    std::vector<int32_t> colcount;    // nnz(L(:,j)) incl. diagonal, simplicial count
+    int64_t lnz = 0;
+    double flops = 0;                 // sum_j colcount_j^2
+
+    // supernodes (= fronts), numbered in postorder
+    int64_t nsuper = 0;
+    std::vector<int64_t> super;       // [nsuper+1] first column of each supernode
+    std::vector<int32_t> sn_k;        // pivot columns
+    std::vector<int32_t> sn_m;        // front order (rows of the panel)
+    std::vector<int64_t> rowptr;      // [nsuper+1] into rowidx
+    std::vector<int32_t> rowidx;      // sorted global (permuted) row indices of each front
+    std::vector<int32_t> rel;         // parallel to rowidx: position in the PARENT front (rows >= k only)
+    std::vector<int64_t> px;          // [nsuper+1] panel offsets in Lx (m*k doubles, column-major, ld = m)
+    std::vector<int32_t> sparent;     // supernodal elimination tree (-1 = root)
+    std::vector<int32_t> depth;       // distance from the root of its tree
+    std::vector<int64_t> childptr;    // [nsuper+1]
+    std::vector<int32_t> children;
+    std::vector<int64_t> amap;        // [nnzA] destination in Lx of every caller entry, -1 = not read
+
+    // level schedule: level L holds the fronts at depth L; processed nlevels-1 ... 0
+    int32_t nlevels = 0;
+    std::vector<int64_t> levelptr;    // [nlevels+1]
+    std::vector<int32_t> levellist;   // fronts grouped by level
+    std::vector<int64_t> ux;          // [nsuper] offset of the u x u update matrix in its parity buffer
+    std::vector<int64_t> wx;          // [nsuper] offset of the solve update vector (u doubles)
+    int64_t upd_size[2] = {0, 0};     // doubles per parity buffer (even / odd depth)
+    int64_t wrk_size[2] = {0, 0};     // solve workspace per parity buffer
+    int64_t lsize = 0;                // = px[nsuper]
+    int32_t max_m = 0, max_k = 0;
+    int64_t sum_m = 0;
+};
+
+// Throws std::runtime_error with a message on invalid input. perm may be nullptr.
+// uplo: 'L' or 'U' (cholmod.c:132-181: only that triangle is read).
+void analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
+             const int64_t *perm, const SymOpts &opts, Symbolic &S);
+
+// Fill-reducing ordering of a symmetric graph given as full adjacency without
+// diagonal (adjptr[n+1], adj[]).  Returns perm (new -> old).
+void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
+              int leaf, std::vector<int64_t> &perm);
+
+}  // namespace kvx

@@ -1,0 +1,224 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes/numpy front-end of the CPU oracle.
+
+Restates (for the orthant 'l' cone only) what the reference computes on the KKT
+factor/solve hot path; every function cites the reference lines it follows.
+Never imported by kvxopt_amd/ (the product path fails loudly without its HIP
+library instead of falling back to this).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def _ptr_i(a):
+    return a.ctypes.data_as(_i64p)
+
+
+def _ptr_d(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libkvxoracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libkvxoracle.so")
+        if not os.path.exists(so):
+            build()
+        L = ctypes.CDLL(so)
+        L.kvxo_chol_analyze.restype = ctypes.c_void_p
+        L.kvxo_chol_analyze.argtypes = [ctypes.c_int64, _i64p, _i64p, ctypes.c_int, _i64p]
+        L.kvxo_chol_free.argtypes = [ctypes.c_void_p]
+        L.kvxo_chol_factorize.argtypes = [ctypes.c_void_p, _f64p]
+        L.kvxo_chol_factorize.restype = ctypes.c_int
+        L.kvxo_chol_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, _f64p, ctypes.c_int64, ctypes.c_int64]
+        L.kvxo_chol_solve.restype = ctypes.c_int
+        for f in ("kvxo_chol_n", "kvxo_chol_lnz", "kvxo_chol_minor"):
+            getattr(L, f).restype = ctypes.c_int64
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.kvxo_chol_flops.restype = ctypes.c_double
+        L.kvxo_chol_flops.argtypes = [ctypes.c_void_p]
+        L.kvxo_chol_get_perm.argtypes = [ctypes.c_void_p, _i64p]
+        L.kvxo_chol_get_parent.argtypes = [ctypes.c_void_p, _i64p]
+        L.kvxo_chol_get_L.argtypes = [ctypes.c_void_p, _i64p, _i64p, _f64p]
+        L.kvxo_chol_diag.argtypes = [ctypes.c_void_p, _f64p]
+        L.kvxo_spmv.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _i64p, _i64p, _f64p,
+                                ctypes.c_double, _f64p, ctypes.c_double, _f64p]
+        L.kvxo_rowscale.argtypes = [ctypes.c_int64, _i64p, _i64p, _f64p, _f64p, _f64p]
+        L.kvxo_syrk_partial.argtypes = [ctypes.c_int64, ctypes.c_int64, _i64p, _i64p, _f64p,
+                                        _i64p, _i64p, _f64p]
+        _LIB = L
+    return _LIB
+
+
+class OracleChol:
+    """P*A*P' = L*L' on the CPU (cholmod.c:244-499 semantics; see kvx_oracle.c)."""
+
+    def __init__(self, n, colptr, rowind, uplo="L", perm=None):
+        self.colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        self.rowind = np.ascontiguousarray(rowind, dtype=np.int64)
+        self.n = int(n)
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int64)
+        self._h = lib().kvxo_chol_analyze(self.n, _ptr_i(self.colptr), _ptr_i(self.rowind),
+                                          ord(uplo), None if p is None else _ptr_i(p))
+        if not self._h:
+            raise ValueError("p is not a valid permutation")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kvxo_chol_free(self._h)
+            self._h = None
+
+    @property
+    def lnz(self):
+        return lib().kvxo_chol_lnz(self._h)
+
+    @property
+    def flops(self):
+        return lib().kvxo_chol_flops(self._h)
+
+    @property
+    def minor(self):
+        return lib().kvxo_chol_minor(self._h)
+
+    def perm(self):
+        p = np.empty(self.n, dtype=np.int64)
+        lib().kvxo_chol_get_perm(self._h, _ptr_i(p))
+        return p
+
+    def parent(self):
+        p = np.empty(self.n, dtype=np.int64)
+        lib().kvxo_chol_get_parent(self._h, _ptr_i(p))
+        return p
+
+    def factorize(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.size == self.colptr[-1]
+        st = lib().kvxo_chol_factorize(self._h, _ptr_d(v))
+        if st:
+            raise ArithmeticError(int(self.minor))
+
+    def solve(self, B, sys=0):
+        """B: (n,) or (n, nrhs) Fortran-ordered float64, overwritten."""
+        B2 = B.reshape(self.n, -1, order="F") if B.ndim == 1 else B
+        assert B2.flags.f_contiguous or B2.shape[1] == 1
+        st = lib().kvxo_chol_solve(self._h, int(sys), _ptr_d(B2), B2.shape[1], max(1, self.n))
+        if st == 1:
+            raise ArithmeticError("singular matrix")
+        if st == 2:
+            raise ValueError("called with symbolic factor")
+        if st == 3:
+            raise ValueError("invalid value for sys")
+        return B
+
+    def diag(self):
+        d = np.empty(self.n)
+        lib().kvxo_chol_diag(self._h, _ptr_d(d))
+        return d
+
+    def L(self):
+        Lp = np.empty(self.n + 1, dtype=np.int64)
+        Li = np.empty(self.lnz, dtype=np.int64)
+        Lx = np.empty(self.lnz)
+        lib().kvxo_chol_get_L(self._h, _ptr_i(Lp), _ptr_i(Li), _ptr_d(Lx))
+        return Lp, Li, Lx
+
+
+def spmv(trans, m, n, colptr, rowind, values, x, y, alpha=1.0, beta=0.0):
+    """y := alpha*op(A)*x + beta*y, CCS A (sparse.c:1073-1104)."""
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowind, dtype=np.int64)
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    lib().kvxo_spmv(ord(trans), m, n, _ptr_i(cp), _ptr_i(ri), _ptr_d(v), alpha, _ptr_d(x), beta, _ptr_d(y))
+    return y
+
+
+def atda(ml, n, Gp, Gi, Gx, di, Sp, Si):
+    """S = G' diag(di)^2 G on S's fixed lower pattern: row scale then partial syrk
+    (misc.py:1418-1419,1451 -> sparse.c:1260-1283, 2176-2198)."""
+    Gp = np.ascontiguousarray(Gp, dtype=np.int64)
+    Gi = np.ascontiguousarray(Gi, dtype=np.int64)
+    Gx = np.ascontiguousarray(Gx, dtype=np.float64)
+    Sp = np.ascontiguousarray(Sp, dtype=np.int64)
+    Si = np.ascontiguousarray(Si, dtype=np.int64)
+    di = np.ascontiguousarray(di, dtype=np.float64)
+    Gs = np.empty_like(Gx)
+    lib().kvxo_rowscale(n, _ptr_i(Gp), _ptr_i(Gi), _ptr_d(Gx), _ptr_d(di), _ptr_d(Gs))
+    Sx = np.zeros(Si.size)
+    lib().kvxo_syrk_partial(ml, n, _ptr_i(Gp), _ptr_i(Gi), _ptr_d(Gs), _ptr_i(Sp), _ptr_i(Si), _ptr_d(Sx))
+    return Gs, Sx
+
+
+# --- Nesterov-Todd scaling, orthant ('l') blocks only ------------------------------
+def compute_scaling_l(s, z):
+    """misc.py:284-287: d = sqrt(s./z), di = d**-1, lmbda = sqrt(s.*z)."""
+    d = np.sqrt(s / z)
+    return d, d ** -1, np.sqrt(s * z)
+
+
+def update_scaling_l(d, lmbda, s, z):
+    """misc.py:444-464, in place like the reference: s,z := sqrt; d := d.*s./z;
+    di := d**-1; lmbda := s.*z.  Returns di."""
+    np.sqrt(s, out=s)
+    np.sqrt(z, out=z)
+    d *= s
+    d /= z
+    lmbda[:] = s * z
+    return d ** -1
+
+
+def scale_l(x, d, di, inverse="N"):
+    """misc_solvers.c:132-141 / misc.py:74-82: x := d.*x ('N') or di.*x ('I'),
+    every column; trans is irrelevant for a diagonal W."""
+    w = d if inverse == "N" else di
+    x *= w.reshape(-1, *([1] * (x.ndim - 1)))
+    return x
+
+
+def scale2_l(lmbda, x, inverse="N"):
+    """misc_solvers.c:287-298: x := x./lmbda ('N') or x.*lmbda ('I')."""
+    if inverse == "N":
+        x /= lmbda.reshape(-1, *([1] * (x.ndim - 1)))
+    else:
+        x *= lmbda.reshape(-1, *([1] * (x.ndim - 1)))
+    return x
+
+
+def sprod_l(x, y):
+    """misc_solvers.c:662-669: x := x.*y."""
+    x *= y
+    return x
+
+
+def sinv_l(x, y):
+    """misc_solvers.c:793-800: x := x./y."""
+    x /= y
+    return x
+
+
+def ssqr_l(y):
+    """misc.py:951-952: x := y.*y."""
+    return y * y
+
+
+def sdot_l(x, y):
+    """misc_solvers.c:1018: sum x_i*y_i."""
+    return float(np.dot(x, y))
+
+
+def max_step_l(x):
+    """misc_solvers.c:1065-1071: max_i(-x_i)  (-inf... the reference starts from
+    -FLT_MAX; for ml>0 this is max(-x))."""
+    return float(np.max(-x)) if x.size else -np.finfo(np.float64).max
