@@ -52,6 +52,8 @@ _SIGS = {
     "kvx_chol_get_perm": (ctypes.c_int, [vp, i64p]),
     "kvx_chol_get_supernodes": (ctypes.c_int, [vp, i64p, i64p, i64p, i64p]),
     "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
+    "kvx_chol_prof_select": (ctypes.c_int, [vp, ctypes.c_int]),
+    "kvx_chol_prof_read": (ctypes.c_int, [vp, f64p, i64p]),
     "kvx_chol_free": (None, [vp]),
     "kvx_free": (None, [vp]),
     "kvx_atda_plan": (ctypes.c_int, [i64, i64, i64p, i64p, i64p, i64p, ctypes.POINTER(vp)]),

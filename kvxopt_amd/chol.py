@@ -72,6 +72,18 @@ class Factor:
         raise_for(lib().kvx_chol_last_timing(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    FAMILIES = ("scatter_a", "front_small", "assemble_big", "potrf_diag", "trsm_panel", "syrk_trailing",
+                "fwd_level", "bwd_level")
+
+    def prof_select(self, family):
+        fam = -1 if family is None else (self.FAMILIES.index(family) if isinstance(family, str) else int(family))
+        raise_for(lib().kvx_chol_prof_select(self._h, fam))
+
+    def prof_read(self):
+        ms, cnt = ctypes.c_double(), ctypes.c_int64()
+        raise_for(lib().kvx_chol_prof_read(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return ms.value, cnt.value
+
     # -- numeric -----------------------------------------------------------------------------
     def factorize(self, values):
         """values: host float64 array aligned with (colptr,rowind).  Raises

@@ -64,6 +64,13 @@ struct kvx_chol {
     int *h_status = nullptr;  // pinned
     DevSym ds{};
     std::vector<LevelPlan> plan;
+    // optional per-kernel-family timing (bench.py roofline leg): HIP events around every launch
+    // of ONE selected family on the factor's stream
+    int prof_family = -1;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_ms = 0;
+    int64_t prof_launches = 0;
 };
 
 namespace {
@@ -75,6 +82,35 @@ int upload(T **dst, const std::vector<T> &src)
     HIPCHK(hipMalloc((void **)dst, bytes));
     if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return KVX_OK;
+}
+
+struct ProfScope {
+    kvx_chol *F;
+    bool on;
+    ProfScope(kvx_chol *F_, int fam) : F(F_), on(F_->prof_family == fam)
+    {
+        if (!on) return;
+        if (F->prof_used + 2 > F->prof_ev.size()) {
+            size_t old = F->prof_ev.size();
+            F->prof_ev.resize(old + 256, nullptr);
+            for (size_t i = old; i < F->prof_ev.size(); i++) (void)hipEventCreate(&F->prof_ev[i]);
+        }
+        (void)hipEventRecord(F->prof_ev[F->prof_used++], F->stream);
+    }
+    ~ProfScope()
+    {
+        if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], F->stream);
+    }
+};
+enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7 };
+
+void prof_collect(kvx_chol *F)
+{
+    for (size_t i = 0; i + 1 < F->prof_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, F->prof_ev[i], F->prof_ev[i + 1]) == hipSuccess) { F->prof_ms += ms; F->prof_launches++; }
+    }
+    F->prof_used = 0;
 }
 
 int cls_of(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 96 ? 2 : m <= KVX_SMALL_MAX ? 3 : 4; }
@@ -168,7 +204,7 @@ int enqueue_factor(kvx_chol *F)
     HIPCHK(hipEventRecord(F->ev[0], st));
     HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
-    launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx);
+    { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
     for (int l = S.nlevels - 1; l >= 0; l--) {
         const LevelPlan &P = F->plan[l];
         double *Uout = F->d_U[l & 1];
@@ -176,16 +212,18 @@ int enqueue_factor(kvx_chol *F)
         if (P.cnt[4] > 0) {
             const int32_t *list = F->d_lists + P.off[4];
             if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
-            launch_assemble_big(st, F->ds, list, P.cnt[4], P.maxm[4], F->d_Lx, Uch, Uout);
+            { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, P.cnt[4], P.maxm[4], F->d_Lx, Uch, Uout); }
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                launch_potrf_diag(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_status);
-                launch_trsm_panel(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx);
-                launch_syrk_trailing(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, Uout);
+                { ProfScope ps(F, FAM_POTRF); launch_potrf_diag(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_status); }
+                { ProfScope ps(F, FAM_TRSM); launch_trsm_panel(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx); }
+                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, Uout); }
             }
         }
         for (int c = 3; c >= 0; c--)
-            if (P.cnt[c] > 0)
+            if (P.cnt[c] > 0) {
+                ProfScope ps(F, FAM_SMALL);
                 launch_front_small(st, c, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
+            }
     }
     HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(F->ev[1], st));
@@ -200,6 +238,7 @@ int finish_factor(kvx_chol *F, int64_t *minor)
     if (F->pending) {
         HIPCHK(hipStreamSynchronize(F->stream));
         F->pending = false;
+        prof_collect(F);
         float ms = 0;
         if (hipEventElapsedTime(&ms, F->ev[0], F->ev[1]) == hipSuccess) { F->ms_factor = ms; F->have_ftime = true; }
         int st = *F->h_status;
@@ -217,9 +256,11 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
     for (int l = S.nlevels - 1; l >= 0; l--) {
         const LevelPlan &P = F->plan[l];
         for (int g = 0; g < 3; g++)
-            if (P.scnt[g] > 0)
+            if (P.scnt[g] > 0) {
+                ProfScope ps(F, FAM_FWD);
                 launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
                                  F->d_Lx, X, ldx, nrhs, F->d_W[(l + 1) & 1], F->d_W[l & 1], S.wrk_size[0] > S.wrk_size[1] ? S.wrk_size[0] : S.wrk_size[1]);
+            }
     }
 }
 
@@ -229,9 +270,11 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
     for (int l = 0; l < S.nlevels; l++) {
         const LevelPlan &P = F->plan[l];
         for (int g = 0; g < 3; g++)
-            if (P.scnt[g] > 0)
+            if (P.scnt[g] > 0) {
+                ProfScope ps(F, FAM_BWD);
                 launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
                                  F->d_Lx, X, ldx, nrhs);
+            }
     }
 }
 
@@ -280,6 +323,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(st));
+    prof_collect(F);
     float ms = 0;
     if (hipEventElapsedTime(&ms, F->ev[2], F->ev[3]) == hipSuccess) { F->ms_solve = ms; F->have_stime = true; }
     return KVX_OK;
@@ -551,6 +595,26 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)
     return KVX_OK;
 }
 
+int kvx_chol_prof_select(kvx_chol *F, int family)
+{
+    if (!F || family < -1 || family > 7) return KVX_EINVAL;
+    if (F->pending) finish_factor(F, nullptr);
+    F->prof_family = family;
+    F->prof_ms = 0;
+    F->prof_launches = 0;
+    F->prof_used = 0;
+    return KVX_OK;
+}
+
+int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches)
+{
+    if (!F) return KVX_EINVAL;
+    if (F->pending) finish_factor(F, nullptr);
+    if (total_ms) *total_ms = F->prof_ms;
+    if (launches) *launches = F->prof_launches;
+    return KVX_OK;
+}
+
 void kvx_chol_free(kvx_chol *F)
 {
     if (!F) return;
@@ -564,6 +628,8 @@ void kvx_chol_free(kvx_chol *F)
         if (F->h_status) (void)hipHostFree(F->h_status);
         for (int i = 0; i < 4; i++)
             if (F->ev[i]) (void)hipEventDestroy(F->ev[i]);
+        for (hipEvent_t e : F->prof_ev)
+            if (e) (void)hipEventDestroy(e);
         if (F->stream) (void)hipStreamDestroy(F->stream);
     }
     delete F;

@@ -1,0 +1,122 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md 8(d) (numpy only; CCS with int64 indices)."""
+import numpy as np
+
+
+def _tril_ccs_from_coo(n, rows, cols, vals):
+    """Lower-triangular CCS (sorted rows, duplicates summed) from COO triplets with rows >= cols."""
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    key = cols.astype(np.int64) * n + rows
+    uniq, start = np.unique(key, return_index=True)
+    v = np.add.reduceat(vals, start) if vals.size else vals
+    r = (uniq % n).astype(np.int64)
+    c = (uniq // n).astype(np.int64)
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(colptr, c + 1, 1)
+    np.cumsum(colptr, out=colptr)
+    return colptr, r, v.astype(np.float64)
+
+
+def laplacian_2d(g, h=None):
+    """5-point Laplacian A = I(x)T + T(x)I on a g x h grid, lower triangle as CCS (config 2:
+    g = h = 1000 -> n = 1e6, 2 998 000 stored entries)."""
+    h = g if h is None else h
+    n = g * h
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % g
+    rows = [idx, idx[x + 1 < g] + 1, idx[idx + g < n] + g]
+    cols = [idx, idx[x + 1 < g], idx[idx + g < n]]
+    vals = [np.full(n, 4.0), np.full(rows[1].size, -1.0), np.full(rows[2].size, -1.0)]
+    return (n,) + _tril_ccs_from_coo(n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+
+
+def laplacian_3d(g):
+    """7-point Laplacian on a g^3 grid, lower triangle (config 5 uses g = 200)."""
+    n = g * g * g
+    idx = np.arange(n, dtype=np.int64)
+    x = idx % g
+    y = (idx // g) % g
+    m1, m2, m3 = x + 1 < g, y + 1 < g, idx + g * g < n
+    rows = np.concatenate([idx, idx[m1] + 1, idx[m2] + g, idx[m3] + g * g])
+    cols = np.concatenate([idx, idx[m1], idx[m2], idx[m3]])
+    vals = np.concatenate([np.full(n, 6.0), np.full(m1.sum() + m2.sum() + m3.sum(), -1.0)])
+    return (n,) + _tril_ccs_from_coo(n, rows, cols, vals)
+
+
+def stencil21_2d(g, seed=20):
+    """'~20 nnz/row' north-star variant: radius-2 box+cross stencil (21 points) on a g x g grid,
+    random negative couplings, diagonally dominant (a_ii = 1 + sum |a_ij|), seed 20."""
+    n = g * g
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n, dtype=np.int64)
+    x, y = idx % g, idx // g
+    # 5x5 box minus its 4 corners = 21 points; keep the half with the larger node index
+    offs = [(dx, dy) for dy in range(0, 3) for dx in range(-2, 3)
+            if (dy > 0 or dx > 0) and not (abs(dx) == 2 and abs(dy) == 2)]
+    rows, cols, vals = [], [], []
+    diag = np.ones(n)
+    for dx, dy in offs:
+        m = (x + dx >= 0) & (x + dx < g) & (y + dy < g)
+        a = idx[m]
+        b = a + dx + dy * g
+        v = -rng.uniform(0.1, 1.0, a.size)
+        rows.append(b)
+        cols.append(a)
+        vals.append(v)
+        np.add.at(diag, a, -v)
+        np.add.at(diag, b, -v)
+    rows.append(idx)
+    cols.append(idx)
+    vals.append(diag)
+    return (n,) + _tril_ccs_from_coo(n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
+
+
+def sym_matvec(n, colptr, rowind, values, X):
+    """Y = A X for a symmetric matrix stored as its lower triangle (numpy; test/bench helper)."""
+    X2 = X.reshape(n, -1)
+    cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr))
+    Y = np.zeros_like(X2)
+    np.add.at(Y, rowind, values[:, None] * X2[cols])
+    off = rowind != cols
+    np.add.at(Y, cols[off], values[off, None] * X2[rowind[off]])
+    return Y.reshape(X.shape)
+
+
+def lp_grid(gx, gy, seed=4):
+    """Config-4b structured LP: variables on a gx x gy grid (n = gx*gy), G = M with
+    4 stacked n-row blocks; row j of block t has one entry at node j and one at its neighbour in
+    direction t (down/up/right/left; at the boundary the neighbour is j itself and the duplicate
+    is summed).  Strictly feasible by construction.  Returns dict with G as CCS (ml x n), c, h."""
+    n = gx * gy
+    rng = np.random.default_rng(seed)
+    idx = np.arange(n, dtype=np.int64)
+    x, y = idx % gx, idx // gx
+    nb = [np.where(y + 1 < gy, idx + gx, idx), np.where(y > 0, idx - gx, idx),
+          np.where(x + 1 < gx, idx + 1, idx), np.where(x > 0, idx - 1, idx)]
+    rows, cols, vals = [], [], []
+    for t in range(4):
+        own = rng.uniform(0.5, 1.5, n) * rng.choice([-1.0, 1.0], n)
+        oth = rng.uniform(0.5, 1.5, n) * rng.choice([-1.0, 1.0], n)
+        rows += [t * n + idx, t * n + idx]
+        cols += [idx, nb[t]]
+        vals += [own, oth]
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    ml = 4 * n
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    key = cols * ml + rows
+    uniq, start = np.unique(key, return_index=True)
+    v = np.add.reduceat(vals, start)
+    r, c = uniq % ml, uniq // ml
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(colptr, c + 1, 1)
+    np.cumsum(colptr, out=colptr)
+    x0 = rng.standard_normal(n)
+    s0 = rng.uniform(0.5, 1.5, ml)
+    z0 = rng.uniform(0.5, 1.5, ml)
+    Gx0 = np.zeros(ml)
+    np.add.at(Gx0, r, v * x0[c])
+    h = Gx0 + s0
+    cvec = np.zeros(n)
+    np.add.at(cvec, c, -v * z0[r])
+    return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h}
