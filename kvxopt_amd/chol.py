@@ -25,6 +25,10 @@ class Factor:
         for k, v in (opts or {}).items():
             if k == "nd_leaf":
                 o.reserved[0] = int(v)
+            elif k == "leaf_cols":          # 0 / negative = leaf-subtree amalgamation off
+                o.reserved[1] = int(v) if int(v) > 0 else -1
+            elif k == "leaf_rows":
+                o.reserved[2] = int(v)
             else:
                 setattr(o, k, v)
         p = None

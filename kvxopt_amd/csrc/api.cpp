@@ -58,7 +58,9 @@ struct kvx_chol {
     int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
             *d_amap = nullptr;
     double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
-    double *d_X = nullptr, *d_W[2] = {nullptr, nullptr};
+    double *d_X = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;
+    double *d_Linv = nullptr;
+    int64_t *d_linv_off = nullptr;
     int64_t x_cap = 0;        // right-hand sides the solve workspace holds
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
@@ -151,8 +153,17 @@ int ensure_device(kvx_chol *F)
     HIPCHK(hipMalloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void **)&F->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
+    {
+        // inverted diagonal blocks of the big fronts: ceil(k/NB) blocks of NB x NB each
+        std::vector<int64_t> loff((size_t)S.nsuper, -1);
+        int64_t tot = 0;
+        for (int64_t s = 0; s < S.nsuper; s++)
+            if (S.sn_m[s] > KVX_SMALL_MAX) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
+        if ((rc = upload(&F->d_linv_off, loff))) return rc;
+        HIPCHK(hipMalloc((void **)&F->d_Linv, std::max<int64_t>(tot, 1) * sizeof(double)));
+    }
     F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
-                   F->d_ux, F->d_wx, F->d_childptr, F->d_children};
+                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off};
     // per-level launch plan
     F->plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
@@ -185,10 +196,12 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
     if (nrhs <= F->x_cap) return KVX_OK;
     Symbolic &S = F->S;
     if (F->d_X) { (void)hipFree(F->d_X); F->d_X = nullptr; }
+    if (F->d_WK) { (void)hipFree(F->d_WK); F->d_WK = nullptr; }
     for (int p = 0; p < 2; p++)
         if (F->d_W[p]) { (void)hipFree(F->d_W[p]); F->d_W[p] = nullptr; }
     F->x_cap = 0;
     HIPCHK(hipMalloc((void **)&F->d_X, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&F->d_WK, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
     const int64_t wmax = std::max(S.wrk_size[0], S.wrk_size[1]);   // common per-rhs stride of both parity buffers
     for (int p = 0; p < 2; p++)
         HIPCHK(hipMalloc((void **)&F->d_W[p], std::max<int64_t>(wmax * nrhs, 1) * sizeof(double)));
@@ -214,8 +227,8 @@ int enqueue_factor(kvx_chol *F)
             if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, P.cnt[4], P.maxm[4], F->d_Lx, Uch, Uout); }
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                { ProfScope ps(F, FAM_POTRF); launch_potrf_diag(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_status); }
-                { ProfScope ps(F, FAM_TRSM); launch_trsm_panel(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx); }
+                { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_Linv, F->d_status); }
+                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, F->d_Linv); }
                 { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, Uout); }
             }
         }
@@ -253,13 +266,21 @@ int finish_factor(kvx_chol *F, int64_t *minor)
 void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
 {
     Symbolic &S = F->S;
+    const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
     for (int l = S.nlevels - 1; l >= 0; l--) {
         const LevelPlan &P = F->plan[l];
-        for (int g = 0; g < 3; g++)
+        const double *Wch = F->d_W[(l + 1) & 1];
+        double *Wout = F->d_W[l & 1];
+        if (P.scnt[0] > 0) {
+            ProfScope ps(F, FAM_FWD);
+            launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
+                           X, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
+        }
+        for (int g = 1; g < 3; g++)
             if (P.scnt[g] > 0) {
                 ProfScope ps(F, FAM_FWD);
-                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
-                                 F->d_Lx, X, ldx, nrhs, F->d_W[(l + 1) & 1], F->d_W[l & 1], S.wrk_size[0] > S.wrk_size[1] ? S.wrk_size[0] : S.wrk_size[1]);
+                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : KVX_SMALL_MAX,
+                                 F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
             }
     }
 }
@@ -269,10 +290,15 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
     Symbolic &S = F->S;
     for (int l = 0; l < S.nlevels; l++) {
         const LevelPlan &P = F->plan[l];
-        for (int g = 0; g < 3; g++)
+        if (P.scnt[0] > 0) {
+            ProfScope ps(F, FAM_BWD);
+            launch_bwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
+                           X, ldx, nrhs, F->d_WK, S.n);
+        }
+        for (int g = 1; g < 3; g++)
             if (P.scnt[g] > 0) {
                 ProfScope ps(F, FAM_BWD);
-                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : (g == 1 ? KVX_SMALL_MAX : P.smaxm[g]),
+                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : KVX_SMALL_MAX,
                                  F->d_Lx, X, ldx, nrhs);
             }
     }
@@ -290,7 +316,6 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
     if (rc) return rc;
     if (n == 0 || nrhs == 0) return KVX_OK;
     if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
-    if ((int64_t)S.max_m * 8 + 64 * 65 * 8 > 160 * 1024) { set_err("front too large for the LDS-resident solve"); return KVX_EINVAL; }
     if (sys == 6) return KVX_OK;   // D = I for an LL' factor
     hipStream_t st = F->stream;
     // wstride: both parity buffers are allocated with wrk_size[p]*x_cap; use a common stride
@@ -372,6 +397,8 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
         so.relax_small = o.relax_small;
         so.relax_z1 = o.relax_z1; so.relax_z2 = o.relax_z2; so.relax_z3 = o.relax_z3;
         if (o.reserved[0] > 0) so.nd_leaf = o.reserved[0];
+        if (o.reserved[1] != 0) so.leaf_cols = o.reserved[1] < 0 ? 0 : o.reserved[1];
+        if (o.reserved[2] > 0) so.leaf_rows = o.reserved[2];
         static const int64_t zero = 0;
         analyze(n, n ? colptr : &zero, rowind, uplo, perm, so, F->S);
         F->minor = n;
@@ -622,7 +649,7 @@ void kvx_chol_free(kvx_chol *F)
         (void)hipStreamSynchronize(F->stream);
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
-                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status};
+                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (F->h_status) (void)hipHostFree(F->h_status);

@@ -18,9 +18,27 @@ struct DevSym {
     const int64_t *wx;        // solve update-vector offset in its parity buffer
     const int64_t *childptr;
     const int32_t *children;
+    const int64_t *linv;      // big fronts: offset of the inverted 64x64 diagonal blocks (-1 otherwise)
 };
 
-constexpr int KVX_NB = 32;           // panel width of the blocked big-front factorisation
+#ifdef __HIPCC__
+// sqrt(d) and 1/sqrt(d) without the IEEE division / square-root expansions (each a long chain
+// of dependent FP64 ops): hardware v_rsq_f64 seed (~2^-26) + two Newton steps, then one
+// correction of the root.  Results are within 1-2 ulp; d must be > 0 and normal.
+__device__ __forceinline__ void kvx_sqrt_rsqrt(double d, double &root, double &inv)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    r = r * __builtin_fma(-hd * r, r, 1.5);
+    r = r * __builtin_fma(-hd * r, r, 1.5);
+    double x = d * r;
+    x = __builtin_fma(0.5 * r, __builtin_fma(-x, x, d), x);
+    root = x;
+    inv = r;
+}
+#endif
+
+constexpr int KVX_NB = 64;           // panel width of the blocked big-front factorisation
 constexpr int KVX_SMALL_MAX = 128;   // fronts up to this order are factored inside LDS
 constexpr int KVX_TILE = 64;         // trailing-update tile
 
@@ -31,10 +49,10 @@ void launch_front_small(hipStream_t st, int cls, const DevSym &ds, const int32_t
                         double *Lx, const double *Uchild, double *Uout, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
-void launch_potrf_diag(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
-                       double *Lx, int *status);
-void launch_trsm_panel(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                       double *Lx);
+void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
+                      double *Lx, double *Linv, int *status);
+void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                     double *Lx, const double *Linv);
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                           double *Lx, double *Uout);
 
@@ -45,6 +63,12 @@ void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int
                       const double *Wchild, double *Wout, int64_t wstride);
 void launch_bwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                       const double *Lx, double *X, int64_t ldx, int nrhs);
+// big fronts (m > KVX_SMALL_MAX): multi-workgroup solves using the inverted diagonal blocks
+void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
+                    const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs,
+                    double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride);
+void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
+                    const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs, double *WK, int64_t ldw);
 // out[k + r*ldo] = in[perm[k] + r*ldi]  (gather)   /   out[perm[k] + r*ldo] = in[k + r*ldi]  (scatter)
 void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
                         double *out, int64_t ldo);

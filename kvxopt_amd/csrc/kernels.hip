@@ -8,8 +8,8 @@
 //   * a front of order m <= 128 lives entirely in LDS: panel load, extend-add of the
 //     children's update matrices, partial Cholesky, Schur complement, write-back -- every
 //     HBM byte of the front is touched once;
-//   * larger fronts run a blocked right-looking factorisation in HBM/L2 whose trailing
-//     update is FP64 MFMA (v_mfma_f64_16x16x4_f64), 64-wide wavefronts, 64x64 tiles;
+//   * larger fronts run a blocked right-looking factorisation in HBM/L2 (kernels_big.hip)
+//     whose panel solve and trailing update are FP64 MFMA (v_mfma_f64_16x16x4_f64);
 //   * extend-add is parent-pull (each workgroup owns target columns), so there are no
 //     atomics and the result is bitwise reproducible.
 #include "device.hpp"
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(NT) void k_front_small(DevSym ds, const int32_t *__
             if (tid == 0) atomicMin(status, ds.first[s] + j);
             d = 1.0;
         }
-        const double ljj = sqrt(d);
-        const double inv = 1.0 / ljj;
+        double ljj, inv;
+        kvx_sqrt_rsqrt(d, ljj, inv);
         __syncthreads();
         for (int i = j + 1 + tid; i < m; i += NT) F[i + j * m] *= inv;
         if (tid == 0) F[j + j * m] = ljj;
@@ -181,169 +181,6 @@ void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, 
     if (count <= 0) return;
     dim3 grid((unsigned)((max_m + ASM_TC - 1) / ASM_TC), (unsigned)count);
     hipLaunchKernelGGL(k_assemble_big, grid, dim3(256), 0, st, ds, list, Lx, Uchild, Uout);
-}
-
-// ------------------------------------------------------------------------------------------
-// Big fronts, step jb of the blocked factorisation: (1) Cholesky of the NB x NB diagonal block
-__global__ __launch_bounds__(256) void k_potrf_diag(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                    double *__restrict__ Lx, int *status)
-{
-    constexpr int NB = KVX_NB, LD = NB + 1;
-    __shared__ double D[NB * LD];
-    const int s = list[blockIdx.x];
-    const int k = ds.k[s], m = ds.m[s], tid = threadIdx.x;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
-    double *P = Lx + ds.px[s];
-    for (int idx = tid; idx < nbk * nbk; idx += 256) {
-        const int j = idx / nbk, i = idx - j * nbk;
-        D[i * LD + j] = (i >= j) ? P[(jb + i) + (int64_t)(jb + j) * m] : 0.0;
-    }
-    __syncthreads();
-    for (int j = 0; j < nbk; j++) {
-        double d = D[j * LD + j];
-        if (!(d > 0.0)) {
-            if (tid == 0) atomicMin(status, ds.first[s] + jb + j);
-            d = 1.0;
-        }
-        const double ljj = sqrt(d), inv = 1.0 / ljj;
-        __syncthreads();
-        if (tid > j && tid < nbk) D[tid * LD + j] *= inv;
-        if (tid == j) D[j * LD + j] = ljj;
-        __syncthreads();
-        const int r = nbk - j - 1;
-        for (int idx = tid; idx < r * r; idx += 256) {
-            const int c = j + 1 + idx / r, i = j + 1 + idx % r;
-            if (i >= c) D[i * LD + c] -= D[i * LD + j] * D[c * LD + j];
-        }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < nbk * nbk; idx += 256) {
-        const int j = idx / nbk, i = idx - j * nbk;
-        if (i >= j) P[(jb + i) + (int64_t)(jb + j) * m] = D[i * LD + j];
-    }
-}
-
-void launch_potrf_diag(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
-                       double *Lx, int *status)
-{
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_potrf_diag, dim3((unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, status);
-}
-
-// (2) rows below the diagonal block: X := X * L11^{-T}, one row per thread
-__global__ __launch_bounds__(256) void k_trsm_panel(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                    double *__restrict__ Lx)
-{
-    constexpr int NB = KVX_NB, LD = NB + 1;
-    __shared__ double D[NB * LD];
-    const int s = list[blockIdx.y];
-    const int k = ds.k[s], m = ds.m[s], tid = threadIdx.x;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
-    const int rbase = jb + nbk + blockIdx.x * 256;
-    if (rbase >= m) return;
-    double *P = Lx + ds.px[s];
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int j = idx / NB, i = idx - j * NB;
-        double v;
-        if (i < nbk && j < nbk) {
-            v = (i >= j) ? P[(jb + i) + (int64_t)(jb + j) * m] : 0.0;
-            if (i == j) v = 1.0 / v;
-        } else v = (i == j) ? 1.0 : 0.0;
-        D[i * LD + j] = v;
-    }
-    __syncthreads();
-    const int r = rbase + tid;
-    if (r < m) {
-        double x[NB];
-#pragma unroll
-        for (int j = 0; j < NB; j++) x[j] = (j < nbk) ? P[r + (int64_t)(jb + j) * m] : 0.0;
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            double acc = x[j];
-#pragma unroll
-            for (int l = 0; l < j; l++) acc -= x[l] * D[j * LD + l];
-            x[j] = acc * D[j * LD + j];
-        }
-#pragma unroll
-        for (int j = 0; j < NB; j++)
-            if (j < nbk) P[r + (int64_t)(jb + j) * m] = x[j];
-    }
-}
-
-void launch_trsm_panel(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                       double *Lx)
-{
-    if (count <= 0) return;
-    int rows = max_m - jb - 1;
-    if (rows <= 0) return;
-    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)count);
-    hipLaunchKernelGGL(k_trsm_panel, grid, dim3(256), 0, st, ds, list, jb, Lx);
-}
-
-// (3) trailing update C -= L21 L21' on 64x64 tiles with FP64 MFMA.  The trailing matrix spans
-// the rest of the panel (columns < k, stored in Lx with ld = m) and the update matrix
-// (columns >= k, stored with ld = u).  Operand roles are swapped (A-operand <- tile columns,
-// B-operand <- tile rows) so that the 16 lanes sharing an accumulator register address
-// consecutive ROWS of C: column-major stores stay coalesced.
-__global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                       double *__restrict__ Lx, double *__restrict__ Uo)
-{
-    constexpr int NB = KVX_NB;
-    const int s = list[blockIdx.z];
-    const int k = ds.k[s], m = ds.m[s], u = m - k;
-    if (jb >= k) return;
-    const int ti = blockIdx.x, tj = blockIdx.y;
-    if (tj > ti) return;
-    const int nbk = min(NB, k - jb);
-    const int t0 = jb + nbk;
-    const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
-    if (r0 >= m) return;
-    double *P = Lx + ds.px[s];
-    double *U = Uo + ds.ux[s];
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int rr = r0 + 16 * w + lr;
-    for (int ks = 0; ks < nbk; ks += 4) {
-        const int kc = ks + lk;
-        const bool kin = kc < nbk;
-        const int64_t coff = (int64_t)(jb + kc) * m;
-        const double b = (kin && rr < m) ? P[rr + coff] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cc = c0 + 16 * t + lr;
-            const double a = (kin && cc < m) ? P[cc + coff] : 0.0;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
-    }
-    // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row
-    const int r = r0 + 16 * w + lr;
-    if (r < m) {
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int c = c0 + 16 * t + lk + 4 * q;
-                if (c <= r) {
-                    if (c < k) P[r + (int64_t)c * m] -= acc[t][q];
-                    else U[(r - k) + (int64_t)(c - k) * u] -= acc[t][q];
-                }
-            }
-    }
-}
-
-void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout)
-{
-    if (count <= 0) return;
-    int rows = max_m - jb - 1;   // upper bound of the trailing order (nbk >= 1)
-    if (rows <= 0) return;
-    unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
-    dim3 grid(T, T, (unsigned)count);
-    hipLaunchKernelGGL(k_syrk_trailing, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout);
 }
 
 // ------------------------------------------------------------------------------------------

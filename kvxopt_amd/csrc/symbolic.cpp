@@ -269,9 +269,44 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         nrow[s] = S.colcount[sstart[s]];
     }
     std::vector<int64_t> mstart(sstart.begin(), sstart.end() - 1);  // merged first column
+    // (a) leaf-subtree amalgamation: a supernode whose children are all leaves of the (merged)
+    // tree is fused with ALL of them into one dense leaf front when the fused front stays small.
+    // A GPU pays a fixed price per front (a workgroup, dependent index loads, a launch slot);
+    // the minimum-degree leaves of a 2-D/3-D mesh otherwise produce hundreds of thousands of
+    // fronts of order < 16.
+    if (opts.leaf_cols > 0) {
+        std::vector<char> haskids((size_t)ns0, 0), allleaf((size_t)ns0, 1);
+        std::vector<int64_t> kidcols((size_t)ns0, 0), firstkid((size_t)ns0, -1);
+        for (int64_t s = 0; s < ns0; s++) {      // postorder: the children of s were decided before s
+            bool leaf = !haskids[s];
+            if (haskids[s] && allleaf[s]) {
+                const int64_t ktot = ncol[s] + kidcols[s];
+                const int64_t u = nrow[s] - ncol[s];
+                if (ktot <= opts.leaf_cols && ktot + u <= opts.leaf_rows) {
+                    const int64_t fk = firstkid[s];
+                    for (int64_t c = fk; c < s; c++) dead[c] = 1;
+                    const double dense = (double)ktot * (double)(ktot + u) - (double)ktot * (double)(ktot - 1) / 2;
+                    double have = 0;
+                    for (int64_t j = mstart[fk]; j < sstart[s + 1]; j++) have += S.colcount[j];
+                    zeros[s] = dense - have;
+                    ncol[s] = ktot;
+                    nrow[s] = ktot + u;
+                    mstart[s] = mstart[fk];
+                    leaf = true;                 // fused: a leaf of the merged tree
+                }
+            }
+            const int64_t p = sp0[s];
+            if (p >= 0) {
+                if (!haskids[p]) { haskids[p] = 1; firstkid[p] = s; }
+                if (!leaf) allleaf[p] = 0;
+                kidcols[p] += ncol[s];
+            }
+        }
+    }
+    // (b) chain amalgamation along last-child edges
     for (int64_t s = 0; s + 1 < ns0; s++) {
         int64_t p = sp0[s];
-        if (p != s + 1) continue;
+        if (dead[s] || p < 0 || sstart[s + 1] != mstart[p]) continue;
         double nsc = (double)ncol[s], npc = (double)ncol[p];
         double mp = (double)nrow[p], ms = (double)nrow[s];
         double newz = nsc * (nsc + mp - ms);

@@ -18,6 +18,8 @@ struct SymOpts {
     int relax_small = 4;
     double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
     int nd_leaf = 96;        // nested-dissection leaf size
+    int leaf_cols = 32;      // leaf-subtree amalgamation: fuse while pivots <= leaf_cols ...
+    int leaf_rows = 64;      // ... and front order <= leaf_rows (0 cols = off)
 };
 
 struct Symbolic {

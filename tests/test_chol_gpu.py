@@ -105,7 +105,7 @@ def test_user_perm_options_and_refactor():
     rng = np.random.default_rng(5)
     parity(n, cp, ri, vx, perm=rng.permutation(n))
     parity(n, cp, ri, vx, opts={"ordering": 1})            # natural order: a deep, thin tree
-    parity(n, cp, ri, vx, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0})
+    parity(n, cp, ri, vx, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0, "leaf_cols": 0})
     parity(n, cp, ri, vx, opts={"nd_leaf": 6})
     # numeric refactor on the same symbolic (misc.py:1462): new values, same handle
     F, O = parity(n, cp, ri, vx)

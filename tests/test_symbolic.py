@@ -54,9 +54,9 @@ def test_user_perm_natural_and_options():
     check_structure(n, cp, ri, perm=rng.permutation(n))
     check_structure(n, cp, ri, perm=np.arange(n))
     check_structure(n, cp, ri, opts={"ordering": 1})
-    check_structure(n, cp, ri, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0})
+    check_structure(n, cp, ri, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0, "leaf_cols": 0})
     check_structure(n, cp, ri, opts={"nd_leaf": 8})
-    F, a = check_structure(n, cp, ri, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0})
+    F, a = check_structure(n, cp, ri, opts={"relax_small": 0, "relax_z1": 0.0, "relax_z2": 0.0, "relax_z3": 0.0, "leaf_cols": 0})
     k = np.diff(F.supernodes()[0])
     assert a["lsize"] == a["lnz"] + int(np.sum(k * (k - 1) // 2))   # no relaxation: panels = nnz(L) + upper corners
     with pytest.raises(ValueError):
