@@ -29,13 +29,14 @@ static void set_err(const std::string &s) { g_err = s; }
     } while (0)
 
 struct LevelPlan {
-    // fronts of the level sorted by m descending: [big | cls3 | cls2 | cls1 | cls0]
-    int64_t off[5];      // offset into d_lists of class c (4 = big)
-    int cnt[5];
-    int maxm[5];
+    // fronts of the level grouped by kernel class (symbolic.hpp front_class), big first
+    int64_t off[KVX_NCLS];   // offset into d_lists of class c
+    int cnt[KVX_NCLS];
+    int maxm[KVX_NCLS];
+    int maxk[KVX_NCLS];
     int big_maxk = 0;
     int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
-    // solve groups: [m > 128], [33..128], [<= 32]
+    // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
     int64_t soff[3];
     int scnt[3];
     int smaxm[3];
@@ -49,6 +50,8 @@ struct kvx_chol {
     bool pending = false;     // a factorisation was enqueued and its status not yet read
     int64_t minor = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[2] = {nullptr, nullptr};   // independent kernel classes of one level run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_ftime = false, have_stime = false;
     double ms_factor = 0, ms_solve = 0;
@@ -61,6 +64,8 @@ struct kvx_chol {
     double *d_X = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;
     double *d_Linv = nullptr;
     int64_t *d_linv_off = nullptr;
+    FrontDesc *d_fd = nullptr;
+    ChildDesc *d_cd = nullptr;
     int64_t x_cap = 0;        // right-hand sides the solve workspace holds
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
@@ -89,7 +94,8 @@ int upload(T **dst, const std::vector<T> &src)
 struct ProfScope {
     kvx_chol *F;
     bool on;
-    ProfScope(kvx_chol *F_, int fam) : F(F_), on(F_->prof_family == fam)
+    hipStream_t st;
+    ProfScope(kvx_chol *F_, int fam, hipStream_t st_ = nullptr) : F(F_), on(F_->prof_family == fam), st(st_ ? st_ : F_->stream)
     {
         if (!on) return;
         if (F->prof_used + 2 > F->prof_ev.size()) {
@@ -97,11 +103,11 @@ struct ProfScope {
             F->prof_ev.resize(old + 256, nullptr);
             for (size_t i = old; i < F->prof_ev.size(); i++) (void)hipEventCreate(&F->prof_ev[i]);
         }
-        (void)hipEventRecord(F->prof_ev[F->prof_used++], F->stream);
+        (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
     }
     ~ProfScope()
     {
-        if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], F->stream);
+        if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
     }
 };
 enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7 };
@@ -115,7 +121,6 @@ void prof_collect(kvx_chol *F)
     F->prof_used = 0;
 }
 
-int cls_of(int m) { return m <= 32 ? 0 : m <= 64 ? 1 : m <= 96 ? 2 : m <= KVX_SMALL_MAX ? 3 : 4; }
 
 int ensure_device(kvx_chol *F)
 {
@@ -128,6 +133,11 @@ int ensure_device(kvx_chol *F)
     Symbolic &S = F->S;
     HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&F->side[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&F->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
     int rc;
     std::vector<int32_t> first((size_t)S.nsuper), perm32((size_t)S.n);
     for (int64_t s = 0; s < S.nsuper; s++) first[s] = (int32_t)S.super[s];
@@ -153,35 +163,57 @@ int ensure_device(kvx_chol *F)
     HIPCHK(hipMalloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void **)&F->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
+    std::vector<int64_t> loff_host;
     {
         // inverted diagonal blocks of the big fronts: ceil(k/NB) blocks of NB x NB each
-        std::vector<int64_t> loff((size_t)S.nsuper, -1);
+        std::vector<int64_t> &loff = loff_host;
+        loff.assign((size_t)S.nsuper, -1);
         int64_t tot = 0;
         for (int64_t s = 0; s < S.nsuper; s++)
-            if (S.sn_m[s] > KVX_SMALL_MAX) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
+            if (front_class(S.sn_m[s], S.sn_k[s]) == KVX_CLS_BIG) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
         if ((rc = upload(&F->d_linv_off, loff))) return rc;
         HIPCHK(hipMalloc((void **)&F->d_Linv, std::max<int64_t>(tot, 1) * sizeof(double)));
     }
+    {
+        std::vector<FrontDesc> fd((size_t)S.nsuper);
+        std::vector<ChildDesc> cd(S.children.size());
+        for (int64_t s = 0; s < S.nsuper; s++) {
+            FrontDesc &d = fd[s];
+            d.k = S.sn_k[s]; d.m = S.sn_m[s]; d.first = (int32_t)S.super[s];
+            d.nchild = (int32_t)(S.childptr[s + 1] - S.childptr[s]);
+            d.px = S.px[s]; d.rowptr = S.rowptr[s]; d.ux = S.ux[s]; d.wx = S.wx[s]; d.childptr = S.childptr[s];
+            d.linv = loff_host[s];
+            for (int64_t c = S.childptr[s]; c < S.childptr[s + 1]; c++) {
+                int32_t ch = S.children[c];
+                ChildDesc &e = cd[c];
+                e.kc = S.sn_k[ch]; e.uc = S.sn_m[ch] - S.sn_k[ch];
+                e.rel = S.rowptr[ch] + S.sn_k[ch]; e.ux = S.ux[ch]; e.wx = S.wx[ch];
+            }
+        }
+        if ((rc = upload(&F->d_fd, fd))) return rc;
+        if ((rc = upload(&F->d_cd, cd))) return rc;
+    }
     F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
-                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off};
+                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd};
     // per-level launch plan
     F->plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
         LevelPlan &P = F->plan[l];
-        for (int c = 0; c < 5; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; }
+        for (int c = 0; c < KVX_NCLS; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; P.maxk[c] = 0; }
         for (int g = 0; g < 3; g++) { P.soff[g] = 0; P.scnt[g] = 0; P.smaxm[g] = 0; }
         for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
             int s = S.levellist[q];
             int m = S.sn_m[s], k = S.sn_k[s];
-            int c = cls_of(m);
+            int c = front_class(m, k);
             if (P.cnt[c] == 0) P.off[c] = q;
             P.cnt[c]++;
             P.maxm[c] = std::max(P.maxm[c], m);
-            if (c == 4) {
+            P.maxk[c] = std::max(P.maxk[c], k);
+            if (c == KVX_CLS_BIG) {
                 P.big_maxk = std::max(P.big_maxk, k);
                 P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
             }
-            int g = m > KVX_SMALL_MAX ? 0 : m > 32 ? 1 : 2;
+            int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
             if (P.scnt[g] == 0) P.soff[g] = q;
             P.scnt[g]++;
             P.smaxm[g] = std::max(P.smaxm[g], m);
@@ -222,21 +254,43 @@ int enqueue_factor(kvx_chol *F)
         const LevelPlan &P = F->plan[l];
         double *Uout = F->d_U[l & 1];
         const double *Uch = F->d_U[(l + 1) & 1];
-        if (P.cnt[4] > 0) {
-            const int32_t *list = F->d_lists + P.off[4];
+        // The fronts of one level are independent: the big-front chain stays on the main stream,
+        // the LDS-front and wave-front launches fork onto two side streams and join at level end.
+        int nlds = 0, nwave = 0;
+        for (int c = KVX_CLS_LDS128; c < KVX_NCLS; c++) (c < KVX_CLS_WAVE0 ? nlds : nwave) += P.cnt[c];
+        const bool have_big = P.cnt[KVX_CLS_BIG] > 0;
+        const bool fork_lds = nlds > 0 && (have_big || nwave > 0);
+        const bool fork_wave = nwave > 0 && have_big;
+        hipStream_t s_lds = fork_lds ? F->side[0] : st;
+        hipStream_t s_wave = fork_wave ? F->side[1] : st;
+        if (fork_lds || fork_wave) {
+            HIPCHK(hipEventRecord(F->ev_fork, st));
+            if (fork_lds) HIPCHK(hipStreamWaitEvent(F->side[0], F->ev_fork, 0));
+            if (fork_wave) HIPCHK(hipStreamWaitEvent(F->side[1], F->ev_fork, 0));
+        }
+        for (int c = KVX_CLS_LDS128; c < KVX_NCLS; c++)
+            if (P.cnt[c] > 0) {
+                if (c < KVX_CLS_WAVE0) {
+                    ProfScope ps(F, FAM_SMALL, s_lds);
+                    launch_front_small(s_lds, c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[c] <= 32 ? 32 : 64, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
+                } else {
+                    ProfScope ps(F, FAM_SMALL, s_wave);
+                    launch_front_wave(s_wave, wave_class_mcap(c), wave_class_kmax(c), F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
+                }
+            }
+        if (have_big) {
+            const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
+            const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
             if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
-            { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, P.cnt[4], P.maxm[4], F->d_Lx, Uch, Uout); }
+            { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, P.cnt[4], jb, F->d_Lx, F->d_Linv, F->d_status); }
-                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, F->d_Linv); }
-                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, P.cnt[4], P.maxm[4], jb, F->d_Lx, Uout); }
+                { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, jb, F->d_Lx, F->d_Linv, F->d_status); }
+                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
+                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout); }
             }
         }
-        for (int c = 3; c >= 0; c--)
-            if (P.cnt[c] > 0) {
-                ProfScope ps(F, FAM_SMALL);
-                launch_front_small(st, c, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
-            }
+        if (fork_lds) { HIPCHK(hipEventRecord(F->ev_join[0], F->side[0])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[0], 0)); }
+        if (fork_wave) { HIPCHK(hipEventRecord(F->ev_join[1], F->side[1])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[1], 0)); }
     }
     HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipEventRecord(F->ev[1], st));
@@ -279,7 +333,7 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         for (int g = 1; g < 3; g++)
             if (P.scnt[g] > 0) {
                 ProfScope ps(F, FAM_FWD);
-                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : KVX_SMALL_MAX,
+                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 64 : KVX_SMALL_MAX,
                                  F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
             }
     }
@@ -298,7 +352,7 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         for (int g = 1; g < 3; g++)
             if (P.scnt[g] > 0) {
                 ProfScope ps(F, FAM_BWD);
-                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 32 : KVX_SMALL_MAX,
+                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 64 : KVX_SMALL_MAX,
                                  F->d_Lx, X, ldx, nrhs);
             }
     }
@@ -649,7 +703,7 @@ void kvx_chol_free(kvx_chol *F)
         (void)hipStreamSynchronize(F->stream);
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
-                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off};
+                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (F->h_status) (void)hipHostFree(F->h_status);
@@ -657,6 +711,11 @@ void kvx_chol_free(kvx_chol *F)
             if (F->ev[i]) (void)hipEventDestroy(F->ev[i]);
         for (hipEvent_t e : F->prof_ev)
             if (e) (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; i++) {
+            if (F->side[i]) (void)hipStreamDestroy(F->side[i]);
+            if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
+        }
+        if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
         if (F->stream) (void)hipStreamDestroy(F->stream);
     }
     delete F;

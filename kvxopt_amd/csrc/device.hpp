@@ -19,6 +19,21 @@ struct DevSym {
     const int64_t *childptr;
     const int32_t *children;
     const int64_t *linv;      // big fronts: offset of the inverted 64x64 diagonal blocks (-1 otherwise)
+    // Array-of-structures twins of the above: one 64-byte record per front and one 32-byte record
+    // per (parent, child) edge, so that a workgroup reaches its operands after two dependent
+    // loads instead of five (the per-front kernels are latency-bound on small levels).
+    const struct FrontDesc *fd;
+    const struct ChildDesc *cd;
+};
+
+struct FrontDesc {            // 64 bytes
+    int32_t k, m, first, nchild;
+    int64_t px, rowptr, ux, wx, childptr, linv;
+};
+struct ChildDesc {            // 32 bytes, indexed like DevSym::children
+    int32_t uc, kc;           // update rows / pivot columns of the child
+    int64_t rel;              // index into DevSym::rel of the child's first update row
+    int64_t ux, wx;           // child's update matrix / update vector offsets (previous level's parity buffer)
 };
 
 #ifdef __HIPCC__
@@ -44,9 +59,12 @@ constexpr int KVX_TILE = 64;         // trailing-update tile
 
 // ---- launchers (kernels.hip) ---------------------------------------------------------------
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx);
-// cls: 0: m<=32 (1 wave), 1: m<=64, 2: m<=96, 3: m<=128
-void launch_front_small(hipStream_t st, int cls, const DevSym &ds, const int32_t *list, int count,
+// LDS-front kernel (kernels_wave.hip): m <= mcap (96 or 128), k <= kmax (32 or 64)
+void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
                         double *Lx, const double *Uchild, double *Uout, int *status);
+// wave-per-front kernel (kernels_wave.hip): m <= mcap (32/48/64), k <= kmax (16/32)
+void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
+                       double *Lx, const double *Uchild, double *Uout, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,

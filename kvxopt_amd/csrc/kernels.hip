@@ -5,9 +5,8 @@
 // (reference call sites src/C/cholmod.c:362, :483, :677, :735).  Design (own, MI355X-first):
 //   * fronts (supernodes) of one elimination-tree level are independent -> one launch per
 //     level and size class, one workgroup per front;
-//   * a front of order m <= 128 lives entirely in LDS: panel load, extend-add of the
-//     children's update matrices, partial Cholesky, Schur complement, write-back -- every
-//     HBM byte of the front is touched once;
+//   * a front of order m <= 128 is factored on chip (kernels_wave.hip): registers + an LDS image,
+//     every HBM byte of the front touched once;
 //   * larger fronts run a blocked right-looking factorisation in HBM/L2 (kernels_big.hip)
 //     whose panel solve and trailing update are FP64 MFMA (v_mfma_f64_16x16x4_f64);
 //   * extend-add is parent-pull (each workgroup owns target columns), so there are no
@@ -39,95 +38,6 @@ void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int
     int64_t blocks = (nnz + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_scatter_a, dim3((unsigned)blocks), dim3(256), 0, st, Ax, amap, nnz, Lx);
-}
-
-// ------------------------------------------------------------------------------------------
-// Small fronts: the whole m x m front in LDS (column-major, ld = m).
-template <int NT>
-__global__ __launch_bounds__(NT) void k_front_small(DevSym ds, const int32_t *__restrict__ list,
-                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
-                                                    double *__restrict__ Uo, int *status)
-{
-    extern __shared__ double F[];
-    const int s = list[blockIdx.x];
-    const int k = ds.k[s], m = ds.m[s], u = m - k, tid = threadIdx.x;
-    double *P = Lx + ds.px[s];
-    const int mk = m * k, mm = m * m;
-    for (int i = tid; i < mk; i += NT) F[i] = P[i];
-    for (int i = mk + tid; i < mm; i += NT) F[i] = 0.0;
-    __syncthreads();
-    // extend-add of the children's update matrices (children one after another: deterministic)
-    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
-        const int ch = ds.children[c];
-        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
-        if (uc == 0) continue;
-        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
-        const double *U = Uc + ds.ux[ch];
-        if (NT == 64) {
-            for (int j = 0; j < uc; j++) {
-                const int tj = rl[j] * m;
-                for (int i = j + tid; i < uc; i += 64) F[rl[i] + tj] += U[i + (int64_t)j * uc];
-            }
-        } else {
-            const int wv = tid >> 6, ln = tid & 63;
-            for (int j = wv; j < uc; j += NT / 64) {
-                const int tj = rl[j] * m;
-                for (int i = j + ln; i < uc; i += 64) F[rl[i] + tj] += U[i + (int64_t)j * uc];
-            }
-        }
-        __syncthreads();
-    }
-    // right-looking Cholesky of the k pivot columns (updates confined to the panel columns)
-    for (int j = 0; j < k; j++) {
-        double d = F[j + j * m];
-        if (!(d > 0.0)) {
-            if (tid == 0) atomicMin(status, ds.first[s] + j);
-            d = 1.0;
-        }
-        double ljj, inv;
-        kvx_sqrt_rsqrt(d, ljj, inv);
-        __syncthreads();
-        for (int i = j + 1 + tid; i < m; i += NT) F[i + j * m] *= inv;
-        if (tid == 0) F[j + j * m] = ljj;
-        __syncthreads();
-        const int nc = k - j - 1;      // remaining panel columns
-        const int nr = m - j - 1;
-        for (int idx = tid; idx < nc * nr; idx += NT) {
-            const int c = j + 1 + idx / nr, i = j + 1 + idx % nr;
-            if (i >= c) F[i + c * m] -= F[i + j * m] * F[c + j * m];
-        }
-        __syncthreads();
-    }
-    // Schur complement of the update rows straight to HBM: U = F22 - L21 L21'
-    if (u > 0) {
-        double *Uout = Uo + ds.ux[s];
-        for (int idx = tid; idx < u * u; idx += NT) {
-            const int l = idx / u, i = idx - l * u;
-            if (i >= l) {
-                double acc = F[(k + i) + (k + l) * m];
-                for (int jj = 0; jj < k; jj++) acc -= F[(k + i) + jj * m] * F[(k + l) + jj * m];
-                Uout[idx] = acc;
-            }
-        }
-    }
-    for (int i = tid; i < mk; i += NT) P[i] = F[i];
-}
-
-void launch_front_small(hipStream_t st, int cls, const DevSym &ds, const int32_t *list, int count,
-                        double *Lx, const double *Uchild, double *Uout, int *status)
-{
-    if (count <= 0) return;
-    static const int cap[4] = {32, 64, 96, 128};
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 128 * 8);
-        attr_set = true;
-    }
-    size_t lds = (size_t)cap[cls] * cap[cls] * sizeof(double);
-    if (cls == 0)
-        hipLaunchKernelGGL(k_front_small<64>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status);
-    else
-        hipLaunchKernelGGL(k_front_small<256>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -306,8 +216,8 @@ void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int
         attr_set = true;
     }
     dim3 grid((unsigned)count, (unsigned)nrhs);
-    if (max_m <= 32)
-        hipLaunchKernelGGL(k_fwd_level<64>, grid, dim3(64), solve_lds(32), st, ds, list, Lx, X, ldx, Wchild, Wout, wstride, 32);
+    if (max_m <= 64)
+        hipLaunchKernelGGL(k_fwd_level<64>, grid, dim3(64), solve_lds(64), st, ds, list, Lx, X, ldx, Wchild, Wout, wstride, 64);
     else
         hipLaunchKernelGGL(k_fwd_level<256>, grid, dim3(256), solve_lds(max_m), st, ds, list, Lx, X, ldx, Wchild, Wout, wstride, max_m);
 }
@@ -323,8 +233,8 @@ void launch_bwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int
         attr_set = true;
     }
     dim3 grid((unsigned)count, (unsigned)nrhs);
-    if (max_m <= 32)
-        hipLaunchKernelGGL(k_bwd_level<64>, grid, dim3(64), solve_lds(32), st, ds, list, Lx, X, ldx, 32);
+    if (max_m <= 64)
+        hipLaunchKernelGGL(k_bwd_level<64>, grid, dim3(64), solve_lds(64), st, ds, list, Lx, X, ldx, 64);
     else
         hipLaunchKernelGGL(k_bwd_level<256>, grid, dim3(256), solve_lds(max_m), st, ds, list, Lx, X, ldx, max_m);
 }

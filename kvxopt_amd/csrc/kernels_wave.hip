@@ -1,0 +1,279 @@
+// Small fronts (order m <= 128): the bulk of nnz(L) on mesh problems lives here.
+//
+//   k_front_wave<KMAX> : m <= 64, k <= 32.  One 64-lane wavefront owns one front, no workgroup
+//                        barrier anywhere.
+//   k_front_lds<KMAX>  : m <= 128, k <= 64.  One 256-thread workgroup per front, two barriers.
+//
+// Shared design:
+//   * lane r holds ROW r of the panel in registers a[0..KMAX) -- column j of L is then one
+//     register across the wave, its diagonal is a v_readlane away, and the right-looking update
+//     a[c] -= a[j] * L[c][j] needs only a readlane of lane c: no LDS round trip and no barrier per
+//     column (rows 64.. of an LDS front are solved by substitution against L11 broadcast from LDS);
+//   * the children's update matrices are extend-added into an LDS image of the front with all
+//     HBM loads of a batch in flight at once (these kernels are latency-bound on small levels);
+//   * the Schur complement U = F22 - L21 L21' is FP64 MFMA (v_mfma_f64_16x16x4_f64) from the LDS
+//     image, streamed to HBM; the panel is read and written exactly once, coalesced.
+// HBM-bound by design: algorithmic bytes = 16 m k + 8 u(u+1)/2 + the children's triangles.
+//
+// Reference role: cholmod_l_factorize (src/C/cholmod.c:362) for these supernodes.
+#include "device.hpp"
+
+#include <utility>
+
+namespace kvx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wv_readlane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// column step J of the register-resident panel factorisation (lane r = row r, r < 64)
+template <int KMAX, int J>
+__device__ __forceinline__ void wave_col_step(double (&a)[KMAX], int k, int r, int *status, int col0, double *invd)
+{
+    if (J < k) {                                   // wave-uniform
+        double d = wv_readlane(a[J], J);
+        if (!(d > 0.0)) {
+            if (r == 0) atomicMin(status, col0 + J);
+            d = 1.0;
+        }
+        double ljj, inv;
+        kvx_sqrt_rsqrt(d, ljj, inv);
+        if (invd != nullptr && r == 0) invd[J] = inv;
+        const double v = (r == J) ? ljj : (r > J ? a[J] * inv : 0.0);
+        a[J] = v;
+#pragma unroll
+        for (int c = J + 1; c < KMAX; c++) {
+            const double lc = wv_readlane(v, c);   // L[c][J]: lane c's entry of this column
+            a[c] = __builtin_fma(-v, lc, a[c]);
+        }
+    }
+}
+template <int KMAX, int... Js>
+__device__ __forceinline__ void wave_col_steps(double (&a)[KMAX], int k, int r, int *status, int col0, double *invd,
+                                               std::integer_sequence<int, Js...>)
+{
+    (wave_col_step<KMAX, Js>(a, k, r, status, col0, invd), ...);
+}
+
+// substitution step J for rows that hold no pivot (rows >= 64 of an LDS front): L11 comes from LDS
+template <int KMAX, int J>
+__device__ __forceinline__ void sub_col_step(double (&a)[KMAX], int k, const double *F, int m, const double *invd)
+{
+    if (J < k) {
+        const double v = a[J] * invd[J];
+        a[J] = v;
+        const double *col = F + J * m;
+#pragma unroll
+        for (int c = J + 1; c < KMAX; c++) {
+            const double lc = col[c < k ? c : J];  // broadcast read; columns >= k are padding
+            a[c] = __builtin_fma(-v, lc, a[c]);
+        }
+    }
+}
+template <int KMAX, int... Js>
+__device__ __forceinline__ void sub_col_steps(double (&a)[KMAX], int k, const double *F, int m, const double *invd,
+                                              std::integer_sequence<int, Js...>)
+{
+    (sub_col_step<KMAX, Js>(a, k, F, m, invd), ...);
+}
+
+// Extend-add of one child's update matrix (lower triangle, uc x uc, ld = uc) into the LDS image F.
+// Thread (i = tid % RP, ph = tid / RP) owns child row i and the columns j = ph (mod NP); the HBM
+// loads of a batch of B columns are issued before any LDS update so that B loads are in flight.
+template <int NT, int RP>
+__device__ __forceinline__ void extend_add_child(double *F, int m, const int *relsh, const double *U, int uc, int tid)
+{
+    constexpr int NP = NT / RP, B = 8;
+    const int i = tid % RP, ph = tid / RP;
+    const bool row_ok = i < uc;
+    const int myrow = row_ok ? relsh[i] : 0;
+    for (int jb = 0; jb < uc; jb += NP * B) {
+        double v[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int j = jb + ph + q * NP;
+            v[q] = (row_ok && j <= i) ? U[i + (int64_t)j * uc] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const int j = jb + ph + q * NP;
+            if (row_ok && j <= i) F[myrow + relsh[j] * m] += v[q];
+        }
+    }
+}
+
+// Schur complement tile (ti, tj) of U = F22 - X X', X = rows k.. of the panel in the LDS image
+__device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u, int ti, int tj, bool kids,
+                                           double *Uout, int lane)
+{
+    const int lr = lane & 15, lk = lane >> 4;
+    const int rr = 16 * ti + lr, cc = 16 * tj + lr;
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int ks = 0; ks < k; ks += 4) {
+        const int kc = ks + lk;
+        const bool kin = kc < k;
+        const double av = (kin && cc < u) ? F[(k + cc) + kc * m] : 0.0;
+        const double bv = (kin && rr < u) ? F[(k + rr) + kc * m] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    // lane holds D[i = lk + 4q][j = lr]: i <-> tile column, j <-> tile row
+    if (rr < u) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = 16 * tj + lk + 4 * q;
+            if (c <= rr) {
+                const double base = kids ? F[(k + rr) + (k + c) * m] : 0.0;
+                Uout[rr + (int64_t)c * u] = base - acc[q];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__restrict__ list,
+                                                   double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                   double *__restrict__ Uo, int *status, int mcap)
+{
+    extern __shared__ double F[];                  // m x m image of the front (ld = m), then 64 ints
+    int *relsh = (int *)(F + mcap * mcap);
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, u = m - k, r = threadIdx.x;
+    double *P = Lx + fd.px;
+    const bool kids = fd.nchild > 0;
+    double a[KMAX];
+    if (kids) {
+        const int mk = m * k, mm = m * m;
+        for (int i = r; i < mk; i += 64) F[i] = P[i];
+        for (int i = mk + r; i < mm; i += 64) F[i] = 0.0;
+        for (int c = 0; c < fd.nchild; c++) {
+            const ChildDesc cd = ds.cd[fd.childptr + c];
+            if (cd.uc == 0) continue;
+            __syncthreads();                       // single-wave workgroup: orders the LDS traffic
+            if (r < cd.uc) relsh[r] = ds.rel[cd.rel + r];
+            __syncthreads();
+            extend_add_child<64, 64>(F, m, relsh, Uc + cd.ux, cd.uc, r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) a[j] = (j < k && r < m) ? F[r + j * m] : 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) a[j] = (j < k && r < m) ? P[r + (int64_t)j * m] : 0.0;
+    }
+    wave_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, std::make_integer_sequence<int, KMAX>());
+    if (r < m) {
+#pragma unroll
+        for (int j = 0; j < KMAX; j++)
+            if (j < k) {
+                P[r + (int64_t)j * m] = a[j];
+                F[r + j * m] = a[j];
+            }
+    }
+    if (u == 0) return;
+    __syncthreads();
+    double *Uout = Uo + fd.ux;
+    const int T = (u + 15) >> 4;
+    for (int ti = 0; ti < T; ti++)
+        for (int tj = 0; tj <= ti; tj++) schur_tile(F, m, k, u, ti, tj, kids, Uout, r);
+}
+
+// ------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__restrict__ list,
+                                                   double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                   double *__restrict__ Uo, int *status, int mcap)
+{
+    extern __shared__ double F[];                  // m x m image (ld = m), KMAX inverse pivots, 128 ints
+    double *invd = F + mcap * mcap;
+    int *relsh = (int *)(invd + KMAX);
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, u = m - k, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+    double *P = Lx + fd.px;
+    const bool kids = fd.nchild > 0;
+    const int mk = m * k, mm = m * m;
+    for (int i = tid; i < mk; i += 256) F[i] = P[i];
+    if (kids) {
+        for (int i = mk + tid; i < mm; i += 256) F[i] = 0.0;
+        for (int c = 0; c < fd.nchild; c++) {
+            const ChildDesc cd = ds.cd[fd.childptr + c];
+            if (cd.uc == 0) continue;
+            __syncthreads();
+            if (tid < cd.uc) relsh[tid] = ds.rel[cd.rel + tid];
+            __syncthreads();
+            extend_add_child<256, 128>(F, m, relsh, Uc + cd.ux, cd.uc, tid);
+        }
+    }
+    __syncthreads();
+    double a[KMAX];
+    const int row = tid;                           // waves 0,1 hold rows 0..127
+    if (wv < 2) {
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) a[j] = (j < k && row < m) ? F[row + j * m] : 0.0;
+    }
+    if (wv == 0) {
+        wave_col_steps<KMAX>(a, k, ln, status, fd.first, invd, std::make_integer_sequence<int, KMAX>());
+        if (row < m) {
+#pragma unroll
+            for (int j = 0; j < KMAX; j++)
+                if (j < k) { F[row + j * m] = a[j]; P[row + (int64_t)j * m] = a[j]; }
+        }
+    }
+    __syncthreads();
+    if (wv == 1 && m > 64) {
+        sub_col_steps<KMAX>(a, k, F, m, invd, std::make_integer_sequence<int, KMAX>());
+        if (row < m) {
+#pragma unroll
+            for (int j = 0; j < KMAX; j++)
+                if (j < k) { F[row + j * m] = a[j]; P[row + (int64_t)j * m] = a[j]; }
+        }
+    }
+    if (u == 0) return;
+    __syncthreads();
+    double *Uout = Uo + fd.ux;
+    const int T = (u + 15) >> 4;
+    int t = 0;
+    for (int ti = 0; ti < T; ti++)
+        for (int tj = 0; tj <= ti; tj++, t++)
+            if ((t & 3) == wv) schur_tile(F, m, k, u, ti, tj, kids, Uout, ln);
+}
+
+// wave kernel: mcap = LDS image capacity (32 / 48 / 64); kmax: 16 or 32
+void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
+                       double *Lx, const double *Uchild, double *Uout, int *status)
+{
+    if (count <= 0) return;
+    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 64 * sizeof(int);
+    if (kmax <= 16)
+        hipLaunchKernelGGL(k_front_wave<16>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+    else
+        hipLaunchKernelGGL(k_front_wave<32>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+}
+
+// LDS kernel: mcap = 96 or 128; kmax = 32 or 64 (k of every front in the list must be <= kmax)
+void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
+                        double *Lx, const double *Uchild, double *Uout, int *status)
+{
+    if (count <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_front_lds<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_front_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        attr_set = true;
+    }
+    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 64 * sizeof(double) + 128 * sizeof(int);
+    if (kmax <= 32)
+        hipLaunchKernelGGL(k_front_lds<32>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+    else
+        hipLaunchKernelGGL(k_front_lds<64>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+}
+
+}  // namespace kvx

@@ -428,11 +428,14 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         std::vector<int64_t> cur(S.levelptr.begin(), S.levelptr.end() - 1);
         for (int64_t s = 0; s < ns; s++) S.levellist[(size_t)cur[S.depth[s]]++] = (int32_t)s;
     }
-    // within a level: largest fronts first (big fronts get a contiguous head of the update
-    // buffer, long-running workgroups are dispatched first)
+    // within a level: grouped by kernel class (big fronts first: they get a contiguous head of
+    // the update buffer), largest fronts first inside a class (long workgroups dispatched first)
     for (int32_t l = 0; l < S.nlevels; l++)
         std::stable_sort(S.levellist.begin() + S.levelptr[l], S.levellist.begin() + S.levelptr[l + 1],
-                         [&](int32_t a, int32_t b) { return S.sn_m[a] > S.sn_m[b]; });
+                         [&](int32_t a, int32_t b) {
+                             const int ca = front_class(S.sn_m[a], S.sn_k[a]), cb = front_class(S.sn_m[b], S.sn_k[b]);
+                             return ca != cb ? ca < cb : S.sn_m[a] > S.sn_m[b];
+                         });
     S.ux.assign((size_t)ns, 0);
     S.wx.assign((size_t)ns, 0);
     S.upd_size[0] = S.upd_size[1] = 0;

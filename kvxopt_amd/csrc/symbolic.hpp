@@ -12,6 +12,21 @@
 
 namespace kvx {
 
+// Kernel class of a front (drives the order inside a level and the launch plan).
+//   0            : big     (m > 128 or k > 64) blocked HBM/L2 path, MFMA panel steps
+//   1, 2         : LDS     (m <= 128 / 96, k <= 64) one 256-thread workgroup per front
+//   3 .. 8       : wave    (m <= 64/48/32, k <= 32/16) one wavefront per front
+enum { KVX_CLS_BIG = 0, KVX_CLS_LDS128 = 1, KVX_CLS_LDS96 = 2, KVX_CLS_WAVE0 = 3, KVX_NCLS = 9 };
+inline int front_class(int m, int k)
+{
+    if (m > 128 || k > 64) return KVX_CLS_BIG;
+    if (m > 64 || k > 32) return m > 96 ? KVX_CLS_LDS128 : KVX_CLS_LDS96;
+    const int mc = m <= 32 ? 2 : (m <= 48 ? 1 : 0);
+    return KVX_CLS_WAVE0 + 2 * mc + (k <= 16 ? 1 : 0);
+}
+inline int wave_class_mcap(int cls) { static const int c[3] = {64, 48, 32}; return c[(cls - KVX_CLS_WAVE0) / 2]; }
+inline int wave_class_kmax(int cls) { return ((cls - KVX_CLS_WAVE0) & 1) ? 16 : 32; }
+
 struct SymOpts {
     int ordering = 0;        // 0 = built-in ND + minimum degree, 1 = natural
     int postorder = 1;
