@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <utility>
 
 namespace kvx {
 
@@ -18,7 +19,7 @@ struct DevSym {
     const int64_t *wx;        // solve update-vector offset in its parity buffer
     const int64_t *childptr;
     const int32_t *children;
-    const int64_t *linv;      // big fronts: offset of the inverted 64x64 diagonal blocks (-1 otherwise)
+    const int64_t *linv;      // big fronts: offset of the reciprocal pivots in Dinv (-1 otherwise)
     // Array-of-structures twins of the above: one 64-byte record per front and one 32-byte record
     // per (parent, child) edge, so that a workgroup reaches its operands after two dependent
     // loads instead of five (the per-front kernels are latency-bound on small levels).
@@ -37,6 +38,22 @@ struct ChildDesc {            // 32 bytes, indexed like DevSym::children
 };
 
 #ifdef __HIPCC__
+// Predicated load WITHOUT a branch: hipcc turns `c ? p[i] : 0.0` into an exec-masked branch with
+// an exposed s_waitcnt per load (64 such loads serialise into 64 L2 round trips, ~20 us); an
+// always-valid address plus a select keeps all loads of an unrolled batch in flight.
+__device__ __forceinline__ double kvx_ld0(const double *__restrict__ p, int64_t idx, bool ok)
+{
+    const double v = p[ok ? idx : 0];
+    return ok ? v : 0.0;
+}
+__device__ __forceinline__ double kvx_readlane(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // sqrt(d) and 1/sqrt(d) without the IEEE division / square-root expansions (each a long chain
 // of dependent FP64 ops): hardware v_rsq_f64 seed (~2^-26) + two Newton steps, then one
 // correction of the root.  Results are within 1-2 ulp; d must be > 0 and normal.
@@ -50,6 +67,41 @@ __device__ __forceinline__ void kvx_sqrt_rsqrt(double d, double &root, double &i
     x = __builtin_fma(0.5 * r, __builtin_fma(-x, x, d), x);
     root = x;
     inv = r;
+}
+
+// Column step J of a register-resident right-looking Cholesky sweep: lane r holds row r, the
+// columns live in a[0..KMAX).  The pivot travels by one v_readlane; the multipliers of column J
+// are broadcast through a 64-double LDS buffer (measured on MI355X: a readlane pair + fma costs
+// ~40 cycles per use, an LDS broadcast read + fma ~10), and the loads of the buffer overlap the
+// rsqrt chain because the UNSCALED column is published and scaled by 1/d on the consumer side.
+// cb2: LDS double[2][64] (double-buffered by J parity); dinv: optional output of 1/l_jj.
+template <int KMAX, int J>
+__device__ __forceinline__ void kvx_col_step(double (&a)[KMAX], int k, int r, int *status, int col0,
+                                             double *dinv, double *cb2)
+{
+    if (J < k) {                                   // wave-uniform
+        double *cb = cb2 + (J & 1) * 64;
+        const double aj = a[J];
+        cb[r] = aj;
+        double d = kvx_readlane(aj, J);
+        if (!(d > 0.0)) {
+            if (r == 0) atomicMin(status, col0 + J);
+            d = 1.0;
+        }
+        double ljj, inv;
+        kvx_sqrt_rsqrt(d, ljj, inv);
+        if (dinv != nullptr && r == 0) dinv[J] = inv;
+        const double w = (r > J) ? aj * (inv * inv) : 0.0;
+#pragma unroll
+        for (int c = J + 1; c < KMAX; c++) a[c] = __builtin_fma(-w, cb[c], a[c]);
+        a[J] = (r == J) ? ljj : (r > J ? aj * inv : 0.0);
+    }
+}
+template <int KMAX, int... Js>
+__device__ __forceinline__ void kvx_col_steps(double (&a)[KMAX], int k, int r, int *status, int col0, double *dinv,
+                                              double *cb2, std::integer_sequence<int, Js...>)
+{
+    (kvx_col_step<KMAX, Js>(a, k, r, status, col0, dinv, cb2), ...);
 }
 #endif
 

@@ -1,14 +1,16 @@
-// Big fronts (order m > KVX_SMALL_MAX): blocked right-looking factorisation in HBM/L2 with
+// Big fronts (order m > 128 or k > 64): blocked right-looking factorisation in HBM/L2 with
 // 64-column panel steps, and multi-workgroup triangular solves.
 //
 // Per panel step jb (three dependent launches, every big front of the level batched):
-//   k_potrf_blk   : Cholesky of the 64x64 diagonal block AND its inverse, register-resident
-//                   (512 threads: waves 0-3 factor, waves 4-7 carry the inverse), one barrier per
-//                   column;
+//   k_potrf_blk   : Cholesky of the 64x64 diagonal block AND its inverse.  512 threads: waves 0-3
+//                   factor, waves 4-7 build the inverse by the same column sweep; thread (row i,
+//                   column phase q) keeps 16 columns in registers; the pivot column and the pivot row
+//                   of the inverse are broadcast through LDS (measured: LDS broadcast + fma ~10-13
+//                   cycles, v_readlane pair + fma ~40); one barrier per column;
 //   k_trsm_blk    : X := A * Linv' for the rows below, FP64 MFMA (v_mfma_f64_16x16x4_f64);
 //   k_syrk_trailing: C -= X X' on 64x64 tiles, FP64 MFMA.
 // The inverses of the diagonal blocks stay resident: the solves use them as 64x64 mat-vecs, so a
-// big front's triangular solve has no 64-long dependent chain and can be spread over workgroups.
+// big front's triangular solve has no 64-long dependent chain and is spread over workgroups.
 //
 // Reference role: cholmod_l_factorize / cholmod_l_solve (src/C/cholmod.c:362, 483).
 #include "device.hpp"
@@ -21,119 +23,132 @@ namespace kvx {
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = KVX_NB;
 
-__device__ inline double readlane_d(double v, int lane)
-{
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Register-resident 64x64 Cholesky + inverse, one barrier per column.
-// Thread (i = tid & 63, q = (tid >> 6) & 3): the factor role (waves 0-3) holds D[i][q + 4(g + t)] in
-// a[t] while column group g (columns 4g .. 4g+3) is eliminated -- after each group the finished
-// column is stored and the register window shifts down, so the loop body is compiled once (a fully
-// unrolled 64-step sweep is 125 KB of code and runs at instruction-fetch speed).  The inverse role
-// (waves 4-7) builds Y = D^{-1} by forward substitution on the identity with the same column
-// sweep; it holds Y[i][q + 4(g - t)] in a[t] (window shifts up; columns "< 0" are zero).
-// Blocks shorter than 64 are padded with the identity.
+// ------------------------------------------------------------------------------------------
+// 64x64 diagonal block: Cholesky factor AND its inverse in one 512-thread workgroup.
+// Thread (row i = tid & 63, column phase q) keeps 16 columns in registers.  Factor role (waves
+// 0-3): a[t] = D[i][q + 4(g + t)], the window slides down as column groups finish.  Inverse role
+// (waves 4-7): a[t] = Y[i][q + 4(g - t)], Y = D^{-1} by forward substitution on the identity with
+// the same column sweep, run ONE STEP BEHIND the factor role so that it needs no rsqrt chain.
+// LDS: cbp[3][128] = unscaled pivot column k at [0..63], 1/l_kk at [64], zeros above (triple
+// buffered: the inverse role reads column k-1 while column k+1 is being published);
+// yrp[2][128] = row of Y at [64..127], zeros below (windows reaching "column < 0" read zeros).
+// Everything inside the 16-register loops is branch-free with immediate LDS offsets: these kernels
+// are bound by instruction issue of single waves (lab measurements in DESIGN.md).
 template <int JS>
-__device__ __forceinline__ void potrf_substep(double (&a)[16], double (*colbuf)[NB + 1], int g, int i, int q,
-                                              bool inv_role, int *status, int col0)
+__device__ __forceinline__ void potrf_fstep(double (&a)[16], double *cbp, int &kb, int g, int i, int q,
+                                            int *status, int col0)
 {
     const int j = 4 * g + JS;
-    double *cb = colbuf[JS & 1];
-    if (!inv_role && q == JS) {
-        double v = a[0];
-        double d = readlane_d(v, j);
-        if (!(d > 0.0)) {
-            if (i == 0) atomicMin(status, col0 + j);
-            d = 1.0;
-        }
-        double ljj, inv;
-        kvx_sqrt_rsqrt(d, ljj, inv);
-        v = (i == j) ? ljj : (i > j ? v * inv : 0.0);
-        a[0] = v;
-        cb[i] = v;
-        if (i == 0) cb[NB] = inv;
+    double *cb = cbp + kb * 128;
+    kb = (kb == 2) ? 0 : kb + 1;
+    if (q == JS) cb[i] = a[0];
+    __syncthreads();
+    double d = cb[j];
+    if (!(d > 0.0)) {
+        if (q == JS && i == 0) atomicMin(status, col0 + j);
+        d = 1.0;
+    }
+    double ljj, inv;
+    kvx_sqrt_rsqrt(d, ljj, inv);
+    if (q == JS && i == 0) cb[64] = inv;
+    const double ci = cb[i];
+    const double w = (i > j) ? ci * (inv * inv) : 0.0;
+    const double *src = cb + q + 4 * g;
+    double lc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) lc[t] = src[4 * t];
+    const double w0 = (q > JS) ? w : 0.0;              // window 0: only columns right of the pivot
+    a[0] = __builtin_fma(-w0, lc[0], a[0]);
+#pragma unroll
+    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, lc[t], a[t]);
+    if (q == JS) a[0] = (i == j) ? ljj : (i > j ? ci * inv : 0.0);
+}
+
+// inverse role, column j = 4g + JS: publish row j of Y, barrier, update with column j of L
+template <int JS>
+__device__ __forceinline__ void potrf_istep(double (&a)[16], double &myinv, double *cbp, double *yrp, int &kb,
+                                            int g, int i, int q)
+{
+    const int j = 4 * g + JS;
+    double *yr = yrp + (j & 1) * 128 + 64 + q + 4 * g;
+    if (i == j) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) yr[-4 * t] = a[t];
     }
     __syncthreads();
-    const double li = cb[i];      // column j of L: 0 above the diagonal, l_jj on it
-    // Updates are branch-free per register and skip dead windows with SCALAR branches only (g, q, JS
-    // are wave-uniform).  Entries above the diagonal (c > i) and windows past column 63 carry
-    // don't-care values that are never stored, so they need no per-lane predicate.
-    if (!inv_role) {
-        const int nlive = 16 - g;                          // windows t < nlive map to columns < 64
+    const double *cb = cbp + kb * 128;
+    kb = (kb == 2) ? 0 : kb + 1;
+    const double inv = cb[64];
+    const double ci = cb[i];
+    const double w = (i > j) ? ci * (inv * inv) : 0.0;
+    myinv = (i == j) ? inv : myinv;                    // row i of Y is scaled by 1/l_ii once, at the end
+    double yv[16];
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            if (t < nlive) {
-                const double lc = cb[q + 4 * (g + t)];
-                if (t > 0 || q > JS) a[t] = __builtin_fma(-li, lc, a[t]);
-            }
-        }
-    } else {
-        const double invd = cb[NB];
-        const bool piv = (i == j);
-        const double lo = piv ? 0.0 : li;                  // rows above j have li == 0 already
+    for (int t = 0; t < 16; t++) yv[t] = yr[-4 * t];
+    const double w0 = (q <= JS) ? w : 0.0;
+    a[0] = __builtin_fma(-w0, yv[0], a[0]);
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            if (t <= g && (t > 0 || q <= JS)) {            // columns c = q + 4(g - t) in [0, j]
-                const double yj = readlane_d(a[t], j) * invd;
-                const double v = __builtin_fma(-lo, yj, a[t]);
-                a[t] = piv ? yj : v;
-            }
-        }
-    }
+    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, yv[t], a[t]);
 }
 
 __global__ __launch_bounds__(512) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                    double *__restrict__ Lx, double *__restrict__ Linv, int *status)
 {
-    __shared__ double colbuf[2][NB + 1];       // column j of L, plus 1/l_jj in slot NB
-    const int s = list[blockIdx.x];
-    const int k = ds.k[s], m = ds.m[s];
+    __shared__ double cbp[3 * 128];
+    __shared__ double yrp[2 * 128];
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m;
     if (jb >= k) return;
     const int nbk = min(NB, k - jb);
     const int tid = threadIdx.x, i = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);       // wave-uniform: keep it scalar
+    const int q = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     const bool inv_role = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
-    double *P = Lx + ds.px[s];
-    double *Yg = Linv + ds.linv[s] + (int64_t)(jb / NB) * NB * NB;
-    const int col0 = ds.first[s] + jb;
+    double *P = Lx + fd.px;
+    double *Yg = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
+    const int col0 = fd.first + jb;
     double a[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) {
         const int c = q + 4 * t;
-        if (inv_role) a[t] = 0.0;
-        else if (i < nbk && c <= i) a[t] = P[(jb + i) + (int64_t)(jb + c) * m];
-        else a[t] = (c == i) ? 1.0 : 0.0;
+        const double v = kvx_ld0(P, (jb + i) + (int64_t)(jb + c) * m, !inv_role && i < nbk && c <= i);
+        a[t] = inv_role ? 0.0 : ((i < nbk && c <= i) ? v : (c == i ? 1.0 : 0.0));   // identity padding
     }
-    const int ngrp = (nbk + 3) >> 2;                       // identity padding beyond nbk needs no sweep
-    for (int g = 0; g < ngrp; g++) {
-        if (inv_role) {
-            // open the window on column group g: Y starts as the identity
-#pragma unroll
-            for (int t = 15; t > 0; t--) a[t] = a[t - 1];
-            a[0] = (q + 4 * g == i) ? 1.0 : 0.0;
-        }
-        potrf_substep<0>(a, colbuf, g, i, q, inv_role, status, col0);
-        potrf_substep<1>(a, colbuf, g, i, q, inv_role, status, col0);
-        potrf_substep<2>(a, colbuf, g, i, q, inv_role, status, col0);
-        potrf_substep<3>(a, colbuf, g, i, q, inv_role, status, col0);
-        if (!inv_role) {
+    if (tid < 384) cbp[tid] = 0.0;
+    if (tid < 256) yrp[tid] = 0.0;
+    __syncthreads();
+    const int ngrp = (nbk + 3) >> 2;                       // the padding beyond nbk needs no sweep
+    int kb = 0;
+    if (!inv_role) {
+        for (int g = 0; g < ngrp; g++) {
+            potrf_fstep<0>(a, cbp, kb, g, i, q, status, col0);
+            potrf_fstep<1>(a, cbp, kb, g, i, q, status, col0);
+            potrf_fstep<2>(a, cbp, kb, g, i, q, status, col0);
+            potrf_fstep<3>(a, cbp, kb, g, i, q, status, col0);
             const int c = q + 4 * g;                       // this thread's finished column
             if (i < nbk && c <= i) P[(jb + i) + (int64_t)(jb + c) * m] = a[0];
 #pragma unroll
             for (int t = 0; t < 15; t++) a[t] = a[t + 1];
             a[15] = 0.0;
         }
-    }
-    if (inv_role && i < nbk) {
+        __syncthreads();                                   // lets the inverse role finish the last column
+    } else {
+        double myinv = 1.0;
+        __syncthreads();                                   // pairs with the factor role's first barrier
+        for (int g = 0; g < ngrp; g++) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int c = q + 4 * (ngrp - 1 - t);
-            if (c >= 0 && c <= i) Yg[i + c * NB] = a[t];
+            for (int t = 15; t > 0; t--) a[t] = a[t - 1];
+            a[0] = (q + 4 * g == i) ? 1.0 : 0.0;           // open the window on column group g: Y starts as I
+            potrf_istep<0>(a, myinv, cbp, yrp, kb, g, i, q);
+            potrf_istep<1>(a, myinv, cbp, yrp, kb, g, i, q);
+            potrf_istep<2>(a, myinv, cbp, yrp, kb, g, i, q);
+            potrf_istep<3>(a, myinv, cbp, yrp, kb, g, i, q);
+        }
+        if (i < nbk) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int c = q + 4 * (ngrp - 1 - t);
+                if (c >= 0 && c <= i) Yg[i + c * NB] = a[t] * myinv;
+            }
         }
     }
 }
@@ -147,36 +162,49 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
 
 // ------------------------------------------------------------------------------------------
 // X := A * Linv' for a 64-row block below the diagonal block.  Output roles swapped as in the
-// trailing update (D[i][j]: i <-> panel column, j <-> row) so that stores run along rows.
+// trailing update (D[i][j]: i <-> panel column, j <-> row) so that stores run along rows.  All
+// operand loads of the 16 k-steps are branch-free; Linv is lower triangular, so k-groups above a
+// column tile are skipped.
 __global__ __launch_bounds__(256) void k_trsm_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                   double *__restrict__ Lx, const double *__restrict__ Linv)
 {
-    const int s = list[blockIdx.y];
-    const int k = ds.k[s], m = ds.m[s];
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const int k = fd.k, m = fd.m;
     if (jb >= k) return;
     const int nbk = min(NB, k - jb);
     const int r0 = jb + nbk + blockIdx.x * 64;
     if (r0 >= m) return;
-    double *P = Lx + ds.px[s];
-    const double *Y = Linv + ds.linv[s] + (int64_t)(jb / NB) * NB * NB;
+    double *P = Lx + fd.px;
+    const double *Y = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
     const int rr = r0 + 16 * w + lr;
+    const bool rin = rr < m;
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int ks = 0; ks < nbk; ks += 4) {
-        const int kc = ks + lk;
-        const bool kin = kc < nbk;
-        const double b = (kin && rr < m) ? P[rr + (int64_t)(jb + kc) * m] : 0.0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (16 * t + 15 < ks) continue;            // Linv is lower triangular: Y[c][p] = 0 for p > c
-            const int cc = 16 * t + lr;
-            const double a = (kin && cc < nbk && kc <= cc) ? Y[cc + kc * NB] : 0.0;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    for (int kg = 0; kg < NB; kg += 16) {
+        if (kg < nbk) {                             // wave-uniform
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int kc = kg + 4 * qq + lk;
+                const bool kin = kc < nbk;
+                bq[qq] = kvx_ld0(P, rr + (int64_t)(jb + kc) * m, kin && rin);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int cc = 16 * t + lr;
+                    aq[qq][t] = (16 * t + 15 >= kg) ? kvx_ld0(Y, cc + kc * NB, kin && cc < nbk && kc <= cc) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (16 * t + 15 >= kg) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[qq][t], bq[qq], acc[t], 0, 0, 0);
         }
     }
-    if (rr < m) {
+    if (rin) {
 #pragma unroll
         for (int t = 0; t < 4; t++)
 #pragma unroll
@@ -203,8 +231,8 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo)
 {
-    const int s = list[blockIdx.z];
-    const int k = ds.k[s], m = ds.m[s], u = m - k;
+    const FrontDesc fd = ds.fd[list[blockIdx.z]];
+    const int k = fd.k, m = fd.m, u = m - k;
     if (jb >= k) return;
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (tj > ti) return;
@@ -212,38 +240,58 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     const int t0 = jb + nbk;
     const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
     if (r0 >= m) return;
-    double *P = Lx + ds.px[s];
-    double *U = Uo + ds.ux[s];
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     const int rr = r0 + 16 * w + lr;
-    for (int ks = 0; ks < nbk; ks += 4) {
-        const int kc = ks + lk;
-        const bool kin = kc < nbk;
-        const int64_t coff = (int64_t)(jb + kc) * m;
-        const double b = (kin && rr < m) ? P[rr + coff] : 0.0;
+    const bool rin = rr < m;
+    bool cin[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int cc = c0 + 16 * t + lr;
-            const double a = (kin && cc < m) ? P[cc + coff] : 0.0;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; t++) cin[t] = (c0 + 16 * t + lr) < m;
+    // Operand loads of 4 k-steps (20 loads per lane, branch-free) are issued before their 16 MFMAs.
+#pragma unroll
+    for (int kg = 0; kg < NB; kg += 16) {
+        if (kg < nbk) {                             // wave-uniform
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int kc = kg + 4 * q + lk;
+                const bool kin = kc < nbk;
+                const int64_t coff = (int64_t)(jb + kc) * m;
+                bq[q] = kvx_ld0(P, rr + coff, kin && rin);
+#pragma unroll
+                for (int t = 0; t < 4; t++) aq[q][t] = kvx_ld0(P, (c0 + 16 * t + lr) + coff, kin && cin[t]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
         }
     }
-    // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row
-    if (rr < m) {
+    // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row.
+    // Branch-free read-modify-write: all 16 loads go out (clamped addresses), then 16 predicated stores.
+    const int rs = min(rr, m - 1);
+    double *ptr[4][4];
+    double old[4][4];
+    bool ok[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+    for (int t = 0; t < 4; t++)
 #pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const int c = c0 + 16 * t + lk + 4 * qq;
-                if (c <= rr) {
-                    if (c < k) P[rr + (int64_t)c * m] -= acc[t][qq];
-                    else U[(rr - k) + (int64_t)(c - k) * u] -= acc[t][qq];
-                }
-            }
-    }
+        for (int q = 0; q < 4; q++) {
+            const int c = c0 + 16 * t + lk + 4 * q;
+            ok[t][q] = rin && c <= rr;
+            const int cs = min(c, rs);
+            ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
+            old[t][q] = *ptr[t][q];
+        }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
 }
 
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,

@@ -6,9 +6,9 @@
 //
 // Shared design:
 //   * lane r holds ROW r of the panel in registers a[0..KMAX) -- column j of L is then one
-//     register across the wave, its diagonal is a v_readlane away, and the right-looking update
-//     a[c] -= a[j] * L[c][j] needs only a readlane of lane c: no LDS round trip and no barrier per
-//     column (rows 64.. of an LDS front are solved by substitution against L11 broadcast from LDS);
+//     register across the wave; its pivot travels by v_readlane and its multipliers by an LDS
+//     broadcast (kvx_col_step, device.hpp): no barrier per column (rows 64.. of an LDS front are
+//     solved by substitution against L11 broadcast from LDS);
 //   * the children's update matrices are extend-added into an LDS image of the front with all
 //     HBM loads of a batch in flight at once (these kernels are latency-bound on small levels);
 //   * the Schur complement U = F22 - L21 L21' is FP64 MFMA (v_mfma_f64_16x16x4_f64) from the LDS
@@ -23,44 +23,6 @@
 namespace kvx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ double wv_readlane(double v, int lane)
-{
-    const long long b = __double_as_longlong(v);
-    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// column step J of the register-resident panel factorisation (lane r = row r, r < 64)
-template <int KMAX, int J>
-__device__ __forceinline__ void wave_col_step(double (&a)[KMAX], int k, int r, int *status, int col0, double *invd)
-{
-    if (J < k) {                                   // wave-uniform
-        double d = wv_readlane(a[J], J);
-        if (!(d > 0.0)) {
-            if (r == 0) atomicMin(status, col0 + J);
-            d = 1.0;
-        }
-        double ljj, inv;
-        kvx_sqrt_rsqrt(d, ljj, inv);
-        if (invd != nullptr && r == 0) invd[J] = inv;
-        const double v = (r == J) ? ljj : (r > J ? a[J] * inv : 0.0);
-        a[J] = v;
-#pragma unroll
-        for (int c = J + 1; c < KMAX; c++) {
-            const double lc = wv_readlane(v, c);   // L[c][J]: lane c's entry of this column
-            a[c] = __builtin_fma(-v, lc, a[c]);
-        }
-    }
-}
-template <int KMAX, int... Js>
-__device__ __forceinline__ void wave_col_steps(double (&a)[KMAX], int k, int r, int *status, int col0, double *invd,
-                                               std::integer_sequence<int, Js...>)
-{
-    (wave_col_step<KMAX, Js>(a, k, r, status, col0, invd), ...);
-}
 
 // substitution step J for rows that hold no pivot (rows >= 64 of an LDS front): L11 comes from LDS
 template <int KMAX, int J>
@@ -99,7 +61,7 @@ __device__ __forceinline__ void extend_add_child(double *F, int m, const int *re
 #pragma unroll
         for (int q = 0; q < B; q++) {
             const int j = jb + ph + q * NP;
-            v[q] = (row_ok && j <= i) ? U[i + (int64_t)j * uc] : 0.0;
+            v[q] = kvx_ld0(U, i + (int64_t)j * uc, row_ok && j <= i);
         }
 #pragma unroll
         for (int q = 0; q < B; q++) {
@@ -119,8 +81,8 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
     for (int ks = 0; ks < k; ks += 4) {
         const int kc = ks + lk;
         const bool kin = kc < k;
-        const double av = (kin && cc < u) ? F[(k + cc) + kc * m] : 0.0;
-        const double bv = (kin && rr < u) ? F[(k + rr) + kc * m] : 0.0;
+        const double av = kvx_ld0(F, (k + cc) + kc * m, kin && cc < u);
+        const double bv = kvx_ld0(F, (k + rr) + kc * m, kin && rr < u);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
     // lane holds D[i = lk + 4q][j = lr]: i <-> tile column, j <-> tile row
@@ -129,7 +91,7 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
         for (int q = 0; q < 4; q++) {
             const int c = 16 * tj + lk + 4 * q;
             if (c <= rr) {
-                const double base = kids ? F[(k + rr) + (k + c) * m] : 0.0;
+                const double base = kvx_ld0(F, (k + rr) + (k + c) * m, kids);
                 Uout[rr + (int64_t)c * u] = base - acc[q];
             }
         }
@@ -142,8 +104,9 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
-    extern __shared__ double F[];                  // m x m image of the front (ld = m), then 64 ints
-    int *relsh = (int *)(F + mcap * mcap);
+    extern __shared__ double F[];                  // m x m image of the front (ld = m), 2x64 column buffer, 64 ints
+    double *cb2 = F + mcap * mcap;
+    int *relsh = (int *)(cb2 + 128);
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m, u = m - k, r = threadIdx.x;
     double *P = Lx + fd.px;
@@ -163,12 +126,12 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = (j < k && r < m) ? F[r + j * m] : 0.0;
+        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(F, r + j * m, j < k && r < m);
     } else {
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = (j < k && r < m) ? P[r + (int64_t)j * m] : 0.0;
+        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
     }
-    wave_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, std::make_integer_sequence<int, KMAX>());
+    kvx_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, cb2, std::make_integer_sequence<int, KMAX>());
     if (r < m) {
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
@@ -191,9 +154,10 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
-    extern __shared__ double F[];                  // m x m image (ld = m), KMAX inverse pivots, 128 ints
+    extern __shared__ double F[];                  // m x m image (ld = m), 64 inverse pivots, 2x64 column buffer, 128 ints
     double *invd = F + mcap * mcap;
-    int *relsh = (int *)(invd + KMAX);
+    double *cb2 = invd + 64;
+    int *relsh = (int *)(cb2 + 128);
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m, u = m - k, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
@@ -217,10 +181,10 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
     const int row = tid;                           // waves 0,1 hold rows 0..127
     if (wv < 2) {
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = (j < k && row < m) ? F[row + j * m] : 0.0;
+        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(F, row + j * m, j < k && row < m);
     }
     if (wv == 0) {
-        wave_col_steps<KMAX>(a, k, ln, status, fd.first, invd, std::make_integer_sequence<int, KMAX>());
+        kvx_col_steps<KMAX>(a, k, ln, status, fd.first, invd, cb2, std::make_integer_sequence<int, KMAX>());
         if (row < m) {
 #pragma unroll
             for (int j = 0; j < KMAX; j++)
@@ -251,7 +215,7 @@ void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, con
                        double *Lx, const double *Uchild, double *Uout, int *status)
 {
     if (count <= 0) return;
-    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 64 * sizeof(int);
+    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 128 * sizeof(double) + 64 * sizeof(int);
     if (kmax <= 16)
         hipLaunchKernelGGL(k_front_wave<16>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     else
@@ -269,7 +233,7 @@ void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, co
         (void)hipFuncSetAttribute((const void *)k_front_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_set = true;
     }
-    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 64 * sizeof(double) + 128 * sizeof(int);
+    const size_t lds = (size_t)mcap * mcap * sizeof(double) + (64 + 128) * sizeof(double) + 128 * sizeof(int);
     if (kmax <= 32)
         hipLaunchKernelGGL(k_front_lds<32>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     else

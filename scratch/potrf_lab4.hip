@@ -1,0 +1,133 @@
+// lab 2: instruction-lean 8-wave potrf+inverse sweep (padded LDS buffers, immediate offsets)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
+constexpr int NB = 64;
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &inv){ double r=__builtin_amdgcn_rsq(d); const double hd=0.5*d; r=r*__builtin_fma(-hd*r,r,1.5); r=r*__builtin_fma(-hd*r,r,1.5); double x=d*r; x=__builtin_fma(0.5*r,__builtin_fma(-x,x,d),x); root=x; inv=r; }
+
+// LDS: cbp[3][128]: unscaled pivot column k at [0..63], 1/l_kk at [64], zeros above (triple-buffered: the
+// inverse role reads column k-1 while the factor role already publishes column k+1);
+// yrp[2][128]: row of Y at [64..127], zeros below (windows that reach "column < 0" read zeros).
+// Barrier B_k: the factor role has published column k; the inverse role has published row k-1 of Y and
+// then runs step k-1 (one step behind, so it needs no rsqrt chain: 1/l is read from LDS).
+template <int JS>
+__device__ __forceinline__ void fstep(double (&a)[16], double *cbp, int &kb, int g, int i, int q, int *status)
+{
+    const int j = 4 * g + JS;
+    double *cb = cbp + kb * 128;
+    kb = (kb == 2) ? 0 : kb + 1;
+    if (q == JS) cb[i] = a[0];
+    __syncthreads();
+    double d = cb[j];
+    if (!(d > 0.0)) { if (q == JS && i == 0) atomicMin(status, j); d = 1.0; }
+    double ljj, inv;
+    sqrt_rsqrt(d, ljj, inv);
+    if (q == JS && i == 0) cb[64] = inv;
+    const double ci = cb[i];
+    const double w = (i > j) ? ci * (inv * inv) : 0.0;
+    const double *src = cb + q + 4 * g;
+    double lc[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) lc[t] = src[4 * t];
+    const double w0 = (q > JS) ? w : 0.0;
+    a[0] = __builtin_fma(-w0, lc[0], a[0]);
+#pragma unroll
+    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, lc[t], a[t]);
+    if (q == JS) a[0] = (i == j) ? ljj : (i > j ? ci * inv : 0.0);
+}
+
+// inverse role, column j = 4g + JS: publish row j of Y, barrier B_{j+1}, update with column j
+template <int JS>
+__device__ __forceinline__ void istep(double (&a)[16], double &myinv, double *cbp, double *yrp, int &kb, int g, int i, int q)
+{
+    const int j = 4 * g + JS;
+    double *yr = yrp + (j & 1) * 128 + 64 + q + 4 * g;
+    if (i == j) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) yr[-4 * t] = a[t];
+    }
+    __syncthreads();
+    const double *cb = cbp + kb * 128;
+    kb = (kb == 2) ? 0 : kb + 1;
+    const double inv = cb[64];
+    const double ci = cb[i];
+    const double w = (i > j) ? ci * (inv * inv) : 0.0;
+    myinv = (i == j) ? inv : myinv;
+    double yv[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) yv[t] = yr[-4 * t];
+    const double w0 = (q <= JS) ? w : 0.0;
+    a[0] = __builtin_fma(-w0, yv[0], a[0]);
+#pragma unroll
+    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, yv[t], a[t]);
+}
+
+__global__ __launch_bounds__(512) void k_potrf(double *P, double *Yg, int m, unsigned long long *cyc, int *status)
+{
+    __shared__ double cbp[3 * 128];
+    __shared__ double yrp[2 * 128];
+    const int tid = threadIdx.x, i = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    const bool inv_role = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    double a[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) { const int c = q + 4 * t; const double v = P[i + (c <= i ? c : 0) * m]; a[t] = inv_role ? 0.0 : (c <= i ? v : 0.0); }
+    if (tid < 384) cbp[tid] = 0.0;
+    if (tid < 256) yrp[tid] = 0.0;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const int ngrp = 16;
+    int kb = 0;
+    if (!inv_role) {
+        for (int g = 0; g < ngrp; g++) {
+            fstep<0>(a, cbp, kb, g, i, q, status);
+            fstep<1>(a, cbp, kb, g, i, q, status);
+            fstep<2>(a, cbp, kb, g, i, q, status);
+            fstep<3>(a, cbp, kb, g, i, q, status);
+            const int c = q + 4 * g;
+            if (c <= i) P[i + c * m] = a[0];
+#pragma unroll
+            for (int t = 0; t < 15; t++) a[t] = a[t + 1];
+            a[15] = 0.0;
+        }
+        __syncthreads();                       // B_64: lets the inverse role finish column 63
+    } else {
+        double myinv = 1.0;
+        __syncthreads();                       // B_0
+        for (int g = 0; g < ngrp; g++) {
+#pragma unroll
+            for (int t = 15; t > 0; t--) a[t] = a[t - 1];
+            a[0] = (q + 4 * g == i) ? 1.0 : 0.0;
+            istep<0>(a, myinv, cbp, yrp, kb, g, i, q);
+            istep<1>(a, myinv, cbp, yrp, kb, g, i, q);
+            istep<2>(a, myinv, cbp, yrp, kb, g, i, q);
+            istep<3>(a, myinv, cbp, yrp, kb, g, i, q);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) { const int c = q + 4 * (15 - t); if (c >= 0 && c <= i) Yg[i + c * NB] = a[t] * myinv; }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) cyc[0] = t1 - t0;
+}
+
+int main(){
+  const int m = 64; std::vector<double> A(m*m), L(m*m,0.0);
+  for (int j=0;j<m;j++) for (int i=0;i<m;i++) A[i+j*m] = (i==j) ? 70.0+i : 1.0/(1+abs(i-j));
+  // host cholesky
+  L = A; for (int j=0;j<m;j++){ double d=L[j+j*m]; for(int p=0;p<j;p++) d-=L[j+p*m]*L[j+p*m]; d=sqrt(d); L[j+j*m]=d; for(int i=j+1;i<m;i++){ double s=L[i+j*m]; for(int p=0;p<j;p++) s-=L[i+p*m]*L[j+p*m]; L[i+j*m]=s/d; } }
+  double *dP, *dY; unsigned long long *dc; int *ds; hipMalloc(&dP, m*m*8); hipMalloc(&dY, 64*64*8); hipMalloc(&dc, 8); hipMalloc(&ds,4);
+  hipMemset(dY,0,64*64*8);
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best=1e9; unsigned long long cy=0;
+  for (int rep=0; rep<5; rep++){ hipMemcpy(dP, A.data(), m*m*8, hipMemcpyHostToDevice); hipEventRecord(e0); hipLaunchKernelGGL(k_potrf, 1, 512, 0, 0, dP, dY, m, dc, ds); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms,e0,e1); if (ms<best) best=ms; hipMemcpy(&cy, dc, 8, hipMemcpyDeviceToHost);} 
+  std::vector<double> R(m*m), Y(m*m); hipMemcpy(R.data(), dP, m*m*8, hipMemcpyDeviceToHost); hipMemcpy(Y.data(), dY, m*m*8, hipMemcpyDeviceToHost);
+  double el=0, ey=0;
+  for (int j=0;j<m;j++) for (int i=j;i<m;i++) el=fmax(el,fabs(R[i+j*m]-L[i+j*m]));
+  // check Y*L = I (lower)
+  for (int i=0;i<m;i++) for (int j=0;j<=i;j++){ double s=0; for(int p=j;p<=i;p++) s+=Y[i+p*m]*L[p+j*m]; ey=fmax(ey,fabs(s-(i==j))); }
+  printf("lean 512: %.1f us (event) sweep %llu cycles = %.0f per column; max|L-Lref| %.2e  max|Y L - I| %.2e\n", best*1e3, cy, cy/64.0, el, ey);
+  return 0;
+}
