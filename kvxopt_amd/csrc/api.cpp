@@ -66,6 +66,7 @@ struct kvx_chol {
     int64_t *d_linv_off = nullptr;
     FrontDesc *d_fd = nullptr;
     ChildDesc *d_cd = nullptr;
+    int32_t *d_tiles = nullptr;
     int64_t x_cap = 0;        // right-hand sides the solve workspace holds
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
@@ -177,6 +178,7 @@ int ensure_device(kvx_chol *F)
     {
         std::vector<FrontDesc> fd((size_t)S.nsuper);
         std::vector<ChildDesc> cd(S.children.size());
+        std::vector<int32_t> tiles;
         for (int64_t s = 0; s < S.nsuper; s++) {
             FrontDesc &d = fd[s];
             d.k = S.sn_k[s]; d.m = S.sn_m[s]; d.first = (int32_t)S.super[s];
@@ -188,13 +190,26 @@ int ensure_device(kvx_chol *F)
                 ChildDesc &e = cd[c];
                 e.kc = S.sn_k[ch]; e.uc = S.sn_m[ch] - S.sn_k[ch];
                 e.rel = S.rowptr[ch] + S.sn_k[ch]; e.ux = S.ux[ch]; e.wx = S.wx[ch];
+                e.tile = -1;
+                if (front_class(d.m, d.k) == KVX_CLS_BIG) {
+                    // tiles[x] = first update column j of the child with rel[j] >= x * KVX_ASM_TC
+                    e.tile = (int64_t)tiles.size();
+                    const int ntile = (d.m + KVX_ASM_TC - 1) / KVX_ASM_TC;
+                    const int32_t *rl = S.rel.data() + e.rel;
+                    int j = 0;
+                    for (int x = 0; x <= ntile; x++) {
+                        while (j < e.uc && rl[j] < x * KVX_ASM_TC) j++;
+                        tiles.push_back(j);
+                    }
+                }
             }
         }
         if ((rc = upload(&F->d_fd, fd))) return rc;
         if ((rc = upload(&F->d_cd, cd))) return rc;
+        if ((rc = upload(&F->d_tiles, tiles))) return rc;
     }
     F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
-                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd};
+                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
     // per-level launch plan
     F->plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
@@ -330,11 +345,16 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
             launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
                            X, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
         }
-        for (int g = 1; g < 3; g++)
-            if (P.scnt[g] > 0) {
+        if (P.scnt[1] > 0) {
+            ProfScope ps(F, FAM_FWD);
+            launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX,
+                             F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+        }
+        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
+            if (P.cnt[c] > 0) {
                 ProfScope ps(F, FAM_FWD);
-                launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 64 : KVX_SMALL_MAX,
-                                 F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+                launch_fwd_wave(F->stream, F->ds, F->d_lists + P.off[c], P.cnt[c], wave_class_kmax(c),
+                                F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
             }
     }
 }
@@ -349,11 +369,15 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
             launch_bwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
                            X, ldx, nrhs, F->d_WK, S.n);
         }
-        for (int g = 1; g < 3; g++)
-            if (P.scnt[g] > 0) {
+        if (P.scnt[1] > 0) {
+            ProfScope ps(F, FAM_BWD);
+            launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX, F->d_Lx, X, ldx, nrhs);
+        }
+        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
+            if (P.cnt[c] > 0) {
                 ProfScope ps(F, FAM_BWD);
-                launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[g], P.scnt[g], g == 2 ? 64 : KVX_SMALL_MAX,
-                                 F->d_Lx, X, ldx, nrhs);
+                launch_bwd_wave(F->stream, F->ds, F->d_lists + P.off[c], P.cnt[c], wave_class_mcap(c), wave_class_kmax(c),
+                                F->d_Lx, X, ldx, nrhs);
             }
     }
 }
@@ -703,7 +727,7 @@ void kvx_chol_free(kvx_chol *F)
         (void)hipStreamSynchronize(F->stream);
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
-                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd};
+                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (F->h_status) (void)hipHostFree(F->h_status);

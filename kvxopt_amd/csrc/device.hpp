@@ -25,16 +25,18 @@ struct DevSym {
     // loads instead of five (the per-front kernels are latency-bound on small levels).
     const struct FrontDesc *fd;
     const struct ChildDesc *cd;
+    const int32_t *tiles;     // per child of a big front: first child column landing in each 16-column parent tile
 };
 
 struct FrontDesc {            // 64 bytes
     int32_t k, m, first, nchild;
     int64_t px, rowptr, ux, wx, childptr, linv;
 };
-struct ChildDesc {            // 32 bytes, indexed like DevSym::children
+struct ChildDesc {            // 40 bytes, indexed like DevSym::children
     int32_t uc, kc;           // update rows / pivot columns of the child
     int64_t rel;              // index into DevSym::rel of the child's first update row
     int64_t ux, wx;           // child's update matrix / update vector offsets (previous level's parity buffer)
+    int64_t tile;             // offset into DevSym::tiles (children of big fronts only, else -1)
 };
 
 #ifdef __HIPCC__
@@ -108,6 +110,7 @@ __device__ __forceinline__ void kvx_col_steps(double (&a)[KMAX], int k, int r, i
 constexpr int KVX_NB = 64;           // panel width of the blocked big-front factorisation
 constexpr int KVX_SMALL_MAX = 128;   // fronts up to this order are factored inside LDS
 constexpr int KVX_TILE = 64;         // trailing-update tile
+constexpr int KVX_ASM_TC = 16;       // parent columns owned by one extend-add workgroup (big fronts)
 
 // ---- launchers (kernels.hip) ---------------------------------------------------------------
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx);
@@ -133,6 +136,11 @@ void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int
                       const double *Wchild, double *Wout, int64_t wstride);
 void launch_bwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                       const double *Lx, double *X, int64_t ldx, int nrhs);
+// wave classes (m <= 64, k <= 32): one wavefront per front, no LDS image (kernels_wave.hip)
+void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
+                     const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);
+void launch_bwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int mcap, int kmax,
+                     const double *Lx, double *X, int64_t ldx, int nrhs);
 // big fronts (m > KVX_SMALL_MAX): multi-workgroup solves using the inverted diagonal blocks
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs,

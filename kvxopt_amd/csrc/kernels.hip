@@ -41,44 +41,50 @@ void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Big fronts: extend-add in HBM.  Workgroup (x, front) owns target columns [32x, 32x+32) of the
-// parent front and pulls the matching columns of every child, children in sequence.
-constexpr int ASM_TC = 32;
-
+// Big fronts: extend-add in HBM.  Workgroup (x, front) owns target columns [16x, 16x+16) of the
+// parent front and pulls the matching columns of every child, children in sequence (parent-pull:
+// no atomics, bitwise reproducible).  The child columns that land in the tile come from a host-built
+// table (ChildDesc::tile) instead of a binary search of dependent loads, and every lane keeps four
+// independent row updates in flight: the kernel is a chain of indirect accesses, i.e. latency-bound.
 __global__ __launch_bounds__(256) void k_assemble_big(DevSym ds, const int32_t *__restrict__ list,
                                                       double *__restrict__ Lx, const double *__restrict__ Uc,
                                                       double *__restrict__ Uo)
 {
-    const int s = list[blockIdx.y];
-    const int k = ds.k[s], m = ds.m[s], u = m - k;
-    const int c0 = blockIdx.x * ASM_TC;
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const int k = fd.k, m = fd.m, u = m - k;
+    const int c0 = blockIdx.x * KVX_ASM_TC;
     if (c0 >= m) return;
-    const int c1 = min(c0 + ASM_TC, m);
-    double *P = Lx + ds.px[s];
-    double *U = Uo + ds.ux[s];
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
-        const int ch = ds.children[c];
-        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
+    for (int c = 0; c < fd.nchild; c++) {
+        const ChildDesc cd = ds.cd[fd.childptr + c];
+        const int uc = cd.uc;
         if (uc == 0) continue;
-        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
-        // child columns whose target column falls in [c0, c1): rl is increasing
-        int lo = 0, hi = uc;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c0) lo = mid + 1; else hi = mid; }
-        const int jlo = lo;
-        hi = uc;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (rl[mid] < c1) lo = mid + 1; else hi = mid; }
-        const int jhi = lo;
-        const double *Uch = Uc + ds.ux[ch];
+        const int32_t *rl = ds.rel + cd.rel;
+        const int jlo = ds.tiles[cd.tile + blockIdx.x], jhi = ds.tiles[cd.tile + blockIdx.x + 1];
+        const double *Uch = Uc + cd.ux;
         for (int j = jlo + wv; j < jhi; j += 4) {
             const int tc = rl[j];
             const double *src = Uch + (int64_t)j * uc;
-            if (tc < k) {
-                double *dst = P + (int64_t)tc * m;
-                for (int i = j + ln; i < uc; i += 64) dst[rl[i]] += src[i];
-            } else {
-                double *dst = U + (int64_t)(tc - k) * u - k;
-                for (int i = j + ln; i < uc; i += 64) dst[rl[i]] += src[i];
+            double *dst = (tc < k) ? P + (int64_t)tc * m : U + (int64_t)(tc - k) * u - k;
+            for (int i0 = j + ln; i0 < uc; i0 += 256) {
+                int r[4];
+                double v[4], old[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = i0 + 64 * q;
+                    ok[q] = i < uc;
+                    const int ii = ok[q] ? i : j;          // row j is always a valid, in-range row
+                    r[q] = rl[ii];
+                    v[q] = src[ii];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) old[q] = dst[r[q]];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (ok[q]) dst[r[q]] = old[q] + v[q];
             }
         }
         __syncthreads();
@@ -89,7 +95,7 @@ void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, 
                          double *Lx, const double *Uchild, double *Uout)
 {
     if (count <= 0) return;
-    dim3 grid((unsigned)((max_m + ASM_TC - 1) / ASM_TC), (unsigned)count);
+    dim3 grid((unsigned)((max_m + KVX_ASM_TC - 1) / KVX_ASM_TC), (unsigned)count);
     hipLaunchKernelGGL(k_assemble_big, grid, dim3(256), 0, st, ds, list, Lx, Uchild, Uout);
 }
 

@@ -210,6 +210,114 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
             if ((t & 3) == wv) schur_tile(F, m, k, u, ti, tj, kids, Uout, ln);
 }
 
+// ------------------------------------------------------------------------------------------
+// Triangular solves for the wave classes (m <= 64, k <= 32): one wavefront per front and rhs.
+// Forward: lane r = row r with its panel row in registers (the panel is read once, coalesced);
+// the running right-hand side lives one value per lane and the pivot value travels by readlane.
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_fwd_wave(DevSym ds, const int32_t *__restrict__ list,
+                                                 const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx,
+                                                 const double *__restrict__ Wc, double *__restrict__ Wo, int64_t wstride)
+{
+    __shared__ double wsh[64];
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, r = threadIdx.x;
+    const double *P = Lx + fd.px;
+    double *x = X + (int64_t)blockIdx.y * ldx + fd.first;
+    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
+    double *wo = Wo + (int64_t)blockIdx.y * wstride + fd.wx;
+    double a[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+    double w = kvx_ld0(x, r, r < k);
+    if (fd.nchild > 0) {
+        wsh[r] = w;
+        for (int c = 0; c < fd.nchild; c++) {
+            const ChildDesc cd = ds.cd[fd.childptr + c];
+            if (cd.uc == 0) continue;
+            const bool ok = r < cd.uc;
+            const int t = ok ? ds.rel[cd.rel + r] : 0;
+            const double v = kvx_ld0(wc + cd.wx, r, ok);
+            __syncthreads();
+            if (ok) wsh[t] += v;
+        }
+        __syncthreads();
+        w = wsh[r];
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+        if (j < k) {                               // wave-uniform
+            const double yj = kvx_readlane(w, j) / kvx_readlane(a[j], j);
+            w = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w) : w);
+        }
+    }
+    if (r < k) x[r] = w;
+    else if (r < m) wo[r - k] = w;
+}
+
+// Backward: lane j = pivot column j with its panel COLUMN in registers; rows are swept from the
+// bottom, the solved value of row r is broadcast by readlane and every column to its left adds
+// its L[r][j] * x_r.
+template <int KMAX, int MMAX>
+__global__ __launch_bounds__(64) void k_bwd_wave(DevSym ds, const int32_t *__restrict__ list,
+                                                 const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
+{
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, ln = threadIdx.x;
+    const double *P = Lx + fd.px;
+    double *xg = X + (int64_t)blockIdx.y * ldx;
+    const int32_t *rows = ds.rowidx + fd.rowptr;
+    // lane ln < k holds column ln: a[r] = L[r][ln]; lane ln also carries x of row ln (rows < m)
+    const int col = ln < k ? ln : 0;
+    double a[MMAX];
+#pragma unroll
+    for (int rr = 0; rr < MMAX; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+    const int grow = (ln < m) ? (ln < k ? fd.first + ln : rows[ln]) : 0;
+    double xv = kvx_ld0(xg, grow, ln < m);         // y (pivot rows) or already-solved ancestors (update rows)
+    double acc = 0.0;
+#pragma unroll
+    for (int rr = MMAX - 1; rr >= 0; rr--) {
+        if (rr < m) {                              // wave-uniform
+            double xr;
+            if (rr < k) {
+                // finalise row rr: lane rr owns acc and the diagonal
+                const double t = (xv - acc) / ((ln == rr) ? a[rr] : 1.0);
+                xr = kvx_readlane(t, rr);
+                if (ln == rr) xv = xr;
+            } else {
+                xr = kvx_readlane(xv, rr);
+            }
+            acc = (ln < rr) ? __builtin_fma(a[rr], xr, acc) : acc;
+        }
+    }
+    if (ln < k) xg[fd.first + ln] = xv;
+}
+
+void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
+                     const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    if (kmax <= 16)
+        hipLaunchKernelGGL(k_fwd_wave<16>, grid, dim3(64), 0, st, ds, list, Lx, X, ldx, Wchild, Wout, wstride);
+    else
+        hipLaunchKernelGGL(k_fwd_wave<32>, grid, dim3(64), 0, st, ds, list, Lx, X, ldx, Wchild, Wout, wstride);
+}
+
+void launch_bwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int mcap, int kmax,
+                     const double *Lx, double *X, int64_t ldx, int nrhs)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    (void)kmax;
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    if (mcap <= 32)
+        hipLaunchKernelGGL((k_bwd_wave<32, 32>), grid, dim3(64), 0, st, ds, list, Lx, X, ldx);
+    else if (mcap <= 48)
+        hipLaunchKernelGGL((k_bwd_wave<32, 48>), grid, dim3(64), 0, st, ds, list, Lx, X, ldx);
+    else
+        hipLaunchKernelGGL((k_bwd_wave<32, 64>), grid, dim3(64), 0, st, ds, list, Lx, X, ldx);
+}
+
 // wave kernel: mcap = LDS image capacity (32 / 48 / 64); kmax: 16 or 32
 void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
                        double *Lx, const double *Uchild, double *Uout, int *status)
