@@ -332,6 +332,38 @@ int finish_factor(kvx_chol *F, int64_t *minor)
     return F->minor < F->S.n ? KVX_ENOTPOSDEF : KVX_OK;
 }
 
+// Fork the independent kernel groups of one level onto the side streams; join at level end.
+struct LevelStreams {
+    kvx_chol *F;
+    hipStream_t lds, wave;
+    bool fork_lds, fork_wave;
+    LevelStreams(kvx_chol *F_, bool have_big, bool have_lds, bool have_wave) : F(F_)
+    {
+        fork_lds = have_lds && (have_big || have_wave);
+        fork_wave = have_wave && have_big;
+        lds = fork_lds ? F->side[0] : F->stream;
+        wave = fork_wave ? F->side[1] : F->stream;
+        if (fork_lds || fork_wave) {
+            (void)hipEventRecord(F->ev_fork, F->stream);
+            if (fork_lds) (void)hipStreamWaitEvent(F->side[0], F->ev_fork, 0);
+            if (fork_wave) (void)hipStreamWaitEvent(F->side[1], F->ev_fork, 0);
+        }
+    }
+    void join()
+    {
+        if (fork_lds) { (void)hipEventRecord(F->ev_join[0], F->side[0]); (void)hipStreamWaitEvent(F->stream, F->ev_join[0], 0); }
+        if (fork_wave) { (void)hipEventRecord(F->ev_join[1], F->side[1]); (void)hipStreamWaitEvent(F->stream, F->ev_join[1], 0); }
+    }
+};
+
+// all wave classes of a level form one contiguous range of the level list
+static void wave_range(const LevelPlan &P, int64_t &off, int &cnt)
+{
+    off = 0; cnt = 0;
+    for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
+        if (P.cnt[c] > 0) { if (cnt == 0) off = P.off[c]; cnt += P.cnt[c]; }
+}
+
 void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
 {
     Symbolic &S = F->S;
@@ -340,22 +372,24 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         const LevelPlan &P = F->plan[l];
         const double *Wch = F->d_W[(l + 1) & 1];
         double *Wout = F->d_W[l & 1];
+        int64_t woff; int wcnt;
+        wave_range(P, woff, wcnt);
+        LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
+        if (wcnt > 0) {
+            ProfScope ps(F, FAM_FWD, ls.wave);
+            launch_fwd_wave(ls.wave, F->ds, F->d_lists + woff, wcnt, 32, F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+        }
+        if (P.scnt[1] > 0) {
+            ProfScope ps(F, FAM_FWD, ls.lds);
+            launch_fwd_level(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX,
+                             F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+        }
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_FWD);
             launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
                            X, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
         }
-        if (P.scnt[1] > 0) {
-            ProfScope ps(F, FAM_FWD);
-            launch_fwd_level(F->stream, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX,
-                             F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
-        }
-        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
-            if (P.cnt[c] > 0) {
-                ProfScope ps(F, FAM_FWD);
-                launch_fwd_wave(F->stream, F->ds, F->d_lists + P.off[c], P.cnt[c], wave_class_kmax(c),
-                                F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
-            }
+        ls.join();
     }
 }
 
@@ -364,21 +398,23 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
     Symbolic &S = F->S;
     for (int l = 0; l < S.nlevels; l++) {
         const LevelPlan &P = F->plan[l];
+        int64_t woff; int wcnt;
+        wave_range(P, woff, wcnt);
+        LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
+        if (wcnt > 0) {
+            ProfScope ps(F, FAM_BWD, ls.wave);
+            launch_bwd_wave(ls.wave, F->ds, F->d_lists + woff, wcnt, 64, 32, F->d_Lx, X, ldx, nrhs);
+        }
+        if (P.scnt[1] > 0) {
+            ProfScope ps(F, FAM_BWD, ls.lds);
+            launch_bwd_level(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX, F->d_Lx, X, ldx, nrhs);
+        }
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_BWD);
             launch_bwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
                            X, ldx, nrhs, F->d_WK, S.n);
         }
-        if (P.scnt[1] > 0) {
-            ProfScope ps(F, FAM_BWD);
-            launch_bwd_level(F->stream, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX, F->d_Lx, X, ldx, nrhs);
-        }
-        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
-            if (P.cnt[c] > 0) {
-                ProfScope ps(F, FAM_BWD);
-                launch_bwd_wave(F->stream, F->ds, F->d_lists + P.off[c], P.cnt[c], wave_class_mcap(c), wave_class_kmax(c),
-                                F->d_Lx, X, ldx, nrhs);
-            }
+        ls.join();
     }
 }
 
