@@ -159,6 +159,15 @@ int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y);
 int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host);
 int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host);
 
+/* ---- BLAS-1 glue on device vectors: replaces the blas.axpy / scal / copy calls and elementwise
+ * products the interior-point loop makes between KKT solves (coneprog.py:1126-1433). ------------- */
+int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y);     /* y += alpha x        */
+int kvx_vec_scal_dev(int64_t n, double alpha, double *x);                       /* x *= alpha          */
+int kvx_vec_addc_dev(int64_t n, double c, double *x);                           /* x += c              */
+int kvx_vec_fill_dev(int64_t n, double c, double *x);                           /* x := c              */
+int kvx_vec_copy_dev(int64_t n, const double *x, double *y);                    /* y := x              */
+int kvx_vec_xmy_dev(int64_t n, double a, const double *x, const double *y, double b, double *z); /* z := a x.*y + b z */
+
 /* ---- sparse mat-vec: replaces base.gemv on spmatrix (sparse.c:1073-1104) ----------------- */
 /* y := alpha*op(A)*x + beta*y, A m x n CCS with int64 indices on the device. trans 'N'/'T'. */
 int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap_dev, const int64_t *Ai_dev,

@@ -70,6 +70,12 @@ _SIGS = {
     "kvx_nt_ssqr_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_nt_sdot_dev": (ctypes.c_int, [i64, vp, vp, f64p]),
     "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),
+    "kvx_vec_axpy_dev": (ctypes.c_int, [i64, f64, vp, vp]),
+    "kvx_vec_scal_dev": (ctypes.c_int, [i64, f64, vp]),
+    "kvx_vec_addc_dev": (ctypes.c_int, [i64, f64, vp]),
+    "kvx_vec_fill_dev": (ctypes.c_int, [i64, f64, vp]),
+    "kvx_vec_copy_dev": (ctypes.c_int, [i64, vp, vp]),
+    "kvx_vec_xmy_dev": (ctypes.c_int, [i64, f64, vp, vp, f64, vp]),
     "kvx_spmv_dev": (ctypes.c_int, [ctypes.c_int, i64, i64, vp, vp, vp, f64, vp, f64, vp]),
     "kvx_dev_malloc": (ctypes.c_int, [ctypes.POINTER(vp), i64]),
     "kvx_dev_free": (ctypes.c_int, [vp]),

@@ -1,0 +1,226 @@
+"""Drop-in for `kvxopt.cholmod` on MI355X: same functions, argument meaning and error behaviour as
+the reference's src/C/cholmod.c (method table cholmod.c:988-1005), backed by the HIP supernodal
+Cholesky of libkvxhip.so.  No CPU fallback: numeric calls raise RuntimeError without a GPU.
+
+    symbolic(A, p=None, uplo='L') -> F            cholmod.c:244-291
+    numeric(A, F)                                  cholmod.c:322-398
+    solve(F, B, sys=0, nrhs=-1, ldB=0, offsetB=0)  cholmod.c:429-499
+    spsolve(F, B, sys=0) -> X                      cholmod.c:524-587
+    linsolve(A, B, p=None, uplo='L', nrhs=-1, ldB=0, offsetB=0)   cholmod.c:618-753
+    splinsolve(A, B, p=None, uplo='L') -> X        cholmod.c:774-881
+    diag(F) -> d                                   cholmod.c:900-945
+    getfactor(F) -> L                              cholmod.c:948-985
+    options                                        dict, validated on every call (cholmod.c:87-129)
+
+Differences kept on purpose: `numeric` raises ArithmeticError(minor) on a non-positive-
+definite matrix as DOCUMENTED (cholmod.c:308-310); the reference build tests a stale status there
+(quirk Q1) and only fails at the next solve -- `solve` here raises as well.
+Only options['supernodal'] == 2 (the reference default) is implemented.
+"""
+import numpy as np
+
+from . import base
+from .base import matrix, spmatrix
+from .chol import Factor
+
+options = {}
+
+
+def _check_options():
+    """cholmod.c:87-129: unknown keys or wrongly typed values -> ValueError, on every entry."""
+    opts = {}
+    for k, v in options.items():
+        if not isinstance(k, str):
+            continue
+        if k == "supernodal" and isinstance(v, int) and not isinstance(v, bool):
+            opts["supernodal"] = v
+        elif k == "print" and isinstance(v, int) and not isinstance(v, bool):
+            pass
+        elif k == "nmethods" and isinstance(v, int) and not isinstance(v, bool):
+            opts["nmethods"] = v
+        elif k == "postorder" and isinstance(v, bool):
+            opts["postorder"] = int(v)
+        elif k == "dbound" and isinstance(v, float):
+            opts["dbound"] = v
+        else:
+            raise ValueError("invalid value for CHOLMOD parameter: %-.20s" % k)
+    if opts.get("supernodal", 2) != 2:
+        raise ValueError("kvxopt_amd.cholmod implements options['supernodal'] = 2 (supernodal LL') only")
+    opts.pop("nmethods", None)
+    return opts
+
+
+class _F:
+    """Opaque factor (the reference returns a PyCapsule named 'CHOLMOD SYM D FACTOR L'/'U')."""
+
+    def __init__(self, fac, uplo, pattern):
+        self.fac = fac
+        self.uplo = uplo
+        self.pattern = pattern          # (colptr, rowind) analysed
+        self.name = "CHOLMOD SYM D FACTOR " + uplo
+
+
+def _sp(A, what="A"):
+    if not (isinstance(A, spmatrix) or hasattr(A, "CCS")):
+        raise TypeError("%s is not a square sparse matrix" % what)
+    return base._as_ccs(A)
+
+
+def _perm(p, n):
+    if p is None:
+        return None
+    if isinstance(p, matrix):
+        if p.typecode != "i":
+            raise TypeError("p must be a matrix with typecode 'i'")
+        q = p._a
+    elif hasattr(p, "typecode"):
+        if p.typecode != "i":
+            raise TypeError("p must be a matrix with typecode 'i'")
+        q = np.array(list(p), dtype=np.int64)
+    else:
+        q = np.asarray(p)
+        if q.dtype.kind not in "iu":
+            raise TypeError("p must be a matrix with typecode 'i'")
+    q = np.asarray(q, dtype=np.int64).reshape(-1)
+    if q.size != n:
+        raise TypeError("length of p is too small")
+    return q
+
+
+def symbolic(A, p=None, uplo="L"):
+    opts = _check_options()
+    m, n, cp, ri, v = _sp(A)
+    if m != n:
+        raise TypeError("A is not a square sparse matrix")
+    q = _perm(p, n)
+    if uplo not in ("L", "U"):
+        raise ValueError("possible values of uplo are: 'L', 'U'")
+    try:
+        fac = Factor(n, cp, ri, uplo, q, {k: opts[k] for k in ("postorder", "dbound") if k in opts})
+    except ValueError as e:
+        if "permutation" in str(e):
+            raise ValueError("p is not a valid permutation")
+        raise
+    return _F(fac, uplo, (cp.copy(), ri.copy()))
+
+
+def numeric(A, F):
+    _check_options()
+    m, n, cp, ri, v = _sp(A)
+    if m != n:
+        raise TypeError("A is not a sparse matrix")
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    if n != F.fac.n or cp.size != F.pattern[0].size or ri.size != F.pattern[1].size:
+        raise ValueError("factorization failed")       # pattern differs from the analysed one
+    F.fac.factorize(v)                                   # ArithmeticError(minor) if not positive definite
+
+
+def _solve_args(F, B, sys, nrhs, ldB, offsetB):
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    if not F.fac.info()["is_numeric"] and F.fac.info()["minor"] == F.fac.n:
+        raise ValueError("called with symbolic factor")
+    if sys < 0 or sys > 8:
+        raise ValueError("invalid value for sys")
+    buf, size = base._dense_buffer(B)
+    n = F.fac.n
+    if nrhs < 0:
+        nrhs = size[1]
+    return buf, size, n, nrhs
+
+
+def solve(F, B, sys=0, nrhs=-1, ldB=0, offsetB=0):
+    _check_options()
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    inf = F.fac.info()
+    if not inf["is_numeric"] and inf["minor"] >= F.fac.n:
+        raise ValueError("called with symbolic factor")
+    if inf["minor"] < F.fac.n:
+        raise ArithmeticError("singular matrix")
+    if sys < 0 or sys > 8:
+        raise ValueError("invalid value for sys")
+    buf, size = base._dense_buffer(B)
+    n = F.fac.n
+    if nrhs < 0:
+        nrhs = size[1]
+    if n == 0 or nrhs == 0:
+        return
+    if ldB == 0:
+        ldB = max(1, size[0])
+    if ldB < max(1, n):
+        raise ValueError("illegal value of ldB")
+    if offsetB < 0:
+        raise ValueError("offsetB must be a nonnegative integer")
+    if offsetB + (nrhs - 1) * ldB + n > buf.size:
+        raise TypeError("length of B is too small")
+    F.fac.solve(buf, sys=sys, nrhs=nrhs, ldB=ldB, offset=offsetB)
+
+
+def spsolve(F, B, sys=0):
+    _check_options()
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    inf = F.fac.info()
+    if not inf["is_numeric"] and inf["minor"] >= F.fac.n:
+        raise ValueError("called with symbolic factor")
+    if inf["minor"] < F.fac.n:
+        raise ArithmeticError("singular matrix")
+    if sys < 0 or sys > 8:
+        raise ValueError("invalid value for sys")
+    m, ncol, cp, ri, v = _sp(B, "B")
+    if m != F.fac.n:
+        raise ValueError("incompatible dimensions for B")
+    if F.fac.n == 0 or ncol == 0:
+        return spmatrix([], [], [], (m, ncol))
+    Xp, Xi, Xx = F.fac.spsolve(ncol, cp, ri, v, sys)
+    return spmatrix.from_ccs(m, ncol, Xp, Xi, Xx)
+
+
+def linsolve(A, B, p=None, uplo="L", nrhs=-1, ldB=0, offsetB=0):
+    _check_options()
+    m, n, cp, ri, v = _sp(A)
+    if m != n:
+        raise TypeError("A is not a sparse matrix")
+    buf, size = base._dense_buffer(B)
+    if nrhs < 0:
+        nrhs = size[1]
+    if n == 0 or nrhs == 0:
+        return
+    F = symbolic(A, p, uplo)
+    numeric(A, F)
+    solve(F, B, 0, nrhs, ldB, offsetB)
+
+
+def splinsolve(A, B, p=None, uplo="L"):
+    _check_options()
+    m, n, cp, ri, v = _sp(A)
+    if m != n:
+        raise TypeError("A is not a square sparse matrix")
+    bm = B.size[0]
+    if bm != n:
+        raise ValueError("incompatible dimensions for B")
+    F = symbolic(A, p, uplo)
+    numeric(A, F)
+    return spsolve(F, B, 0)
+
+
+def diag(F):
+    _check_options()
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    inf = F.fac.info()
+    if not inf["is_numeric"] or inf["minor"] < F.fac.n:
+        raise ValueError("F must be a nonsingular supernodal Cholesky factor")
+    return matrix(F.fac.diag(), (F.fac.n, 1))
+
+
+def getfactor(F):
+    _check_options()
+    if not isinstance(F, _F):
+        raise TypeError("F is not a CHOLMOD factor")
+    if not F.fac.info()["is_numeric"]:
+        raise ValueError("F must be a numeric Cholesky factor")
+    Lp, Li, Lx = F.fac.get_factor()
+    return spmatrix.from_ccs(F.fac.n, F.fac.n, Lp, Li, Lx)

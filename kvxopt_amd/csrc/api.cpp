@@ -52,6 +52,7 @@ struct kvx_chol {
     hipStream_t stream = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};   // independent kernel classes of one level run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_ftime = false, have_stime = false;
     double ms_factor = 0, ms_solve = 0;
@@ -139,6 +140,7 @@ int ensure_device(kvx_chol *F)
         HIPCHK(hipEventCreateWithFlags(&F->ev_join[i], hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&F->ev_in, hipEventDisableTiming));
     int rc;
     std::vector<int32_t> first((size_t)S.nsuper), perm32((size_t)S.n);
     for (int64_t s = 0; s < S.nsuper; s++) first[s] = (int32_t)S.super[s];
@@ -253,6 +255,16 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
     for (int p = 0; p < 2; p++)
         HIPCHK(hipMalloc((void **)&F->d_W[p], std::max<int64_t>(wmax * nrhs, 1) * sizeof(double)));
     F->x_cap = nrhs;
+    return KVX_OK;
+}
+
+// Device-pointer entry points: the caller's producers run on the legacy null stream (the kvx_nt_* /
+// kvx_atda_* / kvx_spmv_* calls, torch's default stream); the factor's stream is non-blocking, so
+// order it explicitly behind them.
+int wait_for_caller(kvx_chol *F)
+{
+    HIPCHK(hipEventRecord(F->ev_in, nullptr));
+    HIPCHK(hipStreamWaitEvent(F->stream, F->ev_in, 0));
     return KVX_OK;
 }
 
@@ -532,6 +544,7 @@ int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev)
     if (!F) return KVX_EINVAL;
     int rc = ensure_device(F);
     if (rc) return rc;
+    if ((rc = wait_for_caller(F))) return rc;
     if (F->S.nnzA > 0)
         HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, F->S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
     return enqueue_factor(F);
@@ -566,6 +579,8 @@ int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_
 {
     if (!F) return KVX_EINVAL;
     if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    int rc = wait_for_caller(F);
+    if (rc) return rc;
     return solve_dev(F, sys, B_dev, nrhs, ldB);
 }
 
@@ -776,6 +791,7 @@ void kvx_chol_free(kvx_chol *F)
             if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
         }
         if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
+        if (F->ev_in) (void)hipEventDestroy(F->ev_in);
         if (F->stream) (void)hipStreamDestroy(F->stream);
     }
     delete F;

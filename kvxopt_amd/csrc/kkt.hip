@@ -55,6 +55,24 @@ __global__ void k_div(int64_t n, double *__restrict__ x, const double *__restric
 __global__ void k_mul(int64_t n, double *__restrict__ x, const double *__restrict__ y) { GS_LOOP(i, n) x[i] *= y[i]; }
 __global__ void k_sqr(int64_t n, double *__restrict__ x, const double *__restrict__ y) { GS_LOOP(i, n) { const double v = y[i]; x[i] = v * v; } }
 
+__global__ void k_axpy(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y) { GS_LOOP(i, n) y[i] += alpha * x[i]; }
+__global__ void k_scal(int64_t n, double alpha, double *__restrict__ x) { GS_LOOP(i, n) x[i] *= alpha; }
+__global__ void k_addc(int64_t n, double c, double *__restrict__ x) { GS_LOOP(i, n) x[i] += c; }
+__global__ void k_fill(int64_t n, double c, double *__restrict__ x) { GS_LOOP(i, n) x[i] = c; }
+// z := a * (x .* y) + b * z
+__global__ void k_xmy(int64_t n, double a, const double *__restrict__ x, const double *__restrict__ y, double b, double *__restrict__ z)
+{ GS_LOOP(i, n) z[i] = a * (x[i] * y[i]) + (b == 0.0 ? 0.0 : b * z[i]); }
+void launch_axpy(hipStream_t st, int64_t n, double alpha, const double *x, double *y)
+{ if (n > 0) hipLaunchKernelGGL(k_axpy, dim3(grid_for(n)), dim3(256), 0, st, n, alpha, x, y); }
+void launch_vscal(hipStream_t st, int64_t n, double alpha, double *x)
+{ if (n > 0) hipLaunchKernelGGL(k_scal, dim3(grid_for(n)), dim3(256), 0, st, n, alpha, x); }
+void launch_addc(hipStream_t st, int64_t n, double c, double *x)
+{ if (n > 0) hipLaunchKernelGGL(k_addc, dim3(grid_for(n)), dim3(256), 0, st, n, c, x); }
+void launch_fill(hipStream_t st, int64_t n, double c, double *x)
+{ if (n > 0) hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(256), 0, st, n, c, x); }
+void launch_xmy(hipStream_t st, int64_t n, double a, const double *x, const double *y, double b, double *z)
+{ if (n > 0) hipLaunchKernelGGL(k_xmy, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, y, b, z); }
+
 void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const double *z, double *d, double *di, double *lm)
 { if (n > 0) hipLaunchKernelGGL(k_compute_scaling, dim3(grid_for(n)), dim3(256), 0, st, n, s, z, d, di, lm); }
 void launch_update_scaling(hipStream_t st, int64_t n, double *s, double *z, double *d, double *di, double *lm)
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(256) void k_spmv_t(int64_t n, const int64_t *__rest
         if (sub == 0) y[j] = (beta == 0.0 ? 0.0 : beta * y[j]) + alpha * acc;
     }
 }
-__global__ void k_scal(int64_t n, double beta, double *__restrict__ y)
+__global__ void k_beta(int64_t n, double beta, double *__restrict__ y)
 {
     GS_LOOP(i, n) y[i] = (beta == 0.0) ? 0.0 : beta * y[i];
 }
@@ -188,7 +206,7 @@ void launch_spmv(hipStream_t st, int trans, int64_t m, int64_t n, const int64_t 
     if (trans == 'T') {
         if (n > 0) hipLaunchKernelGGL(k_spmv_t, dim3(grid_for(n * 16)), dim3(256), 0, st, n, Ap, Ai, Ax, alpha, x, beta, y);
     } else {
-        if (m > 0 && beta != 1.0) hipLaunchKernelGGL(k_scal, dim3(grid_for(m)), dim3(256), 0, st, m, beta, y);
+        if (m > 0 && beta != 1.0) hipLaunchKernelGGL(k_beta, dim3(grid_for(m)), dim3(256), 0, st, m, beta, y);
         if (n > 0) hipLaunchKernelGGL(k_spmv_n, dim3(grid_for(n)), dim3(256), 0, st, n, Ap, Ai, Ax, alpha, x, y);
     }
 }

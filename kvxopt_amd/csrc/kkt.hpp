@@ -10,6 +10,11 @@ void launch_scale(hipStream_t st, int64_t n, int64_t ncols, int64_t ldx, double 
 void launch_div(hipStream_t st, int64_t n, double *x, const double *y);
 void launch_mul(hipStream_t st, int64_t n, double *x, const double *y);
 void launch_sqr(hipStream_t st, int64_t n, double *x, const double *y);
+void launch_axpy(hipStream_t st, int64_t n, double alpha, const double *x, double *y);
+void launch_vscal(hipStream_t st, int64_t n, double alpha, double *x);
+void launch_addc(hipStream_t st, int64_t n, double c, double *x);
+void launch_fill(hipStream_t st, int64_t n, double c, double *x);
+void launch_xmy(hipStream_t st, int64_t n, double a, const double *x, const double *y, double b, double *z);
 void launch_dot(hipStream_t st, int64_t n, const double *x, const double *y, double *part, double *out);
 void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, double *out);
 int reduce_scratch_doubles();

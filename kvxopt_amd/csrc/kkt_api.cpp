@@ -265,6 +265,20 @@ int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host)
     return KVX_OK;
 }
 
+// ---- BLAS-1 glue of the interior-point loop on device vectors (blas.axpy/scal/copy/dot calls of coneprog.py) ----
+int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y)
+{ launch_axpy(nullptr, n, alpha, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_vec_scal_dev(int64_t n, double alpha, double *x)
+{ launch_vscal(nullptr, n, alpha, x); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_vec_addc_dev(int64_t n, double c, double *x)
+{ launch_addc(nullptr, n, c, x); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_vec_fill_dev(int64_t n, double c, double *x)
+{ launch_fill(nullptr, n, c, x); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_vec_copy_dev(int64_t n, const double *x, double *y)
+{ if (n > 0) HIPCHK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, nullptr)); return KVX_OK; }
+int kvx_vec_xmy_dev(int64_t n, double a, const double *x, const double *y, double b, double *z)
+{ launch_xmy(nullptr, n, a, x, y, b, z); HIPCHK(hipGetLastError()); return KVX_OK; }
+
 int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double alpha,
                  const double *x, double beta, double *y)
 {

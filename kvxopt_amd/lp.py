@@ -1,0 +1,338 @@
+"""Device-resident cone-LP interior-point driver for the orthant cone (inequality form, p = 0):
+
+    minimize c'x  subject to  G x + s = h,  s >= 0          (G sparse, ml x n)
+
+A restatement of the reference's `coneprog.conelp` (src/python/coneprog.py:31-1436) specialised to
+dims = {'l': ml, 'q': [], 's': []} and no equality constraints, with the default KKT solver
+`misc.kkt_chol2` (src/python/misc.py:1352-1567).  Every vector lives in HBM for the whole solve; per
+iteration the host sees only scalars (gap, residual norms, step lengths).  Per iteration, as in the
+reference: 1 numeric refactorisation of S = G' diag(di^2) G on a fixed symbolic analysis,
+3 KKT solves, 2 products with G and 2 with G', the NT-scaling update -- all HIP kernels of
+libkvxhip.so.  No CPU fallback.
+
+Equality constraints (p > 0, K = A S^{-1} A') go through the host-array compatibility layer
+(`kvxopt_amd.misc.kkt_chol2`); the device-resident driver raises for them for now.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib, base
+from ._lib import DeviceBuffer, lib, raise_for
+from .chol import Factor
+
+EXPON = 3          # coneprog.py:423
+STEP = 0.99        # coneprog.py:424
+
+
+class DVec:
+    """A float64 vector in HBM with the BLAS-1 / NT-scaling operations of the C ABI."""
+
+    def __init__(self, n, init=None):
+        self.n = int(n)
+        self.buf = DeviceBuffer(8 * max(self.n, 1))
+        if init is not None:
+            self.set(init)
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    def set(self, a):
+        self.buf.upload(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+        return self
+
+    def get(self):
+        return self.buf.download(np.float64, self.n)
+
+    def fill(self, v):
+        raise_for(lib().kvx_vec_fill_dev(self.n, float(v), self.ptr)); return self
+
+    def copy_from(self, x):
+        raise_for(lib().kvx_vec_copy_dev(self.n, x.ptr, self.ptr)); return self
+
+    def axpy(self, x, alpha=1.0):                       # self += alpha * x
+        raise_for(lib().kvx_vec_axpy_dev(self.n, float(alpha), x.ptr, self.ptr)); return self
+
+    def scal(self, alpha):
+        raise_for(lib().kvx_vec_scal_dev(self.n, float(alpha), self.ptr)); return self
+
+    def addc(self, c):
+        raise_for(lib().kvx_vec_addc_dev(self.n, float(c), self.ptr)); return self
+
+    def mul(self, y):                                   # self .*= y   (misc.scale / sprod / scale2 'I')
+        raise_for(lib().kvx_nt_sprod_dev(self.n, self.ptr, y.ptr)); return self
+
+    def div(self, y):                                   # self ./= y   (sinv / scale2 'N')
+        raise_for(lib().kvx_nt_sinv_dev(self.n, self.ptr, y.ptr)); return self
+
+    def sqr_of(self, y):                                # self := y.*y  (misc.ssqr)
+        raise_for(lib().kvx_nt_ssqr_dev(self.n, self.ptr, y.ptr)); return self
+
+    def xmy(self, a, x, y, b=0.0):                      # self := a * x.*y + b * self
+        raise_for(lib().kvx_vec_xmy_dev(self.n, float(a), x.ptr, y.ptr, float(b), self.ptr)); return self
+
+    def dot(self, y):
+        if self.n == 0:
+            return 0.0
+        r = ctypes.c_double()
+        raise_for(lib().kvx_nt_sdot_dev(self.n, self.ptr, y.ptr, ctypes.byref(r)))
+        return r.value
+
+    def nrm2(self):
+        return math.sqrt(self.dot(self))
+
+    def max_step(self):                                 # misc.max_step 'l' block: max_i(-x_i)
+        r = ctypes.c_double()
+        raise_for(lib().kvx_nt_max_step_dev(self.n, self.ptr, ctypes.byref(r)))
+        return r.value
+
+
+class SpMatDev:
+    """CCS matrix resident in HBM (int64 indices as in the reference, kvxopt.h:46)."""
+
+    def __init__(self, m, n, colptr, rowind, values):
+        self.m, self.n = int(m), int(n)
+        self.cp = DeviceBuffer.from_array(np.ascontiguousarray(colptr, dtype=np.int64))
+        self.ri = DeviceBuffer.from_array(np.ascontiguousarray(rowind, dtype=np.int64)) if len(rowind) else DeviceBuffer(8)
+        self.vx = DeviceBuffer.from_array(np.ascontiguousarray(values, dtype=np.float64)) if len(values) else DeviceBuffer(8)
+
+    def gemv(self, x, y, trans="N", alpha=1.0, beta=0.0):
+        """y := alpha*op(A)*x + beta*y  (base.gemv -> sparse.c:1073-1104)."""
+        raise_for(lib().kvx_spmv_dev(ord(trans), self.m, self.n, self.cp.ptr, self.ri.ptr, self.vx.ptr,
+                                     float(alpha), x.ptr, float(beta), y.ptr))
+
+
+class KKTChol2Dev:
+    """Device-resident `misc.kkt_chol2` for sparse G and p = 0 (misc.py:1389-1563)."""
+
+    def __init__(self, ml, n, Gp, Gi, Gx, chol_opts=None):
+        self.ml, self.n = ml, n
+        Gp = np.ascontiguousarray(Gp, dtype=np.int64)
+        Gi = np.ascontiguousarray(Gi, dtype=np.int64)
+        h = ctypes.c_void_p()
+        raise_for(lib().kvx_atda_plan(ml, n, _lib.pi(Gp), _lib.pi(Gi), None, None, ctypes.byref(h)))
+        self._plan = h
+        snz = ctypes.c_int64()
+        raise_for(lib().kvx_atda_pattern(h, ctypes.byref(snz), None, None))
+        self.Sp = np.empty(n + 1, dtype=np.int64)
+        Si = np.empty(max(snz.value, 1), dtype=np.int64)
+        raise_for(lib().kvx_atda_pattern(h, ctypes.byref(snz), _lib.pi(self.Sp), _lib.pi(Si)))
+        self.Si = Si[:snz.value].copy()
+        # first call of the reference fixes the pattern of S and analyses it once (misc.py:1422-1432)
+        self.fac = Factor(n, self.Sp, self.Si, "L", None, chol_opts)
+        self.G = SpMatDev(ml, n, Gp, Gi, Gx)
+        self.w = DVec(ml)
+        self.t = DVec(ml)
+        self.Sx = DVec(self.Si.size)
+        self.di = None
+        self.nfactor = 0
+
+    def __del__(self):
+        if getattr(self, "_plan", None):
+            lib().kvx_atda_free(self._plan)
+            self._plan = None
+
+    def factor(self, di):
+        """S = G' diag(di)^2 G on the fixed pattern, numeric refactorisation (misc.py:1418-1462).
+        Raises ArithmeticError when S is not positive definite."""
+        self.w.sqr_of(di)
+        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr, None, self.Sx.ptr))
+        self.fac.factorize_dev(self.Sx.ptr, sync=True)
+        self.di = di
+        self.nfactor += 1
+
+    def solve(self, x, z):
+        """Overwrites (x, z) with (ux, W*uz) (misc.py:1489-1563 with p = 0)."""
+        di = self.di
+        z.mul(di)                                        # z := W^{-1} z                (misc.py:1513)
+        self.t.xmy(1.0, di, z)                           # t := di .* z
+        self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)   # x += Gs' z       (misc.py:1524)
+        self.fac.solve_dev(x.ptr, 0, 1, max(1, self.n))  # x := S^{-1} x   (sys 7,4 then 5,8: misc.py:1531-1558)
+        self.G.gemv(x, self.t, trans="N")                # t := G x
+        z.xmy(1.0, di, self.t, -1.0)                     # z := Gs x - z                (misc.py:1563)
+
+
+def conelp(c, G, h, options=None, chol_opts=None):
+    """Solve the inequality-form LP on the GPU.  c: (n,), h: (ml,), G: spmatrix-like (ml x n, sparse).
+    Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
+    _lib.require_device()
+    opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
+    opts.update(options or {})
+    MAXITERS, ABSTOL, RELTOL, FEASTOL = opts["maxiters"], opts["abstol"], opts["reltol"], opts["feastol"]
+    show = opts["show_progress"]
+    ml, n, Gp, Gi, Gx = base._as_ccs(G)
+    c_h = np.asarray(c._a if isinstance(c, base.matrix) else c, dtype=np.float64).reshape(-1)
+    h_h = np.asarray(h._a if isinstance(h, base.matrix) else h, dtype=np.float64).reshape(-1)
+    if c_h.size != n or h_h.size != ml:
+        raise TypeError("dimensions of c, G, h do not match")
+    if ml < n:
+        raise ValueError("Rank(A) < p or Rank([G; A]) < n")          # coneprog.py:572-573 with p = 0
+
+    kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+    Gd = kkt.G
+    cv, hv = DVec(n, c_h), DVec(ml, h_h)
+    x, dx, x1, rx, hrx = (DVec(n) for _ in range(5))
+    s, z, ds, dz, z1, rz, hrz, th, ws3, tmp, lmbda, lmbdasq, d, di = (DVec(ml) for _ in range(14))
+
+    resx0 = max(1.0, cv.nrm2())
+    resy0 = 1.0
+    resz0 = max(1.0, hv.nrm2())
+
+    def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True):
+        return {"x": x.get() if xs else None, "y": np.zeros(0) if zs else None,
+                "s": s.get() if xs else None, "z": z.get() if zs else None,
+                "status": status, "gap": gap, "relative gap": relgap,
+                "primal objective": pcost, "dual objective": dcost,
+                "primal infeasibility": pres, "dual infeasibility": dres,
+                "primal slack": -s.max_step() if xs else None, "dual slack": -z.max_step() if zs else None,
+                "residual as primal infeasibility certificate": pinfres,
+                "residual as dual infeasibility certificate": dinfres,
+                "iterations": iters, "factorizations": kkt.nfactor}
+
+    # ---- starting point (coneprog.py:662-822): factor with W = I ------------------------------------
+    d.fill(1.0); di.fill(1.0)
+    try:
+        kkt.factor(di)
+    except ArithmeticError:
+        raise ValueError("Rank(A) < p or Rank([G; A]) < n")
+    x.fill(0.0); s.copy_from(hv)
+    kkt.solve(x, s)
+    s.scal(-1.0)
+    ts = s.max_step()
+    dx.copy_from(cv).scal(-1.0); z.fill(0.0)
+    kkt.solve(dx, z)
+    tz = z.max_step()
+    nrms, nrmz = s.nrm2(), z.nrm2()
+    gap = s.dot(z)
+    pcost = cv.dot(x)
+    dcost = -hv.dot(z)
+    relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
+    if ts <= 0 and tz <= 0 and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL)):
+        rx.copy_from(cv); Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
+        resx = rx.nrm2()
+        Gd.gemv(x, rz, trans="N"); rz.axpy(s); rz.axpy(hv, -1.0)
+        resz = rz.nrm2()
+        return result("optimal", 0, gap, relgap, pcost, dcost, max(0.0, resz / resz0), resx / resx0, None, None)
+    if ts >= -1e-8 * max(nrms, 1.0):
+        s.addc(1.0 + ts)
+    if tz >= -1e-8 * max(nrmz, 1.0):
+        z.addc(1.0 + tz)
+
+    tau, kappa = 1.0, 1.0
+    gap = s.dot(z)
+    dg = dgi = lmbda_g = 1.0
+    for iters in range(MAXITERS + 1):
+        # residuals (coneprog.py:861-896)
+        Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=0.0)
+        hresx = hrx.nrm2()
+        rx.copy_from(hrx).axpy(cv, -tau)
+        resx = rx.nrm2() / tau
+        hresy = resy = 0.0
+        Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
+        hresz = hrz.nrm2()
+        rz.copy_from(hrz).axpy(hv, -tau)
+        resz = rz.nrm2() / tau
+        cx, by, hz = cv.dot(x), 0.0, hv.dot(z)
+        rt = kappa + cx + by + hz
+        pcost, dcost = cx / tau, -(by + hz) / tau
+        relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
+        pres = max(resy / resy0, resz / resz0)
+        dres = resx / resx0
+        pinfres = hresx / resx0 / (-hz - by) if hz + by < 0.0 else None
+        dinfres = max(hresy / resy0, hresz / resz0) / (-cx) if cx < 0.0 else None
+        if show:
+            if iters == 0:
+                print("% 10s% 12s% 10s% 8s% 7s % 5s" % ("pcost", "dcost", "gap", "pres", "dres", "k/t"))
+            print("%2d: % 8.4e % 8.4e % 4.0e% 7.0e% 7.0e% 7.0e" % (iters, pcost, dcost, gap, pres, dres, kappa / tau))
+
+        if (pres <= FEASTOL and dres <= FEASTOL and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL))) \
+                or iters == MAXITERS:
+            x.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+            if iters == MAXITERS:
+                return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+            return result("optimal", iters, gap, relgap, pcost, dcost, pres, dres, None, None)
+        elif pinfres is not None and pinfres <= FEASTOL:
+            z.scal(1.0 / (-hz - by))
+            return result("primal infeasible", iters, None, None, None, 1.0, None, None, pinfres, None, xs=False)
+        elif dinfres is not None and dinfres <= FEASTOL:
+            x.scal(1.0 / (-cx)); s.scal(1.0 / (-cx))
+            return result("dual infeasible", iters, None, None, -1.0, None, None, None, None, dinfres, zs=False)
+
+        # NT scaling at the first iteration (coneprog.py:1031-1043 -> misc.py:284-287)
+        if iters == 0:
+            raise_for(lib().kvx_nt_compute_scaling_dev(ml, s.ptr, z.ptr, d.ptr, di.ptr, lmbda.ptr))
+            dg = math.sqrt(kappa / tau)
+            dgi = math.sqrt(tau / kappa)
+            lmbda_g = math.sqrt(tau * kappa)
+        lmbdasq.sqr_of(lmbda)
+        lmbdasq_g = lmbda_g ** 2
+
+        # factor + first solve (coneprog.py:1066-1077)
+        try:
+            kkt.factor(di)
+            x1.copy_from(cv).scal(-1.0)
+            z1.copy_from(hv)
+            kkt.solve(x1, z1)
+            x1.scal(dgi); z1.scal(dgi)
+        except ArithmeticError:
+            x.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+        th.copy_from(hv).mul(di)                         # th = W^{-T} h      (coneprog.py:1126-1128)
+        z1z1 = z1.dot(z1)
+
+        mu = (lmbda.dot(lmbda) + lmbda_g ** 2) / (1 + ml)
+        sigma = 0.0
+        wkappa3 = 0.0
+        for i in (0, 1):
+            # right-hand side of the Newton system (coneprog.py:1250-1298)
+            ds.copy_from(lmbdasq)
+            dkappa = lmbdasq_g
+            if i == 1:
+                ds.axpy(ws3).addc(-sigma * mu)
+                dkappa += wkappa3 - sigma * mu
+            dx.copy_from(rx).scal(1.0 - sigma)
+            dz.copy_from(rz).scal(1.0 - sigma)
+            dtau = (1.0 - sigma) * rt
+            # f6_no_ir (coneprog.py:1130-1195)
+            ds.div(lmbda).scal(-1.0)                     # s := -lmbda o\ s
+            tmp.xmy(1.0, ds, d)                          # W^T * s
+            dz.axpy(tmp).scal(-1.0)                      # z := -(z + W^T s)
+            kkt.solve(dx, dz)
+            dkappa = -dkappa / lmbda_g
+            dtau += dkappa / dgi
+            dtau = dgi * (dtau + cv.dot(dx) + 0.0 + th.dot(dz)) / (1.0 + z1z1)
+            dx.axpy(x1, dtau)
+            dz.axpy(z1, dtau)
+            ds.axpy(dz, -1.0)
+            dkappa -= dtau
+            if i == 0:
+                ws3.xmy(1.0, ds, dz)                     # ds o dz for the corrector   (coneprog.py:1303-1306)
+                wkappa3 = dtau * dkappa
+            # step length (coneprog.py:1314-1333)
+            ds.div(lmbda); dz.div(lmbda)
+            ts, tz = ds.max_step(), dz.max_step()
+            tt = -dtau / lmbda_g
+            tk = -dkappa / lmbda_g
+            t = max(0.0, ts, tz, tt, tk)
+            if t == 0.0:
+                step = 1.0
+            else:
+                step = min(1.0, 1.0 / t) if i == 0 else min(1.0, STEP / t)
+            if i == 0:
+                sigma = (1.0 - step) ** EXPON
+
+        # update (coneprog.py:1336-1436)
+        x.axpy(dx, step)
+        ds.scal(step).addc(1.0); dz.scal(step).addc(1.0)
+        ds.mul(lmbda); dz.mul(lmbda)
+        raise_for(lib().kvx_nt_update_scaling_dev(ml, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr))
+        dg *= math.sqrt(1.0 - step * tk) / math.sqrt(1.0 - step * tt)
+        dgi = 1.0 / dg
+        lmbda_g *= math.sqrt(1.0 - step * tt) * math.sqrt(1.0 - step * tk)
+        s.xmy(1.0, lmbda, d)
+        z.xmy(1.0, lmbda, di)
+        kappa, tau = lmbda_g / dgi, lmbda_g * dgi
+        gap = (lmbda.nrm2() / tau) ** 2
+    raise AssertionError("unreachable")

@@ -1,0 +1,235 @@
+"""Generates tests/golden/*.npz|json from the REFERENCE itself (run in the build container only;
+/root/reference does not exist on the GPU box, the fixtures it writes travel instead).
+
+What runs:
+  * the reference's in-tree C extensions (base, blas, lapack, misc_solvers) built from the sources
+    where they lie by oracle/build_ref.sh into oracle/_ref/ (git-ignored), and the reference's own
+    src/python/*.py, staged by SYMLINK under /tmp/kvx_ref_stage/kvxopt (never copied into the repo);
+  * `kvxopt.cholmod` cannot be built here (SuiteSparse CHOLMOD is absent from the image).  For the
+    fixtures that exercise misc.kkt_chol2's sparse branch and conelp with sparse G, the staging
+    package gets a TEST DOUBLE for that one module backed by the CPU oracle (oracle/kvx_oracle.c,
+    itself pinned on the reference's documented known answers).  Fixtures produced that way are
+    tagged "via": "reference python + oracle cholesky"; the pure-reference ones (dense-G LAPACK
+    branch, misc_solvers C kernels, base.gemm/syrk) are tagged "via": "reference".
+
+Only numbers are written: inputs and expected outputs.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+STAGE = "/tmp/kvx_ref_stage"
+sys.path.insert(0, ROOT)
+
+
+def stage():
+    subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "build_ref.sh")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libkvxoracle.so"])
+    import shutil
+    pkg = os.path.join(STAGE, "kvxopt")
+    shutil.rmtree(pkg, ignore_errors=True)
+    os.makedirs(pkg)
+    for f in os.listdir(os.path.join(ROOT, "oracle", "_ref")):
+        if f.endswith(".so"):
+            os.symlink(os.path.join(ROOT, "oracle", "_ref", f), os.path.join(pkg, f))
+    for f in os.listdir(os.path.join(REF, "src", "python")):
+        if f.endswith(".py"):
+            os.symlink(os.path.join(REF, "src", "python", f), os.path.join(pkg, f))
+    os.symlink(os.path.join(HERE, "ref_cholmod_shim.py"), os.path.join(pkg, "cholmod.py"))
+    sys.path.insert(0, STAGE)
+
+
+def tolist(m):
+    return np.array(list(m), dtype=float)
+
+
+def g1_nt_scaling(kx):
+    """NT-scaling 'l' ops of misc.py / misc_solvers.c on seeded inputs."""
+    from kvxopt import matrix, misc, misc_solvers
+    out = {}
+    for ml in (1, 7, 1000):
+        rng = np.random.default_rng(100 + ml)
+        s = rng.uniform(0.1, 3.0, ml); z = rng.uniform(0.1, 3.0, ml)
+        dims = {"l": ml, "q": [], "s": []}
+        lm = matrix(0.0, (ml, 1))
+        W = misc.compute_scaling(matrix(s), matrix(z), lm, dims)
+        case = {"s": s, "z": z, "d": tolist(W["d"]), "di": tolist(W["di"]), "lmbda": tolist(lm)}
+        # scale: 1 and 3 columns, all trans/inverse combinations
+        X = rng.standard_normal((ml, 3))
+        for tr in "NT":
+            for inv in "NI":
+                x = matrix(X.copy(order="F"))
+                misc_solvers.scale(x, W, trans=tr, inverse=inv)
+                case["scale_%s%s" % (tr, inv)] = np.array(x)
+        case["X"] = X
+        x1 = rng.standard_normal(ml); y1 = rng.uniform(0.5, 2.0, ml)
+        for name, fn in (("scale2_N", lambda a: misc_solvers.scale2(lm, a, dims)),
+                         ("scale2_I", lambda a: misc_solvers.scale2(lm, a, dims, inverse="I")),
+                         ("sprod", lambda a: misc_solvers.sprod(a, matrix(y1), dims)),
+                         ("sinv", lambda a: misc_solvers.sinv(a, matrix(y1), dims))):
+            a = matrix(x1.copy()); fn(a); case[name] = tolist(a)
+        a = matrix(0.0, (ml, 1)); misc.ssqr(a, matrix(x1), dims); case["ssqr"] = tolist(a)
+        case["x1"] = x1; case["y1"] = y1
+        case["sdot"] = np.array(misc_solvers.sdot(matrix(x1), matrix(y1), dims))
+        case["max_step"] = np.array(misc_solvers.max_step(matrix(x1), dims))
+        # update_scaling (in place)
+        ds = rng.uniform(0.2, 2.0, ml); dz = rng.uniform(0.2, 2.0, ml)
+        W2 = {"d": matrix(tolist(W["d"])), "di": matrix(tolist(W["di"])), "v": [], "beta": [], "r": [], "rti": []}
+        lm2 = matrix(tolist(lm)); ms, mz = matrix(ds.copy()), matrix(dz.copy())
+        misc.update_scaling(W2, lm2, ms, mz)
+        case.update({"us_ds": ds, "us_dz": dz, "us_s": tolist(ms), "us_z": tolist(mz), "us_d": tolist(W2["d"]),
+                     "us_di": tolist(W2["di"]), "us_lmbda": tolist(lm2)})
+        for k, v in case.items():
+            out["ml%d_%s" % (ml, k)] = v
+    np.savez_compressed(os.path.join(HERE, "g1_nt_scaling.npz"), **out)
+
+
+def ccs(A):
+    cp, ri, v = A.CCS
+    return np.array(list(cp), dtype=np.int64), np.array(list(ri), dtype=np.int64), np.array(list(v), dtype=float)
+
+
+def rand_sparse(rng, m, n, dens):
+    from kvxopt import spmatrix
+    mask = rng.random((m, n)) < dens
+    for j in range(n):
+        mask[rng.integers(m), j] = True
+    for i in range(m):
+        if not mask[i].any():
+            mask[i, rng.integers(n)] = True
+    I, J = np.nonzero(mask)
+    V = rng.standard_normal(I.size)
+    return spmatrix(V.tolist(), I.tolist(), J.tolist(), (m, n))
+
+
+def g2_assembly():
+    """base.gemm(spdiag(di), G, Gs, partial=True); base.syrk full and partial; S += H."""
+    from kvxopt import base, matrix, spmatrix
+    rng = np.random.default_rng(202)
+    G = rand_sparse(rng, 40, 12, 0.15)
+    di = rng.uniform(0.5, 2.0, 40)
+    Gs = spmatrix(0.0, G.I, G.J, G.size)
+    base.gemm(spmatrix(matrix(di), list(range(40)), list(range(40))), G, Gs, partial=True)
+    S = spmatrix([], [], [], (12, 12), "d")
+    base.syrk(Gs, S, trans="T")
+    out = {}
+    out["G_cp"], out["G_ri"], out["G_v"] = ccs(G)
+    out["di"] = di
+    out["Gs_v"] = ccs(Gs)[2]
+    out["S_cp"], out["S_ri"], out["S_v"] = ccs(S)
+    di2 = rng.uniform(0.5, 2.0, 40)
+    base.gemm(spmatrix(matrix(di2), list(range(40)), list(range(40))), G, Gs, partial=True)
+    base.syrk(Gs, S, trans="T", partial=True)
+    out["di2"] = di2
+    out["S2_v"] = ccs(S)[2]
+    H = spmatrix([1.0, 2.0, 0.5, 3.0], [0, 5, 11, 11], [0, 2, 3, 11], (12, 12))
+    S += H
+    out["H_cp"], out["H_ri"], out["H_v"] = ccs(H)
+    out["SH_cp"], out["SH_ri"], out["SH_v"] = ccs(S)
+    np.savez_compressed(os.path.join(HERE, "g2_assembly.npz"), **out)
+
+
+def g3_kkt():
+    """misc.kkt_chol2 factor/solve triples: dense-G branch (pure reference, LAPACK) and sparse-G branch
+    (reference python + oracle cholesky); p = 0 and p > 0."""
+    from kvxopt import matrix, misc, spmatrix
+    out = {}
+    for tag, p in (("p0", 0), ("p3", 3)):
+        rng = np.random.default_rng(303 + p)
+        ml, n = 30, 8
+        G = rand_sparse(rng, ml, n, 0.25)
+        A = rand_sparse(rng, p, n, 0.5) if p else spmatrix([], [], [], (0, n))
+        dims = {"l": ml, "q": [], "s": []}
+        d = rng.uniform(0.5, 2.0, ml)
+        W = {"d": matrix(d), "di": matrix(1.0 / d), "v": [], "beta": [], "r": [], "rti": []}
+        bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(ml)
+        res = {}
+        for branch, Gm, Am in (("dense", matrix(G), matrix(A) if p else matrix(0.0, (0, n))), ("sparse", G, A)):
+            f = misc.kkt_chol2(Gm, dims, Am)
+            # first call with W = I (as conelp does), then the real W: exercises the fixed-pattern refactor
+            W1 = {"d": matrix(1.0, (ml, 1)), "di": matrix(1.0, (ml, 1)), "v": [], "beta": [], "r": [], "rti": []}
+            f(W1)
+            solve = f(W)
+            x, y, z = matrix(bx.copy()), matrix(by.copy()) if p else matrix(0.0, (0, 1)), matrix(bz.copy())
+            solve(x, y, z)
+            res[branch] = (tolist(x), tolist(y), tolist(z))
+        assert np.allclose(res["dense"][0], res["sparse"][0], rtol=1e-9, atol=1e-11), "branches disagree"
+        assert np.allclose(res["dense"][2], res["sparse"][2], rtol=1e-9, atol=1e-11)
+        out[tag + "_G_cp"], out[tag + "_G_ri"], out[tag + "_G_v"] = ccs(G)
+        if p:
+            out[tag + "_A_cp"], out[tag + "_A_ri"], out[tag + "_A_v"] = ccs(A)
+        out[tag + "_d"] = d
+        out[tag + "_bx"], out[tag + "_by"], out[tag + "_bz"] = bx, by, bz
+        out[tag + "_x"], out[tag + "_y"], out[tag + "_z"] = res["dense"]          # pure reference result
+        out[tag + "_xs"], out[tag + "_ys"], out[tag + "_zs"] = res["sparse"]
+    np.savez_compressed(os.path.join(HERE, "g3_kkt_chol2.npz"), **out)
+
+
+def g4_conelp():
+    """conelp traces: structured grid LPs of SURVEY 8(d) config 4b (scaled down) and infeasible cases."""
+    from kvxopt import matrix, solvers, spmatrix, misc
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    out = {}
+    meta = {}
+    cases = [("grid6x5", workloads.lp_grid(6, 5)), ("grid25x20", workloads.lp_grid(25, 20))]
+    for name, P in cases:
+        ml, n = P["ml"], P["n"]
+        cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
+        G = spmatrix(P["Gx"].tolist(), P["Gi"].tolist(), cols.tolist(), (ml, n))
+        c, h = matrix(P["c"]), matrix(P["h"])
+        dvals = []
+        dims = {"l": ml, "q": [], "s": []}
+        A0 = spmatrix([], [], [], (0, n))
+        fac = misc.kkt_chol2(matrix(G), dims, matrix(0.0, (0, n)))
+
+        def kktsolver(W, fac=fac, dvals=dvals):
+            dvals.append(tolist(W["d"]))
+            return fac(W)
+        sol_d = solvers.conelp(c, matrix(G), h, kktsolver=kktsolver)        # pure reference (dense branch)
+        sol_s = solvers.conelp(c, G, h)                                     # reference python + oracle cholesky
+        assert sol_d["status"] == sol_s["status"] == "optimal"
+        assert sol_d["iterations"] == sol_s["iterations"]
+        assert np.allclose(tolist(sol_d["x"]), tolist(sol_s["x"]), rtol=1e-7, atol=1e-9)
+        out[name + "_x"] = tolist(sol_d["x"]); out[name + "_s"] = tolist(sol_d["s"]); out[name + "_z"] = tolist(sol_d["z"])
+        out[name + "_d_per_iter"] = np.array(dvals[1:])       # W['d'] handed to kktsolver at every iteration
+        meta[name] = {k: sol_d[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective",
+                                           "dual objective", "primal infeasibility", "dual infeasibility")}
+        meta[name]["iterations_sparse_branch"] = sol_s["iterations"]
+    # primal infeasible: x >= 1 and x <= 0 ;  dual infeasible (unbounded): minimise -x st -x <= 0
+    G = spmatrix([-1.0, 1.0], [0, 1], [0, 0], (2, 1))
+    sol = solvers.conelp(matrix([1.0]), G, matrix([-1.0, 0.0]))
+    meta["primal_infeasible"] = {"status": sol["status"], "iterations": sol["iterations"],
+                                 "z": list(sol["z"]), "residual": sol["residual as primal infeasibility certificate"]}
+    G = spmatrix([-1.0, -1.0], [0, 1], [0, 1], (2, 2))
+    sol = solvers.conelp(matrix([-1.0, 0.5]), G, matrix([0.0, 0.0]))
+    meta["dual_infeasible"] = {"status": sol["status"], "iterations": sol["iterations"], "x": list(sol["x"]),
+                               "residual": sol["residual as dual infeasibility certificate"]}
+    # the documentation LP (examples/doc/chap8/lp.py; tests/test_examples.py:31-34 expects x = [1, 1])
+    c = matrix([-4., -5.]); Gd = matrix([[2., 1., -1., 0.], [1., 2., 0., -1.]]); h = matrix([3., 3., 0., 0.])
+    from kvxopt import sparse
+    sol = solvers.conelp(c, sparse(Gd), h)
+    meta["doc_lp"] = {"status": sol["status"], "iterations": sol["iterations"], "x": list(sol["x"]),
+                      "primal objective": sol["primal objective"]}
+    np.savez_compressed(os.path.join(HERE, "g4_conelp.npz"), **out)
+    json.dump({"via": {"*_x/_s/_z/_d_per_iter": "reference (dense-G LAPACK branch), cross-checked against "
+                       "reference python + oracle cholesky (sparse branch)",
+                       "primal_infeasible/dual_infeasible/doc_lp": "reference python + oracle cholesky"},
+               "cases": meta}, open(os.path.join(HERE, "g4_conelp.json"), "w"), indent=1, default=float)
+
+
+if __name__ == "__main__":
+    stage()
+    import kvxopt
+    print("reference kvxopt", kvxopt.__version__)
+    g1_nt_scaling(kvxopt)
+    g2_assembly()
+    g3_kkt()
+    g4_conelp()
+    print("goldens written to", HERE)

@@ -1,0 +1,235 @@
+"""GPU parity of the KKT-step pieces around the Cholesky factor -- NT scaling, normal-equations
+assembly, sparse mat-vec, misc.kkt_chol2 and the device-resident LP driver -- against golden vectors
+generated from the REFERENCE (tests/golden/make_goldens.py) and against the CPU oracle.
+
+Floating-point tolerance: elementwise kernels are compared to 1e-14 relative (identical formulas,
+one rounding each); assembled sums / solves to 1e-10 relative (BASELINE.json north_star bar)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from kvxopt_amd import _lib, base, cholmod, lp, misc, workloads
+from kvxopt_amd.base import matrix, spmatrix
+from oracle import kvx_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    _lib.require_device()
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300) if a.size else 0.0
+
+
+def W_of(d, di):
+    return {"d": matrix(d), "di": matrix(di), "v": [], "beta": [], "r": [], "rti": []}
+
+
+@pytest.mark.parametrize("ml", [1, 7, 1000])
+def test_nt_scaling_golden(golden_dir, ml):
+    """G1: misc.compute_scaling / update_scaling / ssqr and misc_solvers.scale / scale2 / sprod / sinv /
+    sdot / max_step of the reference on seeded inputs."""
+    g = np.load(os.path.join(golden_dir, "g1_nt_scaling.npz"))
+    k = lambda name: g["ml%d_%s" % (ml, name)]
+    dims = {"l": ml, "q": [], "s": []}
+    lm = matrix(0.0, (ml, 1))
+    W = misc.compute_scaling(matrix(k("s")), matrix(k("z")), lm, dims)
+    assert rel(W["d"]._a, k("d")) < 1e-14 and rel(W["di"]._a, k("di")) < 1e-14 and rel(lm._a, k("lmbda")) < 1e-14
+    for tr in "NT":
+        for inv in "NI":
+            x = matrix(k("X").copy(order="F"))
+            misc.scale(x, W, trans=tr, inverse=inv)
+            assert rel(x.a, k("scale_%s%s" % (tr, inv))) < 1e-14
+    x1, y1 = k("x1"), k("y1")
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims); assert rel(a._a, k("scale2_N")) < 1e-14
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, inverse="I"); assert rel(a._a, k("scale2_I")) < 1e-14
+    a = matrix(x1.copy()); misc.sprod(a, matrix(y1), dims); assert rel(a._a, k("sprod")) < 1e-14
+    a = matrix(x1.copy()); misc.sinv(a, matrix(y1), dims); assert rel(a._a, k("sinv")) < 1e-14
+    a = matrix(0.0, (ml, 1)); misc.ssqr(a, matrix(x1), dims); assert rel(a._a, k("ssqr")) < 1e-14
+    assert abs(misc.sdot(matrix(x1), matrix(y1), dims) - float(k("sdot"))) <= 1e-12 * max(1.0, abs(float(k("sdot"))))
+    assert misc.max_step(matrix(x1), dims) == float(k("max_step"))
+    W2 = W_of(k("d").copy(), k("di").copy())
+    lm2, ms, mz = matrix(k("lmbda").copy()), matrix(k("us_ds").copy()), matrix(k("us_dz").copy())
+    misc.update_scaling(W2, lm2, ms, mz)
+    for got, name in ((ms, "us_s"), (mz, "us_z"), (W2["d"], "us_d"), (W2["di"], "us_di"), (lm2, "us_lmbda")):
+        assert rel(got._a, k(name)) < 1e-14, name
+
+
+def test_assembly_golden(golden_dir):
+    """G2: base.gemm(spdiag(di), G, Gs, partial=True), base.syrk full + partial, S += H."""
+    g = np.load(os.path.join(golden_dir, "g2_assembly.npz"))
+    G = spmatrix.from_ccs(40, 12, g["G_cp"], g["G_ri"], g["G_v"])
+    Gs = spmatrix.from_ccs(40, 12, g["G_cp"].copy(), g["G_ri"].copy(), np.zeros(g["G_v"].size))
+    base.gemm(base.spdiag(matrix(g["di"])), G, Gs, partial=True)
+    assert rel(Gs.values, g["Gs_v"]) < 1e-15
+    S = spmatrix([], [], [], (12, 12))
+    base.syrk(Gs, S, trans="T")
+    assert np.array_equal(S.colptr, g["S_cp"]) and np.array_equal(S.rowind, g["S_ri"])      # same pattern as the reference
+    assert rel(S.values, g["S_v"]) < 1e-13
+    base.gemm(base.spdiag(matrix(g["di2"])), G, Gs, partial=True)
+    base.syrk(Gs, S, trans="T", partial=True)
+    assert rel(S.values, g["S2_v"]) < 1e-13
+    S += spmatrix.from_ccs(12, 12, g["H_cp"], g["H_ri"], g["H_v"])
+    assert np.array_equal(S.colptr, g["SH_cp"]) and np.array_equal(S.rowind, g["SH_ri"]) and rel(S.values, g["SH_v"]) < 1e-13
+
+
+@pytest.mark.parametrize("tag,p", [("p0", 0), ("p3", 3)])
+def test_kkt_chol2_golden(golden_dir, tag, p):
+    """G3: misc.kkt_chol2(G, dims, A): first call with W = I (fixes the pattern), second call with the
+    real scaling (numeric refactor on the same symbolic), then one solve -- against the reference's
+    dense-G LAPACK branch (pure reference) on the same inputs.  p = 0 exercises the 0 x 0 K path."""
+    g = np.load(os.path.join(golden_dir, "g3_kkt_chol2.npz"))
+    ml, n = 30, 8
+    G = spmatrix.from_ccs(ml, n, g[tag + "_G_cp"], g[tag + "_G_ri"], g[tag + "_G_v"])
+    A = spmatrix.from_ccs(p, n, g[tag + "_A_cp"], g[tag + "_A_ri"], g[tag + "_A_v"]) if p else spmatrix([], [], [], (0, n))
+    dims = {"l": ml, "q": [], "s": []}
+    f = misc.kkt_chol2(G, dims, A)
+    f(W_of(np.ones(ml), np.ones(ml)))
+    solve = f(W_of(g[tag + "_d"].copy(), 1.0 / g[tag + "_d"]))
+    x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
+    solve(x, y, z)
+    assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
+    if p:
+        assert rel(y._a, g[tag + "_y"]) < 1e-10
+
+
+def test_kkt_chol2_rejects_other_cones():
+    with pytest.raises(ValueError):
+        misc.kkt_chol2(spmatrix([1.0], [0], [0], (3, 1)), {"l": 0, "q": [3], "s": []}, spmatrix([], [], [], (0, 1)))
+
+
+def test_atda_and_spmv_vs_oracle():
+    """Bigger assembly / mat-vec against the CPU oracle (row scale + partial syrk of sparse.c)."""
+    P = workloads.lp_grid(40, 30)
+    ml, n = P["ml"], P["n"]
+    rng = np.random.default_rng(9)
+    di = rng.uniform(0.3, 3.0, ml)
+    kkt = lp.KKTChol2Dev(ml, n, P["Gp"], P["Gi"], P["Gx"])
+    dv = lp.DVec(ml, di)
+    kkt.factor(dv)
+    Sx = kkt.Sx.get()
+    Gs, Sref = orc.atda(ml, n, P["Gp"], P["Gi"], P["Gx"], di, kkt.Sp, kkt.Si)
+    assert rel(Sx, Sref) < 1e-13
+    x = rng.standard_normal(n); y = rng.standard_normal(ml)
+    yd, xd = lp.DVec(ml, y), lp.DVec(n, x)
+    kkt.G.gemv(xd, yd, trans="N", alpha=2.0, beta=-0.5)
+    yo = y.copy(); orc.spmv("N", ml, n, P["Gp"], P["Gi"], P["Gx"], x, yo, 2.0, -0.5)
+    assert rel(yd.get(), yo) < 1e-13
+    kkt.G.gemv(yd, xd, trans="T", alpha=-1.0, beta=1.0)
+    xo = x.copy(); orc.spmv("T", ml, n, P["Gp"], P["Gi"], P["Gx"], yo, xo, -1.0, 1.0)
+    assert rel(xd.get(), xo) < 1e-12
+    # KKT solve against a dense solve of the full KKT system
+    bx, bz = rng.standard_normal(n), rng.standard_normal(ml)
+    xv, zv = lp.DVec(n, bx), lp.DVec(ml, bz)
+    kkt.solve(xv, zv)
+    Gd = np.zeros((ml, n)); Gd[P["Gi"], np.repeat(np.arange(n), np.diff(P["Gp"]))] = P["Gx"]
+    d = 1.0 / di
+    K = np.block([[np.zeros((n, n)), Gd.T], [Gd, -np.diag(d * d)]])
+    sol = np.linalg.solve(K, np.concatenate([bx, bz]))
+    assert rel(xv.get(), sol[:n]) < 1e-9 and rel(zv.get(), d * sol[n:]) < 1e-9
+
+
+@pytest.mark.parametrize("name,gx,gy", [("grid6x5", 6, 5), ("grid25x20", 25, 20)])
+def test_conelp_golden(golden_dir, name, gx, gy):
+    """G4: the reference's conelp on the structured grid LP (config 4b generator): same iteration
+    count, same NT scaling at every iteration, same solution."""
+    g = np.load(os.path.join(golden_dir, "g4_conelp.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_conelp.json")))["cases"][name]
+    P = workloads.lp_grid(gx, gy)
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    sol = lp.conelp(P["c"], G, P["h"])
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    assert rel(sol["x"], g[name + "_x"]) < 1e-7 and rel(sol["s"], g[name + "_s"]) < 1e-6 and rel(sol["z"], g[name + "_z"]) < 1e-6
+    assert abs(sol["primal objective"] - meta["primal objective"]) < 1e-7 * max(1.0, abs(meta["primal objective"]))
+    assert sol["factorizations"] == meta["iterations"] + 1           # 1 initial + 1 per iteration, symbolic reused
+
+
+def test_conelp_doc_and_infeasible(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, "g4_conelp.json")))["cases"]
+    # examples/doc/chap8/lp.py (tests/test_examples.py:31-34 expects x = [1, 1] to 5 places)
+    G = spmatrix([2., 1., -1., 1., 2., -1.], [0, 1, 2, 0, 1, 3], [0, 0, 0, 1, 1, 1], (4, 2))
+    sol = lp.conelp(np.array([-4., -5.]), G, np.array([3., 3., 0., 0.]))
+    assert sol["status"] == "optimal" and sol["iterations"] == meta["doc_lp"]["iterations"]
+    assert np.allclose(sol["x"], [1.0, 1.0], atol=1e-5) and np.allclose(sol["x"], meta["doc_lp"]["x"], atol=1e-8)
+    G = spmatrix([-1.0, 1.0], [0, 1], [0, 0], (2, 1))
+    sol = lp.conelp(np.array([1.0]), G, np.array([-1.0, 0.0]))
+    assert sol["status"] == "primal infeasible" and sol["iterations"] == meta["primal_infeasible"]["iterations"]
+    assert np.allclose(sol["z"], meta["primal_infeasible"]["z"], atol=1e-7) and sol["x"] is None
+    G = spmatrix([-1.0, -1.0], [0, 1], [0, 1], (2, 2))
+    sol = lp.conelp(np.array([-1.0, 0.5]), G, np.array([0.0, 0.0]))
+    assert sol["status"] == "dual infeasible" and sol["iterations"] == meta["dual_infeasible"]["iterations"]
+    assert np.allclose(sol["x"], meta["dual_infeasible"]["x"], rtol=1e-6) and sol["z"] is None
+    with pytest.raises(ValueError):                                     # ml < n: Rank([G; A]) < n (coneprog.py:572-573)
+        lp.conelp(np.zeros(3), spmatrix([1.0], [0], [0], (1, 3)), np.ones(1))
+
+
+def test_cholmod_module_api():
+    """Error behaviour and option handling of the kvxopt.cholmod mirror (cholmod.c error macros)."""
+    A = spmatrix([10, 3, 5, -2, 5, 2], [0, 2, 1, 3, 2, 3], [0, 0, 1, 1, 2, 3])     # spsolvers.rst:556
+    X = matrix(np.arange(8.0), (4, 2))
+    cholmod.linsolve(A, X)
+    assert np.allclose(X.a, [[-0.14634146, 0.04878049], [1.33333333, 4.0], [0.48780488, 1.17073171], [2.83333333, 7.5]])
+    F = cholmod.symbolic(A)
+    with pytest.raises(ValueError):
+        cholmod.solve(F, matrix(np.ones(4)))                   # symbolic factor (cholmod.c:452-453)
+    cholmod.numeric(A, F)
+    assert abs(2.0 * np.sum(np.log(cholmod.diag(F)._a)) - 5.50533153593) < 1e-10        # spsolvers.rst:765
+    Xi = cholmod.splinsolve(A, spmatrix(1.0, range(4), range(4)))
+    assert np.allclose(Xi.todense()[0, 0], 1.22e-01, atol=5e-4)
+    L = cholmod.getfactor(F)
+    Ld = L.todense()
+    p = F.fac.perm()
+    Afull = A.todense() + np.tril(A.todense(), -1).T
+    assert np.allclose(Ld @ Ld.T, Afull[np.ix_(p, p)], atol=1e-12)
+    cholmod.options["supernodal"] = 0
+    with pytest.raises(ValueError):
+        cholmod.symbolic(A)
+    cholmod.options.clear()
+    cholmod.options["bogus"] = 1
+    with pytest.raises(ValueError):
+        cholmod.symbolic(A)                                    # cholmod.c:118-124
+    cholmod.options.clear()
+    with pytest.raises(TypeError):
+        cholmod.symbolic(spmatrix([1.0], [0], [0], (2, 3)))
+    with pytest.raises(ValueError):
+        cholmod.symbolic(A, uplo="X")
+    with pytest.raises(ValueError):
+        cholmod.symbolic(A, p=matrix([0, 0, 1, 2], tc="i"))
+    bad = spmatrix([1.0, 2.0, 1.0], [0, 1, 1], [0, 0, 1])
+    Fb = cholmod.symbolic(bad)
+    with pytest.raises(ArithmeticError) as e:
+        cholmod.numeric(bad, Fb)
+    assert e.value.args[0] == 1
+    with pytest.raises(ArithmeticError):
+        cholmod.solve(Fb, matrix(np.ones(2)))
+    with pytest.raises(ValueError):
+        cholmod.diag(Fb)
+
+
+def test_lp_full_size_properties():
+    """BASELINE.json configs[3] (4b, ml = 200 000, n = 50 000): KKT-step properties without an oracle
+    run -- assembled S is SPD and the KKT solve satisfies the reduced system to 1e-10."""
+    P = workloads.lp_grid(250, 200)
+    ml, n = P["ml"], P["n"]
+    rng = np.random.default_rng(4)
+    di = rng.uniform(0.2, 5.0, ml)
+    kkt = lp.KKTChol2Dev(ml, n, P["Gp"], P["Gi"], P["Gx"])
+    kkt.factor(lp.DVec(ml, di))
+    bx, bz = rng.standard_normal(n), rng.standard_normal(ml)
+    xv, zv = lp.DVec(n, bx), lp.DVec(ml, bz)
+    kkt.solve(xv, zv)
+    ux, wz = xv.get(), zv.get()
+    cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
+    Gx_ = np.zeros(ml); np.add.at(Gx_, P["Gi"], P["Gx"] * ux[cols])
+    uz = wz * di                                                   # uz = W^{-1} (W uz)
+    # second block row: G ux - W'W uz = bz
+    assert np.linalg.norm(Gx_ - uz / (di * di) - bz) / np.linalg.norm(bz) < 1e-10
+    Gtz = np.zeros(n); np.add.at(Gtz, cols, P["Gx"] * uz[P["Gi"]])
+    assert np.linalg.norm(Gtz - bx) / np.linalg.norm(bx) < 1e-9   # first block row: G' uz = bx
