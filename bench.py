@@ -48,7 +48,7 @@ def front_stats(F):
     k = np.diff(sup)
     m = nrows
     u = m - k
-    small = m <= 128
+    small = (m <= 128) & (k <= 64)          # wave + LDS kernel classes (symbolic.hpp front_class)
     # children update-matrix entries read by each front = sum over its children of u_c(u_c+1)/2
     child_tri = np.zeros(len(m))
     has_parent = parent >= 0
@@ -58,15 +58,15 @@ def front_stats(F):
     # LDS-front kernel: panel read + write (m*k doubles each), children's lower triangles read,
     # own update lower triangle written, child relative indices (int32) read
     bytes_small = float(np.sum((2 * m * k + child_tri + u * (u + 1) / 2)[small]) * 8 + np.sum(child_u[small]) * 4)
-    # blocked big-front trailing update: sum over panel steps of nbk * t * (t + 1) flops
+    # blocked big-front trailing update: sum over 64-column panel steps of nbk * t * (t + 1) flops
     flops_syrk = 0.0
     for kk, mm in zip(k[~small], m[~small]):
         jb = 0
         while jb < kk:
-            nbk = min(32, kk - jb)
+            nbk = min(64, kk - jb)              # KVX_NB
             t = mm - jb - nbk
             flops_syrk += float(nbk) * t * (t + 1)
-            jb += 32
+            jb += 64
     lsize = float(np.sum(m * k))
     sum_m = float(np.sum(m))
     return {"bytes_small": bytes_small, "flops_syrk": flops_syrk, "lsize": lsize, "sum_m": sum_m,
