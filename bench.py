@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-family", default="auto")
+    ap.add_argument("--chol-opts", default="", help="JSON dict of analysis options (nd_leaf, leaf_cols, leaf_rows, relax_*) for experiments")
+    ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop and the CPU baseline (experiments)")
     return ap.parse_args()
 
 
@@ -94,7 +96,7 @@ def main():
     g = args.grid
     n, colptr, rowind, values = workloads.laplacian_2d(g)
     t0 = time.time()
-    F = Factor(n, colptr, rowind, "L")
+    F = Factor(n, colptr, rowind, "L", None, json.loads(args.chol_opts) if args.chol_opts else None)
     t_analyze = time.time() - t0
     info = F.info()
     nrhs = args.nrhs
@@ -142,13 +144,19 @@ def main():
     # --- roofline leg: dominant kernel family timed live with HIP events on the factor's stream
     st = front_stats(F)
     fam_times = {}
-    for fam in Factor.FAMILIES:
+    for fam in (Factor.FAMILIES if not args.quick else ()):
         F.prof_select(fam)
         for _ in range(2):
             step()
         ms, cnt = F.prof_read()
         fam_times[fam] = (ms / 2.0, cnt // 2)
     F.prof_select(None)
+    if args.quick:
+        if rank == 0:
+            print(json.dumps({"value": work * args.steps * world / dt / 1e9, "ms_per_step": dt / args.steps * 1e3, "ms_factor": ms_factor,
+                              "ms_solve": ms_solve, "rel_residual": relres, "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]),
+                              "lsize": int(info["lsize"]), "opts": args.chol_opts}))
+        return
     dom = max(fam_times, key=lambda f: fam_times[f][0]) if args.roofline_family == "auto" else args.roofline_family
     dom_ms, dom_launches = fam_times[dom]
     if dom == "syrk_trailing":

@@ -73,6 +73,13 @@ struct kvx_chol {
     int *h_status = nullptr;  // pinned
     DevSym ds{};
     std::vector<LevelPlan> plan;
+    // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
+    // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
+    bool use_graph = true;
+    int factor_calls = 0;
+    hipGraphExec_t g_factor = nullptr;
+    struct SolveGraph { int kind; int nrhs; int calls; hipGraphExec_t exec; };
+    std::vector<SolveGraph> g_solve;
     // optional per-kernel-family timing (bench.py roofline leg): HIP events around every launch
     // of ONE selected family on the factor's stream
     int prof_family = -1;
@@ -236,6 +243,7 @@ int ensure_device(kvx_chol *F)
             P.smaxm[g] = std::max(P.smaxm[g], m);
         }
     }
+    { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -244,6 +252,9 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
 {
     if (nrhs <= F->x_cap) return KVX_OK;
     Symbolic &S = F->S;
+    for (auto &g : F->g_solve)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    F->g_solve.clear();                          // the captured sweeps point into the old workspace
     if (F->d_X) { (void)hipFree(F->d_X); F->d_X = nullptr; }
     if (F->d_WK) { (void)hipFree(F->d_WK); F->d_WK = nullptr; }
     for (int p = 0; p < 2; p++)
@@ -269,11 +280,10 @@ int wait_for_caller(kvx_chol *F)
 }
 
 // enqueue the numeric factorisation; d_Ax already holds the values
-int enqueue_factor(kvx_chol *F)
+int enqueue_factor_body(kvx_chol *F)
 {
     Symbolic &S = F->S;
     hipStream_t st = F->stream;
-    HIPCHK(hipEventRecord(F->ev[0], st));
     HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
     HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
     { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
@@ -320,6 +330,40 @@ int enqueue_factor(kvx_chol *F)
         if (fork_wave) { HIPCHK(hipEventRecord(F->ev_join[1], F->side[1])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[1], 0)); }
     }
     HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+// Capture `body` (which enqueues on F->stream and, through events, on the side streams) into an
+// executable graph.  Returns nullptr (and leaves the stream usable) if capture is not possible.
+template <class Body>
+hipGraphExec_t capture_graph(kvx_chol *F, Body body)
+{
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (hipStreamBeginCapture(F->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    int rc = body();
+    hipError_t e = hipStreamEndCapture(F->stream, &graph);
+    if (rc != KVX_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return nullptr; }
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); exec = nullptr; }
+    (void)hipGraphDestroy(graph);
+    return exec;
+}
+
+int enqueue_factor(kvx_chol *F)
+{
+    hipStream_t st = F->stream;
+    HIPCHK(hipEventRecord(F->ev[0], st));
+    const bool graph_ok = F->use_graph && F->prof_family < 0;
+    F->factor_calls++;
+    if (graph_ok && !F->g_factor && F->factor_calls >= 2)
+        F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });
+    if (graph_ok && F->g_factor) {
+        HIPCHK(hipGraphLaunch(F->g_factor, st));
+    } else {
+        int rc = enqueue_factor_body(F);
+        if (rc) return rc;
+    }
     HIPCHK(hipEventRecord(F->ev[1], st));
     HIPCHK(hipGetLastError());
     F->pending = true;
@@ -451,25 +495,33 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
         double *Bc = B + r0 * ldB;
         if ((rc = ensure_solve_ws(F, nr))) return rc;
         HIPCHK(hipEventRecord(F->ev[2], st));
-        switch (sys) {
-        case 0:
-            launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
-            enqueue_fwd(F, F->d_X, n, nr);
-            enqueue_bwd(F, F->d_X, n, nr);
-            launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, Bc, ldB);
-            break;
-        case 1: enqueue_fwd(F, Bc, ldB, nr); enqueue_bwd(F, Bc, ldB, nr); break;
-        case 2: case 4: enqueue_fwd(F, Bc, ldB, nr); break;
-        case 3: case 5: enqueue_bwd(F, Bc, ldB, nr); break;
-        case 7:
-            launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
-            HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
-            break;
-        case 8:
-            launch_perm_scatter(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
-            HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
-            break;
+        // every system is solved on the staging block d_X (n x nr, ld = n): fixed pointers, so the
+        // triangular sweeps can be replayed from a captured graph
+        const int kind = (sys == 0 || sys == 1) ? 0 : ((sys == 2 || sys == 4) ? 1 : ((sys == 3 || sys == 5) ? 2 : -1));
+        if (sys == 0 || sys == 7) launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
+        else if (sys == 8) launch_perm_scatter(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
+        else HIPCHK(hipMemcpy2DAsync(F->d_X, n * sizeof(double), Bc, ldB * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
+        if (kind >= 0) {
+            auto body = [&]() -> int {
+                if (kind == 0 || kind == 1) enqueue_fwd(F, F->d_X, n, nr);
+                if (kind == 0 || kind == 2) enqueue_bwd(F, F->d_X, n, nr);
+                return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
+            };
+            hipGraphExec_t exec = nullptr;
+            if (F->use_graph && F->prof_family < 0) {
+                kvx_chol::SolveGraph *slot = nullptr;
+                for (auto &g : F->g_solve)
+                    if (g.kind == kind && g.nrhs == nr) slot = &g;
+                if (!slot) { F->g_solve.push_back({kind, nr, 0, nullptr}); slot = &F->g_solve.back(); }
+                slot->calls++;
+                if (!slot->exec && slot->calls >= 2 && F->g_solve.size() <= 16) slot->exec = capture_graph(F, body);
+                exec = slot->exec;
+            }
+            if (exec) HIPCHK(hipGraphLaunch(exec, st));
+            else if ((rc = body())) return rc;
         }
+        if (sys == 0) launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, Bc, ldB);
+        else HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(F->ev[3], st));
         HIPCHK(hipGetLastError());
     }
@@ -784,6 +836,9 @@ void kvx_chol_free(kvx_chol *F)
         if (F->h_status) (void)hipHostFree(F->h_status);
         for (int i = 0; i < 4; i++)
             if (F->ev[i]) (void)hipEventDestroy(F->ev[i]);
+        if (F->g_factor) (void)hipGraphExecDestroy(F->g_factor);
+        for (auto &g : F->g_solve)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
         for (hipEvent_t e : F->prof_ev)
             if (e) (void)hipEventDestroy(e);
         for (int i = 0; i < 2; i++) {
