@@ -337,47 +337,125 @@ __global__ __launch_bounds__(256) void k_fwd_big_init(DevSym ds, const int32_t *
     }
 }
 
-// step jb: y_b = Linv_b * w_b (every workgroup recomputes it), x_b := y_b, rows below -= L(:,b) y_b
-__global__ __launch_bounds__(256) void k_fwd_big_step(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                      const double *__restrict__ Lx, const double *__restrict__ Linv,
-                                                      double *__restrict__ X, int64_t ldx,
-                                                      double *__restrict__ WK, int64_t ldw,
-                                                      double *__restrict__ Wo, int64_t wstride)
+// Super-step over up to SB = 256 pivot columns [jb0, jb0 + nb).  The solves of the top fronts are a
+// chain of dependent launches, so the step is built for latency: every workgroup (1024 threads) solves
+// the nb x nb diagonal part redundantly and then updates its own 256 rows below the super-block.
+// All global operands of the diagonal solve -- the four 64 x 64 inverses and the six sub-diagonal
+// 64 x 64 blocks of L, 40 doubles per thread -- are loaded into registers up front (they do not depend
+// on the running vector); the dependent chain  y_s = Linv_s w_s,  w_t -= L(t, s) y_s (t > s)  then
+// runs out of registers and LDS only.  Lane = row, wave = 4 columns; partial sums meet in LDS in a
+// fixed order (bitwise reproducible).
+constexpr int SB = 256;
+constexpr int SOLVE_NT = 1024;
+
+// sub-diagonal block (ib, s), ib > s, of the 4 x 4 block lower triangle -> 0..5
+__device__ __forceinline__ constexpr int sblk(int ib, int s) { return ib * (ib - 1) / 2 + s; }
+
+__global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int32_t *__restrict__ list, int jb0,
+                                                           const double *__restrict__ Lx, const double *__restrict__ Linv,
+                                                           double *__restrict__ X, int64_t ldx,
+                                                           double *__restrict__ WK, int64_t ldw,
+                                                           double *__restrict__ Wo, int64_t wstride)
 {
-    __shared__ double part[4][NB];
-    __shared__ double ysh[NB];
-    const int s = list[blockIdx.y];
-    const int k = ds.k[s], m = ds.m[s], f = ds.first[s], tid = threadIdx.x;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
-    const int rbase = jb + nbk + blockIdx.x * 256;
+    __shared__ double red[3 * 16 * NB];
+    __shared__ double wsh[SB];
+    __shared__ double ysh[SB];
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
+    if (jb0 >= k) return;
+    const int nb = min(SB, k - jb0);
+    const int rbase = jb0 + nb + blockIdx.x * 256;
     if (blockIdx.x > 0 && rbase >= m) return;
-    const double *P = Lx + ds.px[s];
-    const double *Y = Linv + ds.linv[s] + (int64_t)(jb / NB) * NB * NB;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *P = Lx + fd.px;
+    const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
     double *x = X + (int64_t)blockIdx.z * ldx + f;
     double *wk = WK + (int64_t)blockIdx.z * ldw + f;
-    double *wo = Wo + (int64_t)blockIdx.z * wstride + ds.wx[s];
-    {
-        const int i = tid & 63, q = tid >> 6;
-        double acc = 0.0;
-        if (i < nbk)
-            for (int p = q; p <= i; p += 4) acc += Y[i + p * NB] * wk[jb + p];
-        part[q][i] = acc;
+    double *wo = Wo + (int64_t)blockIdx.z * wstride + fd.wx;
+    const int nsub = (nb + NB - 1) / NB;
+
+    double yI[4][4], lB[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int p = 4 * w + c;
+            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + p * NB, s * NB + lane < nb && p <= lane);
+        }
+#pragma unroll
+    for (int ib = 1; ib < 4; ib++)
+#pragma unroll
+        for (int s = 0; s < ib; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                             ib * NB + lane < nb);
+    if (tid < SB) {
+        wsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
+        ysh[tid] = 0.0;
     }
     __syncthreads();
-    if (tid < NB) {
-        const double y = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        ysh[tid] = y;
-        if (blockIdx.x == 0 && tid < nbk) x[jb + tid] = y;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (s < nsub) {
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) part = __builtin_fma(yI[s][c], wsh[s * NB + 4 * w + c], part);
+            red[w * NB + lane] = part;
+            __syncthreads();
+            if (tid < NB) {
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) t += red[q * NB + tid];
+                ysh[s * NB + tid] = t;
+            }
+            __syncthreads();
+            if (s + 1 < nsub) {
+#pragma unroll
+                for (int ib = s + 1; ib < 4; ib++) {
+                    double pp = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pp = __builtin_fma(lB[sblk(ib, s)][c], ysh[s * NB + 4 * w + c], pp);
+                    red[((ib - s - 1) * 16 + w) * NB + lane] = pp;
+                }
+                __syncthreads();
+                if (tid < (3 - s) * NB) {
+                    const int ib0 = tid >> 6;               // 0 .. 2-s
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) t += red[(ib0 * 16 + q) * NB + lane];
+                    wsh[(s + 1) * NB + tid] -= t;
+                }
+                __syncthreads();
+            }
+        }
     }
+    if (blockIdx.x == 0 && tid < nb) x[jb0 + tid] = ysh[tid];
+    // rows below the super-block: thread = (row, 64-column quarter), partial sums meet in LDS
+    const int rr = tid & 255;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int r = rbase + rr;
+    double acc = 0.0;
+    if (q * NB < nb && rbase < m) {
+        const bool okr = r < m;
+        const double *Pr = P + (okr ? r : 0) + (int64_t)(jb0 + q * NB) * m;
+        const int nc = min(NB, nb - q * NB);
+#pragma unroll 1
+        for (int j0 = 0; j0 < nc; j0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = kvx_ld0(Pr, (int64_t)(j0 + j) * m, okr && j0 + j < nc);
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc = __builtin_fma(v[j], ysh[q * NB + j0 + j], acc);
+        }
+    }
+    red[q * 256 + rr] = acc;
     __syncthreads();
-    const int r = rbase + tid;
-    if (r < m) {
-        const double *Pr = P + r + (int64_t)jb * m;
-        double acc = 0.0;
-        for (int j = 0; j < nbk; j++) acc += Pr[(int64_t)j * m] * ysh[j];
-        if (r < k) wk[r] -= acc;
-        else wo[r - k] -= acc;
+    if (tid < 256 && r < m) {
+        const double t = (red[rr] + red[256 + rr]) + (red[512 + rr] + red[768 + rr]);
+        if (r < k) wk[r] -= t;
+        else wo[r - k] -= t;
     }
 }
 
@@ -402,44 +480,108 @@ __global__ __launch_bounds__(256) void k_bwd_big_init(DevSym ds, const int32_t *
     if (ln == 0) wk[c] = x[f + c] - acc;
 }
 
-__global__ __launch_bounds__(256) void k_bwd_big_step(DevSym ds, const int32_t *__restrict__ list, int bidx,
-                                                      const double *__restrict__ Lx, const double *__restrict__ Linv,
-                                                      double *__restrict__ X, int64_t ldx,
-                                                      double *__restrict__ WK, int64_t ldw)
+// sum over the 64 lanes of four values at once: after the call the lanes with (lane & 3) == j hold the
+// total of v[o], o = 2 * (j & 1) + (j >> 1).  Halving exchange first (4 -> 2 -> 1 values per lane), then a
+// plain butterfly; 7 shuffles instead of 24, fixed order.
+__device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane)
 {
-    __shared__ double part[4][NB];
-    __shared__ double xsh[NB];
-    const int s = list[blockIdx.y];
-    const int k = ds.k[s], m = ds.m[s], f = ds.first[s], tid = threadIdx.x;
-    const int jb = bidx * NB;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
-    if (blockIdx.x > 0 && (int)blockIdx.x * 256 >= jb) return;
-    const double *P = Lx + ds.px[s];
-    const double *Y = Linv + ds.linv[s] + (int64_t)bidx * NB * NB;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const double s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
+    const double k0 = (b0 ? v2 : v0) + __shfl_xor(s0, 1);
+    const double k1 = (b0 ? v3 : v1) + __shfl_xor(s1, 1);
+    double r = (b1 ? k1 : k0) + __shfl_xor(b1 ? k0 : k1, 2);
+    r += __shfl_xor(r, 4);
+    r += __shfl_xor(r, 8);
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    return r;
+}
+
+// Backward super-step over the pivot columns [jb0, jb0 + nb), nb <= 256, the mirror image of the
+// forward one:  x_s = Linv_s' t_s  from the last 64-column sub-block to the first,  t_c -= L(s, c)' x_s
+// for the earlier sub-blocks, operands prefetched into registers.  The products are transposed ones,
+// so lane = row (the summation index, contiguous in memory) and wave = 4 outputs, summed across the
+// wave with wave_sum4.  Workgroup x then owns 64 earlier pivot columns of the front:
+// t_c -= L(b, c)' x_b over the nb rows of the super-block.
+__global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int32_t *__restrict__ list, int sidx,
+                                                           const double *__restrict__ Lx, const double *__restrict__ Linv,
+                                                           double *__restrict__ X, int64_t ldx,
+                                                           double *__restrict__ WK, int64_t ldw)
+{
+    __shared__ double tsh[SB];
+    __shared__ double xsh[SB];
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
+    const int jb0 = sidx * SB;
+    if (jb0 >= k) return;
+    const int nb = min(SB, k - jb0);
+    if (blockIdx.x > 0 && (int)blockIdx.x * NB >= jb0) return;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int o = 2 * (lane & 1) + ((lane >> 1) & 1);        // the output wave_sum4 leaves in this lane
+    const double *P = Lx + fd.px;
+    const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
     double *x = X + (int64_t)blockIdx.z * ldx + f;
     double *wk = WK + (int64_t)blockIdx.z * ldw + f;
-    {
-        // x_b = Linv_b' t_b :  x[i] = sum_{p >= i} Y[p][i] t[p]
-        const int i = tid & 63, q = tid >> 6;
-        double acc = 0.0;
-        if (i < nbk)
-            for (int p = i + q; p < nbk; p += 4) acc += Y[p + i * NB] * wk[jb + p];
-        part[q][i] = acc;
+    const int nsub = (nb + NB - 1) / NB;
+
+    double yI[4][4], lB[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int i = 4 * w + c;                          // output (column of Linv_s), lane = row p >= i
+            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + i * NB, s * NB + lane < nb && i <= lane);
+        }
+#pragma unroll
+    for (int ib = 1; ib < 4; ib++)
+#pragma unroll
+        for (int s = 0; s < ib; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                             ib * NB + lane < nb);
+    if (tid < SB) {
+        tsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
+        xsh[tid] = 0.0;
     }
     __syncthreads();
-    if (tid < NB) {
-        const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        xsh[tid] = v;
-        if (blockIdx.x == 0 && tid < nbk) x[jb + tid] = v;
+#pragma unroll
+    for (int s = 3; s >= 0; s--) {
+        if (s < nsub) {
+            const double tv = tsh[s * NB + lane];
+            const double r = wave_sum4(yI[s][0] * tv, yI[s][1] * tv, yI[s][2] * tv, yI[s][3] * tv, lane);
+            if (lane < 4) xsh[s * NB + 4 * w + o] = r;
+            __syncthreads();
+            if (s > 0) {
+                const double xv = xsh[s * NB + lane];
+#pragma unroll
+                for (int c = 0; c < s; c++) {
+                    const double u = wave_sum4(lB[sblk(s, c)][0] * xv, lB[sblk(s, c)][1] * xv, lB[sblk(s, c)][2] * xv,
+                                               lB[sblk(s, c)][3] * xv, lane);
+                    if (lane < 4) tsh[c * NB + 4 * w + o] -= u;
+                }
+                __syncthreads();
+            }
+        }
     }
-    __syncthreads();
-    const int c = blockIdx.x * 256 + tid;        // earlier pivot column
-    if (c < jb) {
-        const double *Pc = P + jb + (int64_t)c * m;
-        double acc = 0.0;
-        for (int i = 0; i < nbk; i++) acc += Pc[i] * xsh[i];
-        wk[c] -= acc;
+    if (blockIdx.x == 0 && tid < nb) x[jb0 + tid] = xsh[tid];
+    // earlier pivot columns c0 + 4w .. +3 of the front, rows jb0 + lane + 64 j
+    const int c0 = blockIdx.x * NB + 4 * w;
+    if (c0 < jb0) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        double v[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[c][j] = kvx_ld0(P, (int64_t)(jb0 + lane + j * NB) + (int64_t)(c0 + c) * m, lane + j * NB < nb && c0 + c < jb0);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[c] = __builtin_fma(v[c][j], xsh[lane + j * NB], a[c]);
+        const double u = wave_sum4(a[0], a[1], a[2], a[3], lane);
+        if (lane < 4 && c0 + o < jb0) wk[c0 + o] -= u;
     }
 }
 
@@ -450,10 +592,10 @@ void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
     if (count <= 0 || nrhs <= 0) return;
     hipLaunchKernelGGL(k_fwd_big_init, dim3((unsigned)count, (unsigned)nrhs), dim3(256), 0, st, ds, list, X, ldx, WK, ldw,
                        Wchild, Wout, wstride);
-    for (int jb = 0; jb < max_k; jb += NB) {
+    for (int jb = 0; jb < max_k; jb += SB) {
         int rows = max_m - jb - 1;
         unsigned gx = (unsigned)std::max(1, (rows + 255) / 256);
-        hipLaunchKernelGGL(k_fwd_big_step, dim3(gx, (unsigned)count, (unsigned)nrhs), dim3(256), 0, st, ds, list, jb, Lx, Linv,
+        hipLaunchKernelGGL(k_fwd_big_step, dim3(gx, (unsigned)count, (unsigned)nrhs), dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv,
                            X, ldx, WK, ldw, Wout, wstride);
     }
 }
@@ -465,9 +607,9 @@ void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
     (void)max_m;
     hipLaunchKernelGGL(k_bwd_big_init, dim3((unsigned)((max_k + 3) / 4), (unsigned)count, (unsigned)nrhs), dim3(256), 0, st,
                        ds, list, Lx, X, ldx, WK, ldw);
-    for (int b = (max_k + NB - 1) / NB - 1; b >= 0; b--) {
-        unsigned gx = (unsigned)std::max(1, (b * NB + 255) / 256);
-        hipLaunchKernelGGL(k_bwd_big_step, dim3(gx, (unsigned)count, (unsigned)nrhs), dim3(256), 0, st, ds, list, b, Lx, Linv,
+    for (int b = (max_k + SB - 1) / SB - 1; b >= 0; b--) {
+        unsigned gx = (unsigned)std::max(1, b * SB / NB);
+        hipLaunchKernelGGL(k_bwd_big_step, dim3(gx, (unsigned)count, (unsigned)nrhs), dim3(SOLVE_NT), 0, st, ds, list, b, Lx, Linv,
                            X, ldx, WK, ldw);
     }
 }
