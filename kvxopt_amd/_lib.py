@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkvxhip.so")
+LIB_PATH = os.environ.get("KVX_LIB_PATH") or os.path.join(_HERE, "libkvxhip.so")
 
 KVX_OK, KVX_EINVAL, KVX_ENOMEM, KVX_ENOTPOSDEF, KVX_ESYMBOLIC, KVX_ESINGULAR, KVX_EDEVICE, KVX_EPERM = range(8)
 

@@ -50,8 +50,8 @@ struct kvx_chol {
     bool pending = false;     // a factorisation was enqueued and its status not yet read
     int64_t minor = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side[2] = {nullptr, nullptr};   // independent kernel classes of one level run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // independent kernel classes of one level run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_ftime = false, have_stime = false;
@@ -142,7 +142,7 @@ int ensure_device(kvx_chol *F)
     Symbolic &S = F->S;
     HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         HIPCHK(hipStreamCreateWithFlags(&F->side[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&F->ev_join[i], hipEventDisableTiming));
     }
@@ -291,30 +291,41 @@ int enqueue_factor_body(kvx_chol *F)
         const LevelPlan &P = F->plan[l];
         double *Uout = F->d_U[l & 1];
         const double *Uch = F->d_U[(l + 1) & 1];
-        // The fronts of one level are independent: the big-front chain stays on the main stream,
-        // the LDS-front and wave-front launches fork onto two side streams and join at level end.
-        int nlds = 0, nwave = 0;
-        for (int c = KVX_CLS_LDS128; c < KVX_NCLS; c++) (c < KVX_CLS_WAVE0 ? nlds : nwave) += P.cnt[c];
+        // The fronts of one level are independent: the big-front chain stays on the main stream; the
+        // two LDS classes and the wave classes fork onto side streams and join at level end (each of
+        // these launches is latency-bound by its slowest front, so they must overlap, not queue up).
         const bool have_big = P.cnt[KVX_CLS_BIG] > 0;
-        const bool fork_lds = nlds > 0 && (have_big || nwave > 0);
-        const bool fork_wave = nwave > 0 && have_big;
-        hipStream_t s_lds = fork_lds ? F->side[0] : st;
-        hipStream_t s_wave = fork_wave ? F->side[1] : st;
-        if (fork_lds || fork_wave) {
-            HIPCHK(hipEventRecord(F->ev_fork, st));
-            if (fork_lds) HIPCHK(hipStreamWaitEvent(F->side[0], F->ev_fork, 0));
-            if (fork_wave) HIPCHK(hipStreamWaitEvent(F->side[1], F->ev_fork, 0));
+        int nwave = 0;
+        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++) nwave += P.cnt[c];
+        const int grp_cnt[3] = {P.cnt[KVX_CLS_LDS128], P.cnt[KVX_CLS_LDS96], nwave};
+        hipStream_t gst[3];
+        bool forked[3];
+        bool main_taken = have_big, any_fork = false;
+        for (int g = 2; g >= 0; g--) {                     // the last group present keeps the main stream if it is free
+            forked[g] = grp_cnt[g] > 0 && main_taken;
+            if (grp_cnt[g] > 0) main_taken = true;
+            gst[g] = forked[g] ? F->side[g] : st;
+            any_fork |= forked[g];
         }
-        for (int c = KVX_CLS_LDS128; c < KVX_NCLS; c++)
+        if (any_fork) {
+            HIPCHK(hipEventRecord(F->ev_fork, st));
+            for (int g = 0; g < 3; g++)
+                if (forked[g]) HIPCHK(hipStreamWaitEvent(F->side[g], F->ev_fork, 0));
+        }
+        for (int c = KVX_CLS_LDS128; c < KVX_CLS_WAVE0; c++)
             if (P.cnt[c] > 0) {
-                if (c < KVX_CLS_WAVE0) {
-                    ProfScope ps(F, FAM_SMALL, s_lds);
-                    launch_front_small(s_lds, c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[c] <= 32 ? 32 : 64, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
-                } else {
-                    ProfScope ps(F, FAM_SMALL, s_wave);
-                    launch_front_wave(s_wave, wave_class_mcap(c), wave_class_kmax(c), F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
-                }
+                hipStream_t sl = gst[c - KVX_CLS_LDS128];
+                ProfScope ps(F, FAM_SMALL, sl);
+                launch_front_small(sl, c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[c] <= 32 ? 32 : 64, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
             }
+        // wave classes: the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
+        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c += 2) {
+            const int cnt = P.cnt[c] + P.cnt[c + 1];
+            if (cnt == 0) continue;
+            const int64_t off = P.cnt[c] > 0 ? P.off[c] : P.off[c + 1];
+            ProfScope ps(F, FAM_SMALL, gst[2]);
+            launch_front_wave(gst[2], wave_class_mcap(c), P.cnt[c] > 0 ? 32 : 16, F->ds, F->d_lists + off, cnt, F->d_Lx, Uch, Uout, F->d_status);
+        }
         if (have_big) {
             const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
@@ -326,8 +337,8 @@ int enqueue_factor_body(kvx_chol *F)
                 { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout); }
             }
         }
-        if (fork_lds) { HIPCHK(hipEventRecord(F->ev_join[0], F->side[0])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[0], 0)); }
-        if (fork_wave) { HIPCHK(hipEventRecord(F->ev_join[1], F->side[1])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[1], 0)); }
+        for (int g = 0; g < 3; g++)
+            if (forked[g]) { HIPCHK(hipEventRecord(F->ev_join[g], F->side[g])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[g], 0)); }
     }
     HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
@@ -841,7 +852,7 @@ void kvx_chol_free(kvx_chol *F)
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
         for (hipEvent_t e : F->prof_ev)
             if (e) (void)hipEventDestroy(e);
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < 3; i++) {
             if (F->side[i]) (void)hipStreamDestroy(F->side[i]);
             if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
         }

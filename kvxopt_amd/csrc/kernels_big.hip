@@ -2,11 +2,9 @@
 // 64-column panel steps, and multi-workgroup triangular solves.
 //
 // Per panel step jb (three dependent launches, every big front of the level batched):
-//   k_potrf_blk   : Cholesky of the 64x64 diagonal block AND its inverse.  512 threads: waves 0-3
-//                   factor, waves 4-7 build the inverse by the same column sweep; thread (row i,
-//                   column phase q) keeps 16 columns in registers; the pivot column and the pivot row
-//                   of the inverse are broadcast through LDS (measured: LDS broadcast + fma ~10-13
-//                   cycles, v_readlane pair + fma ~40); one barrier per column;
+//   k_potrf_blk   : Cholesky of the 64x64 diagonal block AND its inverse, in LDS: 16-column blocks,
+//                   the 16x16 diagonal blocks by a register column sweep of one wave (factor and
+//                   inverse in the same instruction stream), everything else FP64 MFMA;
 //   k_trsm_blk    : X := A * Linv' for the rows below, FP64 MFMA (v_mfma_f64_16x16x4_f64);
 //   k_syrk_trailing: C -= X X' on 64x64 tiles, FP64 MFMA.
 // The inverses of the diagonal blocks stay resident: the solves use them as 64x64 mat-vecs, so a
@@ -24,130 +22,168 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = KVX_NB;
 
 // ------------------------------------------------------------------------------------------
-// 64x64 diagonal block: Cholesky factor AND its inverse in one 512-thread workgroup.
-// Thread (row i = tid & 63, column phase q) keeps 16 columns in registers.  Factor role (waves
-// 0-3): a[t] = D[i][q + 4(g + t)], the window slides down as column groups finish.  Inverse role
-// (waves 4-7): a[t] = Y[i][q + 4(g - t)], Y = D^{-1} by forward substitution on the identity with
-// the same column sweep, run ONE STEP BEHIND the factor role so that it needs no rsqrt chain.
-// LDS: cbp[3][128] = unscaled pivot column k at [0..63], 1/l_kk at [64], zeros above (triple
-// buffered: the inverse role reads column k-1 while column k+1 is being published);
-// yrp[2][128] = row of Y at [64..127], zeros below (windows reaching "column < 0" read zeros).
-// Everything inside the 16-register loops is branch-free with immediate LDS offsets: these kernels
-// are bound by instruction issue of single waves (lab measurements in DESIGN.md).
-template <int JS>
-__device__ __forceinline__ void potrf_fstep(double (&a)[16], double *cbp, int &kb, int g, int i, int q,
-                                            int *status, int col0)
+// 64x64 diagonal block: Cholesky factor AND its inverse, one 256-thread workgroup, entirely in LDS.
+// Right-looking over four 16-column blocks; per block step s:
+//   A  wave 0 factors the 16x16 diagonal block and inverts it in the SAME instruction stream: lanes
+//      0-15 hold the rows of the block, lanes 16-31 the columns of Y = D^{-1} (forward substitution
+//      on the identity).  Both are "acc[t] -= mult * column_j[t], t > j" with a per-lane multiplier
+//      (row r: a_rj / d_j; column c of Y: y_jc / d_j), so the inverse costs no extra instruction.
+//      The unscaled pivot column travels by LDS broadcast, the pivot by v_readlane; no barrier.
+//   B  FP64 MFMA, one 16x16 task per wave: the tiles below, X = A Dinv' (TRSM through the inverse),
+//      and block row s of the 64x64 inverse, Y(s,j) = -Dinv_s sum_p L(s,p) Y(p,j).
+//   C  FP64 MFMA trailing update of the remaining tiles, C -= X X'.
+// Three barriers per block step.  The sequential part is the 64 pivot steps of phase A (~300 cycles
+// each: rsqrt chain + one LDS round trip); everything else is a handful of MFMAs.
+constexpr int PLD = 80;    // leading dimension of the LDS image of the block (conflict-free MFMA operand reads)
+constexpr int YLD = 65;    // leading dimension of the inverse (transposed operand reads hit distinct banks)
+
+template <int J>
+__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int r, bool fac, int *status, int colbase)
 {
-    const int j = 4 * g + JS;
-    double *cb = cbp + kb * 128;
-    kb = (kb == 2) ? 0 : kb + 1;
-    if (q == JS) cb[i] = a[0];
-    __syncthreads();
-    double d = cb[j];
+    double *cb = colbuf + (J & 1) * 16;
+    const double aj = acc[J];
+    if (fac) cb[r] = aj;
+    double d = kvx_readlane(aj, J);
     if (!(d > 0.0)) {
-        if (q == JS && i == 0) atomicMin(status, col0 + j);
+        if (fac && r == 0) atomicMin(status, colbase + J);
         d = 1.0;
     }
     double ljj, inv;
     kvx_sqrt_rsqrt(d, ljj, inv);
-    if (q == JS && i == 0) cb[64] = inv;
-    const double ci = cb[i];
-    const double w = (i > j) ? ci * (inv * inv) : 0.0;
-    const double *src = cb + q + 4 * g;
-    double lc[16];
+    const double w = (fac && r <= J) ? 0.0 : aj * (inv * inv);
 #pragma unroll
-    for (int t = 0; t < 16; t++) lc[t] = src[4 * t];
-    const double w0 = (q > JS) ? w : 0.0;              // window 0: only columns right of the pivot
-    a[0] = __builtin_fma(-w0, lc[0], a[0]);
-#pragma unroll
-    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, lc[t], a[t]);
-    if (q == JS) a[0] = (i == j) ? ljj : (i > j ? ci * inv : 0.0);
+    for (int t = J + 1; t < 16; t++) acc[t] = __builtin_fma(-w, cb[t], acc[t]);
+    acc[J] = fac ? (r == J ? ljj : (r > J ? aj * inv : 0.0)) : aj * inv;
 }
-
-// inverse role, column j = 4g + JS: publish row j of Y, barrier, update with column j of L
-template <int JS>
-__device__ __forceinline__ void potrf_istep(double (&a)[16], double &myinv, double *cbp, double *yrp, int &kb,
-                                            int g, int i, int q)
+template <int... Js>
+__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int r, bool fac, int *status, int colbase,
+                                             std::integer_sequence<int, Js...>)
 {
-    const int j = 4 * g + JS;
-    double *yr = yrp + (j & 1) * 128 + 64 + q + 4 * g;
-    if (i == j) {
-#pragma unroll
-        for (int t = 0; t < 16; t++) yr[-4 * t] = a[t];
-    }
-    __syncthreads();
-    const double *cb = cbp + kb * 128;
-    kb = (kb == 2) ? 0 : kb + 1;
-    const double inv = cb[64];
-    const double ci = cb[i];
-    const double w = (i > j) ? ci * (inv * inv) : 0.0;
-    myinv = (i == j) ? inv : myinv;                    // row i of Y is scaled by 1/l_ii once, at the end
-    double yv[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) yv[t] = yr[-4 * t];
-    const double w0 = (q <= JS) ? w : 0.0;
-    a[0] = __builtin_fma(-w0, yv[0], a[0]);
-#pragma unroll
-    for (int t = 1; t < 16; t++) a[t] = __builtin_fma(-w, yv[t], a[t]);
+    (diag16_step<Js>(acc, colbuf, r, fac, status, colbase), ...);
 }
 
-__global__ __launch_bounds__(512) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
+__global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                    double *__restrict__ Lx, double *__restrict__ Linv, int *status)
 {
-    __shared__ double cbp[3 * 128];
-    __shared__ double yrp[2 * 128];
+    __shared__ double S[NB * PLD];
+    __shared__ double Yl[NB * YLD];
+    __shared__ double colbuf[2 * 16];
+    __shared__ double scr[4 * 16 * 17];
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m;
     if (jb >= k) return;
     const int nbk = min(NB, k - jb);
+    const int nblk = (nbk + 15) >> 4;
     const int tid = threadIdx.x, i = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
-    const bool inv_role = __builtin_amdgcn_readfirstlane(tid >> 8) != 0;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = tid & 15, lk = (tid >> 4) & 3;
     double *P = Lx + fd.px;
     double *Yg = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
     const int col0 = fd.first + jb;
-    double a[16];
+    {
+        double v[16];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-        const int c = q + 4 * t;
-        const double v = kvx_ld0(P, (jb + i) + (int64_t)(jb + c) * m, !inv_role && i < nbk && c <= i);
-        a[t] = inv_role ? 0.0 : ((i < nbk && c <= i) ? v : (c == i ? 1.0 : 0.0));   // identity padding
+        for (int t = 0; t < 16; t++) {
+            const int c = wv + 4 * t;
+            v[t] = kvx_ld0(P, (jb + i) + (int64_t)(jb + c) * m, i < nbk && c <= i);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = wv + 4 * t;
+            S[i + c * PLD] = (i < nbk && c <= i) ? v[t] : (c == i ? 1.0 : 0.0);      // identity padding
+        }
     }
-    if (tid < 384) cbp[tid] = 0.0;
-    if (tid < 256) yrp[tid] = 0.0;
     __syncthreads();
-    const int ngrp = (nbk + 3) >> 2;                       // the padding beyond nbk needs no sweep
-    int kb = 0;
-    if (!inv_role) {
-        for (int g = 0; g < ngrp; g++) {
-            potrf_fstep<0>(a, cbp, kb, g, i, q, status, col0);
-            potrf_fstep<1>(a, cbp, kb, g, i, q, status, col0);
-            potrf_fstep<2>(a, cbp, kb, g, i, q, status, col0);
-            potrf_fstep<3>(a, cbp, kb, g, i, q, status, col0);
-            const int c = q + 4 * g;                       // this thread's finished column
-            if (i < nbk && c <= i) P[(jb + i) + (int64_t)(jb + c) * m] = a[0];
+    for (int s = 0; s < nblk; s++) {
+        const int j0 = 16 * s;
+        // ---- A: diagonal block and its inverse (wave 0)
+        if (wv == 0) {
+            const bool fac = i < 16;
+            double acc[16];
 #pragma unroll
-            for (int t = 0; t < 15; t++) a[t] = a[t + 1];
-            a[15] = 0.0;
+            for (int c = 0; c < 16; c++) {
+                const double lv = S[(j0 + lr) + (j0 + c) * PLD];
+                acc[c] = fac ? lv : ((i < 32 && c == lr) ? 1.0 : 0.0);
+            }
+            diag16_steps(acc, colbuf, lr, fac, status, col0 + j0, std::make_integer_sequence<int, 16>());
+            if (fac) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) S[(j0 + lr) + (j0 + c) * PLD] = acc[c];          // zeros above the diagonal
+            } else if (i < 32) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) Yl[(j0 + r) + (j0 + lr) * YLD] = acc[r];         // column lr of Dinv
+            }
         }
-        __syncthreads();                                   // lets the inverse role finish the last column
-    } else {
-        double myinv = 1.0;
-        __syncthreads();                                   // pairs with the factor role's first barrier
-        for (int g = 0; g < ngrp; g++) {
+        __syncthreads();
+        // ---- B: tiles below (X = A Dinv') and block row s of the inverse; task t -> wave t
+        {
+            const int ntr = nblk - 1 - s;
+            if (wv < ntr) {
+                const int rb = 16 * (s + 1 + wv);
+                d4 x = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t = 15; t > 0; t--) a[t] = a[t - 1];
-            a[0] = (q + 4 * g == i) ? 1.0 : 0.0;           // open the window on column group g: Y starts as I
-            potrf_istep<0>(a, myinv, cbp, yrp, kb, g, i, q);
-            potrf_istep<1>(a, myinv, cbp, yrp, kb, g, i, q);
-            potrf_istep<2>(a, myinv, cbp, yrp, kb, g, i, q);
-            potrf_istep<3>(a, myinv, cbp, yrp, kb, g, i, q);
+                for (int k0 = 0; k0 < 16; k0 += 4) {
+                    const double av = Yl[(j0 + lr) + (j0 + k0 + lk) * YLD];
+                    const double bv = S[(rb + lr) + (j0 + k0 + lk) * PLD];
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) S[(rb + lr) + (j0 + lk + 4 * q) * PLD] = x[q];
+            } else if (wv < ntr + s) {
+                const int j = wv - ntr;                      // block (s, j), j < s
+                double *sc = scr + wv * (16 * 17);
+                d4 t = (d4){0.0, 0.0, 0.0, 0.0};
+                for (int pb = j; pb < s; pb++) {
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0 += 4) {
+                        const double av = Yl[(16 * pb + k0 + lk) + (16 * j + lr) * YLD];
+                        const double bv = S[(j0 + lr) + (16 * pb + k0 + lk) * PLD];
+                        t = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, t, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) sc[lr + 17 * (lk + 4 * q)] = t[q];                // T[r][c] at r + 17 c
+                d4 y = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4) {
+                    const double av = -sc[(k0 + lk) + 17 * lr];
+                    const double bv = Yl[(j0 + lr) + (j0 + k0 + lk) * YLD];
+                    y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) Yl[(j0 + lr) + (16 * j + lk + 4 * q) * YLD] = y[q];
+            }
         }
-        if (i < nbk) {
+        __syncthreads();
+        // ---- C: trailing update of the tiles (ti, tj), s < tj <= ti < nblk; task t -> wave t & 3
+        {
+            int t = 0;
+            for (int ti = s + 1; ti < nblk; ti++)
+                for (int tj = s + 1; tj <= ti; tj++, t++) {
+                    if ((t & 3) != wv) continue;
+                    d4 c;
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                const int c = q + 4 * (ngrp - 1 - t);
-                if (c >= 0 && c <= i) Yg[i + c * NB] = a[t] * myinv;
+                    for (int q = 0; q < 4; q++) c[q] = S[(16 * ti + lr) + (16 * tj + lk + 4 * q) * PLD];
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0 += 4) {
+                        const double av = -S[(16 * tj + lr) + (j0 + k0 + lk) * PLD];
+                        const double bv = S[(16 * ti + lr) + (j0 + k0 + lk) * PLD];
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) S[(16 * ti + lr) + (16 * tj + lk + 4 * q) * PLD] = c[q];
+                }
+        }
+        if (s + 1 < nblk) __syncthreads();
+    }
+    __syncthreads();
+    if (i < nbk) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = wv + 4 * t;
+            if (c <= i) {
+                P[(jb + i) + (int64_t)(jb + c) * m] = S[i + c * PLD];
+                Yg[i + c * NB] = Yl[i + c * YLD];
             }
         }
     }
@@ -157,7 +193,7 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
                       double *Lx, double *Linv, int *status)
 {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_potrf_blk, dim3((unsigned)count), dim3(512), 0, st, ds, list, jb, Lx, Linv, status);
+    hipLaunchKernelGGL(k_potrf_blk, dim3((unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------

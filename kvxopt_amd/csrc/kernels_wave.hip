@@ -2,13 +2,14 @@
 //
 //   k_front_wave<KMAX> : m <= 64, k <= 32.  One 64-lane wavefront owns one front, no workgroup
 //                        barrier anywhere.
-//   k_front_lds<KMAX>  : m <= 128, k <= 64.  One 256-thread workgroup per front, two barriers.
+//   k_front_lds<KMAX>  : m <= 128, k <= 64.  One 256-thread workgroup per front: wave (h, p) holds
+//                        rows 64 h.. and the columns of parity p; one barrier per pivot column.
 //
 // Shared design:
 //   * lane r holds ROW r of the panel in registers a[0..KMAX) -- column j of L is then one
 //     register across the wave; its pivot travels by v_readlane and its multipliers by an LDS
-//     broadcast (kvx_col_step, device.hpp): no barrier per column (rows 64.. of an LDS front are
-//     solved by substitution against L11 broadcast from LDS);
+//     broadcast (kvx_col_step, device.hpp), no barrier per column; an LDS front splits rows and
+//     column parities over its four waves (quad_col_step) and pays one barrier per column;
 //   * the children's update matrices are extend-added into an LDS image of the front with all
 //     HBM loads of a batch in flight at once (these kernels are latency-bound on small levels);
 //   * the Schur complement U = F22 - L21 L21' is FP64 MFMA (v_mfma_f64_16x16x4_f64) from the LDS
@@ -24,26 +25,44 @@ namespace kvx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// substitution step J for rows that hold no pivot (rows >= 64 of an LDS front): L11 comes from LDS
+// Column step J of an LDS front (m <= 128, k <= 64) spread over the four waves of the workgroup:
+// wave (h, p) holds rows 64 h .. 64 h + 63 and the columns of parity p (column c = 2 t + p in a[t]).
+// The owner parity publishes the UNSCALED column J (all 128 rows) into the J-parity half of cb2, one
+// workgroup barrier, then every wave reads the pivot and its multipliers by LDS broadcast and updates
+// its own columns; double buffering makes the one barrier per column sufficient.
 template <int KMAX, int J>
-__device__ __forceinline__ void sub_col_step(double (&a)[KMAX], int k, const double *F, int m, const double *invd)
+__device__ __forceinline__ void quad_col_step(double (&a)[KMAX / 2], int k, int row, int p, int *status, int col0,
+                                              double *cb2)
 {
-    if (J < k) {
-        const double v = a[J] * invd[J];
-        a[J] = v;
-        const double *col = F + J * m;
-#pragma unroll
-        for (int c = J + 1; c < KMAX; c++) {
-            const double lc = col[c < k ? c : J];  // broadcast read; columns >= k are padding
-            a[c] = __builtin_fma(-v, lc, a[c]);
+    if (J < k) {                                   // workgroup-uniform
+        double *cb = cb2 + (J & 1) * 128;
+        const bool owner = p == (J & 1);           // wave-uniform
+        if (owner) cb[row] = a[J >> 1];
+        __syncthreads();
+        const double aj = cb[row];
+        double d = cb[J];
+        if (!(d > 0.0)) {
+            if (row == 0 && p == 0) atomicMin(status, col0 + J);
+            d = 1.0;
         }
+        double ljj, inv;
+        kvx_sqrt_rsqrt(d, ljj, inv);
+        const double w = (row > J) ? aj * (inv * inv) : 0.0;
+        const double *cbp = cb + p;
+        if ((J & 1) == 0) {                        // column J + 1 = 2 (J/2) + 1 belongs to parity 1 only
+            const double w1 = p ? w : 0.0;
+            a[J >> 1] = owner ? a[J >> 1] : __builtin_fma(-w1, cb[J + 1], a[J >> 1]);
+        }
+#pragma unroll
+        for (int t = (J >> 1) + 1; t < KMAX / 2; t++) a[t] = __builtin_fma(-w, cbp[2 * t], a[t]);
+        if (owner) a[J >> 1] = (row == J) ? ljj : (row > J ? aj * inv : 0.0);
     }
 }
 template <int KMAX, int... Js>
-__device__ __forceinline__ void sub_col_steps(double (&a)[KMAX], int k, const double *F, int m, const double *invd,
-                                              std::integer_sequence<int, Js...>)
+__device__ __forceinline__ void quad_col_steps(double (&a)[KMAX / 2], int k, int row, int p, int *status, int col0,
+                                               double *cb2, std::integer_sequence<int, Js...>)
 {
-    (sub_col_step<KMAX, Js>(a, k, F, m, invd), ...);
+    (quad_col_step<KMAX, Js>(a, k, row, p, status, col0, cb2), ...);
 }
 
 // Extend-add of one child's update matrix (lower triangle, uc x uc, ld = uc) into the LDS image F.
@@ -52,7 +71,7 @@ __device__ __forceinline__ void sub_col_steps(double (&a)[KMAX], int k, const do
 template <int NT, int RP>
 __device__ __forceinline__ void extend_add_child(double *F, int m, const int *relsh, const double *U, int uc, int tid)
 {
-    constexpr int NP = NT / RP, B = 8;
+    constexpr int NP = NT / RP, B = 16;
     const int i = tid % RP, ph = tid / RP;
     const bool row_ok = i < uc;
     const int myrow = row_ok ? relsh[i] : 0;
@@ -69,6 +88,29 @@ __device__ __forceinline__ void extend_add_child(double *F, int m, const int *re
             if (row_ok && j <= i) F[myrow + relsh[j] * m] += v[q];
         }
     }
+}
+
+// All children of a front: the descriptor and the relative indices of child c + 1 are fetched while
+// child c is added, so each child costs one HBM round trip (its update matrix) instead of three.
+template <int NT, int RP>
+__device__ __forceinline__ void extend_add_children(const DevSym &ds, const FrontDesc &fd, double *F, int m, int *relsh,
+                                                    const double *Uc, int tid)
+{
+    ChildDesc cd = ds.cd[fd.childptr];
+    int myrel = tid < cd.uc ? ds.rel[cd.rel + tid] : 0;
+    for (int c = 0; c < fd.nchild; c++) {
+        const bool more = c + 1 < fd.nchild;
+        ChildDesc nx = cd;
+        if (more) nx = ds.cd[fd.childptr + c + 1];
+        __syncthreads();                           // (single-wave workgroups: orders the LDS traffic)
+        if (tid < RP) relsh[tid] = myrel;
+        __syncthreads();
+        const int nrel = (more && tid < nx.uc) ? ds.rel[nx.rel + tid] : 0;
+        extend_add_child<NT, RP>(F, m, relsh, Uc + cd.ux, cd.uc, tid);
+        cd = nx;
+        myrel = nrel;
+    }
+    __syncthreads();
 }
 
 // Schur complement tile (ti, tj) of U = F22 - X X', X = rows k.. of the panel in the LDS image
@@ -111,25 +153,17 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
     const int k = fd.k, m = fd.m, u = m - k, r = threadIdx.x;
     double *P = Lx + fd.px;
     const bool kids = fd.nchild > 0;
+    // the panel goes straight from HBM to registers (all KMAX loads in flight while the children are
+    // assembled); the LDS image starts at zero, collects the children and is added on top
     double a[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
     if (kids) {
-        const int mk = m * k, mm = m * m;
-        for (int i = r; i < mk; i += 64) F[i] = P[i];
-        for (int i = mk + r; i < mm; i += 64) F[i] = 0.0;
-        for (int c = 0; c < fd.nchild; c++) {
-            const ChildDesc cd = ds.cd[fd.childptr + c];
-            if (cd.uc == 0) continue;
-            __syncthreads();                       // single-wave workgroup: orders the LDS traffic
-            if (r < cd.uc) relsh[r] = ds.rel[cd.rel + r];
-            __syncthreads();
-            extend_add_child<64, 64>(F, m, relsh, Uc + cd.ux, cd.uc, r);
-        }
-        __syncthreads();
+        const int mm = m * m;
+        for (int i = r; i < mm; i += 64) F[i] = 0.0;
+        extend_add_children<64, 64>(ds, fd, F, m, relsh, Uc, r);
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(F, r + j * m, j < k && r < m);
-    } else {
-#pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+        for (int j = 0; j < KMAX; j++) a[j] += kvx_ld0(F, r + j * m, j < k && r < m);
     }
     kvx_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, cb2, std::make_integer_sequence<int, KMAX>());
     if (r < m) {
@@ -154,51 +188,30 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
-    extern __shared__ double F[];                  // m x m image (ld = m), 64 inverse pivots, 2x64 column buffer, 128 ints
-    double *invd = F + mcap * mcap;
-    double *cb2 = invd + 64;
-    int *relsh = (int *)(cb2 + 128);
+    extern __shared__ double F[];                  // m x m image (ld = m), 2x128 column buffer, 128 ints
+    double *cb2 = F + mcap * mcap;
+    int *relsh = (int *)(cb2 + 256);
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m, u = m - k, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     double *P = Lx + fd.px;
     const bool kids = fd.nchild > 0;
-    const int mk = m * k, mm = m * m;
-    for (int i = tid; i < mk; i += 256) F[i] = P[i];
+    const int p = wv >> 1, row = (wv & 1) * 64 + ln;    // column parity, row of this thread
+    double a[KMAX / 2];
+#pragma unroll
+    for (int t = 0; t < KMAX / 2; t++) a[t] = kvx_ld0(P, row + (int64_t)(2 * t + p) * m, 2 * t + p < k && row < m);
     if (kids) {
-        for (int i = mk + tid; i < mm; i += 256) F[i] = 0.0;
-        for (int c = 0; c < fd.nchild; c++) {
-            const ChildDesc cd = ds.cd[fd.childptr + c];
-            if (cd.uc == 0) continue;
-            __syncthreads();
-            if (tid < cd.uc) relsh[tid] = ds.rel[cd.rel + tid];
-            __syncthreads();
-            extend_add_child<256, 128>(F, m, relsh, Uc + cd.ux, cd.uc, tid);
-        }
-    }
-    __syncthreads();
-    double a[KMAX];
-    const int row = tid;                           // waves 0,1 hold rows 0..127
-    if (wv < 2) {
+        const int mm = m * m;
+        for (int i = tid; i < mm; i += 256) F[i] = 0.0;
+        extend_add_children<256, 128>(ds, fd, F, m, relsh, Uc, tid);
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(F, row + j * m, j < k && row < m);
+        for (int t = 0; t < KMAX / 2; t++) a[t] += kvx_ld0(F, row + (2 * t + p) * m, 2 * t + p < k && row < m);
     }
-    if (wv == 0) {
-        kvx_col_steps<KMAX>(a, k, ln, status, fd.first, invd, cb2, std::make_integer_sequence<int, KMAX>());
-        if (row < m) {
+    quad_col_steps<KMAX>(a, k, row, p, status, fd.first, cb2, std::make_integer_sequence<int, KMAX>());
+    if (row < m) {
 #pragma unroll
-            for (int j = 0; j < KMAX; j++)
-                if (j < k) { F[row + j * m] = a[j]; P[row + (int64_t)j * m] = a[j]; }
-        }
-    }
-    __syncthreads();
-    if (wv == 1 && m > 64) {
-        sub_col_steps<KMAX>(a, k, F, m, invd, std::make_integer_sequence<int, KMAX>());
-        if (row < m) {
-#pragma unroll
-            for (int j = 0; j < KMAX; j++)
-                if (j < k) { F[row + j * m] = a[j]; P[row + (int64_t)j * m] = a[j]; }
-        }
+        for (int t = 0; t < KMAX / 2; t++)
+            if (2 * t + p < k) { F[row + (2 * t + p) * m] = a[t]; P[row + (int64_t)(2 * t + p) * m] = a[t]; }
     }
     if (u == 0) return;
     __syncthreads();
@@ -341,7 +354,7 @@ void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, co
         (void)hipFuncSetAttribute((const void *)k_front_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_set = true;
     }
-    const size_t lds = (size_t)mcap * mcap * sizeof(double) + (64 + 128) * sizeof(double) + 128 * sizeof(int);
+    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 256 * sizeof(double) + 128 * sizeof(int);
     if (kmax <= 32)
         hipLaunchKernelGGL(k_front_lds<32>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     else
