@@ -50,8 +50,8 @@ struct kvx_chol {
     bool pending = false;     // a factorisation was enqueued and its status not yet read
     int64_t minor = 0;
     hipStream_t stream = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // independent kernel classes of one level run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_ftime = false, have_stime = false;
@@ -72,6 +72,7 @@ struct kvx_chol {
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
     DevSym ds{};
+    int fuse_limit = 2000;     // tiles up to which the trailing update also factors the next diagonal block
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
     // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
@@ -142,7 +143,7 @@ int ensure_device(kvx_chol *F)
     Symbolic &S = F->S;
     HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         HIPCHK(hipStreamCreateWithFlags(&F->side[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&F->ev_join[i], hipEventDisableTiming));
     }
@@ -244,6 +245,7 @@ int ensure_device(kvx_chol *F)
         }
     }
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
+    { const char *e = getenv("KVX_FUSE_LIMIT"); if (e) F->fuse_limit = atoi(e); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -331,10 +333,12 @@ int enqueue_factor_body(kvx_chol *F)
             const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
             if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
+            bool have_diag = false;
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, jb, F->d_Lx, F->d_Linv, F->d_status); }
+                // a fused trailing update of panel jb - 64 has already factored this diagonal block
+                if (!have_diag) { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, jb, F->d_Lx, F->d_Linv, F->d_status); }
                 { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
-                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout); }
+                { ProfScope ps(F, FAM_SYRK); have_diag = launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status, F->fuse_limit); }
             }
         }
         for (int g = 0; g < 3; g++)
@@ -852,7 +856,7 @@ void kvx_chol_free(kvx_chol *F)
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
         for (hipEvent_t e : F->prof_ev)
             if (e) (void)hipEventDestroy(e);
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 4; i++) {
             if (F->side[i]) (void)hipStreamDestroy(F->side[i]);
             if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
         }

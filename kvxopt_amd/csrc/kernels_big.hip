@@ -34,20 +34,31 @@ constexpr int NB = KVX_NB;
 //   C  FP64 MFMA trailing update of the remaining tiles, C -= X X'.
 // Three barriers per block step.  The sequential part is the 64 pivot steps of phase A (~300 cycles
 // each: rsqrt chain + one LDS round trip); everything else is a handful of MFMAs.
-constexpr int PLD = 80;    // leading dimension of the LDS image of the block (conflict-free MFMA operand reads)
-constexpr int YLD = 65;    // leading dimension of the inverse (transposed operand reads hit distinct banks)
+// LDS layout: only the ten 16x16 blocks of the lower block triangle are kept, block (bi, bj) at
+// slot bi (bi + 1) / 2 + bj.  Blocks of the factor have ld 16 (MFMA operand reads are then 512
+// contiguous bytes), blocks of the inverse ld 17 (their transposed operand reads hit distinct banks).
+// ~49 KB in all, so three workgroups fit a CU -- this matters because the trailing-update kernel
+// carries this structure too (see k_syrk_trailing).
+constexpr int SBS = 16 * 16, YBS = 16 * 17;
+__device__ __forceinline__ constexpr int blk_slot(int bi, int bj) { return bi * (bi + 1) / 2 + bj; }
+__device__ __forceinline__ int s_idx(int i, int c) { return blk_slot(i >> 4, c >> 4) * SBS + (i & 15) + (c & 15) * 16; }
+__device__ __forceinline__ int y_idx(int i, int c) { return blk_slot(i >> 4, c >> 4) * YBS + (i & 15) + (c & 15) * 17; }
 
+// One pivot step, branch-free: every lane stores (the non-factor lanes into a dump slot) and a failed
+// pivot is only recorded, in `bad`.  The compiler sinks the updates of the 16 unrolled steps towards
+// their uses (a left-looking schedule that keeps ~250 operands in registers); measured, that is the
+// faster schedule (20 us per 64x64 block against 32 us with the updates pinned to their step), so the
+// kernels that carry this code run one workgroup per CU.
 template <int J>
-__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int r, bool fac, int *status, int colbase)
+__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int wslot, int r, bool fac, int &bad)
 {
-    double *cb = colbuf + (J & 1) * 16;
+    double *cb = colbuf + (J & 1) * 80;
     const double aj = acc[J];
-    if (fac) cb[r] = aj;
+    cb[wslot] = aj;
     double d = kvx_readlane(aj, J);
-    if (!(d > 0.0)) {
-        if (fac && r == 0) atomicMin(status, colbase + J);
-        d = 1.0;
-    }
+    const bool neg = !(d > 0.0);
+    bad = (neg && bad > J) ? J : bad;
+    d = neg ? 1.0 : d;
     double ljj, inv;
     kvx_sqrt_rsqrt(d, ljj, inv);
     const double w = (fac && r <= J) ? 0.0 : aj * (inv * inv);
@@ -56,62 +67,49 @@ __device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, i
     acc[J] = fac ? (r == J ? ljj : (r > J ? aj * inv : 0.0)) : aj * inv;
 }
 template <int... Js>
-__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int r, bool fac, int *status, int colbase,
+__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int wslot, int r, bool fac, int &bad,
                                              std::integer_sequence<int, Js...>)
 {
-    (diag16_step<Js>(acc, colbuf, r, fac, status, colbase), ...);
+    (diag16_step<Js>(acc, colbuf, wslot, r, fac, bad), ...);
 }
 
-__global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                   double *__restrict__ Lx, double *__restrict__ Linv, int *status)
+struct PotrfLds {
+    double S[10 * SBS];        // the block, then its factor (lower block triangle)
+    double Yl[10 * YBS];       // the inverse of the factor
+    double colbuf[2 * 80];     // pivot column at [0, 16), dump slots of the other lanes behind it
+    double scr[3 * 16 * 17];   // per-wave staging of the 16x16 products of phase B
+};
+
+// Factor + invert the block held in lds.S (lower triangle, identity padding beyond nbk; the caller has
+// filled it and passed a barrier).  256 threads.  Ends with a barrier: S = L, Yl = L^{-1}.
+__device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *status, int col0)
 {
-    __shared__ double S[NB * PLD];
-    __shared__ double Yl[NB * YLD];
-    __shared__ double colbuf[2 * 16];
-    __shared__ double scr[4 * 16 * 17];
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
-    const int k = fd.k, m = fd.m;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
     const int nblk = (nbk + 15) >> 4;
-    const int tid = threadIdx.x, i = tid & 63;
+    const int i = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = tid & 15, lk = (tid >> 4) & 3;
-    double *P = Lx + fd.px;
-    double *Yg = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
-    const int col0 = fd.first + jb;
-    {
-        double v[16];
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int c = wv + 4 * t;
-            v[t] = kvx_ld0(P, (jb + i) + (int64_t)(jb + c) * m, i < nbk && c <= i);
-        }
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int c = wv + 4 * t;
-            S[i + c * PLD] = (i < nbk && c <= i) ? v[t] : (c == i ? 1.0 : 0.0);      // identity padding
-        }
-    }
-    __syncthreads();
+#pragma unroll 1
     for (int s = 0; s < nblk; s++) {
-        const int j0 = 16 * s;
+        double *Sd = lds.S + blk_slot(s, s) * SBS;
+        double *Yd = lds.Yl + blk_slot(s, s) * YBS;
         // ---- A: diagonal block and its inverse (wave 0)
         if (wv == 0) {
             const bool fac = i < 16;
             double acc[16];
 #pragma unroll
             for (int c = 0; c < 16; c++) {
-                const double lv = S[(j0 + lr) + (j0 + c) * PLD];
+                const double lv = Sd[lr + 16 * c];
                 acc[c] = fac ? lv : ((i < 32 && c == lr) ? 1.0 : 0.0);
             }
-            diag16_steps(acc, colbuf, lr, fac, status, col0 + j0, std::make_integer_sequence<int, 16>());
+            int bad = 16;
+            diag16_steps(acc, lds.colbuf, fac ? lr : i, lr, fac, bad, std::make_integer_sequence<int, 16>());
+            if (bad < 16 && i == 0) atomicMin(status, col0 + 16 * s + bad);
             if (fac) {
 #pragma unroll
-                for (int c = 0; c < 16; c++) S[(j0 + lr) + (j0 + c) * PLD] = acc[c];          // zeros above the diagonal
+                for (int c = 0; c < 16; c++) Sd[lr + 16 * c] = acc[c];                 // zeros above the diagonal
             } else if (i < 32) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) Yl[(j0 + r) + (j0 + lr) * YLD] = acc[r];         // column lr of Dinv
+                for (int r = 0; r < 16; r++) Yd[r + 17 * lr] = acc[r];                 // column lr of Dinv
             }
         }
         __syncthreads();
@@ -119,39 +117,42 @@ __global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__r
         {
             const int ntr = nblk - 1 - s;
             if (wv < ntr) {
-                const int rb = 16 * (s + 1 + wv);
+                double *St = lds.S + blk_slot(s + 1 + wv, s) * SBS;
                 d4 x = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int k0 = 0; k0 < 16; k0 += 4) {
-                    const double av = Yl[(j0 + lr) + (j0 + k0 + lk) * YLD];
-                    const double bv = S[(rb + lr) + (j0 + k0 + lk) * PLD];
+                    const double av = Yd[lr + 17 * (k0 + lk)];
+                    const double bv = St[lr + 16 * (k0 + lk)];
                     x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) S[(rb + lr) + (j0 + lk + 4 * q) * PLD] = x[q];
+                for (int q = 0; q < 4; q++) St[lr + 16 * (lk + 4 * q)] = x[q];
             } else if (wv < ntr + s) {
                 const int j = wv - ntr;                      // block (s, j), j < s
-                double *sc = scr + wv * (16 * 17);
+                double *sc = lds.scr + wv * (16 * 17);
                 d4 t = (d4){0.0, 0.0, 0.0, 0.0};
                 for (int pb = j; pb < s; pb++) {
+                    const double *Yp = lds.Yl + blk_slot(pb, j) * YBS;
+                    const double *Sp = lds.S + blk_slot(s, pb) * SBS;
 #pragma unroll
                     for (int k0 = 0; k0 < 16; k0 += 4) {
-                        const double av = Yl[(16 * pb + k0 + lk) + (16 * j + lr) * YLD];
-                        const double bv = S[(j0 + lr) + (16 * pb + k0 + lk) * PLD];
+                        const double av = Yp[(k0 + lk) + 17 * lr];
+                        const double bv = Sp[lr + 16 * (k0 + lk)];
                         t = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, t, 0, 0, 0);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) sc[lr + 17 * (lk + 4 * q)] = t[q];                // T[r][c] at r + 17 c
+                for (int q = 0; q < 4; q++) sc[lr + 17 * (lk + 4 * q)] = t[q];         // T[r][c] at r + 17 c
                 d4 y = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int k0 = 0; k0 < 16; k0 += 4) {
                     const double av = -sc[(k0 + lk) + 17 * lr];
-                    const double bv = Yl[(j0 + lr) + (j0 + k0 + lk) * YLD];
+                    const double bv = Yd[lr + 17 * (k0 + lk)];
                     y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
                 }
+                double *Yo = lds.Yl + blk_slot(s, j) * YBS;
 #pragma unroll
-                for (int q = 0; q < 4; q++) Yl[(j0 + lr) + (16 * j + lk + 4 * q) * YLD] = y[q];
+                for (int q = 0; q < 4; q++) Yo[lr + 17 * (lk + 4 * q)] = y[q];
             }
         }
         __syncthreads();
@@ -161,32 +162,68 @@ __global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__r
             for (int ti = s + 1; ti < nblk; ti++)
                 for (int tj = s + 1; tj <= ti; tj++, t++) {
                     if ((t & 3) != wv) continue;
+                    double *Sc = lds.S + blk_slot(ti, tj) * SBS;
+                    const double *Sa = lds.S + blk_slot(tj, s) * SBS;
+                    const double *Sb = lds.S + blk_slot(ti, s) * SBS;
                     d4 c;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) c[q] = S[(16 * ti + lr) + (16 * tj + lk + 4 * q) * PLD];
+                    for (int q = 0; q < 4; q++) c[q] = Sc[lr + 16 * (lk + 4 * q)];
 #pragma unroll
                     for (int k0 = 0; k0 < 16; k0 += 4) {
-                        const double av = -S[(16 * tj + lr) + (j0 + k0 + lk) * PLD];
-                        const double bv = S[(16 * ti + lr) + (j0 + k0 + lk) * PLD];
+                        const double av = -Sa[lr + 16 * (k0 + lk)];
+                        const double bv = Sb[lr + 16 * (k0 + lk)];
                         c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; q++) S[(16 * ti + lr) + (16 * tj + lk + 4 * q) * PLD] = c[q];
+                    for (int q = 0; q < 4; q++) Sc[lr + 16 * (lk + 4 * q)] = c[q];
                 }
         }
-        if (s + 1 < nblk) __syncthreads();
+        __syncthreads();
     }
-    __syncthreads();
+}
+
+// write the factor into the panel and the inverse into the resident Linv slot (lower triangles)
+__device__ __forceinline__ void potrf_store(const PotrfLds &lds, int nbk, int tid, double *P, int m, int jb, double *Yg)
+{
+    const int i = tid & 63, q = tid >> 6;
     if (i < nbk) {
 #pragma unroll
         for (int t = 0; t < 16; t++) {
-            const int c = wv + 4 * t;
+            const int c = q + 4 * t;
             if (c <= i) {
-                P[(jb + i) + (int64_t)(jb + c) * m] = S[i + c * PLD];
-                Yg[i + c * NB] = Yl[i + c * YLD];
+                P[(jb + i) + (int64_t)(jb + c) * m] = lds.S[s_idx(i, c)];
+                Yg[i + c * NB] = lds.Yl[y_idx(i, c)];
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                   double *__restrict__ Lx, double *__restrict__ Linv, int *status)
+{
+    __shared__ PotrfLds lds;
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m;
+    if (jb >= k) return;
+    const int nbk = min(NB, k - jb);
+    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    double *P = Lx + fd.px;
+    {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = q + 4 * t;
+            v[t] = kvx_ld0(P, (jb + i) + (int64_t)(jb + c) * m, i < nbk && c <= i);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = q + 4 * t;
+            if ((c >> 4) <= (i >> 4)) lds.S[s_idx(i, c)] = (i < nbk && c <= i) ? v[t] : (c == i ? 1.0 : 0.0);   // identity padding
+        }
+    }
+    __syncthreads();
+    potrf_lds(lds, nbk, tid, status, fd.first + jb);
+    potrf_store(lds, nbk, tid, P, m, jb, Linv + fd.linv + (int64_t)(jb / NB) * NB * NB);
 }
 
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
@@ -264,14 +301,22 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 // ------------------------------------------------------------------------------------------
 // Trailing update C -= X X' on 64x64 tiles (FP64 MFMA).  The trailing matrix spans the rest of
 // the panel (columns < k, ld = m, in Lx) and the update matrix (columns >= k, ld = u).
+// The workgroup of tile (0, 0) owns the NEXT diagonal block: it keeps the updated tile in LDS and
+// goes straight on to factor and invert it (potrf_lds) while the other tiles of the launch are still
+// being updated -- the 64 sequential pivot steps of the next panel overlap this panel's update
+// instead of waiting for a launch of their own.  (Running the two parts as separate launches on two
+// streams was measured and lost: a cross-queue dependency costs ~10 us inside a graph replay.)
+// FUSE = false is the plain update (no LDS, 116 VGPRs) for launches that are throughput-bound.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                       double *__restrict__ Lx, double *__restrict__ Uo)
+                                                       double *__restrict__ Lx, double *__restrict__ Uo,
+                                                       double *__restrict__ Linv, int *status)
 {
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
     const FrontDesc fd = ds.fd[list[blockIdx.z]];
     const int k = fd.k, m = fd.m, u = m - k;
     if (jb >= k) return;
-    const int ti = blockIdx.x, tj = blockIdx.y;
-    if (tj > ti) return;
     const int nbk = min(NB, k - jb);
     const int t0 = jb + nbk;
     const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
@@ -328,17 +373,37 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
+    if (FUSE && ti == 0 && tj == 0 && t0 < k) {    // workgroup-uniform
+        __shared__ PotrfLds lds;
+        const int nb2 = min(NB, k - t0);
+        const int i = 16 * w + lr;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int cc = 16 * t + lk + 4 * q;
+                if (t <= w) lds.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? old[t][q] - acc[t][q] : (cc == i ? 1.0 : 0.0);
+            }
+        __syncthreads();
+        potrf_lds(lds, nb2, threadIdx.x, status, fd.first + t0);
+        potrf_store(lds, nb2, threadIdx.x, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
+    }
 }
 
-void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout)
+bool launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                          double *Lx, double *Uout, double *Linv, int *status, int fuse_limit)
 {
-    if (count <= 0) return;
+    if (count <= 0) return false;
     int rows = max_m - jb - 1;
-    if (rows <= 0) return;
+    if (rows <= 0) return false;
     unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     dim3 grid(T, T, (unsigned)count);
-    hipLaunchKernelGGL(k_syrk_trailing, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout);
+    const bool fuse = (int64_t)T * (T + 1) / 2 * count <= fuse_limit;
+    if (fuse)
+        hipLaunchKernelGGL(k_syrk_trailing<true>, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+    else
+        hipLaunchKernelGGL(k_syrk_trailing<false>, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+    return fuse;
 }
 
 // ------------------------------------------------------------------------------------------
