@@ -331,7 +331,6 @@ int enqueue_factor_body(kvx_chol *F)
         if (have_big) {
             const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
-            if (P.big_u_len > 0) HIPCHK(hipMemsetAsync(Uout, 0, P.big_u_len * sizeof(double), st));
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             bool have_diag = false;
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
