@@ -451,8 +451,8 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         }
         if (P.scnt[1] > 0) {
             ProfScope ps(F, FAM_FWD, ls.lds);
-            launch_fwd_level(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX,
-                             F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+            launch_fwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], std::max(P.maxk[KVX_CLS_LDS128], P.maxk[KVX_CLS_LDS96]),
+                           F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
         }
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_FWD);
@@ -477,7 +477,7 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         }
         if (P.scnt[1] > 0) {
             ProfScope ps(F, FAM_BWD, ls.lds);
-            launch_bwd_level(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], KVX_SMALL_MAX, F->d_Lx, X, ldx, nrhs);
+            launch_bwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], F->d_Lx, X, ldx, nrhs);
         }
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_BWD);

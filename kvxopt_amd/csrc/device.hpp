@@ -144,6 +144,11 @@ void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int 
                      const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);
 void launch_bwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int mcap, int kmax,
                      const double *Lx, double *X, int64_t ldx, int nrhs);
+// LDS classes (m <= 128, k <= 64): two wavefronts per front (kernels_wave.hip)
+void launch_fwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
+                    const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);
+void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count,
+                    const double *Lx, double *X, int64_t ldx, int nrhs);
 // big fronts (m > KVX_SMALL_MAX): multi-workgroup solves using the inverted diagonal blocks
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs,

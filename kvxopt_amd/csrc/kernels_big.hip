@@ -533,22 +533,24 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
         }
     }
     if (blockIdx.x == 0 && tid < nb) x[jb0 + tid] = ysh[tid];
-    // rows below the super-block: thread = (row, 64-column quarter), partial sums meet in LDS
+    // rows below the super-block: thread = (row, quarter of the nb columns), partial sums meet in LDS
     const int rr = tid & 255;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int r = rbase + rr;
     double acc = 0.0;
-    if (q * NB < nb && rbase < m) {
+    const int cq = ((nb + 63) >> 6) << 4;          // columns per quarter, a multiple of 16 (16 .. 64)
+    if (q * cq < nb && rbase < m) {
         const bool okr = r < m;
-        const double *Pr = P + (okr ? r : 0) + (int64_t)(jb0 + q * NB) * m;
-        const int nc = min(NB, nb - q * NB);
+        const double *Pr = P + (okr ? r : 0) + (int64_t)(jb0 + q * cq) * m;
+        const double *yq = ysh + q * cq;
+        const int nc = min(cq, nb - q * cq);
 #pragma unroll 1
         for (int j0 = 0; j0 < nc; j0 += 16) {
             double v[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) v[j] = kvx_ld0(Pr, (int64_t)(j0 + j) * m, okr && j0 + j < nc);
 #pragma unroll
-            for (int j = 0; j < 16; j++) acc = __builtin_fma(v[j], ysh[q * NB + j0 + j], acc);
+            for (int j = 0; j < 16; j++) acc = __builtin_fma(v[j], yq[j0 + j], acc);
         }
     }
     red[q * 256 + rr] = acc;

@@ -306,6 +306,140 @@ __global__ __launch_bounds__(64) void k_bwd_wave(DevSym ds, const int32_t *__res
     if (ln < k) xg[fd.first + ln] = xv;
 }
 
+// ------------------------------------------------------------------------------------------
+// Triangular solves for the LDS classes (m <= 128, k <= 64): two wavefronts per front and rhs, same
+// register layout as the wave kernels.  Forward: thread r = row r with its panel row in registers;
+// wave 0 (rows 0..63, which hold every pivot) runs the k dependent steps -- the pivot value travels by
+// readlane, the division is a multiplication by a reciprocal computed once per lane -- and wave 1
+// (rows 64..) then needs only a dot product with the finished y.
+template <int KMAX>
+__global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__restrict__ list,
+                                                 const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx,
+                                                 const double *__restrict__ Wc, double *__restrict__ Wo, int64_t wstride)
+{
+    __shared__ double wsh[128];
+    __shared__ double ysh[64];
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, r = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
+    const double *P = Lx + fd.px;
+    double *x = X + (int64_t)blockIdx.y * ldx + fd.first;
+    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
+    double *wo = Wo + (int64_t)blockIdx.y * wstride + fd.wx;
+    double a[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+    const double dg = kvx_ld0(P, r + (int64_t)r * m, r < k);
+    double w = kvx_ld0(x, r, r < k);
+    if (fd.nchild > 0) {
+        wsh[r] = w;
+        ChildDesc cd = ds.cd[fd.childptr];
+        bool ok = r < cd.uc;
+        int t = ok ? ds.rel[cd.rel + r] : 0;
+        double v = kvx_ld0(wc + cd.wx, r, ok);
+        for (int c = 0; c < fd.nchild; c++) {
+            ChildDesc nx = cd;
+            if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
+            __syncthreads();
+            if (ok) wsh[t] += v;
+            if (c + 1 < fd.nchild) {
+                ok = r < nx.uc;
+                t = ok ? ds.rel[nx.rel + r] : 0;
+                v = kvx_ld0(wc + nx.wx, r, ok);
+            }
+            cd = nx;
+        }
+        __syncthreads();
+        w = wsh[r];
+    }
+    if (wv == 0) {
+        const double rinv = 1.0 / (r < k ? dg : 1.0);
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            if (j < k) {                           // workgroup-uniform
+                const double yj = kvx_readlane(w * rinv, j);
+                w = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w) : w);
+            }
+        }
+        if (r < k) ysh[r] = w;
+    }
+    __syncthreads();
+    if (wv == 1) {
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) w = __builtin_fma(-a[j], ysh[j < k ? j : 0], w);   // a[j] = 0 for j >= k
+    }
+    if (r < k) x[r] = w;
+    else if (r < m) wo[r - k] = w;
+}
+
+// Backward: thread (h, j) holds rows 64 h .. 64 h + 63 of pivot column j.  The part of the update rows
+// (already-solved ancestors) is a dot product shared by the two waves; the pivot rows are then swept
+// from the bottom by wave 0, the solved value travelling by readlane.
+__global__ __launch_bounds__(128) void k_bwd_lds(DevSym ds, const int32_t *__restrict__ list,
+                                                 const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
+{
+    __shared__ double xf[128];     // y (pivot rows) / solved ancestors (update rows)
+    __shared__ double xu[128];     // the same with the pivot rows zeroed
+    __shared__ double accsh[64];
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m, tid = threadIdx.x, ln = tid & 63;
+    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *P = Lx + fd.px;
+    double *xg = X + (int64_t)blockIdx.y * ldx;
+    const int32_t *rows = ds.rowidx + fd.rowptr;
+    const int col = ln < k ? ln : 0;
+    double a[64];
+#pragma unroll
+    for (int rr = 0; rr < 64; rr++) {
+        const int row = 64 * h + rr;
+        a[rr] = kvx_ld0(P, row + (int64_t)col * m, ln < k && row < m && row >= ln);
+    }
+    const double dg = kvx_ld0(P, ln + (int64_t)ln * m, ln < k);
+    const int grow = (tid < m) ? (tid < k ? fd.first + tid : rows[tid]) : 0;
+    const double xin = kvx_ld0(xg, grow, tid < m);
+    xf[tid] = xin;
+    xu[tid] = (tid >= k) ? xin : 0.0;
+    __syncthreads();
+    double acc = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 64; rr++) acc = __builtin_fma(a[rr], xu[64 * h + rr], acc);
+    if (h == 1) accsh[ln] = acc;
+    __syncthreads();
+    if (h == 0) {
+        acc += accsh[ln];
+        const double rinv = 1.0 / (ln < k ? dg : 1.0);
+        double xv = xf[ln];
+#pragma unroll
+        for (int rr = 63; rr >= 0; rr--) {
+            if (rr < k) {                          // workgroup-uniform
+                const double xr = kvx_readlane((xv - acc) * rinv, rr);
+                xv = (ln == rr) ? xr : xv;
+                acc = (ln < rr) ? __builtin_fma(a[rr], xr, acc) : acc;
+            }
+        }
+        if (ln < k) xg[fd.first + ln] = xv;
+    }
+}
+
+void launch_fwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
+                    const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    if (kmax <= 32)
+        hipLaunchKernelGGL(k_fwd_lds<32>, grid, dim3(128), 0, st, ds, list, Lx, X, ldx, Wchild, Wout, wstride);
+    else
+        hipLaunchKernelGGL(k_fwd_lds<64>, grid, dim3(128), 0, st, ds, list, Lx, X, ldx, Wchild, Wout, wstride);
+}
+
+void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count,
+                    const double *Lx, double *X, int64_t ldx, int nrhs)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    dim3 grid((unsigned)count, (unsigned)nrhs);
+    hipLaunchKernelGGL(k_bwd_lds, grid, dim3(128), 0, st, ds, list, Lx, X, ldx);
+}
+
 void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
                      const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride)
 {
