@@ -72,7 +72,6 @@ struct kvx_chol {
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
     DevSym ds{};
-    int fuse_limit = 2000;     // tiles up to which the trailing update also factors the next diagonal block
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
     // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
@@ -245,7 +244,6 @@ int ensure_device(kvx_chol *F)
         }
     }
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
-    { const char *e = getenv("KVX_FUSE_LIMIT"); if (e) F->fuse_limit = atoi(e); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -332,12 +330,11 @@ int enqueue_factor_body(kvx_chol *F)
             const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
-            bool have_diag = false;
+            { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                // a fused trailing update of panel jb - 64 has already factored this diagonal block
-                if (!have_diag) { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, jb, F->d_Lx, F->d_Linv, F->d_status); }
+                // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
                 { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
-                { ProfScope ps(F, FAM_SYRK); have_diag = launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status, F->fuse_limit); }
+                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
             }
         }
         for (int g = 0; g < 3; g++)

@@ -126,11 +126,10 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
                       double *Lx, double *Linv, int *status);
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                      double *Lx, const double *Linv);
-// returns true if the launch also factors + inverts the NEXT diagonal block (jb + 64) in the workgroup
-// of tile (0, 0) (fused variant, chosen when the grid has at most fuse_limit tiles); false:
-// launch_potrf_blk(jb + 64) is due
-bool launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout, double *Linv, int *status, int fuse_limit);
+// C -= X X' on the trailing tiles; the workgroup of tile (0, 0) also factors + inverts the NEXT diagonal
+// block (jb + 64), so launch_potrf_blk is needed for the first panel of a front only
+void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                          double *Lx, double *Uout, double *Linv, int *status);
 
 // solves: X is n x nrhs (ld = ldx) in PERMUTED order; W* are parity workspaces, each rhs
 // column uses a slice of wstride doubles.

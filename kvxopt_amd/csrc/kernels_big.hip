@@ -44,13 +44,11 @@ __device__ __forceinline__ constexpr int blk_slot(int bi, int bj) { return bi * 
 __device__ __forceinline__ int s_idx(int i, int c) { return blk_slot(i >> 4, c >> 4) * SBS + (i & 15) + (c & 15) * 16; }
 __device__ __forceinline__ int y_idx(int i, int c) { return blk_slot(i >> 4, c >> 4) * YBS + (i & 15) + (c & 15) * 17; }
 
-// One pivot step, branch-free: every lane stores (the non-factor lanes into a dump slot) and a failed
-// pivot is only recorded, in `bad`.  The compiler sinks the updates of the 16 unrolled steps towards
-// their uses (a left-looking schedule that keeps ~250 operands in registers); measured, that is the
-// faster schedule (20 us per 64x64 block against 32 us with the updates pinned to their step), so the
-// kernels that carry this code run one workgroup per CU.
+// One pivot step, branch-free so that the 16 unrolled steps form one basic block the scheduler can
+// interleave: every lane stores (the non-factor lanes into a dump slot), a failed pivot is only
+// recorded in `bad`, and the diagonal is d * rsqrt(d) like every other entry of the column.
 template <int J>
-__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int wslot, int r, bool fac, int &bad)
+__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad)
 {
     double *cb = colbuf + (J & 1) * 80;
     const double aj = acc[J];
@@ -59,18 +57,21 @@ __device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, i
     const bool neg = !(d > 0.0);
     bad = (neg && bad > J) ? J : bad;
     d = neg ? 1.0 : d;
-    double ljj, inv;
-    kvx_sqrt_rsqrt(d, ljj, inv);
-    const double w = (fac && r <= J) ? 0.0 : aj * (inv * inv);
+    double inv = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware seed + two Newton steps
+    const double hd = 0.5 * d;
+    inv = inv * __builtin_fma(-hd * inv, inv, 1.5);
+    inv = inv * __builtin_fma(-hd * inv, inv, 1.5);
+    const double lj = aj * inv;                    // l_rj; on the diagonal d / sqrt(d)
+    const double w = (rr <= J) ? 0.0 : lj * inv;   // rr: row of a factor lane, a large number on the other lanes
 #pragma unroll
     for (int t = J + 1; t < 16; t++) acc[t] = __builtin_fma(-w, cb[t], acc[t]);
-    acc[J] = fac ? (r == J ? ljj : (r > J ? aj * inv : 0.0)) : aj * inv;
+    acc[J] = (rr < J) ? 0.0 : lj;
 }
 template <int... Js>
-__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int wslot, int r, bool fac, int &bad,
+__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad,
                                              std::integer_sequence<int, Js...>)
 {
-    (diag16_step<Js>(acc, colbuf, wslot, r, fac, bad), ...);
+    (diag16_step<Js>(acc, colbuf, wslot, rr, bad), ...);
 }
 
 struct PotrfLds {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
                 acc[c] = fac ? lv : ((i < 32 && c == lr) ? 1.0 : 0.0);
             }
             int bad = 16;
-            diag16_steps(acc, lds.colbuf, fac ? lr : i, lr, fac, bad, std::make_integer_sequence<int, 16>());
+            diag16_steps(acc, lds.colbuf, fac ? lr : i, fac ? lr : 1000, bad, std::make_integer_sequence<int, 16>());
             if (bad < 16 && i == 0) atomicMin(status, col0 + 16 * s + bad);
             if (fac) {
 #pragma unroll
@@ -306,8 +307,8 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 // being updated -- the 64 sequential pivot steps of the next panel overlap this panel's update
 // instead of waiting for a launch of their own.  (Running the two parts as separate launches on two
 // streams was measured and lost: a cross-queue dependency costs ~10 us inside a graph replay.)
-// FUSE = false is the plain update (no LDS, 116 VGPRs) for launches that are throughput-bound.
-template <bool FUSE>
+// The factor code costs the kernel nothing in occupancy: 126 VGPRs and 50 KB of LDS keep three
+// workgroups per CU, what the plain update (116 VGPRs) had.
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo,
                                                        double *__restrict__ Linv, int *status)
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
-    if (FUSE && ti == 0 && tj == 0 && t0 < k) {    // workgroup-uniform
+    if (ti == 0 && tj == 0 && t0 < k) {            // workgroup-uniform
         __shared__ PotrfLds lds;
         const int nb2 = min(NB, k - t0);
         const int i = 16 * w + lr;
@@ -390,20 +391,15 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     }
 }
 
-bool launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout, double *Linv, int *status, int fuse_limit)
+void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                          double *Lx, double *Uout, double *Linv, int *status)
 {
-    if (count <= 0) return false;
+    if (count <= 0) return;
     int rows = max_m - jb - 1;
-    if (rows <= 0) return false;
+    if (rows <= 0) return;
     unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     dim3 grid(T, T, (unsigned)count);
-    const bool fuse = (int64_t)T * (T + 1) / 2 * count <= fuse_limit;
-    if (fuse)
-        hipLaunchKernelGGL(k_syrk_trailing<true>, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
-    else
-        hipLaunchKernelGGL(k_syrk_trailing<false>, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
-    return fuse;
+    hipLaunchKernelGGL(k_syrk_trailing, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------

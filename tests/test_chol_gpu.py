@@ -173,6 +173,28 @@ def test_error_semantics():
         F.factorize(bad)
 
 
+@pytest.mark.parametrize("g,where", [(90, 0.02), (90, 0.6), (90, 0.97), (90, 0.999), (150, 0.995)])
+def test_not_posdef_column_in_big_fronts(g, where):
+    """The failing column reported from inside the blocked big-front path (16-column LDS blocks of the
+    64-column panels, including the diagonal blocks factored by the trailing-update kernel) is the
+    oracle's: `where` picks the pivot position in the PERMUTED order (late = top separators)."""
+    n, cp, ri, vx = workloads.laplacian_2d(g)
+    F = Factor(n, cp, ri)
+    perm = F.perm()
+    col = int(perm[min(n - 1, int(where * n))])
+    bad = vx.copy()
+    bad[cp[col]] = -1.0 if where < 0.9 else 1e-3               # indefinite leaf pivot / too-small separator pivot
+    O = OracleChol(n, cp, ri, "L", perm)
+    with pytest.raises(ArithmeticError) as eo:
+        O.factorize(bad)
+    with pytest.raises(ArithmeticError) as e:
+        F.factorize(bad)
+    assert e.value.args[0] == eo.value.args[0]
+    F.factorize(vx)
+    x = np.ones(n); F.solve(x)
+    assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - 1) < 1e-9 * np.sqrt(n)
+
+
 def test_empty_and_tiny():
     F = Factor(0, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64))
     F.factorize(np.zeros(0))
