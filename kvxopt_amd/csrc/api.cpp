@@ -72,6 +72,7 @@ struct kvx_chol {
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
     DevSym ds{};
+    int side_map[3] = {0, 0, 1};   // side stream of the LDS128 / LDS96 / wave launches of a level
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
     // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
@@ -244,6 +245,7 @@ int ensure_device(kvx_chol *F)
         }
     }
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
+    { const char *e = getenv("KVX_SIDE_MAP"); if (e && strlen(e) == 3) for (int g = 0; g < 3; g++) F->side_map[g] = std::min(2, std::max(0, e[g] - '0')); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -299,18 +301,19 @@ int enqueue_factor_body(kvx_chol *F)
         for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++) nwave += P.cnt[c];
         const int grp_cnt[3] = {P.cnt[KVX_CLS_LDS128], P.cnt[KVX_CLS_LDS96], nwave};
         hipStream_t gst[3];
-        bool forked[3];
+        bool side_used[3] = {false, false, false};
         bool main_taken = have_big, any_fork = false;
         for (int g = 2; g >= 0; g--) {                     // the last group present keeps the main stream if it is free
-            forked[g] = grp_cnt[g] > 0 && main_taken;
+            const bool fk = grp_cnt[g] > 0 && main_taken;
             if (grp_cnt[g] > 0) main_taken = true;
-            gst[g] = forked[g] ? F->side[g] : st;
-            any_fork |= forked[g];
+            gst[g] = fk ? F->side[F->side_map[g]] : st;
+            if (fk) side_used[F->side_map[g]] = true;
+            any_fork |= fk;
         }
         if (any_fork) {
             HIPCHK(hipEventRecord(F->ev_fork, st));
-            for (int g = 0; g < 3; g++)
-                if (forked[g]) HIPCHK(hipStreamWaitEvent(F->side[g], F->ev_fork, 0));
+            for (int i = 0; i < 3; i++)
+                if (side_used[i]) HIPCHK(hipStreamWaitEvent(F->side[i], F->ev_fork, 0));
         }
         for (int c = KVX_CLS_LDS128; c < KVX_CLS_WAVE0; c++)
             if (P.cnt[c] > 0) {
@@ -337,8 +340,8 @@ int enqueue_factor_body(kvx_chol *F)
                 { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
             }
         }
-        for (int g = 0; g < 3; g++)
-            if (forked[g]) { HIPCHK(hipEventRecord(F->ev_join[g], F->side[g])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[g], 0)); }
+        for (int i = 0; i < 3; i++)
+            if (side_used[i]) { HIPCHK(hipEventRecord(F->ev_join[i], F->side[i])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[i], 0)); }
     }
     HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
