@@ -178,10 +178,10 @@ def main():
     # HBM traffic of the dominant family from the committed PMC passes (profiles/, separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null when no profile matches.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write_per_kernel.json")))
         if g == 1000 and nrhs == 1 and dom in pmc.get("family_bytes_per_step", {}):
             roofline["traffic"] = pmc["family_bytes_per_step"][dom] / max(dom_launches, 1)
-            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/r01_pmc_fetch_write_per_kernel.json)"
+            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/r01b_pmc_fetch_write_per_kernel.json)"
             roofline["algorithmic_bytes_per_launch"] = (alg_bytes / max(dom_launches, 1)) if roofline["bound"] == "hbm" else None
     except Exception:
         pass
