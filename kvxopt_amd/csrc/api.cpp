@@ -72,7 +72,7 @@ struct kvx_chol {
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
     DevSym ds{};
-    int side_map[3] = {0, 0, 1};   // side stream of the LDS128 / LDS96 / wave launches of a level
+    int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
     // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
@@ -245,7 +245,7 @@ int ensure_device(kvx_chol *F)
         }
     }
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
-    { const char *e = getenv("KVX_SIDE_MAP"); if (e && strlen(e) == 3) for (int g = 0; g < 3; g++) F->side_map[g] = std::min(2, std::max(0, e[g] - '0')); }
+    { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -293,41 +293,53 @@ int enqueue_factor_body(kvx_chol *F)
         const LevelPlan &P = F->plan[l];
         double *Uout = F->d_U[l & 1];
         const double *Uch = F->d_U[(l + 1) & 1];
-        // The fronts of one level are independent: the big-front chain stays on the main stream; the
-        // two LDS classes and the wave classes fork onto side streams and join at level end (each of
-        // these launches is latency-bound by its slowest front, so they must overlap, not queue up).
+        // The fronts of one level are independent.  The big-front chain keeps the main stream; the small-
+        // front launches (two LDS classes, three wave row capacities) are each latency-bound by their
+        // slowest front, so they are spread over the streams by estimated duration (longest first onto
+        // the least loaded stream) instead of queueing up: two side streams beside a big chain, main +
+        // two side streams on the levels without big fronts.  Joined at level end.
         const bool have_big = P.cnt[KVX_CLS_BIG] > 0;
-        int nwave = 0;
-        for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++) nwave += P.cnt[c];
-        const int grp_cnt[3] = {P.cnt[KVX_CLS_LDS128], P.cnt[KVX_CLS_LDS96], nwave};
-        hipStream_t gst[3];
-        bool side_used[3] = {false, false, false};
-        bool main_taken = have_big, any_fork = false;
-        for (int g = 2; g >= 0; g--) {                     // the last group present keeps the main stream if it is free
-            const bool fk = grp_cnt[g] > 0 && main_taken;
-            if (grp_cnt[g] > 0) main_taken = true;
-            gst[g] = fk ? F->side[F->side_map[g]] : st;
-            if (fk) side_used[F->side_map[g]] = true;
-            any_fork |= fk;
-        }
-        if (any_fork) {
-            HIPCHK(hipEventRecord(F->ev_fork, st));
-            for (int i = 0; i < 3; i++)
-                if (side_used[i]) HIPCHK(hipStreamWaitEvent(F->side[i], F->ev_fork, 0));
-        }
+        struct Item { int c; int cnt; int64_t off; double est; int stream; };
+        Item items[5];
+        int nitems = 0;
         for (int c = KVX_CLS_LDS128; c < KVX_CLS_WAVE0; c++)
             if (P.cnt[c] > 0) {
-                hipStream_t sl = gst[c - KVX_CLS_LDS128];
-                ProfScope ps(F, FAM_SMALL, sl);
-                launch_front_small(sl, c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[c] <= 32 ? 32 : 64, F->ds, F->d_lists + P.off[c], P.cnt[c], F->d_Lx, Uch, Uout, F->d_status);
+                const double slots = c == KVX_CLS_LDS128 ? 256.0 : 512.0;          // LDS image: one / two fronts per CU
+                items[nitems++] = Item{c, P.cnt[c], P.off[c], (P.maxk[c] > 32 ? 80.0 : 45.0) * std::max(1.0, P.cnt[c] / slots), 0};
             }
-        // wave classes: the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
         for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c += 2) {
             const int cnt = P.cnt[c] + P.cnt[c + 1];
             if (cnt == 0) continue;
-            const int64_t off = P.cnt[c] > 0 ? P.off[c] : P.off[c + 1];
-            ProfScope ps(F, FAM_SMALL, gst[2]);
-            launch_front_wave(gst[2], wave_class_mcap(c), P.cnt[c] > 0 ? 32 : 16, F->ds, F->d_lists + off, cnt, F->d_Lx, Uch, Uout, F->d_status);
+            const int mcap = wave_class_mcap(c);
+            const double base = mcap == 64 ? 35.0 : (mcap == 48 ? 28.0 : 18.0), slots = mcap == 64 ? 1024.0 : (mcap == 48 ? 2048.0 : 4096.0);
+            items[nitems++] = Item{c, cnt, P.cnt[c] > 0 ? P.off[c] : P.off[c + 1], base * std::max(1.0, cnt / slots), 0};
+        }
+        std::sort(items, items + nitems, [](const Item &x, const Item &y) { return x.est > y.est; });
+        double load[3] = {have_big ? 1e30 : 0.0, 0.0, 0.0};                          // main, side[0], side[1]
+        if (F->side_spread == 0) load[0] = have_big ? 1e30 : -1e30;                 // KVX_SIDE_SPREAD=0: everything small on one stream
+        bool side_used[3] = {false, false, false};
+        for (int i = 0; i < nitems; i++) {
+            int best = 0;
+            for (int t = 1; t < 3; t++)
+                if (load[t] < load[best]) best = t;
+            if (F->side_spread == 0) best = have_big ? 1 : 0;
+            load[best] += items[i].est;
+            items[i].stream = best;
+            if (best > 0) side_used[best - 1] = true;
+        }
+        if (side_used[0] || side_used[1]) {
+            HIPCHK(hipEventRecord(F->ev_fork, st));
+            for (int i = 0; i < 2; i++)
+                if (side_used[i]) HIPCHK(hipStreamWaitEvent(F->side[i], F->ev_fork, 0));
+        }
+        for (int i = 0; i < nitems; i++) {
+            const Item &it = items[i];
+            hipStream_t sl = it.stream == 0 ? st : F->side[it.stream - 1];
+            ProfScope ps(F, FAM_SMALL, sl);
+            if (it.c < KVX_CLS_WAVE0)
+                launch_front_small(sl, it.c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[it.c] <= 32 ? 32 : 64, F->ds, F->d_lists + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
+            else    // the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
+                launch_front_wave(sl, wave_class_mcap(it.c), P.cnt[it.c] > 0 ? 32 : 16, F->ds, F->d_lists + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
         if (have_big) {
             const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
