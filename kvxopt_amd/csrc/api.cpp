@@ -62,7 +62,7 @@ struct kvx_chol {
     int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
             *d_amap = nullptr;
     double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
-    double *d_X = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;
+    double *d_X = nullptr, *d_X0 = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;   // d_X0: untouched copy of the rhs for the forward sweep
     double *d_Linv = nullptr;
     int64_t *d_linv_off = nullptr;
     FrontDesc *d_fd = nullptr;
@@ -258,11 +258,13 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     F->g_solve.clear();                          // the captured sweeps point into the old workspace
     if (F->d_X) { (void)hipFree(F->d_X); F->d_X = nullptr; }
+    if (F->d_X0) { (void)hipFree(F->d_X0); F->d_X0 = nullptr; }
     if (F->d_WK) { (void)hipFree(F->d_WK); F->d_WK = nullptr; }
     for (int p = 0; p < 2; p++)
         if (F->d_W[p]) { (void)hipFree(F->d_W[p]); F->d_W[p] = nullptr; }
     F->x_cap = 0;
     HIPCHK(hipMalloc((void **)&F->d_X, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&F->d_X0, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
     HIPCHK(hipMalloc((void **)&F->d_WK, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
     const int64_t wmax = std::max(S.wrk_size[0], S.wrk_size[1]);   // common per-rhs stride of both parity buffers
     for (int p = 0; p < 2; p++)
@@ -469,7 +471,7 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_FWD);
             launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
-                           X, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
+                           X, F->d_X0, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
         }
         ls.join();
     }
@@ -529,7 +531,12 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
         else HIPCHK(hipMemcpy2DAsync(F->d_X, n * sizeof(double), Bc, ldB * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
         if (kind >= 0) {
             auto body = [&]() -> int {
-                if (kind == 0 || kind == 1) enqueue_fwd(F, F->d_X, n, nr);
+                if (kind == 0 || kind == 1) {
+                    // the first forward step of a big front is spread over workgroups that all read the front's
+                    // pivot entries of the rhs while one of them overwrites them with y: they read this copy
+                    (void)hipMemcpyAsync(F->d_X0, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, F->stream);
+                    enqueue_fwd(F, F->d_X, n, nr);
+                }
                 if (kind == 0 || kind == 2) enqueue_bwd(F, F->d_X, n, nr);
                 return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
             };

@@ -150,7 +150,7 @@ void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int c
                     const double *Lx, double *X, int64_t ldx, int nrhs);
 // big fronts (m > KVX_SMALL_MAX): multi-workgroup solves using the inverted diagonal blocks
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
-                    const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs,
+                    const double *Lx, const double *Linv, double *X, const double *X0, int64_t ldx, int nrhs,
                     double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride);
 void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs, double *WK, int64_t ldw);

@@ -405,35 +405,6 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
 // ------------------------------------------------------------------------------------------
 // Big-front forward solve.  wk (n doubles per rhs) carries the running right-hand side of the
 // pivot rows; the update rows accumulate directly in the level's update-vector buffer.
-__global__ __launch_bounds__(256) void k_fwd_big_init(DevSym ds, const int32_t *__restrict__ list,
-                                                      const double *__restrict__ X, int64_t ldx,
-                                                      double *__restrict__ WK, int64_t ldw,
-                                                      const double *__restrict__ Wc, double *__restrict__ Wo, int64_t wstride)
-{
-    const int s = list[blockIdx.x];
-    const int k = ds.k[s], m = ds.m[s], u = m - k, f = ds.first[s], tid = threadIdx.x;
-    const double *x = X + (int64_t)blockIdx.y * ldx;
-    double *wk = WK + (int64_t)blockIdx.y * ldw + f;
-    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
-    double *wo = Wo + (int64_t)blockIdx.y * wstride + ds.wx[s];
-    for (int i = tid; i < k; i += 256) wk[i] = x[f + i];
-    for (int i = tid; i < u; i += 256) wo[i] = 0.0;
-    __syncthreads();
-    for (int64_t c = ds.childptr[s]; c < ds.childptr[s + 1]; c++) {
-        const int ch = ds.children[c];
-        const int kc = ds.k[ch], uc = ds.m[ch] - kc;
-        if (uc == 0) continue;
-        const int32_t *rl = ds.rel + ds.rowptr[ch] + kc;
-        const double *src = wc + ds.wx[ch];
-        for (int i = tid; i < uc; i += 256) {
-            const int t = rl[i];
-            if (t < k) wk[t] += src[i];
-            else wo[t - k] += src[i];
-        }
-        __syncthreads();
-    }
-}
-
 // Super-step over up to SB = 256 pivot columns [jb0, jb0 + nb).  The solves of the top fronts are a
 // chain of dependent launches, so the step is built for latency: every workgroup (1024 threads) solves
 // the nb x nb diagonal part redundantly and then updates its own 256 rows below the super-block.
@@ -448,13 +419,20 @@ constexpr int SOLVE_NT = 1024;
 // sub-diagonal block (ib, s), ib > s, of the 4 x 4 block lower triangle -> 0..5
 __device__ __forceinline__ constexpr int sblk(int ib, int s) { return ib * (ib - 1) / 2 + s; }
 
+// FIRST = true is the step of the first 256 columns and also assembles the front's right-hand side:
+// every workgroup gathers, for the diagonal rows (redundantly) and for its own 256 rows below, the
+// entries of x (pivot rows) and the children's update vectors (parent-pull, children in sequence) in
+// LDS -- no separate initialisation launch in front of the dependent chain.
+template <bool FIRST>
 __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int32_t *__restrict__ list, int jb0,
                                                            const double *__restrict__ Lx, const double *__restrict__ Linv,
-                                                           double *__restrict__ X, int64_t ldx,
+                                                           double *__restrict__ X, const double *__restrict__ X0, int64_t ldx,
                                                            double *__restrict__ WK, int64_t ldw,
+                                                           const double *__restrict__ Wc,
                                                            double *__restrict__ Wo, int64_t wstride)
 {
     __shared__ double red[3 * 16 * NB];
+    __shared__ double own[FIRST ? 256 : 1];
     __shared__ double wsh[SB];
     __shared__ double ysh[SB];
     const FrontDesc fd = ds.fd[list[blockIdx.y]];
@@ -489,10 +467,30 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
                 lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
                                              ib * NB + lane < nb);
     if (tid < SB) {
-        wsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
+        const double *x0 = X0 + (int64_t)blockIdx.z * ldx + f;     // rhs as it was before the sweep (x gets y meanwhile)
+        wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
         ysh[tid] = 0.0;
+        if (FIRST) own[tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
     }
     __syncthreads();
+    if (FIRST && fd.nchild > 0) {
+        const double *wc = Wc + (int64_t)blockIdx.z * wstride;
+        ChildDesc cd = ds.cd[fd.childptr];
+        for (int c = 0; c < fd.nchild; c++) {
+            ChildDesc nx = cd;
+            if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
+            const int32_t *rl = ds.rel + cd.rel;
+            const double *src = wc + cd.wx;
+            for (int i = tid; i < cd.uc; i += SOLVE_NT) {
+                const int t = rl[i];
+                const double v = src[i];
+                if (t < nb) wsh[t] += v;
+                else if (t >= rbase && t < rbase + 256) own[t - rbase] += v;
+            }
+            __syncthreads();
+            cd = nx;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         if (s < nsub) {
@@ -553,8 +551,13 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
     __syncthreads();
     if (tid < 256 && r < m) {
         const double t = (red[rr] + red[256 + rr]) + (red[512 + rr] + red[768 + rr]);
-        if (r < k) wk[r] -= t;
-        else wo[r - k] -= t;
+        if (FIRST) {
+            if (r < k) wk[r] = own[rr] - t;
+            else wo[r - k] = own[rr] - t;
+        } else {
+            if (r < k) wk[r] -= t;
+            else wo[r - k] -= t;
+        }
     }
 }
 
@@ -685,17 +688,17 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
 }
 
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
-                    const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs,
+                    const double *Lx, const double *Linv, double *X, const double *X0, int64_t ldx, int nrhs,
                     double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride)
 {
     if (count <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_fwd_big_init, dim3((unsigned)count, (unsigned)nrhs), dim3(256), 0, st, ds, list, X, ldx, WK, ldw,
-                       Wchild, Wout, wstride);
     for (int jb = 0; jb < max_k; jb += SB) {
         int rows = max_m - jb - 1;
-        unsigned gx = (unsigned)std::max(1, (rows + 255) / 256);
-        hipLaunchKernelGGL(k_fwd_big_step, dim3(gx, (unsigned)count, (unsigned)nrhs), dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv,
-                           X, ldx, WK, ldw, Wout, wstride);
+        dim3 grid((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, (unsigned)nrhs);
+        if (jb == 0)
+            hipLaunchKernelGGL(k_fwd_big_step<true>, grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+        else
+            hipLaunchKernelGGL(k_fwd_big_step<false>, grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
     }
 }
 
