@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""bench_extra.py -- the other measured configurations of the hot path (one JSON line each, 1 GPU).
+
+  chol5   : bench.py's workload again with nrhs = 3 (SURVEY 8(d) config 2 "also nrhs=3")
+  chol21  : the "~20 nnz/row" north-star variant, 21-point stencil on the 1000 x 1000 grid (workloads.stencil21_2d)
+  lp4b    : BASELINE.json configs[3] in inequality form: the device-resident
+            interior-point loop kvxopt_amd.lp.conelp on the 250 x 200 grid LP (ml = 200 000, n = 50 000);
+            metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
+            plus the per-iteration cost of one KKT factor (assembly + numeric Cholesky) and one KKT solve.
+
+The headline line the driver reads is bench.py's; this script documents the rest (results in DESIGN.md section 5).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def chol_case(name, n, colptr, rowind, values, nrhs, steps, warmup):
+    import torch
+    from kvxopt_amd import workloads
+    from kvxopt_amd.chol import Factor
+    t0 = time.time()
+    F = Factor(n, colptr, rowind, "L", None, None)
+    t_an = time.time() - t0
+    info = F.info()
+    dev = torch.device("cuda", 0)
+    vals_d = torch.from_numpy(values).to(dev)
+    B = np.asfortranarray(np.random.default_rng(2).standard_normal((n, nrhs)))
+    b_d = torch.from_numpy(B.reshape(-1, order="F").copy()).to(dev)
+    x_d = torch.empty_like(b_d)
+
+    def step():
+        F.factorize_dev(vals_d.data_ptr(), sync=False)
+        x_d.copy_(b_d)
+        torch.cuda.current_stream().synchronize()
+        F.solve_dev(x_d.data_ptr(), 0, nrhs, n)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    msf, mss = F.timing()
+    X = x_d.cpu().numpy().reshape(n, nrhs, order="F")
+    r = workloads.sym_matvec(n, colptr, rowind, values, X) - B
+    work = info["flops"] + 4.0 * info["lnz"] * nrhs
+    return {"case": name, "metric": "sparse Cholesky factor+solve GF/s", "value": work / dt / 1e9, "unit": "GF/s",
+            "ms_per_step": dt * 1e3, "ms_factor": msf, "ms_solve": mss, "nrhs": nrhs, "n": n, "nnz_lower": int(len(values)),
+            "lnz": int(info["lnz"]), "flops_sum_cj2": info["flops"], "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]),
+            "max_front": int(info["max_front"]), "analyze_s": round(t_an, 3),
+            "rel_residual": float(np.linalg.norm(r) / np.linalg.norm(B))}
+
+
+def lp_case(gx, gy):
+    from kvxopt_amd import lp, workloads
+    from kvxopt_amd.base import spmatrix
+    P = workloads.lp_grid(gx, gy)
+    ml, n = P["ml"], P["n"]
+    cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
+    G = spmatrix(P["Gx"], P["Gi"], cols, (ml, n))
+    lp.conelp(P["c"], G, P["h"], {"maxiters": 2})            # warm-up: HIP module load, first-touch allocations
+    t0 = time.perf_counter()
+    sol = lp.conelp(P["c"], G, P["h"])
+    dt = time.perf_counter() - t0
+    # per-iteration KKT costs on the same pattern
+    kkt = lp.KKTChol2Dev(ml, n, P["Gp"], P["Gi"], P["Gx"])
+    di = lp.DVec(ml, np.random.default_rng(4).uniform(0.2, 5.0, ml))
+    xv, zv = lp.DVec(n, np.ones(n)), lp.DVec(ml, np.ones(ml))
+    for _ in range(3):
+        kkt.factor(di); kkt.solve(xv, zv)
+    from kvxopt_amd import _lib
+    sync = _lib.lib().kvx_dev_sync
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        kkt.factor(di)
+    sync()
+    t_f = (time.perf_counter() - t0) / 20
+    t0 = time.perf_counter()
+    for _ in range(20):
+        kkt.solve(xv, zv)
+    sync()
+    t_s = (time.perf_counter() - t0) / 20
+    return {"case": "lp4b", "metric": "IPM iterations/s", "value": sol["iterations"] / dt, "unit": "iterations/s",
+            "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "ml": ml, "n": n,
+            "gap": sol["gap"], "primal_infeasibility": sol["primal infeasibility"], "dual_infeasibility": sol["dual infeasibility"],
+            "factorizations": sol["factorizations"], "ms_kkt_factor": t_f * 1e3, "ms_kkt_solve": t_s * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="chol5,chol21,lp4b")
+    ap.add_argument("--grid", type=int, default=1000)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench_extra.py needs a HIP device (no CPU fallback)")
+    from kvxopt_amd import workloads
+    for case in args.cases.split(","):
+        if case == "chol5":
+            out = chol_case("chol5 nrhs=3", *workloads.laplacian_2d(args.grid), 3, args.steps, args.warmup)
+        elif case == "chol21":
+            out = chol_case("chol21 (21-point stencil)", *workloads.stencil21_2d(args.grid), 1, args.steps, args.warmup)
+        elif case == "lp4b":
+            out = lp_case(250, 200)
+        else:
+            raise SystemExit("unknown case " + case)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
