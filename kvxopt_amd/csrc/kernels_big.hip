@@ -14,6 +14,8 @@
 #include "device.hpp"
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
 #include <utility>
 
 namespace kvx {
@@ -391,15 +393,163 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same update on 128 x 128 tiles (opt-in, see launch_syrk_trailing for the measurement): the
+// two operand strips X[rows, :] and X[cols, :] staged through LDS in chunks of 16 panel columns
+// (k-major, double-buffered, global loads of chunk c + 1 in flight under the MFMAs of chunk c).
+// Wave (wr, wc) owns a 64 x 64 quarter: 4 x 4 MFMA tiles, 8 LDS operand reads per 16 MFMAs.
+// Per tile 192 KB of operand reads drop to 32 KB (the 64-tile kernel streams every operand from L2
+// once per wave), and the read-modify-write of C is amortised over four times the flops per launch
+// overhead.  Tile (0, 0) still factors the next diagonal block (its top-left quarter, wave (0, 0)).
+constexpr int SY_T = 128, SY_KC = 16, SY_LD = 144;      // LD = 128 + 16: the 4 k-lanes of an operand read hit distinct banks
+
+struct SyrkStage {
+    double xa[2][SY_KC * SY_LD];       // X[cols of the tile][k chunk], k-major
+    double xb[2][SY_KC * SY_LD];       // X[rows of the tile][k chunk]
+};
+union SyrkLds {
+    SyrkStage st;
+    PotrfLds po;
+};
+
+__global__ __launch_bounds__(256) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                          double *__restrict__ Lx, double *__restrict__ Uo,
+                                                          double *__restrict__ Linv, int *status)
+{
+    __shared__ SyrkLds lds;
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    if (tj > ti) return;
+    const FrontDesc fd = ds.fd[list[blockIdx.z]];
+    const int k = fd.k, m = fd.m, u = m - k;
+    if (jb >= k) return;
+    const int nbk = min(NB, k - jb);
+    const int t0 = jb + nbk;
+    const int r0 = t0 + SY_T * ti, c0 = t0 + SY_T * tj;
+    if (r0 >= m) return;
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+    const int l = tid & 63, lr = l & 15, lk = l >> 4;
+    const bool diag = ti == tj;
+    const bool active = !(diag && wr == 0 && wc == 1);             // the upper-right quarter of a diagonal tile is not stored
+    // staging map: thread -> (row of the strip, 8 of the 16 k of a chunk)
+    const int srow = tid & 127, sk0 = (tid >> 7) * 8;
+    const bool ra_ok = c0 + srow < m, rb_ok = r0 + srow < m;
+    const double *Pa = P + min(c0 + srow, m - 1) + (int64_t)jb * m;
+    const double *Pb = P + min(r0 + srow, m - 1) + (int64_t)jb * m;
+    double ga[8], gb[8];
+    const int nchunk = (nbk + SY_KC - 1) / SY_KC;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int kk = sk0 + j;
+        ga[j] = kvx_ld0(Pa, (int64_t)kk * m, ra_ok && kk < nbk);
+        gb[j] = diag ? 0.0 : kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
+    }
+    d4 acc[4][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[s2][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *xa = lds.st.xa[ch & 1], *xb = lds.st.xb[ch & 1];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            xa[(sk0 + j) * SY_LD + srow] = ga[j];
+            if (!diag) xb[(sk0 + j) * SY_LD + srow] = gb[j];
+        }
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int kk = (ch + 1) * SY_KC + sk0 + j;
+                ga[j] = kvx_ld0(Pa, (int64_t)kk * m, ra_ok && kk < nbk);
+                gb[j] = diag ? 0.0 : kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const double *oa = xa + 64 * wc + lr;
+            const double *ob = (diag ? xa : xb) + 64 * wr + lr;
+#pragma unroll
+            for (int ks = 0; ks < SY_KC; ks += 4) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    av[t] = oa[(ks + lk) * SY_LD + 16 * t];
+                    bv[t] = ob[(ks + lk) * SY_LD + 16 * t];
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        acc[s2][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[s2], acc[s2][t], 0, 0, 0);
+            }
+        }
+        // the other buffer is free again once every wave has passed this chunk's barrier; the next
+        // iteration writes it before its own barrier, so one barrier per chunk suffices
+    }
+    // epilogue: lane holds C[row = .. + 16 s2 + lr][col = .. + 16 t + lk + 4 q]; branch-free RMW in batches of 16
+    const bool fuse = ti == 0 && tj == 0 && t0 < k;               // workgroup-uniform
+    const int nb2 = min(NB, k - t0);
+    if (fuse) __syncthreads();                                     // staging buffers are about to become the potrf image
+    if (active) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) {
+            const int rr = r0 + 64 * wr + 16 * s2 + lr;
+            const bool rin = rr < m;
+            const int rs = min(rr, m - 1);
+            double *ptr[4][4];
+            double old[4][4];
+            bool ok[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int c = c0 + 64 * wc + 16 * t + lk + 4 * q;
+                    ok[t][q] = rin && c <= rr;
+                    const int cs = min(c, rs);
+                    ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
+                    old[t][q] = *ptr[t][q];
+                }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double v = old[t][q] - acc[s2][t][q];
+                    if (ok[t][q]) *ptr[t][q] = v;
+                    if (fuse && w == 0) {                          // top-left quarter = the next diagonal block
+                        const int i = 16 * s2 + lr, cc = 16 * t + lk + 4 * q;
+                        if (t <= s2) lds.po.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? v : (cc == i ? 1.0 : 0.0);
+                    }
+                }
+        }
+    }
+    if (fuse) {
+        __syncthreads();
+        potrf_lds(lds.po, nb2, tid, status, fd.first + t0);
+        potrf_store(lds.po, nb2, tid, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
+    }
+}
+
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                           double *Lx, double *Uout, double *Linv, int *status)
 {
     if (count <= 0) return;
     int rows = max_m - jb - 1;
     if (rows <= 0) return;
-    unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
-    dim3 grid(T, T, (unsigned)count);
-    hipLaunchKernelGGL(k_syrk_trailing, grid, dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+    const int64_t T = (rows + KVX_TILE - 1) / KVX_TILE;
+    // Measured (MI355X): with 64-column panels the 128-tile kernel LOSES (21-point stencil, n = 1e6: factor 24 -> 35 ms):
+    // a rank-64 update is bound by the read-modify-write of C (16 B per 128 flops), not by operand traffic, and the
+    // 64-tile kernel overlaps that traffic better at three workgroups per CU.  It pays only with more panel columns
+    // per pass over C (two-level blocking, not built yet), so it is opt-in: KVX_SYRK128_TILES = tile count from which on it is used.
+    const char *e = getenv("KVX_SYRK128_TILES");
+    const int64_t big_limit = e ? atoll(e) : INT64_MAX;
+    if (T * (T + 1) / 2 * count >= big_limit) {
+        unsigned T2 = (unsigned)((rows + SY_T - 1) / SY_T);
+        hipLaunchKernelGGL(k_syrk_trailing128, dim3(T2, T2, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+    } else {                                          // latency regime: more, smaller workgroups
+        hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

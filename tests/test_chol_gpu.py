@@ -195,6 +195,19 @@ def test_not_posdef_column_in_big_fronts(g, where):
     assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - 1) < 1e-9 * np.sqrt(n)
 
 
+def test_syrk128_variant_parity(monkeypatch):
+    """The opt-in 128 x 128 LDS-staged trailing update (KVX_SYRK128_TILES) gives the same factor and
+    solutions as the oracle, including the diagonal blocks it factors in its (0, 0) workgroup."""
+    import scipy.sparse as sp
+    monkeypatch.setenv("KVX_SYRK128_TILES", "1")
+    monkeypatch.setenv("KVX_NO_GRAPH", "1")
+    M = sp.random(2500, 2500, 0.02, random_state=4, format="csc")
+    S = (M @ M.T + sp.eye(2500) * 5.0).tocsc()
+    L = sp.tril(S).tocsc(); L.sort_indices()
+    parity(2500, L.indptr, L.indices, L.data, seed=4)
+    parity(*workloads.laplacian_2d(150), seed=150)
+
+
 def test_empty_and_tiny():
     F = Factor(0, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64))
     F.factorize(np.zeros(0))
