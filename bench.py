@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--roofline-family", default="auto")
     ap.add_argument("--chol-opts", default="", help="JSON dict of analysis options (nd_leaf, leaf_cols, leaf_rows, relax_*) for experiments")
     ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop and the CPU baseline (experiments)")
+    ap.add_argument("--dist", default="replicas", choices=["replicas", "subtree"],
+                    help="N > 1 ranks: 'replicas' = every rank factors its own system (weak scaling, no data-path collective; default); "
+                         "'subtree' = ONE system sharded by elimination-tree subtrees over the ranks (kvxopt_amd.dist.DistFactor: "
+                         "all-reduce of the subtree-root update matrices per factorisation, of update vectors and x per solve; strong scaling)")
     return ap.parse_args()
 
 
@@ -83,12 +87,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
+    backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from kvxopt_amd import workloads
     from kvxopt_amd.chol import Factor
@@ -110,7 +121,17 @@ def main():
     x_d = torch.empty_like(b_d)
     torch.cuda.synchronize()
 
+    DF = None
+    if args.dist == "subtree" and world > 1:
+        from kvxopt_amd.dist import DistFactor
+        DF = DistFactor(n, colptr, rowind, "L", None, json.loads(args.chol_opts) if args.chol_opts else None, device=dev)
+
     def step():
+        if DF is not None:                                   # one system over all ranks
+            DF.factorize(vals_d)
+            x_d.copy_(b_d)
+            DF.solve(x_d, nrhs)
+            return
         F.factorize_dev(vals_d.data_ptr(), sync=False)
         x_d.copy_(b_d)
         torch.cuda.current_stream().synchronize()          # x_d ready before the factor's own stream reads it
@@ -151,6 +172,18 @@ def main():
         ms, cnt = F.prof_read()
         fam_times[fam] = (ms / 2.0, cnt // 2)
     F.prof_select(None)
+    if DF is not None:
+        if rank == 0:
+            print(json.dumps({"metric": "sparse Cholesky factor+solve GF/s", "value": work * args.steps / dt / 1e9, "unit": "GF/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "5-pt Laplacian %dx%d, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (g, g, n, nrhs),
+                                         "parallelism": "subtree-sharded x%d (cut depth %d, %.1f MB all-reduced per factorisation)"
+                                                        % (world, DF.cut, DF.ulen * 8 / 1e6)},
+                              "rel_residual": relres, "roofline": None, "cpu_baseline": None}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.quick:
         if rank == 0:
             print(json.dumps({"value": work * args.steps * world / dt / 1e9, "ms_per_step": dt / args.steps * 1e3, "ms_factor": ms_factor,

@@ -120,6 +120,26 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);
  * prof_read returns the summed kernel time and launch count since the last select. */
 int kvx_chol_prof_select(kvx_chol *F, int family);
 int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches);
+/* ---- subtree-sharded mode: ONE system factored and solved by nranks processes, one GPU each ----------
+ * (no reference counterpart -- the reference is single-process.)  Every rank analyses the same
+ * matrix; kvx_chol_dist_setup cuts the elimination tree at depth `cut`: the subtrees below the cut are owned by
+ * one rank each and only that rank factors / solves them, the top of the tree (depth < cut) is replicated.
+ * The ONE real exchange step per factorisation is the update (Schur-complement) matrices of the subtree roots;
+ * per solve, their update vectors up and the owned pieces of x back.  The library does no communication: each
+ * phase leaves / expects the data to be summed over ranks (all-reduce SUM; non-owned parts are zero) in the
+ * caller's device buffer `xchg` (kvxopt_amd/dist.py drives it with torch.distributed, RCCL on a real node).
+ *   info[0] = cut depth, info[1] = doubles exchanged per factorisation, info[2] = doubles per solve and rhs
+ *   (update vectors), info[3] = n;  xchg must hold max(info[1], max(info[2], n) * nrhs) doubles.            */
+int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner /* nsuper */, int *cut);   /* host-only: the partition */
+int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4]);
+/* phase 0: scatter A, factor this rank's subtrees, pack the root update matrices into xchg.  [all-reduce xchg]
+ * phase 1: unpack, factor the replicated top; *minor as kvx_chol_factorize_dev (take the MIN over ranks). */
+int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg_dev, int64_t *minor);
+/* A x = b.  phase 0: permute b, forward-solve the owned subtrees, pack the root update vectors. [all-reduce]
+ * phase 1: unpack, top forward + backward, owned subtrees backward, pack the owned entries of x.  [all-reduce]
+ * phase 2: unpack x, un-permute into B_dev. */
+int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B_dev, int64_t nrhs, int64_t ldB, double *xchg_dev);
+
 void kvx_chol_free(kvx_chol *F);
 void kvx_free(void *p);
 

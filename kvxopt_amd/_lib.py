@@ -54,6 +54,10 @@ _SIGS = {
     "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
     "kvx_chol_prof_select": (ctypes.c_int, [vp, ctypes.c_int]),
     "kvx_chol_prof_read": (ctypes.c_int, [vp, f64p, i64p]),
+    "kvx_chol_dist_owner": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]),
+    "kvx_chol_dist_setup": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, i64p]),
+    "kvx_chol_dist_factor_phase": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, i64p]),
+    "kvx_chol_dist_solve_phase": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64, vp]),
     "kvx_chol_free": (None, [vp]),
     "kvx_free": (None, [vp]),
     "kvx_atda_plan": (ctypes.c_int, [i64, i64, i64p, i64p, i64p, i64p, ctypes.POINTER(vp)]),

@@ -72,6 +72,13 @@ struct kvx_chol {
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
     DevSym ds{};
+    // subtree-sharded mode (kvx_chol_dist_*): levels >= dist_cut hold only this rank's subtrees, levels < dist_cut
+    // (the top of the tree) are replicated on every rank
+    int dist_rank = 0, dist_nranks = 1, dist_cut = 0;
+    int64_t dist_ulen = 0, dist_wlen = 0;      // doubles of the update-matrix / update-vector region of level dist_cut
+    uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
+    std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
+    std::vector<int64_t> lptr_host;
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
@@ -131,6 +138,35 @@ void prof_collect(kvx_chol *F)
     F->prof_used = 0;
 }
 
+
+// per-level launch plan from F->lists_host / F->lptr_host (the level lists already uploaded to d_lists)
+void build_plan(kvx_chol *F)
+{
+    Symbolic &S = F->S;
+    F->plan.assign((size_t)S.nlevels, LevelPlan());
+    for (int l = 0; l < S.nlevels; l++) {
+        LevelPlan &P = F->plan[l];
+        for (int c = 0; c < KVX_NCLS; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; P.maxk[c] = 0; }
+        for (int g = 0; g < 3; g++) { P.soff[g] = 0; P.scnt[g] = 0; P.smaxm[g] = 0; }
+        for (int64_t q = F->lptr_host[l]; q < F->lptr_host[l + 1]; q++) {
+            int s = F->lists_host[q];
+            int m = S.sn_m[s], k = S.sn_k[s];
+            int c = front_class(m, k);
+            if (P.cnt[c] == 0) P.off[c] = q;
+            P.cnt[c]++;
+            P.maxm[c] = std::max(P.maxm[c], m);
+            P.maxk[c] = std::max(P.maxk[c], k);
+            if (c == KVX_CLS_BIG) {
+                P.big_maxk = std::max(P.big_maxk, k);
+                P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
+            }
+            int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
+            if (P.scnt[g] == 0) P.soff[g] = q;
+            P.scnt[g]++;
+            P.smaxm[g] = std::max(P.smaxm[g], m);
+        }
+    }
+}
 
 int ensure_device(kvx_chol *F)
 {
@@ -220,30 +256,9 @@ int ensure_device(kvx_chol *F)
     }
     F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
                    F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
-    // per-level launch plan
-    F->plan.assign((size_t)S.nlevels, LevelPlan());
-    for (int l = 0; l < S.nlevels; l++) {
-        LevelPlan &P = F->plan[l];
-        for (int c = 0; c < KVX_NCLS; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; P.maxk[c] = 0; }
-        for (int g = 0; g < 3; g++) { P.soff[g] = 0; P.scnt[g] = 0; P.smaxm[g] = 0; }
-        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
-            int s = S.levellist[q];
-            int m = S.sn_m[s], k = S.sn_k[s];
-            int c = front_class(m, k);
-            if (P.cnt[c] == 0) P.off[c] = q;
-            P.cnt[c]++;
-            P.maxm[c] = std::max(P.maxm[c], m);
-            P.maxk[c] = std::max(P.maxk[c], k);
-            if (c == KVX_CLS_BIG) {
-                P.big_maxk = std::max(P.big_maxk, k);
-                P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
-            }
-            int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
-            if (P.scnt[g] == 0) P.soff[g] = q;
-            P.scnt[g]++;
-            P.smaxm[g] = std::max(P.smaxm[g], m);
-        }
-    }
+    F->lists_host = S.levellist;
+    F->lptr_host = S.levelptr;
+    build_plan(F);
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     F->dev_ready = true;
@@ -284,14 +299,18 @@ int wait_for_caller(kvx_chol *F)
 }
 
 // enqueue the numeric factorisation; d_Ax already holds the values
-int enqueue_factor_body(kvx_chol *F)
+// levels lfrom, lfrom - 1, ..., lto; prologue = zero L, reset the status word, scatter A; epilogue = fetch the status
+int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue = true, bool epilogue = true)
 {
     Symbolic &S = F->S;
     hipStream_t st = F->stream;
-    HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
-    HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
-    { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
-    for (int l = S.nlevels - 1; l >= 0; l--) {
+    if (prologue) {
+        HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+        { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
+    }
+    if (lfrom < 0) lfrom = S.nlevels - 1;
+    for (int l = lfrom; l >= lto; l--) {
         const LevelPlan &P = F->plan[l];
         double *Uout = F->d_U[l & 1];
         const double *Uch = F->d_U[(l + 1) & 1];
@@ -357,7 +376,7 @@ int enqueue_factor_body(kvx_chol *F)
         for (int i = 0; i < 3; i++)
             if (side_used[i]) { HIPCHK(hipEventRecord(F->ev_join[i], F->side[i])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[i], 0)); }
     }
-    HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (epilogue) HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
@@ -385,7 +404,7 @@ int enqueue_factor(kvx_chol *F)
     const bool graph_ok = F->use_graph && F->prof_family < 0;
     F->factor_calls++;
     if (graph_ok && !F->g_factor && F->factor_calls >= 2)
-        F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });
+        F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });   // (sharded mode drives the body itself)
     if (graph_ok && F->g_factor) {
         HIPCHK(hipGraphLaunch(F->g_factor, st));
     } else {
@@ -448,11 +467,12 @@ static void wave_range(const LevelPlan &P, int64_t &off, int &cnt)
         if (P.cnt[c] > 0) { if (cnt == 0) off = P.off[c]; cnt += P.cnt[c]; }
 }
 
-void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0)
 {
     Symbolic &S = F->S;
     const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
-    for (int l = S.nlevels - 1; l >= 0; l--) {
+    if (lfrom < 0) lfrom = S.nlevels - 1;
+    for (int l = lfrom; l >= lto; l--) {
         const LevelPlan &P = F->plan[l];
         const double *Wch = F->d_W[(l + 1) & 1];
         double *Wout = F->d_W[l & 1];
@@ -477,10 +497,11 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
     }
 }
 
-void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs)
+void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, int lto = -1)
 {
     Symbolic &S = F->S;
-    for (int l = 0; l < S.nlevels; l++) {
+    if (lto < 0) lto = S.nlevels - 1;
+    for (int l = lfrom; l <= lto; l++) {
         const LevelPlan &P = F->plan[l];
         int64_t woff; int wcnt;
         wave_range(P, woff, wcnt);
@@ -856,6 +877,142 @@ int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches)
     return KVX_OK;
 }
 
+// ---- subtree-sharded mode ------------------------------------------------------------------------
+int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner, int *cut)
+{
+    if (!F || nranks < 1 || !owner || !cut) return KVX_EINVAL;
+    std::vector<int32_t> ow;
+    int c = 0;
+    dist_partition(F->S, nranks, ow, c);
+    std::copy(ow.begin(), ow.end(), owner);
+    *cut = c;
+    return KVX_OK;
+}
+
+int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
+{
+    if (!F || nranks < 1 || rank < 0 || rank >= nranks || !info) return KVX_EINVAL;
+    int rc = ensure_device(F);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(F->stream));
+    Symbolic &S = F->S;
+    std::vector<int32_t> owner;
+    int cut = 0;
+    dist_partition(S, nranks, owner, cut);
+    // level lists: the top unfiltered, the levels from the cut down hold this rank's fronts only
+    F->lists_host.clear();
+    F->lptr_host.assign((size_t)S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; l++) {
+        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
+            const int32_t s = S.levellist[q];
+            if (nranks == 1 || l < cut || owner[s] == rank) F->lists_host.push_back(s);
+        }
+        F->lptr_host[l + 1] = (int64_t)F->lists_host.size();
+    }
+    if (F->d_lists) { HIPCHK(hipFree(F->d_lists)); F->d_lists = nullptr; }
+    if ((rc = upload(&F->d_lists, F->lists_host))) return rc;
+    build_plan(F);
+    if (F->g_factor) { (void)hipGraphExecDestroy(F->g_factor); F->g_factor = nullptr; }
+    for (auto &g : F->g_solve)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    F->g_solve.clear();
+    // regions of the parity buffers used by level `cut` (all of its fronts, owned or not)
+    int64_t ulen = 0, wlen = 0;
+    if (nranks > 1)
+        for (int64_t q = S.levelptr[cut]; q < S.levelptr[cut + 1]; q++) {
+            const int32_t s = S.levellist[q];
+            const int64_t u = S.sn_m[s] - S.sn_k[s];
+            ulen = std::max(ulen, S.ux[s] + u * u);
+            wlen = std::max(wlen, S.wx[s] + u);
+        }
+    // which entries of x this rank reports: its own subtrees' pivots; rank 0 also the top's
+    std::vector<uint8_t> keep((size_t)std::max<int64_t>(S.n, 1), 0);
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        const bool mine = nranks == 1 || (S.depth[s] < cut ? rank == 0 : owner[s] == rank);
+        if (mine)
+            for (int64_t j = S.super[s]; j < S.super[s + 1]; j++) keep[j] = 1;
+    }
+    if (F->d_keep) { HIPCHK(hipFree(F->d_keep)); F->d_keep = nullptr; }
+    if ((rc = upload(&F->d_keep, keep))) return rc;
+    F->dist_rank = rank; F->dist_nranks = nranks; F->dist_cut = nranks == 1 ? 0 : cut;
+    F->dist_ulen = ulen; F->dist_wlen = wlen;
+    info[0] = F->dist_cut; info[1] = ulen; info[2] = wlen; info[3] = S.n;
+    return KVX_OK;
+}
+
+int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
+{
+    if (!F || !F->dev_ready || phase < 0 || phase > 1) return KVX_EINVAL;
+    Symbolic &S = F->S;
+    hipStream_t st = F->stream;
+    const int cut = F->dist_cut;
+    double *Ucut = F->d_U[cut & 1];
+    int rc;
+    if (phase == 0) {
+        if ((rc = wait_for_caller(F))) return rc;
+        if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(F->ev[0], st));
+        // phase 0 covers the levels nlevels-1 .. cut; the update matrices of level `cut` that other ranks own stay zero
+        HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));
+        launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx);
+        if (cut == 0) return KVX_OK;                 // single rank: everything happens in phase 1
+        // deeper levels of the same parity run first and overwrite the region: zero it when level cut+1 is done
+        if ((rc = enqueue_factor_body(F, S.nlevels - 1, cut + 1, false, false))) return rc;
+        if (F->dist_ulen > 0) HIPCHK(hipMemsetAsync(Ucut, 0, F->dist_ulen * sizeof(double), st));
+        if ((rc = enqueue_factor_body(F, cut, cut, false, false))) return rc;
+        if (F->dist_ulen > 0) HIPCHK(hipMemcpyAsync(xchg, Ucut, F->dist_ulen * sizeof(double), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return KVX_OK;
+    }
+    if ((rc = wait_for_caller(F))) return rc;
+    if (cut > 0 && F->dist_ulen > 0) HIPCHK(hipMemcpyAsync(Ucut, xchg, F->dist_ulen * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if ((rc = enqueue_factor_body(F, cut == 0 ? S.nlevels - 1 : cut - 1, 0, false, true))) return rc;
+    HIPCHK(hipEventRecord(F->ev[1], st));
+    F->pending = true;
+    F->have_ftime = false;
+    return finish_factor(F, minor);
+}
+
+int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
+{
+    if (!F || !F->dev_ready || phase < 0 || phase > 2 || nrhs < 1 || nrhs > 65535) return KVX_EINVAL;
+    if (!F->numeric) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    if (F->minor < F->S.n) { set_err("singular matrix"); return KVX_ESINGULAR; }
+    Symbolic &S = F->S;
+    hipStream_t st = F->stream;
+    const int64_t n = S.n;
+    const int nr = (int)nrhs, cut = F->dist_cut;
+    const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
+    int rc;
+    if ((rc = ensure_solve_ws(F, nr))) return rc;
+    if ((rc = wait_for_caller(F))) return rc;
+    double *Wcut = F->d_W[cut & 1];
+    const size_t wbytes = (size_t)F->dist_wlen * sizeof(double);
+    if (phase == 0) {
+        launch_perm_gather(st, F->d_perm, n, nr, B, ldB, F->d_X, n);
+        HIPCHK(hipMemcpyAsync(F->d_X0, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (cut > 0) {
+            enqueue_fwd(F, F->d_X, n, nr, S.nlevels - 1, cut + 1);
+            if (wbytes) HIPCHK(hipMemset2DAsync(Wcut, wstride * sizeof(double), 0, wbytes, nr, st));
+            enqueue_fwd(F, F->d_X, n, nr, cut, cut);
+            if (wbytes) HIPCHK(hipMemcpy2DAsync(xchg, wbytes, Wcut, wstride * sizeof(double), wbytes, nr, hipMemcpyDeviceToDevice, st));
+        }
+    } else if (phase == 1) {
+        if (cut > 0 && wbytes) HIPCHK(hipMemcpy2DAsync(Wcut, wstride * sizeof(double), xchg, wbytes, wbytes, nr, hipMemcpyDeviceToDevice, st));
+        enqueue_fwd(F, F->d_X, n, nr, cut == 0 ? S.nlevels - 1 : cut - 1, 0);
+        enqueue_bwd(F, F->d_X, n, nr, 0, S.nlevels - 1);           // levels >= cut hold only the owned fronts
+        if (F->dist_nranks > 1) launch_mask_rows(st, F->d_keep, n, nr, F->d_X, n);
+        HIPCHK(hipMemcpyAsync(xchg, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIPCHK(hipMemcpyAsync(F->d_X, xchg, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
+        launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, B, ldB);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return KVX_OK;
+}
+
 void kvx_chol_free(kvx_chol *F)
 {
     if (!F) return;
@@ -878,6 +1035,7 @@ void kvx_chol_free(kvx_chol *F)
             if (F->side[i]) (void)hipStreamDestroy(F->side[i]);
             if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
         }
+        if (F->d_keep) (void)hipFree(F->d_keep);
         if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
         if (F->ev_in) (void)hipEventDestroy(F->ev_in);
         if (F->stream) (void)hipStreamDestroy(F->stream);

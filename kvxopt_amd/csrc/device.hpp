@@ -159,6 +159,7 @@ void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs
                         double *out, int64_t ldo);
 void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
                          double *out, int64_t ldo);
+void launch_mask_rows(hipStream_t st, const uint8_t *keep, int64_t n, int nrhs, double *X, int64_t ldx);
 void launch_extract_diag(hipStream_t st, const DevSym &ds, int64_t nsuper, const double *Lx, double *d);
 
 }  // namespace kvx

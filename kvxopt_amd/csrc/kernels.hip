@@ -306,6 +306,18 @@ void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrh
     hipLaunchKernelGGL(k_perm_scatter, grid, dim3(256), 0, st, perm, n, in, ldi, out, ldo);
 }
 
+// x[i] := keep[i] ? x[i] : 0 (sharded solves: every entry of x is reported by exactly one rank, the sum over ranks is x)
+__global__ void k_mask_rows(const uint8_t *__restrict__ keep, int64_t n, double *__restrict__ X, int64_t ldx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !keep[i]) X[i + (int64_t)blockIdx.y * ldx] = 0.0;
+}
+void launch_mask_rows(hipStream_t st, const uint8_t *keep, int64_t n, int nrhs, double *X, int64_t ldx)
+{
+    if (n <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_mask_rows, dim3((unsigned)((n + 255) / 256), (unsigned)nrhs), dim3(256), 0, st, keep, n, X, ldx);
+}
+
 __global__ void k_extract_diag(DevSym ds, int64_t nsuper, const double *__restrict__ Lx, double *__restrict__ d)
 {
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -472,4 +472,48 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         }
 }
 
+void dist_partition(const Symbolic &S, int nranks, std::vector<int32_t> &owner, int &cut)
+{
+    const int64_t ns = S.nsuper;
+    owner.assign((size_t)ns, -1);
+    cut = 0;
+    if (nranks <= 1 || S.nlevels <= 1) { cut = 0; std::fill(owner.begin(), owner.end(), 0); return; }
+    // subtree work: children precede parents in the postordered supernode numbering
+    std::vector<double> wsub((size_t)ns, 0.0);
+    for (int64_t s = 0; s < ns; s++) {
+        const double m = S.sn_m[s], k = S.sn_k[s];
+        wsub[s] += k * m * m + 1.0;
+        if (S.sparent[s] >= 0) wsub[S.sparent[s]] += wsub[s];
+    }
+    // the cut depth minimises (replicated work above the cut) + (largest per-rank sum of subtree work below it),
+    // subtrees assigned longest-first to the least loaded rank
+    auto lpt = [&](int d, std::vector<int32_t> *assign) {
+        std::vector<int32_t> roots;
+        for (int64_t q = S.levelptr[d]; q < S.levelptr[d + 1]; q++) roots.push_back(S.levellist[q]);
+        std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
+        std::vector<double> load((size_t)nranks, 0.0);
+        for (int32_t r : roots) {
+            int best = 0;
+            for (int t = 1; t < nranks; t++)
+                if (load[t] < load[best]) best = t;
+            if (assign) (*assign)[r] = best;
+            load[best] += wsub[r];
+        }
+        return *std::max_element(load.begin(), load.end());
+    };
+    double top = 0.0, best_cost = 0.0;
+    cut = 1;
+    for (int d = 1; d < S.nlevels; d++) {
+        for (int64_t q = S.levelptr[d - 1]; q < S.levelptr[d]; q++) {
+            const int32_t s = S.levellist[q];
+            top += (double)S.sn_k[s] * S.sn_m[s] * S.sn_m[s] + 1.0;
+        }
+        const double cost = top + lpt(d, nullptr);
+        if (d == 1 || cost < best_cost) { best_cost = cost; cut = d; }
+    }
+    lpt(cut, &owner);
+    for (int64_t s = ns - 1; s >= 0; s--)           // parents first
+        if (S.depth[s] > cut) owner[s] = owner[S.sparent[s]];
+}
+
 }  // namespace kvx

@@ -84,4 +84,10 @@ void analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
               int leaf, std::vector<int64_t> &perm);
 
+// Shard the elimination tree over nranks: the fronts at depth < cut are the replicated top of
+// the tree; each front at depth == cut roots a subtree owned by one rank (longest-processing-time assignment
+// on the subtree flop counts).  owner[s] = rank for depth >= cut, -1 for the top.  cut minimises the estimate
+// (work of the replicated top) + (largest per-rank subtree work).  Host-only, deterministic.
+void dist_partition(const Symbolic &S, int nranks, std::vector<int32_t> &owner, int &cut);
+
 }  // namespace kvx
