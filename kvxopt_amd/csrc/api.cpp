@@ -79,6 +79,7 @@ struct kvx_chol {
     uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
     std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
     std::vector<int64_t> lptr_host;
+    int two_level_m = INT_MAX; // levels whose largest front is at least this order use the two-level blocked update (opt-in: KVX_TWO_LEVEL_M)
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
@@ -261,6 +262,7 @@ int ensure_device(kvx_chol *F)
     build_plan(F);
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
+    { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -367,10 +369,25 @@ int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue 
             const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
-            for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
-                // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
-                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
-                { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+            if (bigm >= F->two_level_m) {
+                // 256-column outer blocks, one rank-256 update of the trailing matrix per block.  Opt-in: measured on
+                // MI355X it does not pay yet (dense n = 10240: 17.1 ms either way; 3-D 80^3: 54.9 vs 51.0 ms; 21-point
+                // 1000^2: 31.3 vs 24.3 ms) -- the outer update adds a serial launch per block; it needs look-ahead
+                // (outer update of block b beside the panel chain of block b + 1) and a faster 128-tile kernel
+                constexpr int OB = 256;
+                for (int ob = 0; ob < P.big_maxk; ob += OB) {
+                    for (int jb = ob; jb < std::min(ob + OB, P.big_maxk); jb += KVX_NB) {
+                        { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
+                        { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, ob + OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                    }
+                    { ProfScope ps(F, FAM_SYRK); launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                }
+            } else {
+                for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
+                    // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
+                    { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
+                    { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                }
             }
         }
         for (int i = 0; i < 3; i++)

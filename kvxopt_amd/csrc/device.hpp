@@ -131,6 +131,13 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                           double *Lx, double *Uout, double *Linv, int *status);
 
+// two-level blocking (fronts that are flop-bound): per panel only the rest of the 256-column outer block [.., ob_end),
+// then one rank-(<= ob_len) update of everything right of the outer block [ob, ob + ob_len)
+void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb, int ob_end,
+                       double *Lx, double *Uout, double *Linv, int *status);
+void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
+                       double *Lx, double *Uout, double *Linv, int *status);
+
 // solves: X is n x nrhs (ld = ldx) in PERMUTED order; W* are parity workspaces, each rhs
 // column uses a slice of wstride doubles.
 void launch_fwd_level(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,

@@ -14,6 +14,7 @@
 #include "device.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <cstdlib>
 #include <utility>
@@ -311,9 +312,11 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 // streams was measured and lost: a cross-queue dependency costs ~10 us inside a graph replay.)
 // The factor code costs the kernel nothing in occupancy: 126 VGPRs and 50 KB of LDS keep three
 // workgroups per CU, what the plain update (116 VGPRs) had.
+// col_lim: two-level blocking (launch_panel_updates): only the columns < min(col_lim, k) -- the rest of the
+// current 256-column outer block -- are updated per panel; INT_MAX = the whole trailing matrix.
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo,
-                                                       double *__restrict__ Linv, int *status)
+                                                       double *__restrict__ Linv, int *status, int col_lim)
 {
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (tj > ti) return;
@@ -324,6 +327,8 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     const int t0 = jb + nbk;
     const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
     if (r0 >= m) return;
+    const int cend = col_lim == INT_MAX ? m : min(col_lim, k);
+    if (c0 >= cend) return;
     double *P = Lx + fd.px;
     double *U = Uo + fd.ux;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c = c0 + 16 * t + lk + 4 * q;
-            ok[t][q] = rin && c <= rr;
+            ok[t][q] = rin && c <= rr && c < cend;
             const int cs = min(c, rs);
             ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
             old[t][q] = *ptr[t][q];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
         for (int q = 0; q < 4; q++)
             if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
-    if (ti == 0 && tj == 0 && t0 < k) {            // workgroup-uniform
+    if (ti == 0 && tj == 0 && t0 < cend && t0 < k) {   // workgroup-uniform
         __shared__ PotrfLds lds;
         const int nb2 = min(NB, k - t0);
         const int i = 16 * w + lr;
@@ -412,18 +417,37 @@ union SyrkLds {
     PotrfLds po;
 };
 
-__global__ __launch_bounds__(256) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int jb,
+// Columns [kb, min(kb + klen, k)) of the panel are the update's K range (klen = 64: one panel; 256: the outer
+// update of the two-level blocking, which is what makes this kernel pay: four times the flops per pass over C).
+// (launch bound: two waves per SIMD -- the 128 accumulator registers live in AGPRs, the rest must fit 128 VGPRs;
+// at one wave per SIMD nothing hides the staging loads and the kernel ran at 21 TF/s)
+__global__ __launch_bounds__(256, 2) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
                                                           double *__restrict__ Lx, double *__restrict__ Uo,
                                                           double *__restrict__ Linv, int *status)
 {
     __shared__ SyrkLds lds;
-    const int ti = blockIdx.x, tj = blockIdx.y;
+    // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  The lower
+    // triangle of tiles is cut into 8 x 8 super-blocks and XCD x takes the super-blocks x, x + 8, ...: the 64
+    // workgroups resident on an XCD then share 16 operand strips (4 MB) instead of touching the whole panel.
+    int ti, tj;
+    {
+        const unsigned id = blockIdx.x, xcd = id & 7u, slot = id >> 3;
+        const unsigned L = ((slot >> 6) * 8u + xcd) * 64u + (slot & 63u);
+        const unsigned SB = L >> 6, within = L & 63u;
+        unsigned si = (unsigned)((__builtin_sqrtf(8.0f * (float)SB + 1.0f) - 1.0f) * 0.5f);
+        while ((si + 1) * (si + 2) / 2 <= SB) si++;
+        while (si * (si + 1) / 2 > SB) si--;
+        const unsigned sj = SB - si * (si + 1) / 2;
+        ti = (int)(8 * si + (within >> 3));
+        tj = (int)(8 * sj + (within & 7u));
+    }
     if (tj > ti) return;
     const FrontDesc fd = ds.fd[list[blockIdx.z]];
     const int k = fd.k, m = fd.m, u = m - k;
-    if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
-    const int t0 = jb + nbk;
+    if (kb >= k) return;
+    const int jb = kb;
+    const int nbk = min(klen, k - kb);                             // K of this update
+    const int t0 = kb + nbk;
     const int r0 = t0 + SY_T * ti, c0 = t0 + SY_T * tj;
     if (r0 >= m) return;
     double *P = Lx + fd.px;
@@ -531,6 +555,14 @@ __global__ __launch_bounds__(256) void k_syrk_trailing128(DevSym ds, const int32
     }
 }
 
+// grid of k_syrk_trailing128: 64 workgroups per 8 x 8 super-block of the lower tile triangle, padded to a multiple of 8 super-blocks
+static dim3 syrk128_grid(int rows, int count)
+{
+    const unsigned T2 = (unsigned)((rows + SY_T - 1) / SY_T), S8 = (T2 + 7) / 8;
+    const unsigned nsb = ((S8 * (S8 + 1) / 2 + 7) / 8) * 8;
+    return dim3(nsb * 64u, 1, (unsigned)count);
+}
+
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                           double *Lx, double *Uout, double *Linv, int *status)
 {
@@ -540,16 +572,41 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     const int64_t T = (rows + KVX_TILE - 1) / KVX_TILE;
     // Measured (MI355X): with 64-column panels the 128-tile kernel LOSES (21-point stencil, n = 1e6: factor 24 -> 35 ms):
     // a rank-64 update is bound by the read-modify-write of C (16 B per 128 flops), not by operand traffic, and the
-    // 64-tile kernel overlaps that traffic better at three workgroups per CU.  It pays only with more panel columns
-    // per pass over C (two-level blocking, not built yet), so it is opt-in: KVX_SYRK128_TILES = tile count from which on it is used.
+    // 64-tile kernel overlaps that traffic better at three workgroups per CU.  It pays with more panel columns per pass
+    // over C (launch_syrk_inner / launch_syrk_outer); for single panels it is opt-in: KVX_SYRK128_TILES = tile count
+    // from which on it is used.
     const char *e = getenv("KVX_SYRK128_TILES");
     const int64_t big_limit = e ? atoll(e) : INT64_MAX;
     if (T * (T + 1) / 2 * count >= big_limit) {
-        unsigned T2 = (unsigned)((rows + SY_T - 1) / SY_T);
-        hipLaunchKernelGGL(k_syrk_trailing128, dim3(T2, T2, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+        hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(256), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status);
     } else {                                          // latency regime: more, smaller workgroups
-        hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status);
+        hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
+}
+
+// Two-level blocking for the fronts that are flop-bound (level with a front of order >= KVX_TWO_LEVEL_M): the pivot
+// columns are taken in outer blocks of 256; inside one, each 64-column panel updates only the rest of the outer block
+// (launch_syrk_inner, at most three column tiles wide), and everything to the right of it -- later pivot columns and
+// the update matrix -- gets ONE rank-256 update per outer block (launch_syrk_outer): a quarter of the passes over C.
+// Both still factor the next diagonal block in their (0, 0) workgroup.
+void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb, int ob_end,
+                       double *Lx, double *Uout, double *Linv, int *status)
+{
+    if (count <= 0 || jb + NB >= ob_end) return;
+    int rows = max_m - jb - 1;
+    if (rows <= 0) return;
+    const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
+    const unsigned TC = (unsigned)std::min<int>((int)T, (ob_end - jb - NB + KVX_TILE - 1) / KVX_TILE);
+    hipLaunchKernelGGL(k_syrk_trailing, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
+}
+
+void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
+                       double *Lx, double *Uout, double *Linv, int *status)
+{
+    if (count <= 0) return;
+    int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(256), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -206,6 +206,11 @@ def test_syrk128_variant_parity(monkeypatch):
     L = sp.tril(S).tocsc(); L.sort_indices()
     parity(2500, L.indptr, L.indices, L.data, seed=4)
     parity(*workloads.laplacian_2d(150), seed=150)
+    # the opt-in two-level blocking (per panel only the rest of a 256-column outer block, then one rank-256 update)
+    monkeypatch.delenv("KVX_SYRK128_TILES")
+    monkeypatch.setenv("KVX_TWO_LEVEL_M", "0")
+    parity(2500, L.indptr, L.indices, L.data, seed=5)
+    parity(*workloads.laplacian_2d(150), seed=151)
 
 
 def test_empty_and_tiny():
