@@ -79,7 +79,7 @@ struct kvx_chol {
     uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
     std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
     std::vector<int64_t> lptr_host;
-    int two_level_m = INT_MAX; // levels whose largest front is at least this order use the two-level blocked update (opt-in: KVX_TWO_LEVEL_M)
+    int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
@@ -370,10 +370,12 @@ int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue 
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             if (bigm >= F->two_level_m) {
-                // 256-column outer blocks, one rank-256 update of the trailing matrix per block.  Opt-in: measured on
-                // MI355X it does not pay yet (dense n = 10240: 17.1 ms either way; 3-D 80^3: 54.9 vs 51.0 ms; 21-point
-                // 1000^2: 31.3 vs 24.3 ms) -- the outer update adds a serial launch per block; it needs look-ahead
-                // (outer update of block b beside the panel chain of block b + 1) and a faster 128-tile kernel
+                // 256-column outer blocks, one rank-256 update of the trailing matrix per block (128-tile kernel: 34 TF/s
+                // on a dense trailing matrix; rocBLAS dgemm at K = 256 reaches 48-59).  Measured on MI355X against the
+                // single-level path: dense n = 10240 14.8 vs 16.7 ms, 3-D 80^3 49.6 vs 51.0 ms, but 21-point 1000^2
+                // (fronts <= 5007, many per level) 29.1 vs 24.3 ms -- the outer update is an extra serial launch per
+                // block, so it is used for very large fronts only; look-ahead (outer update of block b beside the panel
+                // chain of block b + 1) is the missing piece
                 constexpr int OB = 256;
                 for (int ob = 0; ob < P.big_maxk; ob += OB) {
                     for (int jb = ob; jb < std::min(ob + OB, P.big_maxk); jb += KVX_NB) {

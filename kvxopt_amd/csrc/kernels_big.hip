@@ -402,7 +402,8 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 // The same update on 128 x 128 tiles (opt-in, see launch_syrk_trailing for the measurement): the
 // two operand strips X[rows, :] and X[cols, :] staged through LDS in chunks of 16 panel columns
 // (k-major, double-buffered, global loads of chunk c + 1 in flight under the MFMAs of chunk c).
-// Wave (wr, wc) owns a 64 x 64 quarter: 4 x 4 MFMA tiles, 8 LDS operand reads per 16 MFMAs.
+// Wave (wr, wc) owns a 64 x 64 quarter: 4 x 4 MFMA tiles, 8 LDS operand reads per 16 MFMAs.  The staging code is
+// branch-free (a diagonal tile simply stages its strip twice): branches around the loads cost more than the loads.
 // Per tile 192 KB of operand reads drop to 32 KB (the 64-tile kernel streams every operand from L2
 // once per wave), and the read-modify-write of C is amortised over four times the flops per launch
 // overhead.  Tile (0, 0) still factors the next diagonal block (its top-left quarter, wave (0, 0)).
@@ -421,7 +422,7 @@ union SyrkLds {
 // update of the two-level blocking, which is what makes this kernel pay: four times the flops per pass over C).
 // (launch bound: two waves per SIMD -- the 128 accumulator registers live in AGPRs, the rest must fit 128 VGPRs;
 // at one wave per SIMD nothing hides the staging loads and the kernel ran at 21 TF/s)
-__global__ __launch_bounds__(256, 2) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
+__global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
                                                           double *__restrict__ Lx, double *__restrict__ Uo,
                                                           double *__restrict__ Linv, int *status)
 {
@@ -453,57 +454,58 @@ __global__ __launch_bounds__(256, 2) void k_syrk_trailing128(DevSym ds, const in
     double *P = Lx + fd.px;
     double *U = Uo + fd.ux;
     const int tid = threadIdx.x;
+    // eight waves: wave (wr, wc) owns rows 32 wr .. +31 and columns 64 wc .. +63 of the tile (2 x 4 MFMA tiles, 64
+    // accumulator registers), so four waves per SIMD are resident to cover each other's LDS and barrier waits
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
     const int l = tid & 63, lr = l & 15, lk = l >> 4;
     const bool diag = ti == tj;
-    const bool active = !(diag && wr == 0 && wc == 1);             // the upper-right quarter of a diagonal tile is not stored
-    // staging map: thread -> (row of the strip, 8 of the 16 k of a chunk)
-    const int srow = tid & 127, sk0 = (tid >> 7) * 8;
+    const bool active = !(diag && wr < 2 && wc == 1);              // the upper-right quarter of a diagonal tile is not stored
+    // staging map: thread -> (row of the strip, 4 of the 16 k of a chunk)
+    const int srow = tid & 127, sk0 = (tid >> 7) * 4;
     const bool ra_ok = c0 + srow < m, rb_ok = r0 + srow < m;
     const double *Pa = P + min(c0 + srow, m - 1) + (int64_t)jb * m;
     const double *Pb = P + min(r0 + srow, m - 1) + (int64_t)jb * m;
-    double ga[8], gb[8];
+    double ga[4], gb[4];
     const int nchunk = (nbk + SY_KC - 1) / SY_KC;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < 4; j++) {
         const int kk = sk0 + j;
         ga[j] = kvx_ld0(Pa, (int64_t)kk * m, ra_ok && kk < nbk);
-        gb[j] = diag ? 0.0 : kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
+        gb[j] = kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
     }
-    d4 acc[4][4];
+    d4 acc[2][4];
 #pragma unroll
-    for (int s2 = 0; s2 < 4; s2++)
+    for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
         for (int t = 0; t < 4; t++) acc[s2][t] = (d4){0.0, 0.0, 0.0, 0.0};
     for (int ch = 0; ch < nchunk; ch++) {
         double *xa = lds.st.xa[ch & 1], *xb = lds.st.xb[ch & 1];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < 4; j++) {
             xa[(sk0 + j) * SY_LD + srow] = ga[j];
-            if (!diag) xb[(sk0 + j) * SY_LD + srow] = gb[j];
+            xb[(sk0 + j) * SY_LD + srow] = gb[j];
         }
         if (ch + 1 < nchunk) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < 4; j++) {
                 const int kk = (ch + 1) * SY_KC + sk0 + j;
                 ga[j] = kvx_ld0(Pa, (int64_t)kk * m, ra_ok && kk < nbk);
-                gb[j] = diag ? 0.0 : kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
+                gb[j] = kvx_ld0(Pb, (int64_t)kk * m, rb_ok && kk < nbk);
             }
         }
         __syncthreads();
         if (active) {
             const double *oa = xa + 64 * wc + lr;
-            const double *ob = (diag ? xa : xb) + 64 * wr + lr;
+            const double *ob = xb + 32 * wr + lr;
 #pragma unroll
             for (int ks = 0; ks < SY_KC; ks += 4) {
-                double av[4], bv[4];
+                double av[4], bv[2];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    av[t] = oa[(ks + lk) * SY_LD + 16 * t];
-                    bv[t] = ob[(ks + lk) * SY_LD + 16 * t];
-                }
+                for (int t = 0; t < 4; t++) av[t] = oa[(ks + lk) * SY_LD + 16 * t];
 #pragma unroll
-                for (int s2 = 0; s2 < 4; s2++)
+                for (int t = 0; t < 2; t++) bv[t] = ob[(ks + lk) * SY_LD + 16 * t];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                     for (int t = 0; t < 4; t++)
                         acc[s2][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], bv[s2], acc[s2][t], 0, 0, 0);
@@ -518,8 +520,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_trailing128(DevSym ds, const in
     if (fuse) __syncthreads();                                     // staging buffers are about to become the potrf image
     if (active) {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) {
-            const int rr = r0 + 64 * wr + 16 * s2 + lr;
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int rr = r0 + 32 * wr + 16 * s2 + lr;
             const bool rin = rr < m;
             const int rs = min(rr, m - 1);
             double *ptr[4][4];
@@ -541,17 +543,17 @@ __global__ __launch_bounds__(256, 2) void k_syrk_trailing128(DevSym ds, const in
                 for (int q = 0; q < 4; q++) {
                     const double v = old[t][q] - acc[s2][t][q];
                     if (ok[t][q]) *ptr[t][q] = v;
-                    if (fuse && w == 0) {                          // top-left quarter = the next diagonal block
-                        const int i = 16 * s2 + lr, cc = 16 * t + lk + 4 * q;
-                        if (t <= s2) lds.po.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? v : (cc == i ? 1.0 : 0.0);
+                    if (fuse && wr < 2 && wc == 0) {               // top-left quarter = the next diagonal block
+                        const int i = 32 * wr + 16 * s2 + lr, cc = 16 * t + lk + 4 * q;
+                        if (t <= 2 * wr + s2) lds.po.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? v : (cc == i ? 1.0 : 0.0);
                     }
                 }
         }
     }
     if (fuse) {
         __syncthreads();
-        potrf_lds(lds.po, nb2, tid, status, fd.first + t0);
-        potrf_store(lds.po, nb2, tid, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
+        potrf_lds(lds.po, nb2, tid, status, fd.first + t0);         // (waves 4-7 only keep its barriers company)
+        if (tid < 256) potrf_store(lds.po, nb2, tid, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
     }
 }
 
@@ -578,7 +580,7 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     const char *e = getenv("KVX_SYRK128_TILES");
     const int64_t big_limit = e ? atoll(e) : INT64_MAX;
     if (T * (T + 1) / 2 * count >= big_limit) {
-        hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(256), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status);
+        hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status);
     } else {                                          // latency regime: more, smaller workgroups
         hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
@@ -606,7 +608,7 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (count <= 0) return;
     int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(256), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status);
+    hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------
