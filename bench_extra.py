@@ -3,6 +3,8 @@
 
   chol5   : bench.py's workload again with nrhs = 3 (SURVEY 8(d) config 2 "also nrhs=3")
   chol21  : the "~20 nnz/row" north-star variant, 21-point stencil on the 1000 x 1000 grid (workloads.stencil21_2d)
+  lap3d   : 7-point Laplacian on a 100^3 grid (n = 1e6; one eighth of config 5's unknowns): the flop-bound regime
+            (nnz(L) = 5.4e8, 2.7e12 flops, top front of order 14 082)
   lp4b    : BASELINE.json configs[3] in inequality form: the device-resident
             interior-point loop kvxopt_amd.lp.conelp on the 250 x 200 grid LP (ml = 200 000, n = 50 000);
             metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
@@ -99,7 +101,7 @@ def lp_case(gx, gy):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="chol5,chol21,lp4b")
+    ap.add_argument("--cases", default="chol5,chol21,lap3d,lp4b")
     ap.add_argument("--grid", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -113,6 +115,8 @@ def main():
             out = chol_case("chol5 nrhs=3", *workloads.laplacian_2d(args.grid), 3, args.steps, args.warmup)
         elif case == "chol21":
             out = chol_case("chol21 (21-point stencil)", *workloads.stencil21_2d(args.grid), 1, args.steps, args.warmup)
+        elif case == "lap3d":
+            out = chol_case("lap3d 100^3", *workloads.laplacian_3d(100), 1, max(2, args.steps // 3), 1)
         elif case == "lp4b":
             out = lp_case(250, 200)
         else:
