@@ -80,6 +80,16 @@ struct kvx_chol {
     std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
     std::vector<int64_t> lptr_host;
     int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
+    // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
+    SubDesc *d_subs = nullptr;
+    int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
+    int nsub = 0;
+    bool use_subtrees = true;
+    std::vector<SubDesc> subs_host;
+    std::vector<int32_t> cd_woff_host;
+    std::vector<uint8_t> in_sub;
+    std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
+    std::vector<int> sw_cnt;
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
@@ -169,6 +179,99 @@ void build_plan(kvx_chol *F)
     }
 }
 
+// Leaf subtrees for the solves: maximal subtrees made of wave-class fronts only, small enough for one wavefront
+// (front count, pivot columns, LDS stack of update vectors).  Host analysis, once: the update vector of a subtree
+// root is written long before its parent's level runs, so it gets a slot of its own behind the recycled part of
+// its parity buffer (S.wx / S.wrk_size are adjusted before anything is uploaded).
+void analyze_subtrees(kvx_chol *F)
+{
+    Symbolic &S = F->S;
+    const int64_t ns = S.nsuper;
+    std::vector<int32_t> cnt((size_t)ns, 1), minidx((size_t)ns);
+    std::vector<uint8_t> ok((size_t)ns, 0);
+    F->in_sub.assign((size_t)ns, 0);
+    F->subs_host.clear();
+    F->cd_woff_host.assign(S.children.size(), 0);
+    for (int64_t s = 0; s < ns; s++) {
+        minidx[s] = (int32_t)s;
+        bool good = front_class(S.sn_m[s], S.sn_k[s]) >= KVX_CLS_WAVE0;
+        for (int64_t c = S.childptr[s]; c < S.childptr[s + 1]; c++) {
+            const int32_t ch = S.children[c];
+            good = good && ok[ch];
+            cnt[s] += cnt[ch];
+            minidx[s] = std::min(minidx[s], minidx[ch]);
+        }
+        const int64_t lo = s - cnt[s] + 1;
+        good = good && cnt[s] <= KVX_SUB_MAXF && minidx[s] == lo && lo >= 0 &&
+               (S.super[s + 1] - S.super[lo]) <= KVX_SUB_MAXCOLS;
+        ok[s] = good;
+    }
+    int64_t extra[2] = {0, 0};
+    const int64_t base[2] = {S.wrk_size[0], S.wrk_size[1]};
+    for (int64_t s = ns - 1; s >= 0; s--) {
+        if (!ok[s] || F->in_sub[s]) continue;
+        if (S.sparent[s] >= 0 && ok[S.sparent[s]]) continue;      // not maximal
+        const int64_t lo = s - cnt[s] + 1;
+        // LDS stack of update vectors in postorder: a front pops its children, then pushes its own
+        int64_t sp = 0, top = 0;
+        std::vector<int64_t> woff((size_t)cnt[s], 0);
+        bool fits = true;
+        for (int64_t q = lo; q <= s; q++) {
+            for (int64_t c = S.childptr[q]; c < S.childptr[q + 1]; c++) sp -= S.sn_m[S.children[c]] - S.sn_k[S.children[c]];
+            woff[q - lo] = sp;
+            if (q != s) sp += S.sn_m[q] - S.sn_k[q];
+            top = std::max(top, sp);
+            if (sp < 0) fits = false;
+        }
+        if (!fits || top > KVX_SUB_STACK) continue;               // stays in the level lists
+        for (int64_t q = lo; q <= s; q++) {
+            F->in_sub[q] = 1;
+            for (int64_t c = S.childptr[q]; c < S.childptr[q + 1]; c++) F->cd_woff_host[c] = (int32_t)woff[S.children[c] - lo];
+        }
+        F->subs_host.push_back(SubDesc{(int32_t)lo, (int32_t)s, (int32_t)S.super[lo], (int32_t)(S.super[s + 1] - S.super[lo])});
+        const int p = S.depth[s] & 1;
+        S.wx[s] = base[p] + extra[p];
+        extra[p] += S.sn_m[s] - S.sn_k[s];
+    }
+    S.wrk_size[0] = base[0] + extra[0];
+    S.wrk_size[1] = base[1] + extra[1];
+}
+
+// per-level solve lists without the subtree fronts, and the subtree tables, on the device
+int build_subtrees(kvx_chol *F)
+{
+    Symbolic &S = F->S;
+    const bool enabled = F->use_subtrees && F->dist_nranks == 1;
+    std::vector<int32_t> lsw;
+    F->sw_off.assign((size_t)S.nlevels, 0);
+    F->sw_cnt.assign((size_t)S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; l++) {
+        F->sw_off[l] = (int64_t)lsw.size();
+        for (int64_t q = F->lptr_host[l]; q < F->lptr_host[l + 1]; q++) {
+            const int32_t f = F->lists_host[q];
+            if (front_class(S.sn_m[f], S.sn_k[f]) >= KVX_CLS_WAVE0 && !(enabled && F->in_sub[f])) lsw.push_back(f);
+        }
+        F->sw_cnt[l] = (int)((int64_t)lsw.size() - F->sw_off[l]);
+    }
+    if (lsw.empty()) lsw.push_back(0);
+    std::vector<SubDesc> subs = F->subs_host;
+    F->nsub = enabled ? (int)subs.size() : 0;
+    if (subs.empty()) subs.push_back(SubDesc{0, -1, 0, 0});
+    std::vector<int32_t> cd_woff = F->cd_woff_host;
+    if (cd_woff.empty()) cd_woff.push_back(0);
+    int rc;
+    for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
+        if (p) (void)hipFree(p);
+    F->d_subs = nullptr; F->d_cd_woff = nullptr; F->d_lists_sw = nullptr; F->d_depth = nullptr;
+    if ((rc = upload(&F->d_subs, subs))) return rc;
+    if ((rc = upload(&F->d_cd_woff, cd_woff))) return rc;
+    if ((rc = upload(&F->d_lists_sw, lsw))) return rc;
+    std::vector<int32_t> dep(S.depth.begin(), S.depth.end());
+    if (dep.empty()) dep.push_back(0);
+    if ((rc = upload(&F->d_depth, dep))) return rc;
+    return KVX_OK;
+}
+
 int ensure_device(kvx_chol *F)
 {
     if (F->dev_ready) return KVX_OK;
@@ -178,6 +281,7 @@ int ensure_device(kvx_chol *F)
         return KVX_EDEVICE;
     }
     Symbolic &S = F->S;
+    analyze_subtrees(F);
     HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
     for (int i = 0; i < 4; i++) {
@@ -260,6 +364,8 @@ int ensure_device(kvx_chol *F)
     F->lists_host = S.levellist;
     F->lptr_host = S.levelptr;
     build_plan(F);
+    { const char *e = getenv("KVX_NO_SUBTREES"); F->use_subtrees = !(e && e[0] == '1'); }
+    if ((rc = build_subtrees(F))) return rc;
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
@@ -478,29 +584,26 @@ struct LevelStreams {
     }
 };
 
-// all wave classes of a level form one contiguous range of the level list
-static void wave_range(const LevelPlan &P, int64_t &off, int &cnt)
-{
-    off = 0; cnt = 0;
-    for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++)
-        if (P.cnt[c] > 0) { if (cnt == 0) off = P.off[c]; cnt += P.cnt[c]; }
-}
-
 void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0)
 {
     Symbolic &S = F->S;
     const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
     if (lfrom < 0) lfrom = S.nlevels - 1;
+    if (lfrom == S.nlevels - 1 && F->nsub > 0) {       // the leaf subtrees: one wavefront each, before any level
+        ProfScope ps(F, FAM_FWD);
+        launch_fwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->d_cd_woff, F->d_Lx, X, ldx, nrhs, F->d_W[0], F->d_W[1], wstride, F->d_depth);
+    }
     for (int l = lfrom; l >= lto; l--) {
         const LevelPlan &P = F->plan[l];
         const double *Wch = F->d_W[(l + 1) & 1];
         double *Wout = F->d_W[l & 1];
-        int64_t woff; int wcnt;
-        wave_range(P, woff, wcnt);
+        const int64_t woff = F->sw_off[l];
+        const int wcnt = F->sw_cnt[l];
+        if (wcnt == 0 && P.scnt[0] == 0 && P.scnt[1] == 0) continue;
         LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
         if (wcnt > 0) {
             ProfScope ps(F, FAM_FWD, ls.wave);
-            launch_fwd_wave(ls.wave, F->ds, F->d_lists + woff, wcnt, 32, F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+            launch_fwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 32, F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
         }
         if (P.scnt[1] > 0) {
             ProfScope ps(F, FAM_FWD, ls.lds);
@@ -522,12 +625,13 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, i
     if (lto < 0) lto = S.nlevels - 1;
     for (int l = lfrom; l <= lto; l++) {
         const LevelPlan &P = F->plan[l];
-        int64_t woff; int wcnt;
-        wave_range(P, woff, wcnt);
+        const int64_t woff = F->sw_off[l];
+        const int wcnt = F->sw_cnt[l];
+        if (wcnt == 0 && P.scnt[0] == 0 && P.scnt[1] == 0) continue;
         LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
         if (wcnt > 0) {
             ProfScope ps(F, FAM_BWD, ls.wave);
-            launch_bwd_wave(ls.wave, F->ds, F->d_lists + woff, wcnt, 64, 32, F->d_Lx, X, ldx, nrhs);
+            launch_bwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 64, 32, F->d_Lx, X, ldx, nrhs);
         }
         if (P.scnt[1] > 0) {
             ProfScope ps(F, FAM_BWD, ls.lds);
@@ -539,6 +643,10 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, i
                            X, ldx, nrhs, F->d_WK, S.n);
         }
         ls.join();
+    }
+    if (lto == S.nlevels - 1 && F->nsub > 0) {        // the leaf subtrees last: every ancestor is solved
+        ProfScope ps(F, FAM_BWD);
+        launch_bwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->d_Lx, X, ldx, nrhs);
     }
 }
 
@@ -931,6 +1039,8 @@ int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
     if (F->d_lists) { HIPCHK(hipFree(F->d_lists)); F->d_lists = nullptr; }
     if ((rc = upload(&F->d_lists, F->lists_host))) return rc;
     build_plan(F);
+    F->dist_nranks = nranks;                         // (sharded mode keeps the subtrees in the level lists)
+    if ((rc = build_subtrees(F))) return rc;
     if (F->g_factor) { (void)hipGraphExecDestroy(F->g_factor); F->g_factor = nullptr; }
     for (auto &g : F->g_solve)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -1055,6 +1165,8 @@ void kvx_chol_free(kvx_chol *F)
             if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
         }
         if (F->d_keep) (void)hipFree(F->d_keep);
+        for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
+            if (p) (void)hipFree(p);
         if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
         if (F->ev_in) (void)hipEventDestroy(F->ev_in);
         if (F->stream) (void)hipStreamDestroy(F->stream);

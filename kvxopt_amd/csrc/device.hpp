@@ -39,6 +39,16 @@ struct ChildDesc {            // 40 bytes, indexed like DevSym::children
     int64_t tile;             // offset into DevSym::tiles (children of big fronts only, else -1)
 };
 
+// A leaf subtree handled by ONE wavefront in the triangular solves (kernels_wave.hip, k_fwd_subtree / k_bwd_subtree):
+// fronts lo..hi (a contiguous range of the postordered numbering, hi = root), whose pivot columns are the contiguous
+// slice [col0, col0 + ncols) of the permuted vector.
+struct SubDesc {
+    int32_t lo, hi, col0, ncols;
+};
+constexpr int KVX_SUB_MAXF = 48;      // fronts per subtree
+constexpr int KVX_SUB_MAXCOLS = 256;  // pivot columns per subtree (LDS slice of x)
+constexpr int KVX_SUB_STACK = 512;    // doubles of update vectors alive at once (LDS stack)
+
 #ifdef __HIPCC__
 // Predicated load WITHOUT a branch: hipcc turns `c ? p[i] : 0.0` into an exec-masked branch with
 // an exposed s_waitcnt per load (64 such loads serialise into 64 L2 round trips, ~20 us); an
@@ -150,6 +160,12 @@ void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int 
                      const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);
 void launch_bwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int mcap, int kmax,
                      const double *Lx, double *X, int64_t ldx, int nrhs);
+// leaf subtrees: one wavefront walks a whole subtree (all of its fronts are wave-class), update vectors on an LDS stack
+void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *cd_woff,
+                        const double *Lx, double *X, int64_t ldx, int nrhs, double *W0, double *W1, int64_t wstride,
+                        const int32_t *depth);
+void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const double *Lx, double *X,
+                        int64_t ldx, int nrhs);
 // LDS classes (m <= 128, k <= 64): two wavefronts per front (kernels_wave.hip)
 void launch_fwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
                     const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);

@@ -440,6 +440,139 @@ void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int c
     hipLaunchKernelGGL(k_bwd_lds, grid, dim3(128), 0, st, ds, list, Lx, X, ldx);
 }
 
+// ------------------------------------------------------------------------------------------
+// Leaf subtrees in the solves.  The bottom of the elimination tree is thousands of small independent subtrees
+// (a nested-dissection leaf ordered by minimum degree: 10-40 wave-class fronts, 8 levels deep).  Level by level
+// they cost one launch + one stream join per level and direction for a few microseconds of work per front.  Here
+// ONE wavefront walks a whole subtree: fronts in postorder (forward) / reverse postorder (backward), its slice of
+// x in LDS, the update vectors of finished children on an LDS stack (offsets precomputed on the host) -- nothing
+// but the panels is read from HBM and no level boundary is crossed.  Only the root's update vector goes out.
+template <int KMAX>
+__global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__restrict__ subs,
+                                                    const int32_t *__restrict__ cd_woff, const double *__restrict__ Lx,
+                                                    double *__restrict__ X, int64_t ldx,
+                                                    double *__restrict__ W0, double *__restrict__ W1, int64_t wstride,
+                                                    const int32_t *__restrict__ depth)
+{
+    __shared__ double xs[KVX_SUB_MAXCOLS];
+    __shared__ double stk[KVX_SUB_STACK];
+    __shared__ double wsh[64];
+    const SubDesc sd = subs[blockIdx.x];
+    const int r = threadIdx.x;
+    double *x = X + (int64_t)blockIdx.y * ldx + sd.col0;
+    for (int i = r; i < sd.ncols; i += 64) xs[i] = x[i];
+    __syncthreads();
+    int sp = 0;                                    // stack pointer: mirrors the host's offsets (children are on top)
+    for (int s = sd.lo; s <= sd.hi; s++) {
+        const FrontDesc fd = ds.fd[s];
+        const int k = fd.k, m = fd.m, xo = fd.first - sd.col0;
+        const double *P = Lx + fd.px;
+        double a[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+        const double dg = kvx_ld0(P, r + (int64_t)r * m, r < k);
+        double w = r < k ? xs[xo + r] : 0.0;
+        if (fd.nchild > 0) {
+            wsh[r] = w;
+            for (int c = 0; c < fd.nchild; c++) {
+                const ChildDesc cd = ds.cd[fd.childptr + c];
+                const int off = cd_woff[fd.childptr + c];
+                const bool ok = r < cd.uc;
+                const int t = ok ? ds.rel[cd.rel + r] : 0;
+                const double v = ok ? stk[off + r] : 0.0;
+                __syncthreads();
+                if (ok) wsh[t] += v;
+                sp -= cd.uc;
+            }
+            __syncthreads();
+            w = wsh[r];
+        }
+        const double rinv = 1.0 / (r < k ? dg : 1.0);
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            if (j < k) {                           // wave-uniform
+                const double yj = kvx_readlane(w * rinv, j);
+                w = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w) : w);
+            }
+        }
+        if (r < k) xs[xo + r] = w;
+        else if (r < m) {
+            if (s == sd.hi) {
+                double *wo = ((depth[s] & 1) ? W1 : W0) + (int64_t)blockIdx.y * wstride + fd.wx;
+                wo[r - k] = w;
+            } else {
+                stk[sp + r - k] = w;
+            }
+        }
+        sp += m - k;
+        __syncthreads();
+    }
+    for (int i = r; i < sd.ncols; i += 64) x[i] = xs[i];
+}
+
+template <int MMAX>
+__global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__restrict__ subs,
+                                                    const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
+{
+    __shared__ double xs[KVX_SUB_MAXCOLS];
+    const SubDesc sd = subs[blockIdx.x];
+    const int ln = threadIdx.x;
+    double *xg = X + (int64_t)blockIdx.y * ldx;
+    for (int i = ln; i < sd.ncols; i += 64) xs[i] = xg[sd.col0 + i];
+    __syncthreads();
+    for (int s = sd.hi; s >= sd.lo; s--) {
+        const FrontDesc fd = ds.fd[s];
+        const int k = fd.k, m = fd.m;
+        const double *P = Lx + fd.px;
+        const int32_t *rows = ds.rowidx + fd.rowptr;
+        const int col = ln < k ? ln : 0;
+        double a[MMAX];
+#pragma unroll
+        for (int rr = 0; rr < MMAX; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+        const double dg = kvx_ld0(P, ln + (int64_t)ln * m, ln < k);
+        const int grow = (ln < m) ? (ln < k ? fd.first + ln : rows[ln]) : sd.col0;
+        const int loc = grow - sd.col0;
+        const bool inl = loc >= 0 && loc < sd.ncols;         // ancestors inside the subtree live in the LDS slice
+        const double xglob = kvx_ld0(xg, grow, ln < m && !inl);
+        double xv = inl ? xs[loc] : xglob;
+        if (ln >= m) xv = 0.0;
+        const double rinv = 1.0 / (ln < k ? dg : 1.0);
+        double acc = 0.0;
+#pragma unroll
+        for (int rr = MMAX - 1; rr >= 0; rr--) {
+            if (rr < m) {                          // wave-uniform
+                double xr;
+                if (rr < k) {
+                    xr = kvx_readlane((xv - acc) * rinv, rr);
+                    if (ln == rr) xv = xr;
+                } else {
+                    xr = kvx_readlane(xv, rr);
+                }
+                acc = (ln < rr) ? __builtin_fma(a[rr], xr, acc) : acc;
+            }
+        }
+        if (ln < k) xs[fd.first - sd.col0 + ln] = xv;
+        __syncthreads();
+    }
+    for (int i = ln; i < sd.ncols; i += 64) xg[sd.col0 + i] = xs[i];
+}
+
+void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *cd_woff,
+                        const double *Lx, double *X, int64_t ldx, int nrhs, double *W0, double *W1, int64_t wstride,
+                        const int32_t *depth)
+{
+    if (nsub <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_fwd_subtree<32>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, cd_woff, Lx, X, ldx,
+                       W0, W1, wstride, depth);
+}
+
+void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const double *Lx, double *X,
+                        int64_t ldx, int nrhs)
+{
+    if (nsub <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_bwd_subtree<64>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+}
+
 void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
                      const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride)
 {
