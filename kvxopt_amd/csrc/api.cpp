@@ -83,7 +83,7 @@ struct kvx_chol {
     // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
     SubDesc *d_subs = nullptr;
     int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
-    int nsub = 0;
+    int nsub = 0, nsub32 = 0;                  // subtrees; the first nsub32 hold only fronts of order <= 32
     bool use_subtrees = true;
     std::vector<SubDesc> subs_host;
     std::vector<int32_t> cd_woff_host;
@@ -241,7 +241,7 @@ void analyze_subtrees(kvx_chol *F)
 int build_subtrees(kvx_chol *F)
 {
     Symbolic &S = F->S;
-    const bool enabled = F->use_subtrees && F->dist_nranks == 1;
+    const bool enabled = F->use_subtrees && F->dist_nranks == 1 && (int64_t)S.rel.size() < INT32_MAX;
     std::vector<int32_t> lsw;
     F->sw_off.assign((size_t)S.nlevels, 0);
     F->sw_cnt.assign((size_t)S.nlevels, 0);
@@ -254,11 +254,27 @@ int build_subtrees(kvx_chol *F)
         F->sw_cnt[l] = (int)((int64_t)lsw.size() - F->sw_off[l]);
     }
     if (lsw.empty()) lsw.push_back(0);
-    std::vector<SubDesc> subs = F->subs_host;
+    std::vector<SubDesc> subs;
+    F->nsub32 = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (const SubDesc &d : F->subs_host) {
+            int mm = 0;
+            for (int q = d.lo; q <= d.hi; q++) mm = std::max(mm, S.sn_m[q]);
+            if ((mm <= 32) == (pass == 0)) subs.push_back(d);
+            if (pass == 0 && mm <= 32) F->nsub32++;
+        }
     F->nsub = enabled ? (int)subs.size() : 0;
+    if (!enabled) F->nsub32 = 0;
     if (subs.empty()) subs.push_back(SubDesc{0, -1, 0, 0});
-    std::vector<int32_t> cd_woff = F->cd_woff_host;
-    if (cd_woff.empty()) cd_woff.push_back(0);
+    // edge records of the subtree walk: (update rows, offset of the relative indices, LDS stack offset) per tree edge
+    std::vector<int32_t> cd_woff(3 * std::max<size_t>(S.children.size(), 1), 0);
+    for (int64_t q = 0; q < S.nsuper; q++)
+        for (int64_t c = S.childptr[q]; c < S.childptr[q + 1]; c++) {
+            const int32_t ch = S.children[c];
+            cd_woff[3 * c] = S.sn_m[ch] - S.sn_k[ch];
+            cd_woff[3 * c + 1] = (int32_t)(S.rowptr[ch] + S.sn_k[ch]);
+            cd_woff[3 * c + 2] = F->cd_woff_host[c];
+        }
     int rc;
     for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
         if (p) (void)hipFree(p);
@@ -646,7 +662,7 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, i
     }
     if (lto == S.nlevels - 1 && F->nsub > 0) {        // the leaf subtrees last: every ancestor is solved
         ProfScope ps(F, FAM_BWD);
-        launch_bwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->d_Lx, X, ldx, nrhs);
+        launch_bwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->nsub32, F->d_Lx, X, ldx, nrhs);
     }
 }
 

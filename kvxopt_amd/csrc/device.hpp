@@ -161,10 +161,10 @@ void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 void launch_bwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int mcap, int kmax,
                      const double *Lx, double *X, int64_t ldx, int nrhs);
 // leaf subtrees: one wavefront walks a whole subtree (all of its fronts are wave-class), update vectors on an LDS stack
-void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *cd_woff,
+void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *edges,
                         const double *Lx, double *X, int64_t ldx, int nrhs, double *W0, double *W1, int64_t wstride,
                         const int32_t *depth);
-void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const double *Lx, double *X,
+void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, int nsub32, const double *Lx, double *X,
                         int64_t ldx, int nrhs);
 // LDS classes (m <= 128, k <= 64): two wavefronts per front (kernels_wave.hip)
 void launch_fwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,

@@ -447,42 +447,71 @@ void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int c
 // ONE wavefront walks a whole subtree: fronts in postorder (forward) / reverse postorder (backward), its slice of
 // x in LDS, the update vectors of finished children on an LDS stack (offsets precomputed on the host) -- nothing
 // but the panels is read from HBM and no level boundary is crossed.  Only the root's update vector goes out.
+// Per front the walk costs two dependent HBM round trips, not five: the next front's descriptor is fetched while
+// the current one is solved, the panel / diagonal / child records of a front go out together, and the children's
+// relative indices (second trip) for all children at once.  edges[3 c .. 3 c + 2] = (update rows, offset of the
+// relative indices, LDS stack offset) of child c, indexed like DevSym::children.
 template <int KMAX>
 __global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__restrict__ subs,
-                                                    const int32_t *__restrict__ cd_woff, const double *__restrict__ Lx,
+                                                    const int32_t *__restrict__ edges, const double *__restrict__ Lx,
                                                     double *__restrict__ X, int64_t ldx,
                                                     double *__restrict__ W0, double *__restrict__ W1, int64_t wstride,
                                                     const int32_t *__restrict__ depth)
 {
+    constexpr int NC = 4;                          // children handled per batch
     __shared__ double xs[KVX_SUB_MAXCOLS];
     __shared__ double stk[KVX_SUB_STACK];
     __shared__ double wsh[64];
     const SubDesc sd = subs[blockIdx.x];
     const int r = threadIdx.x;
     double *x = X + (int64_t)blockIdx.y * ldx + sd.col0;
+    FrontDesc nxt = ds.fd[sd.lo];
     for (int i = r; i < sd.ncols; i += 64) xs[i] = x[i];
     __syncthreads();
     int sp = 0;                                    // stack pointer: mirrors the host's offsets (children are on top)
     for (int s = sd.lo; s <= sd.hi; s++) {
-        const FrontDesc fd = ds.fd[s];
+        const FrontDesc fd = nxt;
+        if (s < sd.hi) nxt = ds.fd[s + 1];
         const int k = fd.k, m = fd.m, xo = fd.first - sd.col0;
         const double *P = Lx + fd.px;
         double a[KMAX];
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+        for (int j0 = 0; j0 < KMAX; j0 += 8) {
+            if (j0 < k) {                          // wave-uniform: leaf fronts have few pivots, skip the unused column groups
+#pragma unroll
+                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+            } else {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; j++) a[j] = 0.0;
+            }
+        }
         const double dg = kvx_ld0(P, r + (int64_t)r * m, r < k);
         double w = r < k ? xs[xo + r] : 0.0;
         if (fd.nchild > 0) {
             wsh[r] = w;
-            for (int c = 0; c < fd.nchild; c++) {
-                const ChildDesc cd = ds.cd[fd.childptr + c];
-                const int off = cd_woff[fd.childptr + c];
-                const bool ok = r < cd.uc;
-                const int t = ok ? ds.rel[cd.rel + r] : 0;
-                const double v = ok ? stk[off + r] : 0.0;
-                __syncthreads();
-                if (ok) wsh[t] += v;
-                sp -= cd.uc;
+            for (int c0 = 0; c0 < fd.nchild; c0 += NC) {
+                int uc[NC], rp[NC], wo[NC], t[NC];
+                double v[NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const bool has = c0 + c < fd.nchild;
+                    const int32_t *e = edges + 3 * (fd.childptr + (has ? c0 + c : 0));
+                    uc[c] = has ? e[0] : 0;
+                    rp[c] = e[1];
+                    wo[c] = e[2];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const bool ok = r < uc[c];
+                    t[c] = ds.rel[rp[c] + (ok ? r : 0)];
+                    v[c] = ok ? stk[wo[c] + r] : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    __syncthreads();               // (one wave: orders the LDS read-modify-writes of successive children)
+                    if (r < uc[c]) wsh[t[c]] += v[c];
+                    sp -= uc[c];
+                }
             }
             __syncthreads();
             w = wsh[r];
@@ -518,22 +547,36 @@ __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__
     const SubDesc sd = subs[blockIdx.x];
     const int ln = threadIdx.x;
     double *xg = X + (int64_t)blockIdx.y * ldx;
+    FrontDesc nxt = ds.fd[sd.hi];
+    int nrow = (ln < nxt.m && ln >= nxt.k) ? ds.rowidx[nxt.rowptr + ln] : sd.col0;   // global index of update row ln
     for (int i = ln; i < sd.ncols; i += 64) xs[i] = xg[sd.col0 + i];
     __syncthreads();
     for (int s = sd.hi; s >= sd.lo; s--) {
-        const FrontDesc fd = ds.fd[s];
+        const FrontDesc fd = nxt;
+        const int myrow = nrow;
+        if (s > sd.lo) nxt = ds.fd[s - 1];
         const int k = fd.k, m = fd.m;
         const double *P = Lx + fd.px;
-        const int32_t *rows = ds.rowidx + fd.rowptr;
         const int col = ln < k ? ln : 0;
+        // lane = pivot column with its entries in registers (a column per lane is an uncoalesced read; staging the panel
+        // through LDS instead was measured and lost: 17 KB per wave costs more occupancy than the coalescing wins)
         double a[MMAX];
 #pragma unroll
-        for (int rr = 0; rr < MMAX; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+        for (int r0 = 0; r0 < MMAX; r0 += 16) {
+            if (r0 < m) {                          // wave-uniform
+#pragma unroll
+                for (int rr = r0; rr < r0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+            } else {
+#pragma unroll
+                for (int rr = r0; rr < r0 + 16; rr++) a[rr] = 0.0;
+            }
+        }
         const double dg = kvx_ld0(P, ln + (int64_t)ln * m, ln < k);
-        const int grow = (ln < m) ? (ln < k ? fd.first + ln : rows[ln]) : sd.col0;
+        const int grow = (ln < m) ? (ln < k ? fd.first + ln : myrow) : sd.col0;
         const int loc = grow - sd.col0;
         const bool inl = loc >= 0 && loc < sd.ncols;         // ancestors inside the subtree live in the LDS slice
         const double xglob = kvx_ld0(xg, grow, ln < m && !inl);
+        if (s > sd.lo) nrow = (ln < nxt.m && ln >= nxt.k) ? ds.rowidx[nxt.rowptr + ln] : sd.col0;   // next front's rows: in flight during the sweep
         double xv = inl ? xs[loc] : xglob;
         if (ln >= m) xv = 0.0;
         const double rinv = 1.0 / (ln < k ? dg : 1.0);
@@ -557,20 +600,24 @@ __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__
     for (int i = ln; i < sd.ncols; i += 64) xg[sd.col0 + i] = xs[i];
 }
 
-void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *cd_woff,
+void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *edges,
                         const double *Lx, double *X, int64_t ldx, int nrhs, double *W0, double *W1, int64_t wstride,
                         const int32_t *depth)
 {
     if (nsub <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_fwd_subtree<32>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, cd_woff, Lx, X, ldx,
+    hipLaunchKernelGGL(k_fwd_subtree<32>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, edges, Lx, X, ldx,
                        W0, W1, wstride, depth);
 }
 
-void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const double *Lx, double *X,
+// the subtree table holds the subtrees whose fronts all have order <= 32 first (nsub32 of them): half the registers
+void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, int nsub32, const double *Lx, double *X,
                         int64_t ldx, int nrhs)
 {
     if (nsub <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_bwd_subtree<64>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+    if (nsub32 > 0)
+        hipLaunchKernelGGL(k_bwd_subtree<32>, dim3((unsigned)nsub32, (unsigned)nrhs), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+    if (nsub > nsub32)
+        hipLaunchKernelGGL(k_bwd_subtree<64>, dim3((unsigned)(nsub - nsub32), (unsigned)nrhs), dim3(64), 0, st, ds, subs + nsub32, Lx, X, ldx);
 }
 
 void launch_fwd_wave(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
