@@ -19,7 +19,7 @@ def short(name):
 
 FAMILY = {"k_scatter_a": "scatter_a", "k_front_wave": "front_small", "k_front_lds": "front_small", "k_assemble_big": "assemble_big",
           "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing",
-          "k_fwd_wave": "fwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_init": "fwd_level", "k_fwd_big_step": "fwd_level",
+          "k_fwd_wave": "fwd_level", "k_fwd_subtree": "fwd_level", "k_bwd_subtree": "bwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_init": "fwd_level", "k_fwd_big_step": "fwd_level",
           "k_bwd_wave": "bwd_level", "k_bwd_lds": "bwd_level", "k_bwd_big_init": "bwd_level", "k_bwd_big_step": "bwd_level"}
 
 # bench line
