@@ -94,7 +94,9 @@ def lp_case(gx, gy):
     sync()
     t_s = (time.perf_counter() - t0) / 20
     return {"case": "lp4b", "metric": "IPM iterations/s", "value": sol["iterations"] / dt, "unit": "iterations/s",
-            "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "ml": ml, "n": n,
+            "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "loop_s": sol["loop seconds"],
+            "iterations_per_s_loop_only": sol["iterations"] / sol["loop seconds"] if sol["loop seconds"] > 0 else None,
+            "ml": ml, "n": n,
             "gap": sol["gap"], "primal_infeasibility": sol["primal infeasibility"], "dual_infeasibility": sol["dual infeasibility"],
             "factorizations": sol["factorizations"], "ms_kkt_factor": t_f * 1e3, "ms_kkt_solve": t_s * 1e3}
 
