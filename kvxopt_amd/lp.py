@@ -108,12 +108,21 @@ class SpMatDev:
 class KKTChol2Dev:
     """Device-resident `misc.kkt_chol2` for sparse G and p = 0 (misc.py:1389-1563)."""
 
-    def __init__(self, ml, n, Gp, Gi, Gx, chol_opts=None):
+    def __init__(self, ml, n, Gp, Gi, Gx, chol_opts=None, Pp=None, Pi=None, Px=None):
+        """Pp, Pi, Px: optional lower-triangular CCS of the QP Hessian H (coneqp): S = H + G' W^-1 W^-T G
+        (misc.py:1425-1426, 1454-1455)."""
         self.ml, self.n = ml, n
         Gp = np.ascontiguousarray(Gp, dtype=np.int64)
         Gi = np.ascontiguousarray(Gi, dtype=np.int64)
         h = ctypes.c_void_p()
-        raise_for(lib().kvx_atda_plan(ml, n, _lib.pi(Gp), _lib.pi(Gi), None, None, ctypes.byref(h)))
+        self.Px = None
+        if Pp is not None:
+            Pp = np.ascontiguousarray(Pp, dtype=np.int64)
+            Pi = np.ascontiguousarray(Pi, dtype=np.int64)
+            self.Px = DVec(max(len(Px), 1), Px if len(Px) else None)
+            raise_for(lib().kvx_atda_plan(ml, n, _lib.pi(Gp), _lib.pi(Gi), _lib.pi(Pp), _lib.pi(Pi), ctypes.byref(h)))
+        else:
+            raise_for(lib().kvx_atda_plan(ml, n, _lib.pi(Gp), _lib.pi(Gi), None, None, ctypes.byref(h)))
         self._plan = h
         snz = ctypes.c_int64()
         raise_for(lib().kvx_atda_pattern(h, ctypes.byref(snz), None, None))
@@ -139,7 +148,8 @@ class KKTChol2Dev:
         """S = G' diag(di)^2 G on the fixed pattern, numeric refactorisation (misc.py:1418-1462).
         Raises ArithmeticError when S is not positive definite."""
         self.w.sqr_of(di)
-        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr, None, self.Sx.ptr))
+        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
+                                              None if self.Px is None else self.Px.ptr, self.Sx.ptr))
         self.fac.factorize_dev(self.Sx.ptr, sync=True)
         self.di = di
         self.nfactor += 1
@@ -342,4 +352,197 @@ def conelp(c, G, h, options=None, chol_opts=None):
         z.xmy(1.0, lmbda, di)
         kappa, tau = lmbda_g / dgi, lmbda_g * dgi
         gap = (lmbda.nrm2() / tau) ** 2
+    raise AssertionError("unreachable")
+
+
+class SymSpMatDev:
+    """Symmetric sparse matrix resident in HBM, given by its lower triangle (the 'L' storage base.symv reads for
+    the quadratic term, coneprog.py:1889-1893): y := alpha*P*x + beta*y as one pass over the lower triangle and one
+    transposed pass over its strictly lower part."""
+
+    def __init__(self, n, colptr, rowind, values):
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowind = np.ascontiguousarray(rowind, dtype=np.int64)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr))
+        if np.any(rowind < cols):
+            raise ValueError("P must be given by its lower triangle")
+        strict = rowind > cols
+        sp = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(sp, cols[strict] + 1, 1)
+        np.cumsum(sp, out=sp)
+        self.low = SpMatDev(n, n, colptr, rowind, values)
+        self.strict = SpMatDev(n, n, sp, rowind[strict], values[strict])
+
+    def symv(self, x, y, alpha=1.0, beta=0.0):
+        self.low.gemv(x, y, trans="N", alpha=alpha, beta=beta)
+        self.strict.gemv(x, y, trans="T", alpha=alpha, beta=1.0)
+
+
+def _lower_ccs(P, n):
+    """Lower triangle (i >= j) of a spmatrix-like P as sorted CCS; entries above the diagonal are ignored, as the
+    reference's symmetric kernels do."""
+    m, n2, Pp, Pi, Px = base._as_ccs(P)
+    if m != n or n2 != n:
+        raise TypeError("'P' must be a 'd' matrix of size (%d, %d)" % (n, n))
+    Pp = np.asarray(Pp, dtype=np.int64); Pi = np.asarray(Pi, dtype=np.int64); Px = np.asarray(Px, dtype=np.float64)
+    cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Pp))
+    keep = Pi >= cols
+    cp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cp, cols[keep] + 1, 1)
+    np.cumsum(cp, out=cp)
+    return cp, Pi[keep].copy(), Px[keep].copy()
+
+
+def coneqp(P, q, G, h, options=None, chol_opts=None):
+    """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h  on the GPU (orthant cone, no equality
+    constraints): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
+    misc.kkt_chol2 with H = P.  P: spmatrix-like, its lower triangle is used.  Returns the reference's result
+    dictionary (coneprog.py:2216-2221) with numpy arrays, plus "factorizations"."""
+    _lib.require_device()
+    opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False,
+            "refinement": 0, "use_correction": True}                        # coneprog.py:1768-1781, 1862-1865
+    opts.update(options or {})
+    MAXITERS, ABSTOL, RELTOL, FEASTOL = opts["maxiters"], opts["abstol"], opts["reltol"], opts["feastol"]
+    show, refinement, correction = opts["show_progress"], int(opts["refinement"]), bool(opts["use_correction"])
+    ml, n, Gp, Gi, Gx = base._as_ccs(G)
+    q_h = np.asarray(q._a if isinstance(q, base.matrix) else q, dtype=np.float64).reshape(-1)
+    h_h = np.asarray(h._a if isinstance(h, base.matrix) else h, dtype=np.float64).reshape(-1)
+    if q_h.size != n or h_h.size != ml:
+        raise TypeError("dimensions of q, G, h do not match")
+    if ml == 0:
+        raise ValueError("coneqp on the GPU needs at least one inequality (dims['l'] > 0)")
+    Pp, Pi, Px = _lower_ccs(P, n)
+    kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
+    Gd, Pd = kkt.G, SymSpMatDev(n, Pp, Pi, Px)
+    qv, hv = DVec(n, q_h), DVec(ml, h_h)
+    x, dx, rx = (DVec(n) for _ in range(3))
+    s, z, ds, dz, rz, ws3, tmp, lmbda, lmbdasq, d, di = (DVec(ml) for _ in range(11))
+    if refinement:
+        wx, wx2 = DVec(n), DVec(n)
+        wz, ws, wz2, ws2 = (DVec(ml) for _ in range(4))
+    resx0 = max(1.0, qv.nrm2())
+    resz0 = max(1.0, hv.nrm2())
+
+    def result(status, iters, gap, relgap, pcost, dcost, pres, dres):
+        return {"x": x.get(), "y": np.zeros(0), "s": s.get(), "z": z.get(), "status": status, "gap": gap,
+                "relative gap": relgap, "primal objective": pcost, "dual objective": dcost,
+                "primal infeasibility": pres, "dual infeasibility": dres,
+                "primal slack": -s.max_step(), "dual slack": -z.max_step(), "iterations": iters,
+                "factorizations": kkt.nfactor}
+
+    # ---- starting point (coneprog.py:2044-2096): factor with W = I, solve [P G'; G -I][x; z] = [-q; h], s = -z
+    d.fill(1.0); di.fill(1.0)
+    try:
+        kkt.factor(di)
+    except ArithmeticError:
+        raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+    x.copy_from(qv).scal(-1.0)
+    z.copy_from(hv)
+    kkt.solve(x, z)
+    s.copy_from(z).scal(-1.0)
+    ts = s.max_step()
+    if ts >= -1e-8 * max(s.nrm2(), 1.0):
+        s.addc(1.0 + ts)
+    tz = z.max_step()
+    if tz >= -1e-8 * max(z.nrm2(), 1.0):
+        z.addc(1.0 + tz)
+    gap = s.dot(z)
+
+    def f4_no_ir(bx, bz, bs):
+        # [P G'; G -W'W][ux; W^-1 uz] = [bx; bz - W'(lmbda o\ bs)],  us = lmbda o\ bs - uz   (coneprog.py:2283-2313)
+        bs.div(lmbda)
+        tmp.xmy(1.0, bs, d)
+        bz.axpy(tmp, -1.0)
+        kkt.solve(bx, bz)
+        bs.axpy(bz, -1.0)
+
+    def res(ux, uz, us, vx, vz, vs):
+        # residual of the Newton equations (coneprog.py:1929-1960) with p = 0
+        Pd.symv(ux, vx, alpha=-1.0, beta=1.0)
+        tmp.xmy(1.0, uz, di)
+        Gd.gemv(tmp, vx, trans="T", alpha=-1.0, beta=1.0)
+        Gd.gemv(ux, vz, trans="N", alpha=-1.0, beta=1.0)
+        tmp.xmy(1.0, us, d)
+        vz.axpy(tmp, -1.0)
+        tmp.copy_from(us).axpy(uz)
+        tmp.mul(lmbda)
+        vs.axpy(tmp, -1.0)
+
+    def f4(bx, bz, bs):
+        if refinement:
+            wx.copy_from(bx); wz.copy_from(bz); ws.copy_from(bs)
+        f4_no_ir(bx, bz, bs)
+        for _ in range(refinement):
+            wx2.copy_from(wx); wz2.copy_from(wz); ws2.copy_from(ws)
+            res(bx, bz, bs, wx2, wz2, ws2)
+            f4_no_ir(wx2, wz2, ws2)
+            bx.axpy(wx2); bz.axpy(wz2); bs.axpy(ws2)
+
+    for iters in range(MAXITERS + 1):
+        # residuals and objectives (coneprog.py:2167-2203)
+        rx.copy_from(qv)
+        Pd.symv(x, rx, alpha=1.0, beta=1.0)
+        f0 = 0.5 * (x.dot(rx) + x.dot(qv))
+        Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
+        resx = rx.nrm2()
+        rz.copy_from(s).axpy(hv, -1.0)
+        Gd.gemv(x, rz, trans="N", alpha=1.0, beta=1.0)
+        resz = rz.nrm2()
+        pcost = f0
+        dcost = f0 + z.dot(rz) - gap
+        relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
+        pres, dres = resz / resz0, resx / resx0
+        if show:
+            if iters == 0:
+                print("% 10s% 12s% 10s% 8s% 7s" % ("pcost", "dcost", "gap", "pres", "dres"))
+            print("%2d: % 8.4e % 8.4e % 4.0e% 7.0e% 7.0e" % (iters, pcost, dcost, gap, pres, dres))
+        if (pres <= FEASTOL and dres <= FEASTOL and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL))) \
+                or iters == MAXITERS:
+            return result("unknown" if iters == MAXITERS else "optimal", iters, gap, relgap, pcost, dcost, pres, dres)
+
+        # scaling (coneprog.py:2230-2231) and KKT factorisation
+        if iters == 0:
+            raise_for(lib().kvx_nt_compute_scaling_dev(ml, s.ptr, z.ptr, d.ptr, di.ptr, lmbda.ptr))
+        lmbdasq.sqr_of(lmbda)
+        try:
+            kkt.factor(di)
+        except ArithmeticError:
+            if iters == 0:
+                raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres)
+
+        mu = gap / ml
+        sigma, eta = 0.0, 0.0
+        for i in (0, 1):
+            # right-hand sides (coneprog.py:2367-2390)
+            ds.fill(0.0)
+            if correction and i == 1:
+                ds.axpy(ws3, -1.0)
+            ds.axpy(lmbdasq, -1.0).addc(sigma * mu)
+            dx.copy_from(rx).scal(-1.0 + eta)
+            dz.copy_from(rz).scal(-1.0 + eta)
+            f4(dx, dz, ds)
+            dsdz = ds.dot(dz)
+            if correction and i == 0:
+                ws3.xmy(1.0, ds, dz)
+            # step to the boundary (coneprog.py:2431-2451)
+            ds.div(lmbda); dz.div(lmbda)
+            t = max(0.0, ds.max_step(), dz.max_step())
+            if t == 0.0:
+                step = 1.0
+            else:
+                step = min(1.0, 1.0 / t) if i == 0 else min(1.0, STEP / t)
+            if i == 0:
+                sigma = min(1.0, max(0.0, 1.0 - step + dsdz / gap * step ** 2)) ** EXPON
+                eta = 0.0
+
+        # update iterates and scaling (coneprog.py:2454-2545)
+        x.axpy(dx, step)
+        ds.scal(step).addc(1.0); dz.scal(step).addc(1.0)
+        ds.mul(lmbda); dz.mul(lmbda)
+        raise_for(lib().kvx_nt_update_scaling_dev(ml, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr))
+        s.xmy(1.0, lmbda, d)
+        z.xmy(1.0, lmbda, di)
+        gap = lmbda.dot(lmbda)
     raise AssertionError("unreachable")

@@ -120,3 +120,14 @@ def lp_grid(gx, gy, seed=4):
     cvec = np.zeros(n)
     np.add.at(cvec, c, -v * z0[r])
     return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h}
+
+
+def qp_grid(gx, gy):
+    """Convex QP on the config-4b grid (goldens G5): G, h of lp_grid (strictly feasible), P = I + (5-point grid
+    Laplacian) / 4 as lower CCS, q = default_rng(8) standard normal."""
+    L = lp_grid(gx, gy)
+    n, cp, ri, vx = laplacian_2d(gx, gy)
+    Px = vx * 0.25
+    Px[cp[:-1]] += 1.0
+    L.update({"Pp": cp, "Pi": ri, "Px": Px, "q": np.random.default_rng(8).standard_normal(n)})
+    return L

@@ -224,6 +224,55 @@ def g4_conelp():
                "cases": meta}, open(os.path.join(HERE, "g4_conelp.json"), "w"), indent=1, default=float)
 
 
+def qp_grid(gx, gy):
+    """The config-4b grid LP turned into a convex QP: same G, h (strictly feasible), P = I + (5-point grid
+    Laplacian) / 4 (sparse, SPD), q = default_rng(8) standard normal.  Returns the LP dict plus lower-CCS P and q."""
+    from kvxopt_amd import workloads
+    L = workloads.lp_grid(gx, gy)
+    n, cp, ri, vx = workloads.laplacian_2d(gx, gy)
+    assert n == L["n"]
+    Px = vx * 0.25
+    Px[cp[:-1]] += 1.0                                  # the diagonal is the first entry of every lower column
+    L.update({"Pp": cp, "Pi": ri, "Px": Px, "q": np.random.default_rng(8).standard_normal(n)})
+    return L
+
+
+def g5_coneqp():
+    """coneqp traces on the grid QPs (misc.kkt_chol2 with H = P: S = P + G' W^-1 W^-T G, misc.py:1425-1426, 1454-1455)."""
+    from kvxopt import matrix, solvers, spmatrix, misc
+    solvers.options["show_progress"] = False
+    out, meta = {}, {}
+    for name, gx, gy in [("qp6x5", 6, 5), ("qp25x20", 25, 20)]:
+        Q = qp_grid(gx, gy)
+        ml, n = Q["ml"], Q["n"]
+        cols = np.repeat(np.arange(n), np.diff(Q["Gp"]))
+        G = spmatrix(Q["Gx"].tolist(), Q["Gi"].tolist(), cols.tolist(), (ml, n))
+        pcols = np.repeat(np.arange(n), np.diff(Q["Pp"]))
+        P = spmatrix(Q["Px"].tolist(), Q["Pi"].tolist(), pcols.tolist(), (n, n))      # lower triangle ('L' storage, coneprog.py:1452-1455)
+        q, h = matrix(Q["q"]), matrix(Q["h"])
+        dims = {"l": ml, "q": [], "s": []}
+        dvals = []
+        fac = misc.kkt_chol2(matrix(G), dims, matrix(0.0, (0, n)))
+
+        def kktsolver(W, fac=fac, dvals=dvals, P=P):
+            dvals.append(tolist(W["d"]))
+            return fac(W, P)
+        sol_d = solvers.coneqp(P, q, matrix(G), h, kktsolver=kktsolver)      # pure reference (dense-G LAPACK branch)
+        sol_s = solvers.coneqp(P, q, G, h)                                    # reference python + oracle cholesky
+        assert sol_d["status"] == sol_s["status"] == "optimal"
+        assert sol_d["iterations"] == sol_s["iterations"]
+        assert np.allclose(tolist(sol_d["x"]), tolist(sol_s["x"]), rtol=1e-7, atol=1e-9)
+        out[name + "_x"] = tolist(sol_d["x"]); out[name + "_s"] = tolist(sol_d["s"]); out[name + "_z"] = tolist(sol_d["z"])
+        out[name + "_d_per_iter"] = np.array(dvals[1:])
+        meta[name] = {k: sol_d[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective",
+                                           "dual objective", "primal infeasibility", "dual infeasibility",
+                                           "primal slack", "dual slack")}
+    np.savez_compressed(os.path.join(HERE, "g5_coneqp.npz"), **out)
+    json.dump({"via": "reference (dense-G LAPACK branch), cross-checked against reference python + oracle cholesky "
+                      "(sparse branch); problem generator: make_goldens.qp_grid (mirrored in kvxopt_amd.workloads.qp_grid)",
+               "cases": meta}, open(os.path.join(HERE, "g5_coneqp.json"), "w"), indent=1, default=float)
+
+
 if __name__ == "__main__":
     stage()
     import kvxopt
@@ -232,4 +281,5 @@ if __name__ == "__main__":
     g2_assembly()
     g3_kkt()
     g4_conelp()
+    g5_coneqp()
     print("goldens written to", HERE)

@@ -170,6 +170,45 @@ def test_conelp_doc_and_infeasible(golden_dir):
         lp.conelp(np.zeros(3), spmatrix([1.0], [0], [0], (1, 3)), np.ones(1))
 
 
+@pytest.mark.parametrize("name,gx,gy", [("qp6x5", 6, 5), ("qp25x20", 25, 20)])
+def test_coneqp_golden(golden_dir, name, gx, gy):
+    """G5: the reference's coneqp on the grid QP (S = P + G' W^-1 W^-T G refactored every iteration): same
+    iteration count, same solution and objectives."""
+    g = np.load(os.path.join(golden_dir, "g5_coneqp.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g5_coneqp.json")))["cases"][name]
+    Q = workloads.qp_grid(gx, gy)
+    G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
+    P = spmatrix.from_ccs(Q["n"], Q["n"], Q["Pp"], Q["Pi"], Q["Px"])
+    sol = lp.coneqp(P, Q["q"], G, Q["h"])
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    assert rel(sol["x"], g[name + "_x"]) < 1e-7 and rel(sol["s"], g[name + "_s"]) < 1e-6 and rel(sol["z"], g[name + "_z"]) < 1e-6
+    for key in ("primal objective", "dual objective"):
+        assert abs(sol[key] - meta[key]) < 1e-8 * max(1.0, abs(meta[key]))
+    assert sol["factorizations"] == meta["iterations"] + 1
+    # iterative refinement changes nothing essential on a well-conditioned problem
+    sol2 = lp.coneqp(P, Q["q"], G, Q["h"], {"refinement": 1})
+    assert sol2["status"] == "optimal" and rel(sol2["x"], g[name + "_x"]) < 1e-7
+    # KKT conditions of the result, checked on the host: P x + q + G' z = 0, G x + s = h, s, z >= 0, s'z small
+    cols = np.repeat(np.arange(Q["n"]), np.diff(Q["Gp"]))
+    Gx_ = np.zeros(Q["ml"]); np.add.at(Gx_, Q["Gi"], Q["Gx"] * sol["x"][cols])
+    Gtz = np.zeros(Q["n"]); np.add.at(Gtz, cols, Q["Gx"] * sol["z"][Q["Gi"]])
+    Px_ = workloads.sym_matvec(Q["n"], Q["Pp"], Q["Pi"], Q["Px"], sol["x"].reshape(-1, 1)).ravel()
+    assert np.linalg.norm(Px_ + Q["q"] + Gtz) < 1e-6 * max(1.0, np.linalg.norm(Q["q"]))
+    assert np.linalg.norm(Gx_ + sol["s"] - Q["h"]) < 1e-6 * max(1.0, np.linalg.norm(Q["h"]))
+    assert sol["s"].min() > 0 and sol["z"].min() > 0 and sol["s"] @ sol["z"] < 1e-4
+
+
+def test_coneqp_errors():
+    Q = workloads.qp_grid(6, 5)
+    G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
+    P = spmatrix.from_ccs(Q["n"], Q["n"], Q["Pp"], Q["Pi"], Q["Px"])
+    with pytest.raises(TypeError):
+        lp.coneqp(P, Q["q"][:-1], G, Q["h"])
+    with pytest.raises(TypeError):
+        lp.coneqp(spmatrix([1.0], [0], [0], (2, 2)), Q["q"], G, Q["h"])
+
+
 def test_cholmod_module_api():
     """Error behaviour and option handling of the kvxopt.cholmod mirror (cholmod.c error macros)."""
     A = spmatrix([10, 3, 5, -2, 5, 2], [0, 2, 1, 3, 2, 3], [0, 0, 1, 1, 2, 3])     # spsolvers.rst:556
