@@ -5,6 +5,8 @@
   chol21  : the "~20 nnz/row" north-star variant, 21-point stencil on the 1000 x 1000 grid (workloads.stencil21_2d)
   lap3d   : 7-point Laplacian on a 100^3 grid (n = 1e6; one eighth of config 5's unknowns): the flop-bound regime
             (nnz(L) = 5.4e8, 2.7e12 flops, top front of order 14 082)
+  lp4a    : BASELINE.json configs[3] literally: standard form, 50 000 equality rows, 200 000
+            variables, G = -I; the equality branch of misc.kkt_chol2 (K = A S^-1 A' refactored every iteration)
   lp4b    : BASELINE.json configs[3] in inequality form: the device-resident
             interior-point loop kvxopt_amd.lp.conelp on the 250 x 200 grid LP (ml = 200 000, n = 50 000);
             metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
@@ -70,7 +72,7 @@ def lp_case(gx, gy):
     ml, n = P["ml"], P["n"]
     cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
     G = spmatrix(P["Gx"], P["Gi"], cols, (ml, n))
-    lp.conelp(P["c"], G, P["h"], {"maxiters": 2})            # warm-up: HIP module load, first-touch allocations
+    lp.conelp(P["c"], G, P["h"], options={"maxiters": 2})            # warm-up: HIP module load, first-touch allocations
     t0 = time.perf_counter()
     sol = lp.conelp(P["c"], G, P["h"])
     dt = time.perf_counter() - t0
@@ -101,9 +103,27 @@ def lp_case(gx, gy):
             "factorizations": sol["factorizations"], "ms_kkt_factor": t_f * 1e3, "ms_kkt_solve": t_s * 1e3}
 
 
+def lp_std_case(gx, gy):
+    from kvxopt_amd import lp, workloads
+    from kvxopt_amd.base import spmatrix
+    L = workloads.lp_grid_std(gx, gy)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    lp.conelp(L["c"], G, L["h"], A=A, b=L["b"], options={"maxiters": 2})
+    t0 = time.perf_counter()
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    dt = time.perf_counter() - t0
+    return {"case": "lp4a", "metric": "IPM iterations/s", "value": sol["iterations"] / dt, "unit": "iterations/s",
+            "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "loop_s": sol["loop seconds"],
+            "iterations_per_s_loop_only": sol["iterations"] / sol["loop seconds"] if sol["loop seconds"] > 0 else None,
+            "equality_rows": L["p"], "variables": L["n"], "gap": sol["gap"],
+            "primal_infeasibility": sol["primal infeasibility"], "dual_infeasibility": sol["dual infeasibility"],
+            "factorizations": sol["factorizations"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default="chol5,chol21,lap3d,lp4b")
+    ap.add_argument("--cases", default="chol5,chol21,lap3d,lp4a,lp4b")
     ap.add_argument("--grid", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -119,6 +139,8 @@ def main():
             out = chol_case("chol21 (21-point stencil)", *workloads.stencil21_2d(args.grid), 1, args.steps, args.warmup)
         elif case == "lap3d":
             out = chol_case("lap3d 100^3", *workloads.laplacian_3d(100), 1, max(2, args.steps // 3), 1)
+        elif case == "lp4a":
+            out = lp_std_case(250, 200)
         elif case == "lp4b":
             out = lp_case(250, 200)
         else:

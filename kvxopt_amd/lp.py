@@ -165,36 +165,144 @@ class KKTChol2Dev:
         z.xmy(1.0, di, self.t, -1.0)                     # z := Gs x - z                (misc.py:1563)
 
 
-def conelp(c, G, h, options=None, chol_opts=None):
-    """Solve the inequality-form LP on the GPU.  c: (n,), h: (ml,), G: spmatrix-like (ml x n, sparse).
-    Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
+class KKTDiagEqDev:
+    """Device-resident `misc.kkt_chol2` with equality constraints (p > 0) for a G whose columns have disjoint row
+    supports (every row of G holds at most one entry -- G = -I of a standard-form LP).  Then
+    S = G' W^-1 W^-T G is DIAGONAL and the reference's K = A S^-1 A' (misc.py:1483-1487, 1545: sparse triangular
+    solves with the factor of S, then a syrk) is one more fixed-pattern assembly, K = sum_k (1/S_kk) A[:,k] A[:,k]',
+    factored numerically on a symbolic analysis done once (the reference re-analyses K at every call, misc.py:1486)."""
+
+    def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts=None):
+        self.ml, self.n, self.p = ml, n, p
+        Gi = np.ascontiguousarray(Gi, dtype=np.int64)
+        if Gi.size and np.bincount(Gi, minlength=ml).max() > 1:
+            raise NotImplementedError("device-resident conelp with equality constraints needs a G with at most one "
+                                      "entry per row (diagonal S); use kvxopt_amd.misc.kkt_chol2 (host arrays) otherwise")
+        self.G = SpMatDev(ml, n, Gp, Gi, Gx)
+        self.G2 = SpMatDev(ml, n, Gp, Gi, np.asarray(Gx, dtype=np.float64) ** 2)
+        self.A = SpMatDev(p, n, Ap, Ai, Ax)
+        # CCS of A' (n x p) = CSR of A
+        Ap = np.asarray(Ap, dtype=np.int64); Ai = np.asarray(Ai, dtype=np.int64); Ax = np.asarray(Ax, dtype=np.float64)
+        cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
+        order = np.lexsort((cols, Ai))
+        ATi, ATx = cols[order], Ax[order]
+        ATp = np.zeros(p + 1, dtype=np.int64)
+        np.add.at(ATp, Ai + 1, 1)
+        np.cumsum(ATp, out=ATp)
+        h = ctypes.c_void_p()
+        raise_for(lib().kvx_atda_plan(n, p, _lib.pi(ATp), _lib.pi(np.ascontiguousarray(ATi)), None, None, ctypes.byref(h)))
+        self._plan = h
+        knz = ctypes.c_int64()
+        raise_for(lib().kvx_atda_pattern(h, ctypes.byref(knz), None, None))
+        self.Kp = np.empty(p + 1, dtype=np.int64)
+        Ki = np.empty(max(knz.value, 1), dtype=np.int64)
+        raise_for(lib().kvx_atda_pattern(h, ctypes.byref(knz), _lib.pi(self.Kp), _lib.pi(Ki)))
+        self.Ki = Ki[:knz.value].copy()
+        self.fac = Factor(p, self.Kp, self.Ki, "L", None, chol_opts)
+        self.ATx = DVec(max(ATx.size, 1), ATx if ATx.size else None)
+        self.Kx = DVec(self.Ki.size)
+        self.w, self.t = DVec(ml), DVec(ml)
+        self.sdiag, self.sinv, self.u = DVec(n), DVec(n), DVec(n)
+        self.di = None
+        self.nfactor = 0
+
+    def __del__(self):
+        if getattr(self, "_plan", None):
+            lib().kvx_atda_free(self._plan)
+            self._plan = None
+
+    def factor(self, di):
+        self.w.sqr_of(di)
+        self.G2.gemv(self.w, self.sdiag, trans="T")                   # S_kk = sum_i di_i^2 G_ik^2
+        if -self.sdiag.max_step() <= 0.0:                             # min_k S_kk <= 0: S is singular
+            raise ArithmeticError(0)
+        self.sinv.fill(1.0).div(self.sdiag)
+        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.ATx.ptr, self.sinv.ptr, None, self.Kx.ptr))
+        self.fac.factorize_dev(self.Kx.ptr, sync=True)
+        self.di = di
+        self.nfactor += 1
+
+    def solve(self, x, y, z):
+        """Overwrites (x, y, z) = (bx, by, bz) with (ux, uy, uz) of misc.py:1489-1563."""
+        di = self.di
+        z.mul(di)
+        self.t.xmy(1.0, di, z)
+        self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)        # x := bx + G' W^-1 W^-T bz
+        self.u.xmy(1.0, self.sinv, x)                                 # u := S^-1 x
+        self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)       # y := A S^-1 x - by
+        self.fac.solve_dev(y.ptr, 0, 1, max(1, self.p))               # y := K^-1 y   = uy
+        self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)
+        x.mul(self.sinv)                                              # x := S^-1 (x - A' uy) = ux
+        self.G.gemv(x, self.t, trans="N")
+        z.xmy(1.0, di, self.t, -1.0)                                  # z := W^-T (G ux - bz) = uz
+
+
+def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
+    """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
+    (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints G must have at most one
+    entry per row (KKTDiagEqDev).  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
     _lib.require_device()
     opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
     opts.update(options or {})
     MAXITERS, ABSTOL, RELTOL, FEASTOL = opts["maxiters"], opts["abstol"], opts["reltol"], opts["feastol"]
     show = opts["show_progress"]
     ml, n, Gp, Gi, Gx = base._as_ccs(G)
+    if dims is not None and (dims.get("q") or dims.get("s") or dims.get("l", ml) != ml):
+        raise NotImplementedError("only the orthant cone dims = {'l': G.size[0], 'q': [], 's': []} runs on the GPU")
     c_h = np.asarray(c._a if isinstance(c, base.matrix) else c, dtype=np.float64).reshape(-1)
     h_h = np.asarray(h._a if isinstance(h, base.matrix) else h, dtype=np.float64).reshape(-1)
     if c_h.size != n or h_h.size != ml:
         raise TypeError("dimensions of c, G, h do not match")
-    if ml < n:
-        raise ValueError("Rank(A) < p or Rank([G; A]) < n")          # coneprog.py:572-573 with p = 0
+    p = 0
+    if A is not None:
+        p, na, Ap, Ai, Ax = base._as_ccs(A)
+        if na != n:
+            raise TypeError("'A' must have %d columns" % n)
+        b_h = np.asarray(b._a if isinstance(b, base.matrix) else b, dtype=np.float64).reshape(-1)
+        if b_h.size != p:
+            raise TypeError("'b' must have length %d" % p)
+    if p > n or p + ml < n:
+        raise ValueError("Rank(A) < p or Rank([G; A]) < n")          # coneprog.py:572-573
 
-    kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+    class _NoY:                                                      # p = 0: the y-blocks of the algorithm are empty
+        def __getattr__(self, name):
+            return lambda *a, **k: self
+        def dot(self, other):
+            return 0.0
+        def nrm2(self):
+            return 0.0
+        def get(self):
+            return np.zeros(0)
+
+    if p > 0:
+        kkt = KKTDiagEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts)
+        Ad = kkt.A
+        bv = DVec(p, b_h)
+        y, dy, y1, ry, hry = (DVec(p) for _ in range(5))
+        ksolve = kkt.solve
+        def Af(u, v, trans="N", alpha=1.0, beta=0.0):
+            Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
+    else:
+        kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+        bv = y = dy = y1 = ry = hry = _NoY()
+        def ksolve(xx, yy, zz):
+            kkt.solve(xx, zz)
+        def Af(u, v, trans="N", alpha=1.0, beta=0.0):
+            if trans == "T" and beta == 0.0:
+                v.fill(0.0)                                          # A' y with p = 0: the zero vector
     Gd = kkt.G
     cv, hv = DVec(n, c_h), DVec(ml, h_h)
     x, dx, x1, rx, hrx = (DVec(n) for _ in range(5))
     s, z, ds, dz, z1, rz, hrz, th, ws3, tmp, lmbda, lmbdasq, d, di = (DVec(ml) for _ in range(14))
 
     resx0 = max(1.0, cv.nrm2())
-    resy0 = 1.0
+    resy0 = max(1.0, bv.nrm2())
     resz0 = max(1.0, hv.nrm2())
 
     t_loop = [None]
 
     def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True):
-        return {"x": x.get() if xs else None, "y": np.zeros(0) if zs else None,
+        return {"x": x.get() if xs else None, "y": y.get() if zs else None,
                 "s": s.get() if xs else None, "z": z.get() if zs else None,
                 "status": status, "gap": gap, "relative gap": relgap,
                 "primal objective": pcost, "dual objective": dcost,
@@ -213,24 +321,26 @@ def conelp(c, G, h, options=None, chol_opts=None):
         kkt.factor(di)
     except ArithmeticError:
         raise ValueError("Rank(A) < p or Rank([G; A]) < n")
-    x.fill(0.0); s.copy_from(hv)
-    kkt.solve(x, s)
+    x.fill(0.0); dy.copy_from(bv); s.copy_from(hv)
+    ksolve(x, dy, s)
     s.scal(-1.0)
     ts = s.max_step()
-    dx.copy_from(cv).scal(-1.0); z.fill(0.0)
-    kkt.solve(dx, z)
+    dx.copy_from(cv).scal(-1.0); y.fill(0.0); z.fill(0.0)
+    ksolve(dx, y, z)
     tz = z.max_step()
     nrms, nrmz = s.nrm2(), z.nrm2()
     gap = s.dot(z)
     pcost = cv.dot(x)
-    dcost = -hv.dot(z)
+    dcost = -bv.dot(y) - hv.dot(z)
     relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
     if ts <= 0 and tz <= 0 and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL)):
-        rx.copy_from(cv); Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
+        rx.copy_from(cv); Af(y, rx, trans="T", alpha=1.0, beta=1.0); Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
         resx = rx.nrm2()
+        ry.copy_from(bv); Af(x, ry, trans="N", alpha=1.0, beta=-1.0)
+        resy = ry.nrm2()
         Gd.gemv(x, rz, trans="N"); rz.axpy(s); rz.axpy(hv, -1.0)
         resz = rz.nrm2()
-        return result("optimal", 0, gap, relgap, pcost, dcost, max(0.0, resz / resz0), resx / resx0, None, None)
+        return result("optimal", 0, gap, relgap, pcost, dcost, max(resy / resy0, resz / resz0), resx / resx0, None, None)
     if ts >= -1e-8 * max(nrms, 1.0):
         s.addc(1.0 + ts)
     if tz >= -1e-8 * max(nrmz, 1.0):
@@ -242,16 +352,20 @@ def conelp(c, G, h, options=None, chol_opts=None):
     t_loop[0] = time.perf_counter()
     for iters in range(MAXITERS + 1):
         # residuals (coneprog.py:861-896)
-        Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=0.0)
+        Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
+        Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=1.0)
         hresx = hrx.nrm2()
         rx.copy_from(hrx).axpy(cv, -tau)
         resx = rx.nrm2() / tau
-        hresy = resy = 0.0
+        Af(x, hry, trans="N")
+        hresy = hry.nrm2()
+        ry.copy_from(hry).axpy(bv, -tau)
+        resy = ry.nrm2() / tau
         Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
         hresz = hrz.nrm2()
         rz.copy_from(hrz).axpy(hv, -tau)
         resz = rz.nrm2() / tau
-        cx, by, hz = cv.dot(x), 0.0, hv.dot(z)
+        cx, by, hz = cv.dot(x), bv.dot(y), hv.dot(z)
         rt = kappa + cx + by + hz
         pcost, dcost = cx / tau, -(by + hz) / tau
         relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
@@ -266,12 +380,12 @@ def conelp(c, G, h, options=None, chol_opts=None):
 
         if (pres <= FEASTOL and dres <= FEASTOL and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL))) \
                 or iters == MAXITERS:
-            x.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+            x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
             if iters == MAXITERS:
                 return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
             return result("optimal", iters, gap, relgap, pcost, dcost, pres, dres, None, None)
         elif pinfres is not None and pinfres <= FEASTOL:
-            z.scal(1.0 / (-hz - by))
+            y.scal(1.0 / (-hz - by)); z.scal(1.0 / (-hz - by))
             return result("primal infeasible", iters, None, None, None, 1.0, None, None, pinfres, None, xs=False)
         elif dinfres is not None and dinfres <= FEASTOL:
             x.scal(1.0 / (-cx)); s.scal(1.0 / (-cx))
@@ -290,11 +404,12 @@ def conelp(c, G, h, options=None, chol_opts=None):
         try:
             kkt.factor(di)
             x1.copy_from(cv).scal(-1.0)
+            y1.copy_from(bv)
             z1.copy_from(hv)
-            kkt.solve(x1, z1)
-            x1.scal(dgi); z1.scal(dgi)
+            ksolve(x1, y1, z1)
+            x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
         except ArithmeticError:
-            x.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+            x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
             return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
         th.copy_from(hv).mul(di)                         # th = W^{-T} h      (coneprog.py:1126-1128)
         z1z1 = z1.dot(z1)
@@ -310,17 +425,20 @@ def conelp(c, G, h, options=None, chol_opts=None):
                 ds.axpy(ws3).addc(-sigma * mu)
                 dkappa += wkappa3 - sigma * mu
             dx.copy_from(rx).scal(1.0 - sigma)
+            dy.copy_from(ry).scal(1.0 - sigma)
             dz.copy_from(rz).scal(1.0 - sigma)
             dtau = (1.0 - sigma) * rt
             # f6_no_ir (coneprog.py:1130-1195)
+            dy.scal(-1.0)
             ds.div(lmbda).scal(-1.0)                     # s := -lmbda o\ s
             tmp.xmy(1.0, ds, d)                          # W^T * s
             dz.axpy(tmp).scal(-1.0)                      # z := -(z + W^T s)
-            kkt.solve(dx, dz)
+            ksolve(dx, dy, dz)
             dkappa = -dkappa / lmbda_g
             dtau += dkappa / dgi
-            dtau = dgi * (dtau + cv.dot(dx) + 0.0 + th.dot(dz)) / (1.0 + z1z1)
+            dtau = dgi * (dtau + cv.dot(dx) + bv.dot(dy) + th.dot(dz)) / (1.0 + z1z1)
             dx.axpy(x1, dtau)
+            dy.axpy(y1, dtau)
             dz.axpy(z1, dtau)
             ds.axpy(dz, -1.0)
             dkappa -= dtau
@@ -342,6 +460,7 @@ def conelp(c, G, h, options=None, chol_opts=None):
 
         # update (coneprog.py:1336-1436)
         x.axpy(dx, step)
+        y.axpy(dy, step)
         ds.scal(step).addc(1.0); dz.scal(step).addc(1.0)
         ds.mul(lmbda); dz.mul(lmbda)
         raise_for(lib().kvx_nt_update_scaling_dev(ml, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr))

@@ -131,3 +131,29 @@ def qp_grid(gx, gy):
     Px[cp[:-1]] += 1.0
     L.update({"Pp": cp, "Pi": ri, "Px": Px, "q": np.random.default_rng(8).standard_normal(n)})
     return L
+
+
+def lp_grid_std(gx, gy):
+    """Config 4a: the literal "m = 50k, n = 200k" standard-form LP at grid size gx x gy --
+    minimise c'x  s.t.  A x = b, x >= 0  with A = M' (n_grid x 4 n_grid, M of lp_grid), G = -I, h = 0.
+    x0, z0 ~ U(0.5, 1.5) (seeds 5, 6), y0 ~ N(0, 1) (seed 7), b = A x0, c = z0 - M y0: strictly feasible.
+    Returns dict with A as CCS (p x nv), G as CCS (nv x nv, -I), c, h, b."""
+    L = lp_grid(gx, gy)
+    p, nv = L["n"], L["ml"]                            # equality rows = grid nodes, variables = rows of M
+    # A = M' : CCS of A (p x nv) = CSR of M; build from M's CCS (ml x n)
+    Mi, Mx = L["Gi"], L["Gx"]
+    Mcols = np.repeat(np.arange(L["n"], dtype=np.int64), np.diff(L["Gp"]))
+    order = np.lexsort((Mcols, Mi))                    # A column j = M row j, entries sorted by A-row (= M column)
+    Ai, Ax, Aj = Mcols[order], Mx[order], Mi[order]
+    Ap = np.zeros(nv + 1, dtype=np.int64)
+    np.add.at(Ap, Aj + 1, 1)
+    np.cumsum(Ap, out=Ap)
+    x0 = np.random.default_rng(5).uniform(0.5, 1.5, nv)
+    z0 = np.random.default_rng(6).uniform(0.5, 1.5, nv)
+    y0 = np.random.default_rng(7).standard_normal(p)
+    b = np.zeros(p); np.add.at(b, Ai, Ax * x0[Aj])
+    My0 = np.zeros(nv); np.add.at(My0, Aj, Ax * y0[Ai])      # M y0 = A' y0
+    c = z0 - My0
+    Gp = np.arange(nv + 1, dtype=np.int64)
+    return {"p": p, "n": nv, "ml": nv, "Ap": Ap, "Ai": Ai.astype(np.int64), "Ax": Ax, "b": b, "c": c,
+            "Gp": Gp, "Gi": np.arange(nv, dtype=np.int64), "Gx": -np.ones(nv), "h": np.zeros(nv)}

@@ -273,6 +273,35 @@ def g5_coneqp():
                "cases": meta}, open(os.path.join(HERE, "g5_coneqp.json"), "w"), indent=1, default=float)
 
 
+def g6_conelp_std():
+    """conelp on the standard-form grid LP of SURVEY 8(d) config 4a (equality constraints, G = -I): the
+    misc.kkt_chol2 branch with K = A S^-1 A' (misc.py:1483-1487, 1545)."""
+    from kvxopt import matrix, solvers, spmatrix, misc
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    out, meta = {}, {}
+    for name, gx, gy in [("std6x5", 6, 5), ("std15x12", 15, 12)]:
+        L = workloads.lp_grid_std(gx, gy)
+        p, nv = L["p"], L["n"]
+        acols = np.repeat(np.arange(nv), np.diff(L["Ap"]))
+        A = spmatrix(L["Ax"].tolist(), L["Ai"].tolist(), acols.tolist(), (p, nv))
+        G = spmatrix((-np.ones(nv)).tolist(), list(range(nv)), list(range(nv)), (nv, nv))
+        c, h, b = matrix(L["c"]), matrix(L["h"]), matrix(L["b"])
+        sol_d = solvers.conelp(c, matrix(G), h, A=matrix(A), b=b, kktsolver="chol2")   # pure reference (dense branch)
+        sol_s = solvers.conelp(c, G, h, A=A, b=b)                                      # reference python + oracle cholesky
+        assert sol_d["status"] == sol_s["status"] == "optimal", (sol_d["status"], sol_s["status"])
+        assert sol_d["iterations"] == sol_s["iterations"]
+        assert np.allclose(tolist(sol_d["x"]), tolist(sol_s["x"]), rtol=1e-6, atol=1e-8)
+        for k in "xysz":
+            out[name + "_" + k] = tolist(sol_d[k])
+        meta[name] = {k: sol_d[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective",
+                                           "dual objective", "primal infeasibility", "dual infeasibility")}
+    np.savez_compressed(os.path.join(HERE, "g6_conelp_std.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch of misc.kkt_chol2), cross-checked against reference python + "
+                      "oracle cholesky (sparse branch); generator kvxopt_amd.workloads.lp_grid_std",
+               "cases": meta}, open(os.path.join(HERE, "g6_conelp_std.json"), "w"), indent=1, default=float)
+
+
 if __name__ == "__main__":
     stage()
     import kvxopt
@@ -282,4 +311,5 @@ if __name__ == "__main__":
     g3_kkt()
     g4_conelp()
     g5_coneqp()
+    g6_conelp_std()
     print("goldens written to", HERE)

@@ -209,6 +209,43 @@ def test_coneqp_errors():
         lp.coneqp(spmatrix([1.0], [0], [0], (2, 2)), Q["q"], G, Q["h"])
 
 
+@pytest.mark.parametrize("name,gx,gy", [("std6x5", 6, 5), ("std15x12", 15, 12)])
+def test_conelp_standard_form_golden(golden_dir, name, gx, gy):
+    """G6: the reference's conelp on the standard-form grid LP of config 4a (A x = b, x >= 0): the equality branch
+    of misc.kkt_chol2 (K = A S^-1 A', misc.py:1483-1487, 1545) -- same iteration count, same x, y, s, z."""
+    g = np.load(os.path.join(golden_dir, "g6_conelp_std.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g6_conelp_std.json")))["cases"][name]
+    L = workloads.lp_grid_std(gx, gy)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    for k, tol in (("x", 1e-6), ("y", 1e-6), ("s", 1e-6), ("z", 1e-6)):
+        assert rel(sol[k], g[name + "_" + k]) < tol, k
+    assert abs(sol["primal objective"] - meta["primal objective"]) < 1e-8 * abs(meta["primal objective"])
+    assert sol["factorizations"] == meta["iterations"] + 1
+    # feasibility on the host
+    acols = np.repeat(np.arange(L["n"]), np.diff(L["Ap"]))
+    Ax_ = np.zeros(L["p"]); np.add.at(Ax_, L["Ai"], L["Ax"] * sol["x"][acols])
+    assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * np.linalg.norm(L["b"]) and sol["x"].min() > -1e-7
+
+
+def test_conelp_equality_errors():
+    L = workloads.lp_grid_std(6, 5)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    with pytest.raises(TypeError):
+        lp.conelp(L["c"], G, L["h"], A=A, b=L["b"][:-1])
+    with pytest.raises(NotImplementedError):                            # S not diagonal: host-array kkt_chol2 only
+        P = workloads.lp_grid(6, 5)
+        G2 = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+        A2 = spmatrix([1.0] * P["n"], [0] * P["n"], list(range(P["n"])), (1, P["n"]))
+        lp.conelp(P["c"], G2, P["h"], A=A2, b=np.ones(1))
+    with pytest.raises(NotImplementedError):
+        lp.conelp(L["c"], G, L["h"], dims={"l": 0, "q": [L["ml"]], "s": []})
+
+
 def test_cholmod_module_api():
     """Error behaviour and option handling of the kvxopt.cholmod mirror (cholmod.c error macros)."""
     A = spmatrix([10, 3, 5, -2, 5, 2], [0, 2, 1, 3, 2, 3], [0, 0, 1, 1, 2, 3])     # spsolvers.rst:556
