@@ -1,12 +1,16 @@
 // Big fronts (order m > 128 or k > 64): blocked right-looking factorisation in HBM/L2 with
 // 64-column panel steps, and multi-workgroup triangular solves.
 //
-// Per panel step jb (three dependent launches, every big front of the level batched):
-//   k_potrf_blk   : Cholesky of the 64x64 diagonal block AND its inverse, in LDS: 16-column blocks,
-//                   the 16x16 diagonal blocks by a register column sweep of one wave (factor and
-//                   inverse in the same instruction stream), everything else FP64 MFMA;
+// Per panel step jb (two dependent launches, every big front of the level batched):
 //   k_trsm_blk    : X := A * Linv' for the rows below, FP64 MFMA (v_mfma_f64_16x16x4_f64);
-//   k_syrk_trailing: C -= X X' on 64x64 tiles, FP64 MFMA.
+//   k_syrk_trailing: C -= X X' on 64x64 tiles, FP64 MFMA; its (0, 0) workgroup goes on to factor and
+//                   invert the NEXT diagonal block (potrf_lds), so the 64 sequential pivots of panel
+//                   jb + 64 overlap the update of panel jb;
+//   k_potrf_blk   : the same factor + inverse of a 64x64 diagonal block as a kernel of its own, for the
+//                   first panel of a front only.  In LDS: 16-column blocks, the 16x16 diagonal blocks by a
+//                   register column sweep of one wave (factor and inverse in the same instruction
+//                   stream), everything else FP64 MFMA.
+// Fronts of order >= 6144: two-level blocking (launch_syrk_inner / launch_syrk_outer, k_syrk_trailing128).
 // The inverses of the diagonal blocks stay resident: the solves use them as 64x64 mat-vecs, so a
 // big front's triangular solve has no 64-long dependent chain and is spread over workgroups.
 //
