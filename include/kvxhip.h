@@ -74,7 +74,9 @@ int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the facto
 
 /* solve(F, B, sys, nrhs, ldB, offsetB) -- cholmod.c:429-499; sys 0..8 = A, LDL', LD, DL', L,
  * L', D, P, P' (:437-439) with D = I.  B (n x nrhs, leading dimension ldB >= max(1,n)) is
- * overwritten.  The caller applies offsetB to the pointer. */
+ * overwritten.  The caller applies offsetB to the pointer.  After kvx_chol_factorize_async_dev the solve
+ * is queued behind the factorisation without a host round trip; a failed factorisation is then reported by
+ * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456). */
 int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB);
 int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
 

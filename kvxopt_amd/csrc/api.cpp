@@ -672,11 +672,18 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
     Symbolic &S = F->S;
     const int64_t n = S.n;
     if (sys < 0 || sys > 8) { set_err("invalid value for sys"); return KVX_EINVAL; }
-    int rc = finish_factor(F, nullptr);
-    if (rc == KVX_ESYMBOLIC) { set_err("called with symbolic factor"); return rc; }
-    if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
-    if (rc) return rc;
-    if (n == 0 || nrhs == 0) return KVX_OK;
+    // A factorisation still in flight on the factor's stream (kvx_chol_factorize_async_dev): the solve is queued
+    // behind it at once -- no host round trip between the two -- and its status is examined when both are done
+    // (on failure B holds garbage and the call reports the singular factor, as it would have before starting).
+    const bool deferred = F->pending;
+    int rc = KVX_OK;
+    if (!deferred) {
+        rc = finish_factor(F, nullptr);
+        if (rc == KVX_ESYMBOLIC) { set_err("called with symbolic factor"); return rc; }
+        if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
+        if (rc) return rc;
+    }
+    if (n == 0 || nrhs == 0) return deferred ? ((rc = finish_factor(F, nullptr)) == KVX_ENOTPOSDEF ? KVX_ESINGULAR : rc) : KVX_OK;
     if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
     if (sys == 6) return KVX_OK;   // D = I for an LL' factor
     hipStream_t st = F->stream;
@@ -723,6 +730,11 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipStreamSynchronize(st));
+    if (deferred) {
+        rc = finish_factor(F, nullptr);
+        if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
+        if (rc) return rc;
+    }
     prof_collect(F);
     float ms = 0;
     if (hipEventElapsedTime(&ms, F->ev[2], F->ev[3]) == hipSuccess) { F->ms_solve = ms; F->have_stime = true; }

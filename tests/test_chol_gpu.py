@@ -213,6 +213,30 @@ def test_syrk128_variant_parity(monkeypatch):
     parity(*workloads.laplacian_2d(150), seed=151)
 
 
+def test_async_factor_then_solve_without_host_round_trip():
+    """kvx_chol_factorize_async_dev followed by kvx_chol_solve_dev: the solve is queued behind the factorisation
+    and the factor's status is examined afterwards -- same answers, and a non-positive pivot still raises."""
+    from kvxopt_amd._lib import DeviceBuffer
+    n, cp, ri, vx = workloads.laplacian_2d(70)
+    F = Factor(n, cp, ri)
+    b = np.random.default_rng(1).standard_normal(n)
+    vd, xd = DeviceBuffer.from_array(vx), DeviceBuffer.from_array(b)
+    F.factorize_dev(vd.ptr, sync=False)
+    F.solve_dev(xd.ptr, 0, 1, n)
+    x = xd.download(np.float64, n)
+    assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x.reshape(-1, 1)).ravel() - b) < 1e-10 * np.linalg.norm(b)
+    bad = vx.copy(); bad[cp[int(F.perm()[n // 2])]] = -3.0
+    F.factorize_dev(DeviceBuffer.from_array(bad).ptr, sync=False)
+    with pytest.raises(ArithmeticError):
+        F.solve_dev(xd.ptr, 0, 1, n)
+    with pytest.raises(ArithmeticError):
+        F.status()
+    F.factorize_dev(vd.ptr, sync=False)                         # and the handle recovers
+    xd2 = DeviceBuffer.from_array(b)
+    F.solve_dev(xd2.ptr, 0, 1, n)
+    assert np.allclose(xd2.download(np.float64, n), x, rtol=0, atol=0)
+
+
 def test_empty_and_tiny():
     F = Factor(0, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64))
     F.factorize(np.zeros(0))
