@@ -164,6 +164,23 @@ class KKTChol2Dev:
         self.G.gemv(x, self.t, trans="N")                # t := G x
         z.xmy(1.0, di, self.t, -1.0)                     # z := Gs x - z                (misc.py:1563)
 
+    def solve2(self, xa, za, xb, zb):
+        """Two KKT systems with the same factor in ONE two-column triangular solve (the interior-point iteration has
+        two right-hand sides that do not depend on each other: the (-c, h) system and the predictor)."""
+        di, n = self.di, self.n
+        if getattr(self, "_x2", None) is None:
+            self._x2 = DVec(2 * max(n, 1))
+        for k, (x, z) in enumerate(((xa, za), (xb, zb))):
+            z.mul(di)
+            self.t.xmy(1.0, di, z)
+            self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)
+            raise_for(lib().kvx_vec_copy_dev(n, x.ptr, self._x2.ptr + 8 * n * k))
+        self.fac.solve_dev(self._x2.ptr, 0, 2, max(1, n))
+        for k, (x, z) in enumerate(((xa, za), (xb, zb))):
+            raise_for(lib().kvx_vec_copy_dev(n, self._x2.ptr + 8 * n * k, x.ptr))
+            self.G.gemv(x, self.t, trans="N")
+            z.xmy(1.0, di, self.t, -1.0)
+
 
 class KKTDiagEqDev:
     """Device-resident `misc.kkt_chol2` with equality constraints (p > 0) for a G whose columns have disjoint row
@@ -236,6 +253,26 @@ class KKTDiagEqDev:
         self.G.gemv(x, self.t, trans="N")
         z.xmy(1.0, di, self.t, -1.0)                                  # z := W^-T (G ux - bz) = uz
 
+    def solve2(self, xa, ya, za, xb, yb, zb):
+        """Two KKT systems, one two-column solve with the factor of K (see KKTChol2Dev.solve2)."""
+        di, p = self.di, self.p
+        if getattr(self, "_y2", None) is None:
+            self._y2 = DVec(2 * max(p, 1))
+        for k, (x, y, z) in enumerate(((xa, ya, za), (xb, yb, zb))):
+            z.mul(di)
+            self.t.xmy(1.0, di, z)
+            self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)
+            self.u.xmy(1.0, self.sinv, x)
+            self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)
+            raise_for(lib().kvx_vec_copy_dev(p, y.ptr, self._y2.ptr + 8 * p * k))
+        self.fac.solve_dev(self._y2.ptr, 0, 2, max(1, p))
+        for k, (x, y, z) in enumerate(((xa, ya, za), (xb, yb, zb))):
+            raise_for(lib().kvx_vec_copy_dev(p, self._y2.ptr + 8 * p * k, y.ptr))
+            self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)
+            x.mul(self.sinv)
+            self.G.gemv(x, self.t, trans="N")
+            z.xmy(1.0, di, self.t, -1.0)
+
 
 def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
@@ -280,6 +317,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         bv = DVec(p, b_h)
         y, dy, y1, ry, hry = (DVec(p) for _ in range(5))
         ksolve = kkt.solve
+        ksolve2 = kkt.solve2
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
     else:
@@ -287,6 +325,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         bv = y = dy = y1 = ry = hry = _NoY()
         def ksolve(xx, yy, zz):
             kkt.solve(xx, zz)
+        def ksolve2(xa, ya, za, xb, yb, zb):
+            kkt.solve2(xa, za, xb, zb)
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             if trans == "T" and beta == 0.0:
                 v.fill(0.0)                                          # A' y with p = 0: the zero vector
@@ -400,25 +440,13 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         lmbdasq.sqr_of(lmbda)
         lmbdasq_g = lmbda_g ** 2
 
-        # factor + first solve (coneprog.py:1066-1077)
-        try:
-            kkt.factor(di)
-            x1.copy_from(cv).scal(-1.0)
-            y1.copy_from(bv)
-            z1.copy_from(hv)
-            ksolve(x1, y1, z1)
-            x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
-        except ArithmeticError:
-            x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
-            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
-        th.copy_from(hv).mul(di)                         # th = W^{-T} h      (coneprog.py:1126-1128)
-        z1z1 = z1.dot(z1)
-
         mu = (lmbda.dot(lmbda) + lmbda_g ** 2) / (1 + ml)
         sigma = 0.0
         wkappa3 = 0.0
-        for i in (0, 1):
-            # right-hand side of the Newton system (coneprog.py:1250-1298)
+        st8 = {}                                          # dkappa, dtau of the Newton step under construction
+
+        def newton_rhs(i):
+            # right-hand side of the Newton system (coneprog.py:1250-1298) and the first half of f6_no_ir (:1130-1160)
             ds.copy_from(lmbdasq)
             dkappa = lmbdasq_g
             if i == 1:
@@ -427,15 +455,36 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             dx.copy_from(rx).scal(1.0 - sigma)
             dy.copy_from(ry).scal(1.0 - sigma)
             dz.copy_from(rz).scal(1.0 - sigma)
-            dtau = (1.0 - sigma) * rt
-            # f6_no_ir (coneprog.py:1130-1195)
+            st8["dtau"] = (1.0 - sigma) * rt
+            st8["dkappa"] = dkappa
             dy.scal(-1.0)
             ds.div(lmbda).scal(-1.0)                     # s := -lmbda o\ s
             tmp.xmy(1.0, ds, d)                          # W^T * s
             dz.axpy(tmp).scal(-1.0)                      # z := -(z + W^T s)
-            ksolve(dx, dy, dz)
-            dkappa = -dkappa / lmbda_g
-            dtau += dkappa / dgi
+
+        # factor + the two solves that do not depend on each other (coneprog.py:1066-1077 and the predictor's f3):
+        # one two-column triangular solve with the new factor
+        try:
+            kkt.factor(di)
+            x1.copy_from(cv).scal(-1.0)
+            y1.copy_from(bv)
+            z1.copy_from(hv)
+            newton_rhs(0)
+            ksolve2(x1, y1, z1, dx, dy, dz)
+            x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
+        except ArithmeticError:
+            x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+        th.copy_from(hv).mul(di)                         # th = W^{-T} h      (coneprog.py:1126-1128)
+        z1z1 = z1.dot(z1)
+
+        for i in (0, 1):
+            if i == 1:
+                newton_rhs(1)
+                ksolve(dx, dy, dz)
+            # second half of f6_no_ir (coneprog.py:1162-1195)
+            dkappa = -st8["dkappa"] / lmbda_g
+            dtau = st8["dtau"] + dkappa / dgi
             dtau = dgi * (dtau + cv.dot(dx) + bv.dot(dy) + th.dot(dz)) / (1.0 + z1z1)
             dx.axpy(x1, dtau)
             dy.axpy(y1, dtau)
