@@ -180,6 +180,10 @@ int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y);
 /* sdot (misc_solvers.c:1018) and max_step (misc_solvers.c:1065-1071: max_i -x_i) */
 int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host);
 int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host);
+/* count <= 32 reductions with one host synchronisation: kind[i] = 0 sdot(x_i, y_i), 1 max_step(x_i) -- bitwise the
+ * values of the single calls (the per-iteration residual norms / objectives of coneprog.py:861-896 in one go). */
+int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, const double *const *x,
+                            const double *const *y, double *out_host);
 
 /* ---- BLAS-1 glue on device vectors: replaces the blas.axpy / scal / copy calls and elementwise
  * products the interior-point loop makes between KKT solves (coneprog.py:1126-1433). ------------- */

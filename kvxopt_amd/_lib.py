@@ -73,6 +73,8 @@ _SIGS = {
     "kvx_nt_sinv_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_nt_ssqr_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_nt_sdot_dev": (ctypes.c_int, [i64, vp, vp, f64p]),
+    "kvx_nt_reduce_multi_dev": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), i64p, ctypes.POINTER(vp),
+                                                ctypes.POINTER(vp), f64p]),
     "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),
     "kvx_vec_axpy_dev": (ctypes.c_int, [i64, f64, vp, vp]),
     "kvx_vec_scal_dev": (ctypes.c_int, [i64, f64, vp]),

@@ -36,7 +36,8 @@ namespace {
 
 struct Scratch {
     double *part = nullptr;
-    double *host = nullptr;
+    double *host = nullptr;     // pinned, 32 doubles
+    double *multi = nullptr;    // device, 32 results of kvx_nt_reduce_multi_dev
 };
 Scratch &scratch()
 {
@@ -48,7 +49,8 @@ int ensure_scratch()
     Scratch &s = scratch();
     if (s.part) return KVX_OK;
     HIPCHK(hipMalloc((void **)&s.part, reduce_scratch_doubles() * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&s.host, sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s.host, 32 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&s.multi, 32 * sizeof(double)));
     return KVX_OK;
 }
 
@@ -262,6 +264,33 @@ int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host)
     launch_maxneg(nullptr, ml, x, s.part, s.part + reduce_scratch_doubles() - 1);
     HIPCHK(hipMemcpy(s.host, s.part + reduce_scratch_doubles() - 1, sizeof(double), hipMemcpyDeviceToHost));
     *result_host = *s.host;
+    return KVX_OK;
+}
+
+// Several reductions, ONE host synchronisation: the interior-point loop needs 6-9 norms and inner products at the
+// same point of every iteration (coneprog.py:861-896), each of which would otherwise stall the GPU for a round trip.
+// kind[i] = 0: sum_j x_i[j] * y_i[j] (sdot);  1: max_j(-x_i[j]) (max_step, 'l' block).  Same kernels, same fixed
+// reduction tree as the single calls, so the values are bitwise those of kvx_nt_sdot_dev / kvx_nt_max_step_dev.
+int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, const double *const *x,
+                            const double *const *y, double *out_host)
+{
+    if (count < 0 || count > 32 || (count > 0 && (!kind || !n || !x || !out_host))) return KVX_EINVAL;
+    if (count == 0) return KVX_OK;
+    int rc = ensure_scratch();
+    if (rc) return rc;
+    Scratch &s = scratch();
+    for (int i = 0; i < count; i++) {
+        if (kind[i] == 0) {
+            if (!y) return KVX_EINVAL;
+            launch_dot(nullptr, n[i], x[i], y[i], s.part, s.multi + i);
+        } else if (kind[i] == 1) {
+            launch_maxneg(nullptr, n[i], x[i], s.part, s.multi + i);
+        } else {
+            return KVX_EINVAL;
+        }
+    }
+    HIPCHK(hipMemcpy(s.host, s.multi, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) out_host[i] = s.host[i];
     return KVX_OK;
 }
 

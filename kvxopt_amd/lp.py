@@ -90,6 +90,26 @@ class DVec:
         return r.value
 
 
+def reduce_multi(items):
+    """Several reductions with ONE host synchronisation (kvx_nt_reduce_multi_dev).  items: ("dot", x, y) or ("max", x)
+    with DVec operands; entries whose operand is not a DVec (the empty y-blocks of p = 0) yield 0.0.  Bitwise the values
+    of DVec.dot / DVec.max_step."""
+    live = [(k, it) for k, it in enumerate(items) if isinstance(it[1], DVec) and it[1].n > 0]
+    out = [0.0] * len(items)
+    if not live:
+        return out
+    m = len(live)
+    kind = (ctypes.c_int32 * m)(*[0 if it[0] == "dot" else 1 for _, it in live])
+    n = (ctypes.c_int64 * m)(*[it[1].n for _, it in live])
+    xs = (ctypes.c_void_p * m)(*[it[1].ptr for _, it in live])
+    ys = (ctypes.c_void_p * m)(*[(it[2].ptr if it[0] == "dot" else None) for _, it in live])
+    res = (ctypes.c_double * m)()
+    raise_for(lib().kvx_nt_reduce_multi_dev(m, kind, n, xs, ys, res))
+    for j, (k, _) in enumerate(live):
+        out[k] = float(res[j])
+    return out
+
+
 class SpMatDev:
     """CCS matrix resident in HBM (int64 indices as in the reference, kvxopt.h:46)."""
 
@@ -388,24 +408,26 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
 
     tau, kappa = 1.0, 1.0
     gap = s.dot(z)
+    lmbda.fill(0.0)
     dg = dgi = lmbda_g = 1.0
     t_loop[0] = time.perf_counter()
     for iters in range(MAXITERS + 1):
-        # residuals (coneprog.py:861-896)
+        # residuals (coneprog.py:861-896); their norms and the objectives come back in one reduction call
         Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
         Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=1.0)
-        hresx = hrx.nrm2()
         rx.copy_from(hrx).axpy(cv, -tau)
-        resx = rx.nrm2() / tau
         Af(x, hry, trans="N")
-        hresy = hry.nrm2()
         ry.copy_from(hry).axpy(bv, -tau)
-        resy = ry.nrm2() / tau
         Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
-        hresz = hrz.nrm2()
         rz.copy_from(hrz).axpy(hv, -tau)
-        resz = rz.nrm2() / tau
-        cx, by, hz = cv.dot(x), bv.dot(y), hv.dot(z)
+        (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = reduce_multi(
+            [("dot", hrx, hrx), ("dot", rx, rx), ("dot", hry, hry), ("dot", ry, ry), ("dot", hrz, hrz), ("dot", rz, rz),
+             ("dot", cv, x), ("dot", bv, y), ("dot", hv, z), ("dot", lmbda, lmbda)])
+        hresx, resx = math.sqrt(v_hrx), math.sqrt(v_rx) / tau
+        hresy, resy = math.sqrt(v_hry), math.sqrt(v_ry) / tau
+        hresz, resz = math.sqrt(v_hrz), math.sqrt(v_rz) / tau
+        if iters > 0:
+            gap = (math.sqrt(lam2) / tau) ** 2           # (coneprog.py:1436; lmbda of the previous update)
         rt = kappa + cx + by + hz
         pcost, dcost = cx / tau, -(by + hz) / tau
         relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
@@ -437,10 +459,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             dg = math.sqrt(kappa / tau)
             dgi = math.sqrt(tau / kappa)
             lmbda_g = math.sqrt(tau * kappa)
+            lam2 = lmbda.dot(lmbda)
         lmbdasq.sqr_of(lmbda)
         lmbdasq_g = lmbda_g ** 2
 
-        mu = (lmbda.dot(lmbda) + lmbda_g ** 2) / (1 + ml)
+        mu = (lam2 + lmbda_g ** 2) / (1 + ml)
         sigma = 0.0
         wkappa3 = 0.0
         st8 = {}                                          # dkappa, dtau of the Newton step under construction
@@ -485,7 +508,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             # second half of f6_no_ir (coneprog.py:1162-1195)
             dkappa = -st8["dkappa"] / lmbda_g
             dtau = st8["dtau"] + dkappa / dgi
-            dtau = dgi * (dtau + cv.dot(dx) + bv.dot(dy) + th.dot(dz)) / (1.0 + z1z1)
+            cdx, bdy, thdz = reduce_multi([("dot", cv, dx), ("dot", bv, dy), ("dot", th, dz)])
+            dtau = dgi * (dtau + cdx + bdy + thdz) / (1.0 + z1z1)
             dx.axpy(x1, dtau)
             dy.axpy(y1, dtau)
             dz.axpy(z1, dtau)
@@ -496,7 +520,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
                 wkappa3 = dtau * dkappa
             # step length (coneprog.py:1314-1333)
             ds.div(lmbda); dz.div(lmbda)
-            ts, tz = ds.max_step(), dz.max_step()
+            ts, tz = reduce_multi([("max", ds), ("max", dz)])
             tt = -dtau / lmbda_g
             tk = -dkappa / lmbda_g
             t = max(0.0, ts, tz, tt, tk)
@@ -519,7 +543,6 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         s.xmy(1.0, lmbda, d)
         z.xmy(1.0, lmbda, di)
         kappa, tau = lmbda_g / dgi, lmbda_g * dgi
-        gap = (lmbda.nrm2() / tau) ** 2
     raise AssertionError("unreachable")
 
 
@@ -584,7 +607,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
     kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
     Gd, Pd = kkt.G, SymSpMatDev(n, Pp, Pi, Px)
     qv, hv = DVec(n, q_h), DVec(ml, h_h)
-    x, dx, rx = (DVec(n) for _ in range(3))
+    x, dx, rx, tmpx = (DVec(n) for _ in range(4))
     s, z, ds, dz, rz, ws3, tmp, lmbda, lmbdasq, d, di = (DVec(ml) for _ in range(11))
     if refinement:
         wx, wx2 = DVec(n), DVec(n)
@@ -648,17 +671,18 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
             bx.axpy(wx2); bz.axpy(wz2); bs.axpy(ws2)
 
     for iters in range(MAXITERS + 1):
-        # residuals and objectives (coneprog.py:2167-2203)
+        # residuals and objectives (coneprog.py:2167-2203): one reduction call for the five inner products
         rx.copy_from(qv)
         Pd.symv(x, rx, alpha=1.0, beta=1.0)
-        f0 = 0.5 * (x.dot(rx) + x.dot(qv))
+        tmpx.copy_from(rx)                               # P x + q, for f0
         Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
-        resx = rx.nrm2()
         rz.copy_from(s).axpy(hv, -1.0)
         Gd.gemv(x, rz, trans="N", alpha=1.0, beta=1.0)
-        resz = rz.nrm2()
+        xPq, xq, v_rx, v_rz, zrz = reduce_multi([("dot", x, tmpx), ("dot", x, qv), ("dot", rx, rx), ("dot", rz, rz), ("dot", z, rz)])
+        f0 = 0.5 * (xPq + xq)
+        resx, resz = math.sqrt(v_rx), math.sqrt(v_rz)
         pcost = f0
-        dcost = f0 + z.dot(rz) - gap
+        dcost = f0 + zrz - gap
         relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
         pres, dres = resz / resz0, resx / resx0
         if show:
@@ -696,7 +720,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
                 ws3.xmy(1.0, ds, dz)
             # step to the boundary (coneprog.py:2431-2451)
             ds.div(lmbda); dz.div(lmbda)
-            t = max(0.0, ds.max_step(), dz.max_step())
+            t = max(0.0, *reduce_multi([("max", ds), ("max", dz)]))
             if t == 0.0:
                 step = 1.0
             else:
