@@ -164,13 +164,14 @@ class KKTChol2Dev:
             lib().kvx_atda_free(self._plan)
             self._plan = None
 
-    def factor(self, di):
+    def factor(self, di, sync=True):
         """S = G' diag(di)^2 G on the fixed pattern, numeric refactorisation (misc.py:1418-1462).
-        Raises ArithmeticError when S is not positive definite."""
+        Raises ArithmeticError when S is not positive definite -- with sync=False only the NEXT solve does (the solve
+        is queued behind the factorisation without a host round trip)."""
         self.w.sqr_of(di)
         raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
                                               None if self.Px is None else self.Px.ptr, self.Sx.ptr))
-        self.fac.factorize_dev(self.Sx.ptr, sync=True)
+        self.fac.factorize_dev(self.Sx.ptr, sync=sync)
         self.di = di
         self.nfactor += 1
 
@@ -248,14 +249,14 @@ class KKTDiagEqDev:
             lib().kvx_atda_free(self._plan)
             self._plan = None
 
-    def factor(self, di):
+    def factor(self, di, sync=True):
         self.w.sqr_of(di)
         self.G2.gemv(self.w, self.sdiag, trans="T")                   # S_kk = sum_i di_i^2 G_ik^2
         if -self.sdiag.max_step() <= 0.0:                             # min_k S_kk <= 0: S is singular
             raise ArithmeticError(0)
         self.sinv.fill(1.0).div(self.sdiag)
         raise_for(lib().kvx_atda_assemble_dev(self._plan, self.ATx.ptr, self.sinv.ptr, None, self.Kx.ptr))
-        self.fac.factorize_dev(self.Kx.ptr, sync=True)
+        self.fac.factorize_dev(self.Kx.ptr, sync=sync)
         self.di = di
         self.nfactor += 1
 
@@ -488,7 +489,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         # factor + the two solves that do not depend on each other (coneprog.py:1066-1077 and the predictor's f3):
         # one two-column triangular solve with the new factor
         try:
-            kkt.factor(di)
+            kkt.factor(di, sync=False)                   # a failed factorisation surfaces in the solve right below
             x1.copy_from(cv).scal(-1.0)
             y1.copy_from(bv)
             z1.copy_from(hv)
