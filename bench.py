@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=1000, help="grid side of the 5-pt Laplacian (config 2: 1000)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
     ap.add_argument("--roofline-family", default="auto")
     ap.add_argument("--chol-opts", default="", help="JSON dict of analysis options (nd_leaf, leaf_cols, leaf_rows, relax_*) for experiments")
     ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop and the CPU baseline (experiments)")
@@ -238,6 +239,26 @@ def main():
                "sample": "same system and permutation, 1 numeric factorisation + 1 solve (%.1f s)" % tc,
                "max_rel_diff_vs_gpu": ref_diff}
 
+    # --- the other half of BASELINE.json's metric: IPM iterations/s of the device-resident conelp on configs[3]
+    # (inequality form), rank 0 only, a few hundred ms; never part of `value`
+    ipm = None
+    if rank == 0 and not args.no_ipm:
+        try:
+            from kvxopt_amd import lp as kvx_lp
+            from kvxopt_amd.base import spmatrix
+            Pl = workloads.lp_grid(250, 200)
+            Gl = spmatrix.from_ccs(Pl["ml"], Pl["n"], Pl["Gp"], Pl["Gi"], Pl["Gx"])
+            kvx_lp.conelp(Pl["c"], Gl, Pl["h"], options={"maxiters": 2})
+            tl0 = time.perf_counter()
+            sl = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])
+            tl = time.perf_counter() - tl0
+            ipm = {"metric": "IPM iterations/s", "value": sl["iterations"] / sl["loop seconds"], "unit": "iterations/s",
+                   "workload": "conelp, grid LP 250x200: ml=200000 inequalities, n=50000 (BASELINE configs[3], inequality form)",
+                   "iterations": sl["iterations"], "status": sl["status"], "loop_s": sl["loop seconds"], "whole_call_s": tl,
+                   "value_whole_call": sl["iterations"] / tl}
+        except Exception as e:                      # the headline line must not depend on this leg
+            ipm = {"error": repr(e)}
+
     if rank == 0:
         total = work * args.steps * world
         out = {
@@ -249,7 +270,7 @@ def main():
                        "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]), "max_front": int(info["max_front"]),
                        "analyze_s": round(t_analyze, 3), "parallelism": "replicas x%d" % world},
             "ms_factor": ms_factor, "ms_solve": ms_solve, "rel_residual": relres,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "ipm": ipm,
         }
         print(json.dumps(out))
     if dist is not None:

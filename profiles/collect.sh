@@ -12,8 +12,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 timeout -k 10 600 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -c 600 $OUT/${TAG}_bench.json; echo
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o s --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_fetch.log 2>&1
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_write.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o s --output-format csv -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ipm > $OUT/${TAG}_stats.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ipm > $OUT/${TAG}_pmc_fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o p --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ipm > $OUT/${TAG}_pmc_write.log 2>&1
 python3 profiles/summarize.py $TAG
 ls $OUT | grep $TAG
