@@ -274,6 +274,7 @@ def main():
         }
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()                  # rank 0 has extra legs (CPU baseline, IPM): leave together
         dist.destroy_process_group()
 
 
