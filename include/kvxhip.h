@@ -180,6 +180,17 @@ int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y);
 /* sdot (misc_solvers.c:1018) and max_step (misc_solvers.c:1065-1071: max_i -x_i) */
 int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host);
 int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host);
+/* Fused 'l'-cone steps of one interior-point iteration (each replaces a fixed run of the reference's BLAS-1 /
+ * misc calls, same operations per element; the loop is bound by launches, not by bytes):
+ *   newton_rhs: ds := -(lmbdasq (+ ws3 - shift)) ./ lmbda,  dz := -(scale*rz + d.*ds)      coneprog.py:1250-1298, 1146-1157
+ *               (ws3 may be NULL: predictor);
+ *   step_post : dz += dtau*z1, ds -= dz, [ws3 := ds.*dz], ds ./= lmbda, dz ./= lmbda        coneprog.py:1186-1191, 1303-1316
+ *   update    : ds := (step*ds + 1).*lmbda (same for dz), misc.update_scaling (misc.py:444-464), s := W'lmbda,
+ *               z := W^-1 lmbda                                                             coneprog.py:1343-1432  */
+int kvx_lp_newton_rhs_dev(int64_t ml, const double *lmbdasq, const double *ws3, double shift, double scale, const double *rz,
+                          const double *lmbda, const double *d, double *ds, double *dz);
+int kvx_lp_step_post_dev(int64_t ml, double dtau, const double *z1, const double *lmbda, double *ds, double *dz, double *ws3);
+int kvx_lp_update_dev(int64_t ml, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s, double *z);
 /* count <= 32 reductions with one host synchronisation: kind[i] = 0 sdot(x_i, y_i), 1 max_step(x_i) -- bitwise the
  * values of the single calls (the per-iteration residual norms / objectives of coneprog.py:861-896 in one go). */
 int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, const double *const *x,

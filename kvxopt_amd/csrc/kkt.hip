@@ -46,6 +46,65 @@ __global__ void k_update_scaling(int64_t n, double *__restrict__ s, double *__re
         lm[i] = ss * zz;
     }
 }
+// ---- fused 'l'-cone steps of the interior-point iteration -----------------------------------------------------------
+// The loop is host-bound (one launch + one ctypes call per BLAS-1 operation of the reference); these three kernels
+// each replace a fixed run of 6-10 of them.  Same operations in the same order per element.
+// (1) right-hand side of a Newton system and the first half of f6_no_ir (coneprog.py:1250-1298, 1146-1157):
+//       ds := -(lmbdasq (+ ws3 - shift)) ./ lmbda ;   dz := -(scale * rz + d .* ds)
+__global__ void k_lp_newton_rhs(int64_t n, const double *__restrict__ lsq, const double *__restrict__ ws3, double shift,
+                                double scale, const double *__restrict__ rz, const double *__restrict__ lm,
+                                const double *__restrict__ d, double *__restrict__ ds, double *__restrict__ dz)
+{
+    GS_LOOP(i, n) {
+        double v = lsq[i];
+        if (ws3) v = (v + ws3[i]) - shift;
+        v = -(v / lm[i]);
+        ds[i] = v;
+        dz[i] = -(scale * rz[i] + v * d[i]);
+    }
+}
+// (2) second half of f6_no_ir and the step-length scaling (coneprog.py:1186-1191, 1303-1316):
+//       dz += dtau * z1 ;  ds -= dz ;  [ws3 := ds .* dz] ;  ds ./= lmbda ;  dz ./= lmbda
+__global__ void k_lp_step_post(int64_t n, double dtau, const double *__restrict__ z1, const double *__restrict__ lm,
+                               double *__restrict__ ds, double *__restrict__ dz, double *__restrict__ ws3)
+{
+    GS_LOOP(i, n) {
+        const double zz = dz[i] + dtau * z1[i];
+        const double ss = ds[i] - zz;
+        if (ws3) ws3[i] = ss * zz;
+        const double l = lm[i];
+        ds[i] = ss / l;
+        dz[i] = zz / l;
+    }
+}
+// (3) end of the iteration (coneprog.py:1343-1432, 'l' block): ds := (step ds + 1) .* lmbda, same for dz, then
+//     update_scaling (misc.py:444-464) and the unscaled iterates s = W' lmbda, z = W^-1 lmbda
+__global__ void k_lp_update(int64_t n, double step, double *__restrict__ ds, double *__restrict__ dz, double *__restrict__ d,
+                            double *__restrict__ di, double *__restrict__ lm, double *__restrict__ s, double *__restrict__ z)
+{
+    GS_LOOP(i, n) {
+        const double l = lm[i];
+        const double ss = sqrt((step * ds[i] + 1.0) * l), zz = sqrt((step * dz[i] + 1.0) * l);
+        ds[i] = ss;
+        dz[i] = zz;
+        const double dd = (d[i] * ss) / zz;
+        d[i] = dd;
+        const double dinv = 1.0 / dd;
+        di[i] = dinv;
+        const double ln = ss * zz;
+        lm[i] = ln;
+        s[i] = ln * dd;
+        z[i] = ln * dinv;
+    }
+}
+void launch_lp_newton_rhs(hipStream_t st, int64_t n, const double *lsq, const double *ws3, double shift, double scale,
+                          const double *rz, const double *lm, const double *d, double *ds, double *dz)
+{ if (n > 0) hipLaunchKernelGGL(k_lp_newton_rhs, dim3(grid_for(n)), dim3(256), 0, st, n, lsq, ws3, shift, scale, rz, lm, d, ds, dz); }
+void launch_lp_step_post(hipStream_t st, int64_t n, double dtau, const double *z1, const double *lm, double *ds, double *dz, double *ws3)
+{ if (n > 0) hipLaunchKernelGGL(k_lp_step_post, dim3(grid_for(n)), dim3(256), 0, st, n, dtau, z1, lm, ds, dz, ws3); }
+void launch_lp_update(hipStream_t st, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lm, double *s, double *z)
+{ if (n > 0) hipLaunchKernelGGL(k_lp_update, dim3(grid_for(n)), dim3(256), 0, st, n, step, ds, dz, d, di, lm, s, z); }
+
 __global__ void k_scale(int64_t n, int64_t ldx, double *__restrict__ x, const double *__restrict__ w)
 {
     double *xc = x + (int64_t)blockIdx.y * ldx;

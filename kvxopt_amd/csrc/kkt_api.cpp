@@ -233,6 +233,13 @@ int kvx_nt_compute_scaling_dev(int64_t ml, const double *s, const double *z, dou
 { launch_compute_scaling(nullptr, ml, s, z, d, di, lmbda); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_nt_update_scaling_dev(int64_t ml, double *s, double *z, double *d, double *di, double *lmbda)
 { launch_update_scaling(nullptr, ml, s, z, d, di, lmbda); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_lp_newton_rhs_dev(int64_t ml, const double *lmbdasq, const double *ws3, double shift, double scale, const double *rz,
+                          const double *lmbda, const double *d, double *ds, double *dz)
+{ launch_lp_newton_rhs(nullptr, ml, lmbdasq, ws3, shift, scale, rz, lmbda, d, ds, dz); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_lp_step_post_dev(int64_t ml, double dtau, const double *z1, const double *lmbda, double *ds, double *dz, double *ws3)
+{ launch_lp_step_post(nullptr, ml, dtau, z1, lmbda, ds, dz, ws3); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_lp_update_dev(int64_t ml, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s, double *z)
+{ launch_lp_update(nullptr, ml, step, ds, dz, d, di, lmbda, s, z); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_nt_scale_dev(int64_t ml, int64_t ncols, int64_t ldx, double *x, const double *w)
 { launch_scale(nullptr, ml, ncols, ldx, x, w); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_nt_scale2_dev(int64_t ml, const double *lmbda, double *x, int inverse)

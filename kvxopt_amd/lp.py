@@ -471,20 +471,16 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
 
         def newton_rhs(i):
             # right-hand side of the Newton system (coneprog.py:1250-1298) and the first half of f6_no_ir (:1130-1160)
-            ds.copy_from(lmbdasq)
             dkappa = lmbdasq_g
             if i == 1:
-                ds.axpy(ws3).addc(-sigma * mu)
                 dkappa += wkappa3 - sigma * mu
+            # ds := -(lmbdasq (+ ws3 - sigma mu)) o\ lmbda,  dz := -((1 - sigma) rz + W' ds): one fused kernel
+            raise_for(lib().kvx_lp_newton_rhs_dev(ml, lmbdasq.ptr, ws3.ptr if i == 1 else None, sigma * mu if i == 1 else 0.0,
+                                                  1.0 - sigma, rz.ptr, lmbda.ptr, d.ptr, ds.ptr, dz.ptr))
             dx.copy_from(rx).scal(1.0 - sigma)
-            dy.copy_from(ry).scal(1.0 - sigma)
-            dz.copy_from(rz).scal(1.0 - sigma)
+            dy.copy_from(ry).scal(-(1.0 - sigma))
             st8["dtau"] = (1.0 - sigma) * rt
             st8["dkappa"] = dkappa
-            dy.scal(-1.0)
-            ds.div(lmbda).scal(-1.0)                     # s := -lmbda o\ s
-            tmp.xmy(1.0, ds, d)                          # W^T * s
-            dz.axpy(tmp).scal(-1.0)                      # z := -(z + W^T s)
 
         # factor + the two solves that do not depend on each other (coneprog.py:1066-1077 and the predictor's f3):
         # one two-column triangular solve with the new factor
@@ -513,14 +509,12 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             dtau = dgi * (dtau + cdx + bdy + thdz) / (1.0 + z1z1)
             dx.axpy(x1, dtau)
             dy.axpy(y1, dtau)
-            dz.axpy(z1, dtau)
-            ds.axpy(dz, -1.0)
             dkappa -= dtau
+            # dz += dtau z1, ds -= dz, [ws3 := ds o dz for the corrector (coneprog.py:1303-1306)], then the scaling by
+            # lmbda for the step length (coneprog.py:1314-1316): one fused kernel
+            raise_for(lib().kvx_lp_step_post_dev(ml, dtau, z1.ptr, lmbda.ptr, ds.ptr, dz.ptr, ws3.ptr if i == 0 else None))
             if i == 0:
-                ws3.xmy(1.0, ds, dz)                     # ds o dz for the corrector   (coneprog.py:1303-1306)
                 wkappa3 = dtau * dkappa
-            # step length (coneprog.py:1314-1333)
-            ds.div(lmbda); dz.div(lmbda)
             ts, tz = reduce_multi([("max", ds), ("max", dz)])
             tt = -dtau / lmbda_g
             tk = -dkappa / lmbda_g
@@ -535,14 +529,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         # update (coneprog.py:1336-1436)
         x.axpy(dx, step)
         y.axpy(dy, step)
-        ds.scal(step).addc(1.0); dz.scal(step).addc(1.0)
-        ds.mul(lmbda); dz.mul(lmbda)
-        raise_for(lib().kvx_nt_update_scaling_dev(ml, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr))
+        # scaled iterates, NT scaling update and unscaled s, z (coneprog.py:1343-1432, misc.py:444-464): one fused kernel
+        raise_for(lib().kvx_lp_update_dev(ml, step, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr, s.ptr, z.ptr))
         dg *= math.sqrt(1.0 - step * tk) / math.sqrt(1.0 - step * tt)
         dgi = 1.0 / dg
         lmbda_g *= math.sqrt(1.0 - step * tt) * math.sqrt(1.0 - step * tk)
-        s.xmy(1.0, lmbda, d)
-        z.xmy(1.0, lmbda, di)
         kappa, tau = lmbda_g / dgi, lmbda_g * dgi
     raise AssertionError("unreachable")
 
