@@ -79,6 +79,9 @@ int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the facto
  * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456). */
 int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB);
 int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
+/* Enqueue only: no host synchronisation; work the caller submits to the null stream afterwards is ordered behind the
+ * solve.  Errors of a factorisation still in flight are reported by the next synchronising call (kvx_chol_status). */
+int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
 
 /* spsolve(F, B, sys) -- cholmod.c:524-587.  B is n x ncol CCS; the result is returned as a
  * newly malloc'ed CCS triple the caller frees with kvx_free(). */

@@ -131,9 +131,10 @@ class Factor:
         raise_for(lib().kvx_chol_solve(self._h, int(sys), ptr, int(nrhs), int(ldB)), "solve step failed")
         return B
 
-    def solve_dev(self, B_ptr, sys=0, nrhs=1, ldB=None):
-        raise_for(lib().kvx_chol_solve_dev(self._h, int(sys), B_ptr, int(nrhs), int(ldB or max(1, self.n))),
-                  "solve step failed")
+    def solve_dev(self, B_ptr, sys=0, nrhs=1, ldB=None, sync=True):
+        """sync=False: enqueue only (kvx_chol_solve_async_dev); later null-stream work is ordered behind the solve."""
+        fn = lib().kvx_chol_solve_dev if sync else lib().kvx_chol_solve_async_dev
+        raise_for(fn(self._h, int(sys), B_ptr, int(nrhs), int(ldB or max(1, self.n))), "solve step failed")
 
     def spsolve(self, ncol, Bp, Bi, Bx, sys=0):
         Bp, Bi, Bx = as_i64(Bp), as_i64(Bi), as_f64(Bx)

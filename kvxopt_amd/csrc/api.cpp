@@ -52,6 +52,7 @@ struct kvx_chol {
     hipStream_t stream = nullptr;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
     hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool have_ftime = false, have_stime = false;
@@ -306,6 +307,7 @@ int ensure_device(kvx_chol *F)
     }
     HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&F->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&F->ev_out, hipEventDisableTiming));
     int rc;
     std::vector<int32_t> first((size_t)S.nsuper), perm32((size_t)S.n);
     for (int64_t s = 0; s < S.nsuper; s++) first[s] = (int32_t)S.super[s];
@@ -667,7 +669,7 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, i
 }
 
 // B_dev: n x nrhs, leading dimension ldB, device memory.
-int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
+int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool async = false)
 {
     Symbolic &S = F->S;
     const int64_t n = S.n;
@@ -728,6 +730,13 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
         else HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(F->ev[3], st));
         HIPCHK(hipGetLastError());
+    }
+    if (async) {
+        // no host synchronisation: the caller's (null-stream) work is ordered behind the solve by an event; a factorisation
+        // that was still in flight stays pending and its status is examined at the next synchronising call
+        HIPCHK(hipEventRecord(F->ev_out, st));
+        HIPCHK(hipStreamWaitEvent(nullptr, F->ev_out, 0));
+        return KVX_OK;
     }
     HIPCHK(hipStreamSynchronize(st));
     if (deferred) {
@@ -843,6 +852,15 @@ int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_
     int rc = wait_for_caller(F);
     if (rc) return rc;
     return solve_dev(F, sys, B_dev, nrhs, ldB);
+}
+
+int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    if (!F) return KVX_EINVAL;
+    if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
+    int rc = wait_for_caller(F);
+    if (rc) return rc;
+    return solve_dev(F, sys, B_dev, nrhs, ldB, true);
 }
 
 int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
@@ -1197,6 +1215,7 @@ void kvx_chol_free(kvx_chol *F)
             if (p) (void)hipFree(p);
         if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
         if (F->ev_in) (void)hipEventDestroy(F->ev_in);
+        if (F->ev_out) (void)hipEventDestroy(F->ev_out);
         if (F->stream) (void)hipStreamDestroy(F->stream);
     }
     delete F;

@@ -158,6 +158,7 @@ class KKTChol2Dev:
         self.Sx = DVec(self.Si.size)
         self.di = None
         self.nfactor = 0
+        self.async_solves = False      # True: solves are only enqueued; check() after the next host synchronisation
 
     def __del__(self):
         if getattr(self, "_plan", None):
@@ -175,13 +176,17 @@ class KKTChol2Dev:
         self.di = di
         self.nfactor += 1
 
+    def check(self):
+        """Raise ArithmeticError if the last (asynchronous) factorisation failed; synchronises the factor's stream."""
+        self.fac.status()
+
     def solve(self, x, z):
         """Overwrites (x, z) with (ux, W*uz) (misc.py:1489-1563 with p = 0)."""
         di = self.di
         z.mul(di)                                        # z := W^{-1} z                (misc.py:1513)
         self.t.xmy(1.0, di, z)                           # t := di .* z
         self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)   # x += Gs' z       (misc.py:1524)
-        self.fac.solve_dev(x.ptr, 0, 1, max(1, self.n))  # x := S^{-1} x   (sys 7,4 then 5,8: misc.py:1531-1558)
+        self.fac.solve_dev(x.ptr, 0, 1, max(1, self.n), sync=not self.async_solves)  # x := S^{-1} x (sys 7,4 then 5,8: misc.py:1531-1558)
         self.G.gemv(x, self.t, trans="N")                # t := G x
         z.xmy(1.0, di, self.t, -1.0)                     # z := Gs x - z                (misc.py:1563)
 
@@ -196,7 +201,7 @@ class KKTChol2Dev:
             self.t.xmy(1.0, di, z)
             self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)
             raise_for(lib().kvx_vec_copy_dev(n, x.ptr, self._x2.ptr + 8 * n * k))
-        self.fac.solve_dev(self._x2.ptr, 0, 2, max(1, n))
+        self.fac.solve_dev(self._x2.ptr, 0, 2, max(1, n), sync=not self.async_solves)
         for k, (x, z) in enumerate(((xa, za), (xb, zb))):
             raise_for(lib().kvx_vec_copy_dev(n, self._x2.ptr + 8 * n * k, x.ptr))
             self.G.gemv(x, self.t, trans="N")
@@ -243,6 +248,7 @@ class KKTDiagEqDev:
         self.sdiag, self.sinv, self.u = DVec(n), DVec(n), DVec(n)
         self.di = None
         self.nfactor = 0
+        self.async_solves = False
 
     def __del__(self):
         if getattr(self, "_plan", None):
@@ -260,6 +266,9 @@ class KKTDiagEqDev:
         self.di = di
         self.nfactor += 1
 
+    def check(self):
+        self.fac.status()
+
     def solve(self, x, y, z):
         """Overwrites (x, y, z) = (bx, by, bz) with (ux, uy, uz) of misc.py:1489-1563."""
         di = self.di
@@ -268,7 +277,7 @@ class KKTDiagEqDev:
         self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)        # x := bx + G' W^-1 W^-T bz
         self.u.xmy(1.0, self.sinv, x)                                 # u := S^-1 x
         self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)       # y := A S^-1 x - by
-        self.fac.solve_dev(y.ptr, 0, 1, max(1, self.p))               # y := K^-1 y   = uy
+        self.fac.solve_dev(y.ptr, 0, 1, max(1, self.p), sync=not self.async_solves)   # y := K^-1 y = uy
         self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)
         x.mul(self.sinv)                                              # x := S^-1 (x - A' uy) = ux
         self.G.gemv(x, self.t, trans="N")
@@ -286,7 +295,7 @@ class KKTDiagEqDev:
             self.u.xmy(1.0, self.sinv, x)
             self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)
             raise_for(lib().kvx_vec_copy_dev(p, y.ptr, self._y2.ptr + 8 * p * k))
-        self.fac.solve_dev(self._y2.ptr, 0, 2, max(1, p))
+        self.fac.solve_dev(self._y2.ptr, 0, 2, max(1, p), sync=not self.async_solves)
         for k, (x, y, z) in enumerate(((xa, ya, za), (xb, yb, zb))):
             raise_for(lib().kvx_vec_copy_dev(p, self._y2.ptr + 8 * p * k, y.ptr))
             self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)
@@ -490,13 +499,16 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             y1.copy_from(bv)
             z1.copy_from(hv)
             newton_rhs(0)
+            kkt.async_solves = True                      # enqueue only: the host runs ahead of the GPU up to the next scalar
             ksolve2(x1, y1, z1, dx, dy, dz)
             x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
+            th.copy_from(hv).mul(di)                     # th = W^{-T} h      (coneprog.py:1126-1128)
+            z1z1 = z1.dot(z1)                            # (first host synchronisation after the factorisation)
+            kkt.check()
         except ArithmeticError:
+            kkt.async_solves = False
             x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
             return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
-        th.copy_from(hv).mul(di)                         # th = W^{-T} h      (coneprog.py:1126-1128)
-        z1z1 = z1.dot(z1)
 
         for i in (0, 1):
             if i == 1:
