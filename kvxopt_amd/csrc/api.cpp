@@ -90,7 +90,8 @@ struct kvx_chol {
     std::vector<int32_t> cd_woff_host;
     std::vector<uint8_t> in_sub;
     std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
-    std::vector<int> sw_cnt;
+    std::vector<int> sw_cnt, sw_kmax;
+    bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;
     // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
@@ -246,13 +247,21 @@ int build_subtrees(kvx_chol *F)
     std::vector<int32_t> lsw;
     F->sw_off.assign((size_t)S.nlevels, 0);
     F->sw_cnt.assign((size_t)S.nlevels, 0);
+    F->sw_kmax.assign((size_t)S.nlevels, 0);
     for (int l = 0; l < S.nlevels; l++) {
         F->sw_off[l] = (int64_t)lsw.size();
+        // the LDS-class fronts and the wave-class fronts left outside the subtrees share one launch per level and sweep
+        int kmax = 0;
         for (int64_t q = F->lptr_host[l]; q < F->lptr_host[l + 1]; q++) {
             const int32_t f = F->lists_host[q];
-            if (front_class(S.sn_m[f], S.sn_k[f]) >= KVX_CLS_WAVE0 && !(enabled && F->in_sub[f])) lsw.push_back(f);
+            const int c = front_class(S.sn_m[f], S.sn_k[f]);
+            if (c == KVX_CLS_BIG || (c >= KVX_CLS_WAVE0 && enabled && F->in_sub[f])) continue;
+            if (!enabled && c < KVX_CLS_WAVE0) continue;           // without subtrees: wave fronts only, their own launch
+            lsw.push_back(f);
+            kmax = std::max(kmax, (int)S.sn_k[f]);
         }
         F->sw_cnt[l] = (int)((int64_t)lsw.size() - F->sw_off[l]);
+        F->sw_kmax[l] = kmax;
     }
     if (lsw.empty()) lsw.push_back(0);
     std::vector<SubDesc> subs;
@@ -265,6 +274,7 @@ int build_subtrees(kvx_chol *F)
             if (pass == 0 && mm <= 32) F->nsub32++;
         }
     F->nsub = enabled ? (int)subs.size() : 0;
+    F->solve_merged = enabled;
     if (!enabled) F->nsub32 = 0;
     if (subs.empty()) subs.push_back(SubDesc{0, -1, 0, 0});
     // edge records of the subtree walk: (update rows, offset of the relative indices, LDS stack offset) per tree edge
@@ -617,15 +627,23 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, 
         double *Wout = F->d_W[l & 1];
         const int64_t woff = F->sw_off[l];
         const int wcnt = F->sw_cnt[l];
-        if (wcnt == 0 && P.scnt[0] == 0 && P.scnt[1] == 0) continue;
-        LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
+        const int nlds = F->solve_merged ? 0 : P.scnt[1];
+        if (wcnt == 0 && P.scnt[0] == 0 && nlds == 0) continue;
+        // with subtrees: every small front of the level that is outside them goes into ONE launch of the LDS kernel;
+        // without (sharded mode): the wave classes keep their own kernel and stream
+        LevelStreams ls(F, P.scnt[0] > 0, F->solve_merged ? wcnt > 0 : nlds > 0, F->solve_merged ? false : wcnt > 0);
         if (wcnt > 0) {
-            ProfScope ps(F, FAM_FWD, ls.wave);
-            launch_fwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 32, F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+            if (F->solve_merged) {
+                ProfScope ps(F, FAM_FWD, ls.lds);
+                launch_fwd_lds(ls.lds, F->ds, F->d_lists_sw + woff, wcnt, F->sw_kmax[l], F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+            } else {
+                ProfScope ps(F, FAM_FWD, ls.wave);
+                launch_fwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 32, F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
+            }
         }
-        if (P.scnt[1] > 0) {
+        if (nlds > 0) {
             ProfScope ps(F, FAM_FWD, ls.lds);
-            launch_fwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], std::max(P.maxk[KVX_CLS_LDS128], P.maxk[KVX_CLS_LDS96]),
+            launch_fwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], nlds, std::max(P.maxk[KVX_CLS_LDS128], P.maxk[KVX_CLS_LDS96]),
                            F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
         }
         if (P.scnt[0] > 0) {
@@ -645,15 +663,21 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, i
         const LevelPlan &P = F->plan[l];
         const int64_t woff = F->sw_off[l];
         const int wcnt = F->sw_cnt[l];
-        if (wcnt == 0 && P.scnt[0] == 0 && P.scnt[1] == 0) continue;
-        LevelStreams ls(F, P.scnt[0] > 0, P.scnt[1] > 0, wcnt > 0);
+        const int nlds = F->solve_merged ? 0 : P.scnt[1];
+        if (wcnt == 0 && P.scnt[0] == 0 && nlds == 0) continue;
+        LevelStreams ls(F, P.scnt[0] > 0, F->solve_merged ? wcnt > 0 : nlds > 0, F->solve_merged ? false : wcnt > 0);
         if (wcnt > 0) {
-            ProfScope ps(F, FAM_BWD, ls.wave);
-            launch_bwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 64, 32, F->d_Lx, X, ldx, nrhs);
+            if (F->solve_merged) {
+                ProfScope ps(F, FAM_BWD, ls.lds);
+                launch_bwd_lds(ls.lds, F->ds, F->d_lists_sw + woff, wcnt, F->d_Lx, X, ldx, nrhs);
+            } else {
+                ProfScope ps(F, FAM_BWD, ls.wave);
+                launch_bwd_wave(ls.wave, F->ds, F->d_lists_sw + woff, wcnt, 64, 32, F->d_Lx, X, ldx, nrhs);
+            }
         }
-        if (P.scnt[1] > 0) {
+        if (nlds > 0) {
             ProfScope ps(F, FAM_BWD, ls.lds);
-            launch_bwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], P.scnt[1], F->d_Lx, X, ldx, nrhs);
+            launch_bwd_lds(ls.lds, F->ds, F->d_lists + P.soff[1], nlds, F->d_Lx, X, ldx, nrhs);
         }
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_BWD);
