@@ -191,6 +191,8 @@ void analyze_subtrees(kvx_chol *F)
     const int64_t ns = S.nsuper;
     std::vector<int32_t> cnt((size_t)ns, 1), minidx((size_t)ns);
     std::vector<uint8_t> ok((size_t)ns, 0);
+    int maxf = 12;     // fronts per subtree: longer walks serialise more fronts in one wavefront, shorter ones leave more to the level loop (flat optimum 8..16)
+    { const char *e = getenv("KVX_SUB_MAXF"); if (e) maxf = std::max(1, std::min(atoi(e), KVX_SUB_MAXF)); }
     F->in_sub.assign((size_t)ns, 0);
     F->subs_host.clear();
     F->cd_woff_host.assign(S.children.size(), 0);
@@ -204,7 +206,7 @@ void analyze_subtrees(kvx_chol *F)
             minidx[s] = std::min(minidx[s], minidx[ch]);
         }
         const int64_t lo = s - cnt[s] + 1;
-        good = good && cnt[s] <= KVX_SUB_MAXF && minidx[s] == lo && lo >= 0 &&
+        good = good && cnt[s] <= maxf && minidx[s] == lo && lo >= 0 &&
                (S.super[s + 1] - S.super[lo]) <= KVX_SUB_MAXCOLS;
         ok[s] = good;
     }

@@ -45,7 +45,7 @@ struct ChildDesc {            // 40 bytes, indexed like DevSym::children
 struct SubDesc {
     int32_t lo, hi, col0, ncols;
 };
-constexpr int KVX_SUB_MAXF = 48;      // fronts per subtree
+constexpr int KVX_SUB_MAXF = 48;      // hard limit of fronts per subtree (default limit 12: KVX_SUB_MAXF)
 constexpr int KVX_SUB_MAXCOLS = 256;  // pivot columns per subtree (LDS slice of x)
 constexpr int KVX_SUB_STACK = 512;    // doubles of update vectors alive at once (LDS stack)
 
