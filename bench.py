@@ -167,11 +167,13 @@ def main():
     st = front_stats(F)
     fam_times = {}
     for fam in (Factor.FAMILIES if not args.quick else ()):
-        F.prof_select(fam)
-        for _ in range(2):
+        samples = []
+        for _ in range(3):                         # median of three single-step readings: one hiccup must not pick the family
+            F.prof_select(fam)
             step()
-        ms, cnt = F.prof_read()
-        fam_times[fam] = (ms / 2.0, cnt // 2)
+            samples.append(F.prof_read())
+        samples.sort(key=lambda t: t[0])
+        fam_times[fam] = (samples[1][0], samples[1][1])
     F.prof_select(None)
     if DF is not None:
         if rank == 0:
