@@ -220,6 +220,56 @@ int kvx_dev_upload(void *dst_dev, const void *src_host, int64_t bytes);
 int kvx_dev_download(void *dst_host, const void *src_dev, int64_t bytes);
 int kvx_dev_sync(void);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Sparse LU (the kvxopt.klu API, src/C/klu.c; SURVEY 8(f)1, BASELINE configs[2]).  Real 'd' matrices, square,
+ * CCS with int64 indices.  Static-structure multifrontal LU with threshold partial pivoting inside the pivot
+ * block of each front; fronts without an acceptable pivot are merged into their parents and the factorisation
+ * repeats (kvxopt_amd/csrc/lu_symbolic.hpp).  Factorisation:  R P A Q = L U + F  with F = 0 (one diagonal
+ * block; no block-triangular form yet), L unit lower, R = diag(1 / Rs).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct kvx_lu_sym kvx_lu_sym;      /* replaces the "KLU SYM D FACTOR" capsule (klu.c:36,276-279)   */
+typedef struct kvx_lu_num kvx_lu_num;      /* replaces the "KLU NUM D FACTOR" capsule (klu.c:38,336-339)   */
+
+/* symbolic(A) -- klu.c:242-291 (klu_analyze :264).  values may be NULL (pattern only: plain maximum
+ * transversal); with values the matching maximises the product of the scaled diagonal.  A structurally
+ * singular pattern is accepted here and reported by the numeric phase (KVX_ESINGULAR), as KLU does.
+ * KVX_EINVAL: n < 1, malformed colptr/rowind. */
+int kvx_lu_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, const double *values, kvx_lu_sym **out);
+void kvx_lu_free_symbolic(kvx_lu_sym *S);
+/* info: n, nnz, base supernodes, merges learned so far, structurally singular (0/1), nnz(L) bound of the
+ * symmetrised pattern, levels, largest base front */
+int kvx_lu_sym_info(kvx_lu_sym *S, int64_t info[8]);
+int kvx_lu_sym_matching(kvx_lu_sym *S, int64_t *rowfor /* n: row on the diagonal of column j */);
+
+/* numeric(A, Fs) -- klu.c:310-379 (klu_factor :336).  nnz must equal the analysed pattern's.  The symbolic
+ * object is updated when fronts are merged (it must outlive the numeric object).
+ * KVX_ESINGULAR -> ArithmeticError("singular matrix") (klu.c:370-371); KVX_EDEVICE: no GPU (never a CPU fallback). */
+int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out);
+int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out);
+/* numeric with a previous factorisation (doc/source/spsolvers.rst:377-388: "a refactorization is performed"):
+ * same pivot sequence, no search; falls back to a full factorisation when a reused pivot is unacceptable. */
+int kvx_lu_refactor(kvx_lu_num *N, int64_t nnz, const double *values);
+int kvx_lu_refactor_dev(kvx_lu_num *N, int64_t nnz, const double *values_dev);
+void kvx_lu_free_numeric(kvx_lu_num *N);
+/* info: fronts, levels, largest front order, largest pivot block, panel doubles, arena doubles, numeric passes, factored */
+int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8]);
+
+/* solve(A, Fs, Fn, B, trans) -- klu.c:593-690 (klu_solve / klu_tsolve :651-665).  trans: 0 = 'N', 1 = 'T'.
+ * B is n x nrhs column-major with leading dimension ldB >= max(1, n), overwritten by the solution. */
+int kvx_lu_solve(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB);
+int kvx_lu_solve_dev(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB);
+
+/* get_numeric(A, Fs, Fn) -- klu.c:392-566 (klu_extract :444).  L, U, F come back as malloc'ed CCS triples
+ * (free with kvx_free), sorted rows, no explicit zeros; P[k] = row of A that is pivot row k, Q[k] = column of A
+ * that is pivot column k, Rs[k] = scale factor of pivot row k (the reference inverts it, klu.c:503-509),
+ * r = block boundaries (nblocks + 1 entries). */
+int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
+                   int64_t **Ui, double **Ux, int64_t *fnz, int64_t **Fp, int64_t **Fi, double **Fx, int64_t *P,
+                   int64_t *Q, double *Rs, int64_t *nblocks, int64_t **r);
+
+/* get_det(A, Fs, Fn) -- klu.c:707-828: prod(Udiag[k] * Rs[k]) * sign(P) * sign(Q). */
+int kvx_lu_det(kvx_lu_num *N, double *det);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,23 @@ _SIGS = {
     "kvx_vec_copy_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_vec_xmy_dev": (ctypes.c_int, [i64, f64, vp, vp, f64, vp]),
     "kvx_spmv_dev": (ctypes.c_int, [ctypes.c_int, i64, i64, vp, vp, vp, f64, vp, f64, vp]),
+    "kvx_lu_analyze": (ctypes.c_int, [i64, i64p, i64p, f64p, ctypes.POINTER(vp)]),
+    "kvx_lu_free_symbolic": (None, [vp]),
+    "kvx_lu_sym_info": (ctypes.c_int, [vp, i64p]),
+    "kvx_lu_sym_matching": (ctypes.c_int, [vp, i64p]),
+    "kvx_lu_factor": (ctypes.c_int, [vp, i64, f64p, ctypes.POINTER(vp)]),
+    "kvx_lu_factor_dev": (ctypes.c_int, [vp, i64, vp, ctypes.POINTER(vp)]),
+    "kvx_lu_refactor": (ctypes.c_int, [vp, i64, f64p]),
+    "kvx_lu_refactor_dev": (ctypes.c_int, [vp, i64, vp]),
+    "kvx_lu_free_numeric": (None, [vp]),
+    "kvx_lu_num_info": (ctypes.c_int, [vp, i64p]),
+    "kvx_lu_solve": (ctypes.c_int, [vp, ctypes.c_int, f64p, i64, i64]),
+    "kvx_lu_solve_dev": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
+    "kvx_lu_extract": (ctypes.c_int, [vp, i64p, ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p),
+                                      i64p, ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p),
+                                      i64p, ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p),
+                                      i64p, i64p, f64p, i64p, ctypes.POINTER(i64p)]),
+    "kvx_lu_det": (ctypes.c_int, [vp, f64p]),
     "kvx_dev_malloc": (ctypes.c_int, [ctypes.POINTER(vp), i64]),
     "kvx_dev_free": (ctypes.c_int, [vp]),
     "kvx_dev_upload": (ctypes.c_int, [vp, vp, i64]),

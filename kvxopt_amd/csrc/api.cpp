@@ -18,6 +18,7 @@ using namespace kvx;
 
 static thread_local std::string g_err;
 static void set_err(const std::string &s) { g_err = s; }
+namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // for the other translation units (lu_api.cpp)
 
 #define HIPCHK(call)                                                                     \
     do {                                                                                 \

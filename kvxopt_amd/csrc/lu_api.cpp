@@ -1,0 +1,510 @@
+// C-ABI entry points of the sparse LU path (include/kvxhip.h, kvx_lu_*): what the reference's src/C/klu.c binds
+// from SuiteSparse KLU (klu_analyze :141, klu_factor :161, klu_solve/klu_tsolve :187-198, klu_extract :444-449,
+// Udiag/Rs/Pnum/Q for the determinant :760-822).  Device-only numeric phase: no CPU fallback.
+#include "../../include/kvxhip.h"
+#include "lu_device.hpp"
+#include "lu_symbolic.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace kvx;
+
+#define HIPCHK(call)                                                             \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));  \
+            return KVX_EDEVICE;                                                  \
+        }                                                                        \
+    } while (0)
+
+struct kvx_lu_sym {
+    LuSymbolic Y;
+};
+
+struct kvx_lu_num {
+    kvx_lu_sym *sym = nullptr;
+    LuPlan P;
+    int64_t n = 0, nnz = 0;
+    bool dev = false, factored = false;
+    hipStream_t st = nullptr;
+    LuFrontD *d_fr = nullptr;
+    int32_t *d_rowidx = nullptr, *d_rel = nullptr, *d_children = nullptr, *d_adst = nullptr, *d_ai32 = nullptr;
+    int32_t *d_ipiv = nullptr, *d_lperm = nullptr, *d_fail = nullptr, *d_lists = nullptr;
+    int64_t *d_asrc = nullptr, *d_prow = nullptr, *d_qcol = nullptr;
+    double *d_rinv = nullptr, *d_rmax = nullptr, *d_Lx = nullptr, *d_Ux = nullptr, *d_arena = nullptr, *d_Ax = nullptr;
+    double *d_W = nullptr, *d_X = nullptr, *d_B = nullptr;
+    int64_t cap_rhs = 0;
+    std::vector<int32_t> lvl_maxm, lvl_maxk;
+    double tol = 1e-3, stol = 1e-3;
+    int64_t attempts = 0;
+};
+
+namespace {
+
+template <class T>
+int up(T **dst, const std::vector<T> &src)
+{
+    HIPCHK(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KVX_OK;
+}
+template <class T>
+int dalloc(T **dst, int64_t count)
+{
+    HIPCHK(hipMalloc((void **)dst, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    return KVX_OK;
+}
+
+void free_structure(kvx_lu_num *N)
+{
+    void *ptrs[] = {N->d_fr, N->d_rowidx, N->d_rel, N->d_children, N->d_adst, N->d_ipiv, N->d_lperm, N->d_fail, N->d_lists,
+                    N->d_asrc, N->d_prow, N->d_qcol, N->d_Lx, N->d_Ux, N->d_arena, N->d_W, N->d_X, N->d_B};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    N->d_fr = nullptr; N->d_rowidx = N->d_rel = N->d_children = N->d_adst = N->d_ipiv = N->d_lperm = N->d_fail = N->d_lists = nullptr;
+    N->d_asrc = N->d_prow = N->d_qcol = nullptr;
+    N->d_Lx = N->d_Ux = N->d_arena = N->d_W = N->d_X = N->d_B = nullptr;
+    N->cap_rhs = 0;
+}
+
+// (Re)build the plan from the symbolic object's merge state and upload it.
+int upload_structure(kvx_lu_num *N)
+{
+    free_structure(N);
+    try {
+        lu_build_plan(N->sym->Y, N->P);
+    } catch (const std::bad_alloc &) {
+        return KVX_ENOMEM;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return KVX_EINVAL;
+    }
+    const LuPlan &P = N->P;
+    if ((int64_t)P.max_m + P.max_k > 8000) {
+        set_last_error("LU front of order " + std::to_string(P.max_m) + " exceeds what the solve kernels hold in LDS");
+        return KVX_EINVAL;
+    }
+    std::vector<LuFrontD> fd((size_t)P.nfront);
+    for (int64_t f = 0; f < P.nfront; f++) {
+        LuFrontD &F = fd[f];
+        F.k = P.fr[f].k; F.m = P.fr[f].m; F.p0 = P.fr[f].p0; F.nchild = P.fr[f].nchild;
+        F.px = P.px[f]; F.rowptr = P.rowptr[f]; F.childptr = P.childptr[f]; F.aptr = P.aptr[f];
+        F.upd_off = P.upd_off[f]; F.wx = P.wx[f]; F.upd_ld = P.upd_ld[f]; F.acnt = (int32_t)(P.aptr[f + 1] - P.aptr[f]);
+    }
+    int rc;
+    if ((rc = up(&N->d_fr, fd))) return rc;
+    if ((rc = up(&N->d_rowidx, P.rowidx))) return rc;
+    if ((rc = up(&N->d_rel, P.rel))) return rc;
+    if ((rc = up(&N->d_children, P.children))) return rc;
+    if ((rc = up(&N->d_adst, P.a_dst))) return rc;
+    if ((rc = up(&N->d_asrc, P.a_src))) return rc;
+    if ((rc = up(&N->d_prow, P.prow))) return rc;
+    if ((rc = up(&N->d_qcol, P.qcol))) return rc;
+    if ((rc = up(&N->d_lists, P.levellist))) return rc;
+    if ((rc = dalloc(&N->d_ipiv, N->n))) return rc;
+    if ((rc = dalloc(&N->d_lperm, N->n))) return rc;
+    if ((rc = dalloc(&N->d_fail, P.nfront))) return rc;
+    if ((rc = dalloc(&N->d_Lx, P.lsize))) return rc;
+    if ((rc = dalloc(&N->d_Ux, P.lsize))) return rc;
+    if ((rc = dalloc(&N->d_arena, P.arena))) return rc;
+    N->lvl_maxm.assign((size_t)P.nlevels, 0);
+    N->lvl_maxk.assign((size_t)P.nlevels, 0);
+    for (int32_t l = 0; l < P.nlevels; l++)
+        for (int64_t q = P.levelptr[l]; q < P.levelptr[l + 1]; q++) {
+            N->lvl_maxm[l] = std::max(N->lvl_maxm[l], P.fr[P.levellist[q]].m);
+            N->lvl_maxk[l] = std::max(N->lvl_maxk[l], P.fr[P.levellist[q]].k);
+        }
+    return KVX_OK;
+}
+
+LuDev dev_view(const kvx_lu_num *N)
+{
+    LuDev d;
+    d.fr = N->d_fr; d.rowidx = N->d_rowidx; d.rel = N->d_rel; d.children = N->d_children;
+    d.a_src = N->d_asrc; d.a_dst = N->d_adst; d.ai32 = N->d_ai32; d.rinv = N->d_rinv;
+    d.Lx = N->d_Lx; d.Ux = N->d_Ux; d.arena = N->d_arena; d.ipiv = N->d_ipiv; d.lperm = N->d_lperm; d.fail = N->d_fail;
+    return d;
+}
+
+int lds_class(int m)
+{
+    static const int cls[] = {16, 32, 48, 64, KVX_LU_LDS_M};
+    for (int c : cls) if (m <= c) return c;
+    return KVX_LU_LDS_M;
+}
+
+// One numeric pass over the current plan.  fail_host receives the per-front flags.
+int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int32_t> &fail_host)
+{
+    const LuPlan &P = N->P;
+    const LuDev d = dev_view(N);
+    HIPCHK(hipMemsetAsync(N->d_rmax, 0, (size_t)N->n * sizeof(double), N->st));
+    launch_lu_rowmax(N->nnz, N->d_ai32, Ax_dev, N->d_rmax, N->st);
+    launch_lu_rinv(N->n, N->d_rmax, N->d_rinv, N->st);
+    for (int32_t l = P.nlevels - 1; l >= 0; l--) {
+        const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nl = P.nlds[l];
+        int64_t q = b;
+        while (q < b + nl) {                                  // runs of one LDS size class (list sorted by m descending)
+            const int c = lds_class(P.fr[P.levellist[q]].m);
+            int64_t q2 = q;
+            while (q2 < b + nl && lds_class(P.fr[P.levellist[q2]].m) == c) q2++;
+            launch_lu_fronts(d, N->d_lists + q, (int)(q2 - q), c, 0, Ax_dev, N->tol, N->stol, reuse, N->st);
+            q = q2;
+        }
+        if (e > b + nl) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, N->lvl_maxk[l], Ax_dev, N->tol, N->stol, reuse, N->st);
+    }
+    HIPCHK(hipGetLastError());
+    fail_host.resize((size_t)P.nfront);
+    HIPCHK(hipMemcpyAsync(fail_host.data(), N->d_fail, (size_t)P.nfront * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
+    HIPCHK(hipStreamSynchronize(N->st));
+    N->attempts++;
+    return KVX_OK;
+}
+
+// Factor with the merge-and-retry loop of lu_symbolic.hpp (4).
+int factor_loop(kvx_lu_num *N, const double *Ax_dev, int reuse)
+{
+    N->factored = false;
+    if (N->sym->Y.structurally_singular) {
+        set_last_error("singular matrix (structurally rank deficient)");
+        return KVX_ESINGULAR;
+    }
+    std::vector<int32_t> fail;
+    for (int iter = 0; iter < 100000; iter++) {
+        int rc = numeric_pass(N, Ax_dev, reuse, fail);
+        if (rc) return rc;
+        const LuPlan &P = N->P;
+        std::vector<int32_t> minimal;
+        std::vector<char> below((size_t)P.nfront, 0);
+        for (int64_t f = 0; f < P.nfront; f++) {
+            const bool flagged = fail[f] != 0;
+            if (flagged && !below[f]) minimal.push_back((int32_t)f);
+            if ((flagged || below[f]) && P.fr[f].parent >= 0) below[P.fr[f].parent] = 1;
+        }
+        if (minimal.empty()) { N->factored = true; return KVX_OK; }
+        if (reuse) { reuse = 0; continue; }                   // klu.c:296-303: a refactorisation that runs into numerical trouble becomes a full one
+        if (!lu_merge_fronts(N->sym->Y, P, minimal)) {
+            set_last_error("singular matrix");
+            return KVX_ESINGULAR;
+        }
+        if ((rc = upload_structure(N))) return rc;
+    }
+    set_last_error("singular matrix");
+    return KVX_ESINGULAR;
+}
+
+int ensure_device(kvx_lu_num *N)
+{
+    if (N->dev) return KVX_OK;
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) {
+        set_last_error("no HIP device: the LU numeric phase has no CPU fallback");
+        return KVX_EDEVICE;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&N->st, hipStreamNonBlocking));
+    std::vector<int32_t> ai32((size_t)N->nnz);
+    for (int64_t p = 0; p < N->nnz; p++) ai32[p] = (int32_t)N->sym->Y.Ai[p];
+    int rc;
+    if ((rc = up(&N->d_ai32, ai32))) return rc;
+    if ((rc = dalloc(&N->d_rinv, N->n))) return rc;
+    if ((rc = dalloc(&N->d_rmax, N->n))) return rc;
+    if ((rc = dalloc(&N->d_Ax, N->nnz))) return rc;
+    N->dev = true;
+    return upload_structure(N);
+}
+
+int ensure_rhs(kvx_lu_num *N, int64_t nrhs)
+{
+    if (nrhs <= N->cap_rhs) return KVX_OK;
+    if (N->d_W) (void)hipFree(N->d_W);
+    if (N->d_X) (void)hipFree(N->d_X);
+    if (N->d_B) (void)hipFree(N->d_B);
+    N->d_W = N->d_X = N->d_B = nullptr;
+    N->cap_rhs = 0;
+    int rc;
+    if ((rc = dalloc(&N->d_W, N->P.wsize * nrhs))) return rc;
+    if ((rc = dalloc(&N->d_X, N->n * nrhs))) return rc;
+    if ((rc = dalloc(&N->d_B, N->n * nrhs))) return rc;
+    N->cap_rhs = nrhs;
+    return KVX_OK;
+}
+
+int solve_on_device(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    const LuPlan &P = N->P;
+    const LuDev d = dev_view(N);
+    const int64_t n = N->n;
+    // A x = b:  L U (Q' x) = R P b         A' x = b:  U' L' (R^-1 P x) = Q' b
+    if (!trans) launch_lu_gather(n, (int)nrhs, N->d_prow, N->d_rinv, B_dev, ldB, N->d_X, n, N->st);
+    else launch_lu_gather(n, (int)nrhs, N->d_qcol, nullptr, B_dev, ldB, N->d_X, n, N->st);
+    for (int32_t l = P.nlevels - 1; l >= 0; l--)
+        launch_lu_fwd(d, N->d_lists + P.levelptr[l], (int)(P.levelptr[l + 1] - P.levelptr[l]), N->lvl_maxm[l], N->lvl_maxk[l],
+                      trans ? 0 : 1, N->d_X, n, (int)nrhs, N->d_W, P.wsize, N->st);
+    for (int32_t l = 0; l < P.nlevels; l++)
+        launch_lu_bwd(d, N->d_lists + P.levelptr[l], (int)(P.levelptr[l + 1] - P.levelptr[l]), N->lvl_maxm[l], N->lvl_maxk[l],
+                      trans ? 1 : 0, N->d_X, n, (int)nrhs, N->st);
+    if (!trans) launch_lu_scatter(n, (int)nrhs, N->d_qcol, nullptr, N->d_X, n, B_dev, ldB, N->st);
+    else launch_lu_scatter(n, (int)nrhs, N->d_prow, N->d_rinv, N->d_X, n, B_dev, ldB, N->st);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int64_t *mdup(const std::vector<int64_t> &v)
+{
+    int64_t *p = (int64_t *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(int64_t));
+    if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(int64_t));
+    return p;
+}
+double *mdup(const std::vector<double> &v)
+{
+    double *p = (double *)std::malloc(std::max<size_t>(v.size(), 1) * sizeof(double));
+    if (p && !v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(double));
+    return p;
+}
+
+struct Trip { int64_t r, c; double v; };
+void to_ccs(int64_t n, std::vector<Trip> &t, std::vector<int64_t> &ptr, std::vector<int64_t> &idx, std::vector<double> &val)
+{
+    std::sort(t.begin(), t.end(), [](const Trip &a, const Trip &b) { return a.c != b.c ? a.c < b.c : a.r < b.r; });
+    ptr.assign((size_t)n + 1, 0);
+    idx.resize(t.size());
+    val.resize(t.size());
+    for (size_t q = 0; q < t.size(); q++) { ptr[t[q].c + 1]++; idx[q] = t[q].r; val[q] = t[q].v; }
+    for (int64_t j = 0; j < n; j++) ptr[j + 1] += ptr[j];
+}
+
+}  // namespace
+
+extern "C" {
+
+int kvx_lu_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, const double *values, kvx_lu_sym **out)
+{
+    if (!out || !colptr || (!rowind && n > 0 && colptr[n] > 0)) return KVX_EINVAL;
+    *out = nullptr;
+    kvx_lu_sym *S = new (std::nothrow) kvx_lu_sym();
+    if (!S) return KVX_ENOMEM;
+    try {
+        lu_analyze(n, colptr, rowind, values, S->Y);
+    } catch (const std::bad_alloc &) {
+        delete S;
+        return KVX_ENOMEM;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        delete S;
+        return KVX_EINVAL;
+    }
+    *out = S;
+    return KVX_OK;
+}
+
+void kvx_lu_free_symbolic(kvx_lu_sym *S) { delete S; }
+
+void kvx_lu_free_numeric(kvx_lu_num *N)
+{
+    if (!N) return;
+    free_structure(N);
+    void *ptrs[] = {N->d_ai32, N->d_rinv, N->d_rmax, N->d_Ax};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (N->st) (void)hipStreamDestroy(N->st);
+    delete N;
+}
+
+int kvx_lu_sym_info(kvx_lu_sym *S, int64_t info[8])
+{
+    if (!S || !info) return KVX_EINVAL;
+    info[0] = S->Y.n; info[1] = S->Y.nnz; info[2] = S->Y.S.nsuper; info[3] = S->Y.nmerges;
+    info[4] = S->Y.structurally_singular ? 1 : 0; info[5] = S->Y.S.lnz; info[6] = S->Y.S.nlevels; info[7] = S->Y.S.max_m;
+    return KVX_OK;
+}
+
+int kvx_lu_sym_matching(kvx_lu_sym *S, int64_t *rowfor)
+{
+    if (!S || !rowfor) return KVX_EINVAL;
+    std::copy(S->Y.rowfor.begin(), S->Y.rowfor.end(), rowfor);
+    return KVX_OK;
+}
+
+static int new_numeric(kvx_lu_sym *S, int64_t nnz, kvx_lu_num **out)
+{
+    if (!S || !out) return KVX_EINVAL;
+    *out = nullptr;
+    if (nnz != S->Y.nnz) { set_last_error("A does not have the analysed sparsity pattern"); return KVX_EINVAL; }
+    kvx_lu_num *N = new (std::nothrow) kvx_lu_num();
+    if (!N) return KVX_ENOMEM;
+    N->sym = S; N->n = S->Y.n; N->nnz = S->Y.nnz;
+    *out = N;
+    return KVX_OK;
+}
+
+int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out)
+{
+    int rc = new_numeric(S, nnz, out);
+    if (rc) return rc;
+    kvx_lu_num *N = *out;
+    if ((rc = ensure_device(N)) || (rc = factor_loop(N, values_dev, 0))) { kvx_lu_free_numeric(N); *out = nullptr; return rc; }
+    return KVX_OK;
+}
+
+int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out)
+{
+    int rc = new_numeric(S, nnz, out);
+    if (rc) return rc;
+    kvx_lu_num *N = *out;
+    if ((rc = ensure_device(N))) { kvx_lu_free_numeric(N); *out = nullptr; return rc; }
+    if (hipMemcpy(N->d_Ax, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = KVX_EDEVICE;
+    if (!rc) rc = factor_loop(N, N->d_Ax, 0);
+    if (rc) { kvx_lu_free_numeric(N); *out = nullptr; return rc; }
+    return KVX_OK;
+}
+
+int kvx_lu_refactor_dev(kvx_lu_num *N, int64_t nnz, const double *values_dev)
+{
+    if (!N || nnz != N->nnz) return KVX_EINVAL;
+    if (!N->factored) return factor_loop(N, values_dev, 0);
+    return factor_loop(N, values_dev, 1);
+}
+
+int kvx_lu_refactor(kvx_lu_num *N, int64_t nnz, const double *values)
+{
+    if (!N || nnz != N->nnz || !values) return KVX_EINVAL;
+    HIPCHK(hipMemcpy(N->d_Ax, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+    return kvx_lu_refactor_dev(N, nnz, N->d_Ax);
+}
+
+int kvx_lu_solve_dev(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    if (!N || (trans != 0 && trans != 1) || nrhs < 0 || ldB < std::max<int64_t>(1, N ? N->n : 1)) return KVX_EINVAL;
+    if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
+    if (nrhs == 0) return KVX_OK;
+    int rc = ensure_rhs(N, nrhs);
+    if (rc) return rc;
+    if ((rc = solve_on_device(N, trans, B_dev, nrhs, ldB))) return rc;
+    HIPCHK(hipStreamSynchronize(N->st));
+    return KVX_OK;
+}
+
+int kvx_lu_solve(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB)
+{
+    if (!N || !B || (trans != 0 && trans != 1) || nrhs < 0 || ldB < std::max<int64_t>(1, N->n)) return KVX_EINVAL;
+    if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
+    if (nrhs == 0) return KVX_OK;
+    int rc = ensure_rhs(N, nrhs);
+    if (rc) return rc;
+    const int64_t n = N->n;
+    HIPCHK(hipMemcpy2DAsync(N->d_B, (size_t)n * sizeof(double), B, (size_t)ldB * sizeof(double), (size_t)n * sizeof(double),
+                            (size_t)nrhs, hipMemcpyHostToDevice, N->st));
+    if ((rc = solve_on_device(N, trans, N->d_B, nrhs, n))) return rc;
+    HIPCHK(hipMemcpy2DAsync(B, (size_t)ldB * sizeof(double), N->d_B, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                            (size_t)nrhs, hipMemcpyDeviceToHost, N->st));
+    HIPCHK(hipStreamSynchronize(N->st));
+    return KVX_OK;
+}
+
+int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8])
+{
+    if (!N || !info) return KVX_EINVAL;
+    info[0] = N->P.nfront; info[1] = N->P.nlevels; info[2] = N->P.max_m; info[3] = N->P.max_k;
+    info[4] = N->P.lsize; info[5] = N->P.arena; info[6] = N->attempts; info[7] = N->factored ? 1 : 0;
+    return KVX_OK;
+}
+
+int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
+                   int64_t **Ui, double **Ux, int64_t *fnz, int64_t **Fp, int64_t **Fi, double **Fx, int64_t *P_out,
+                   int64_t *Q_out, double *Rs, int64_t *nblocks, int64_t **r_out)
+{
+    if (!N || !lnz || !Lp || !Li || !Lx || !unz || !Up || !Ui || !Ux || !fnz || !Fp || !Fi || !Fx || !P_out || !Q_out || !Rs ||
+        !nblocks || !r_out)
+        return KVX_EINVAL;
+    if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
+    const LuPlan &P = N->P;
+    const int64_t n = N->n;
+    std::vector<double> hL((size_t)P.lsize), hU((size_t)P.lsize), rinv((size_t)n);
+    std::vector<int32_t> lperm((size_t)n);
+    HIPCHK(hipMemcpy(hL.data(), N->d_Lx, (size_t)P.lsize * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hU.data(), N->d_Ux, (size_t)P.lsize * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rinv.data(), N->d_rinv, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lperm.data(), N->d_lperm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int64_t> finalpos((size_t)n);
+    for (int64_t f = 0; f < P.nfront; f++) {
+        const int32_t p0 = P.fr[f].p0, k = P.fr[f].k;
+        for (int32_t t = 0; t < k; t++) {
+            finalpos[p0 + lperm[p0 + t]] = p0 + t;
+            P_out[p0 + t] = P.prow[p0 + lperm[p0 + t]];
+        }
+    }
+    for (int64_t j = 0; j < n; j++) { Q_out[j] = P.qcol[j]; Rs[j] = 1.0 / rinv[P_out[j]]; }
+    std::vector<Trip> tl, tu;
+    tl.reserve((size_t)P.lnz_bound);
+    tu.reserve((size_t)P.unz_bound);
+    for (int64_t f = 0; f < P.nfront; f++) {
+        const int32_t p0 = P.fr[f].p0, k = P.fr[f].k, m = P.fr[f].m;
+        const int32_t *rows = P.rowidx.data() + P.rowptr[f];
+        const double *lp = hL.data() + P.px[f], *upn = hU.data() + P.px[f];
+        for (int32_t t = 0; t < k; t++) {
+            tl.push_back({p0 + t, p0 + t, 1.0});
+            for (int32_t i = t + 1; i < m; i++) {
+                const double v = lp[i + (int64_t)t * m];
+                if (v != 0.0) tl.push_back({i < k ? (int64_t)(p0 + i) : finalpos[rows[i]], p0 + t, v});
+            }
+            for (int32_t i = t; i < m; i++) {
+                const double v = upn[i + (int64_t)t * m];
+                if (v != 0.0 || i == t) tu.push_back({p0 + t, i < k ? (int64_t)(p0 + i) : (int64_t)rows[i], v});
+            }
+        }
+    }
+    std::vector<int64_t> lp_, li_, up_, ui_;
+    std::vector<double> lx_, ux_;
+    to_ccs(n, tl, lp_, li_, lx_);
+    to_ccs(n, tu, up_, ui_, ux_);
+    *lnz = (int64_t)li_.size();
+    *unz = (int64_t)ui_.size();
+    *fnz = 0;                                   // one diagonal block: no off-diagonal part F (klu_extract's F, r)
+    *nblocks = 1;
+    *Lp = mdup(lp_); *Li = mdup(li_); *Lx = mdup(lx_);
+    *Up = mdup(up_); *Ui = mdup(ui_); *Ux = mdup(ux_);
+    *Fp = mdup(std::vector<int64_t>((size_t)n + 1, 0)); *Fi = mdup(std::vector<int64_t>()); *Fx = mdup(std::vector<double>());
+    *r_out = mdup(std::vector<int64_t>{0, n});
+    if (!*Lp || !*Li || !*Lx || !*Up || !*Ui || !*Ux || !*Fp || !*Fi || !*Fx || !*r_out) return KVX_ENOMEM;
+    return KVX_OK;
+}
+
+// Determinant as the reference computes it (klu.c:760-822): prod(Udiag[k] * Rs[k]) times the signs of P and Q.
+int kvx_lu_det(kvx_lu_num *N, double *det)
+{
+    if (!N || !det) return KVX_EINVAL;
+    if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
+    const LuPlan &P = N->P;
+    const int64_t n = N->n;
+    int rc = ensure_rhs(N, 1);
+    if (rc) return rc;
+    launch_lu_udiag(dev_view(N), (int)P.nfront, N->d_X, N->st);
+    std::vector<double> ud((size_t)n), rinv((size_t)n);
+    std::vector<int32_t> lperm((size_t)n);
+    HIPCHK(hipMemcpyAsync(ud.data(), N->d_X, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, N->st));
+    HIPCHK(hipMemcpyAsync(rinv.data(), N->d_rinv, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, N->st));
+    HIPCHK(hipMemcpyAsync(lperm.data(), N->d_lperm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
+    HIPCHK(hipStreamSynchronize(N->st));
+    std::vector<int64_t> pf((size_t)n);
+    for (int64_t f = 0; f < P.nfront; f++)
+        for (int32_t t = 0; t < P.fr[f].k; t++) pf[P.fr[f].p0 + t] = P.prow[P.fr[f].p0 + lperm[P.fr[f].p0 + t]];
+    double dd = 1.0;
+    for (int64_t k = 0; k < n; k++) dd *= ud[k] / rinv[pf[k]];
+    int64_t npiv = 0;
+    std::vector<int64_t> w;
+    for (int pass = 0; pass < 2; pass++) {
+        w = pass ? P.qcol : pf;
+        for (int64_t i = 0; i < n; i++)
+            while (w[i] != i) { const int64_t t = w[w[i]]; w[w[i]] = w[i]; w[i] = t; npiv++; }
+    }
+    *det = (npiv & 1) ? -dd : dd;
+    return KVX_OK;
+}
+
+}  // extern "C"

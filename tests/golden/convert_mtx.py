@@ -1,7 +1,8 @@
 """Converts the SuiteSparse-collection DATA files the reference's tests hold
 (/root/reference/tests/*.mtx) into .npz CCS fixtures, read exactly as
 tests/test_sparse_solvers.py:36-68 does (the `symmetric` header is ignored, so bcsstk13 /
-bcsstk24 are lower-triangular general matrices).  Data only; run in the build container."""
+bcsstk24 are lower-triangular general matrices; ACTIVSg2000 and bp_800 are the unsymmetric KLU cases).
+Data only; run in the build container."""
 import os
 import sys
 
@@ -28,7 +29,7 @@ def read(fn):
     return size, np.array(I), np.array(J), np.array(V)
 
 
-for name in ("bcsstk13", "bcsstk24"):
+for name in (sys.argv[1:] or ("bcsstk13", "bcsstk24", "ACTIVSg2000", "bp_800")):
     size, I, J, V = read(os.path.join(REF, name + ".mtx"))
     n = size[0]
     order = np.lexsort((I, J))
