@@ -53,6 +53,19 @@ def lib():
         L.kvxo_chol_get_parent.argtypes = [ctypes.c_void_p, _i64p]
         L.kvxo_chol_get_L.argtypes = [ctypes.c_void_p, _i64p, _i64p, _f64p]
         L.kvxo_chol_diag.argtypes = [ctypes.c_void_p, _f64p]
+        L.kvxo_klu_factor.restype = ctypes.c_void_p
+        L.kvxo_klu_factor.argtypes = [ctypes.c_int64, _i64p, _i64p, _f64p, _i64p, ctypes.c_double]
+        L.kvxo_klu_free.argtypes = [ctypes.c_void_p]
+        L.kvxo_klu_singular.argtypes = [ctypes.c_void_p]
+        L.kvxo_klu_singular.restype = ctypes.c_int
+        for f in ("kvxo_klu_lnz", "kvxo_klu_unz"):
+            getattr(L, f).restype = ctypes.c_int64
+            getattr(L, f).argtypes = [ctypes.c_void_p]
+        L.kvxo_klu_solve.argtypes = [ctypes.c_void_p, ctypes.c_int, _f64p, ctypes.c_int64, ctypes.c_int64]
+        L.kvxo_klu_solve.restype = ctypes.c_int
+        L.kvxo_klu_extract.argtypes = [ctypes.c_void_p, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p, _i64p, _i64p, _f64p]
+        L.kvxo_klu_det.argtypes = [ctypes.c_void_p]
+        L.kvxo_klu_det.restype = ctypes.c_double
         L.kvxo_spmv.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _i64p, _i64p, _f64p,
                                 ctypes.c_double, _f64p, ctypes.c_double, _f64p]
         L.kvxo_rowscale.argtypes = [ctypes.c_int64, _i64p, _i64p, _f64p, _f64p, _f64p]
@@ -222,3 +235,47 @@ def max_step_l(x):
     """misc_solvers.c:1065-1071: max_i(-x_i)  (-inf... the reference starts from
     -FLT_MAX; for ml>0 this is max(-x))."""
     return float(np.max(-x)) if x.size else -np.finfo(np.float64).max
+
+
+class OracleKLU:
+    """Left-looking LU with threshold partial pivoting and row scaling (oracle/klu_oracle.c): the checker for the
+    kvxopt.klu path (reference: src/C/klu.c:141-198, 444-449, 760-822).  Raises ArithmeticError like klu.c:172-174."""
+
+    def __init__(self, n, colptr, rowind, values, Q=None, tol=1e-3):
+        self.n = int(n)
+        cp = np.ascontiguousarray(colptr, dtype=np.int64)
+        ri = np.ascontiguousarray(rowind, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        q = None if Q is None else np.ascontiguousarray(Q, dtype=np.int64)
+        self._h = lib().kvxo_klu_factor(self.n, _ptr_i(cp), _ptr_i(ri), _ptr_d(v), None if q is None else _ptr_i(q), tol)
+        if not self._h:
+            raise MemoryError()
+        if lib().kvxo_klu_singular(self._h):
+            raise ArithmeticError("singular matrix")
+
+    def solve(self, B, trans="N"):
+        X = np.array(B, dtype=np.float64, order="F", copy=True)
+        X2 = X.reshape(self.n, -1, order="F")
+        rc = lib().kvxo_klu_solve(self._h, 0 if trans == "N" else 1, _ptr_d(X2), X2.shape[1], self.n)
+        if rc:
+            raise ArithmeticError("singular matrix")
+        return X
+
+    def extract(self):
+        n = self.n
+        lnz = lib().kvxo_klu_lnz(self._h) + n
+        unz = lib().kvxo_klu_unz(self._h) + n
+        Lp = np.empty(n + 1, np.int64); Li = np.empty(lnz, np.int64); Lx = np.empty(lnz)
+        Up = np.empty(n + 1, np.int64); Ui = np.empty(unz, np.int64); Ux = np.empty(unz)
+        P = np.empty(n, np.int64); Q = np.empty(n, np.int64); Rs = np.empty(n)
+        lib().kvxo_klu_extract(self._h, _ptr_i(Lp), _ptr_i(Li), _ptr_d(Lx), _ptr_i(Up), _ptr_i(Ui), _ptr_d(Ux),
+                               _ptr_i(P), _ptr_i(Q), _ptr_d(Rs))
+        return (Lp, Li, Lx), (Up, Ui, Ux), P, Q, Rs
+
+    def det(self):
+        return lib().kvxo_klu_det(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kvxo_klu_free(self._h)
+            self._h = None
