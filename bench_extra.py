@@ -12,6 +12,10 @@
             metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
             plus the per-iteration cost of one KKT factor (assembly + numeric Cholesky) and one KKT solve.
 
+  klu3    : BASELINE.json configs[2]: klu.linsolve on the ACTIVSg2000 power-flow Jacobian (4000 x 4000, 29 336 entries,
+            tests/golden/ACTIVSg2000.npz), nrhs = 3: symbolic, first numeric, steady-state refactorisation and solve times,
+            next to the CPU oracle and SciPy's SuperLU on the host.
+
 The headline line the driver reads is bench.py's; this script documents the rest (results in DESIGN.md section 5).
 """
 import argparse
@@ -121,6 +125,45 @@ def lp_std_case(gx, gy):
             "factorizations": sol["factorizations"]}
 
 
+def klu_case(steps, warmup):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from kvxopt_amd import klu, _lib
+    from kvxopt_amd.base import spmatrix
+    from oracle.kvx_oracle import OracleKLU        # cpu_baseline leg only
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ACTIVSg2000.npz"))
+    n = int(z["n"])
+    A = spmatrix.from_ccs(n, n, z["colptr"], z["rowind"], z["values"])
+    As = sp.csc_matrix((z["values"], z["rowind"], z["colptr"]), shape=(n, n))
+    B = np.asfortranarray(np.random.default_rng(3).standard_normal((n, 3)))
+    t0 = time.perf_counter(); Fs = klu.symbolic(A); t_sym = time.perf_counter() - t0
+    t0 = time.perf_counter(); Fn = klu.numeric(A, Fs); t_first = time.perf_counter() - t0
+    vals_d = _lib.DeviceBuffer.from_array(A.values)
+    b_d = _lib.DeviceBuffer.from_array(B.reshape(-1, order="F"))
+    def timed(fn):
+        for _ in range(warmup): fn()
+        t0 = time.perf_counter()
+        for _ in range(steps): fn()
+        return (time.perf_counter() - t0) / steps * 1e3
+    ms_refactor = timed(lambda: Fn.num.refactor_dev(vals_d.ptr, A.values.size))
+    ms_solve = timed(lambda: Fn.num.solve_dev(b_d.ptr, "N", 3))
+    ms_tsolve = timed(lambda: Fn.num.solve_dev(b_d.ptr, "T", 3))
+    def lins():
+        X = B.copy(order="F"); klu.linsolve(A, X); return X
+    ms_linsolve = timed(lins)
+    X = lins()
+    resid = float(np.abs(As @ X - B).max())
+    t0 = time.perf_counter(); lu = spla.splu(As); xs = lu.solve(B); t_splu = time.perf_counter() - t0
+    e = Fn.num.extract()
+    t0 = time.perf_counter(); O = OracleKLU(n, A.colptr, A.rowind, A.values, Q=e["Q"]); xo = O.solve(B); t_or = time.perf_counter() - t0
+    return {"case": "klu3 ACTIVSg2000", "metric": "klu.linsolve wall ms (symbolic + numeric + solve, host buffers)", "value": ms_linsolve,
+            "unit": "ms", "n": n, "nnz": int(A.values.size), "nrhs": 3, "ms_symbolic_host": t_sym * 1e3, "ms_first_numeric": t_first * 1e3,
+            "ms_refactor_dev": ms_refactor, "ms_solve_dev": ms_solve, "ms_tsolve_dev": ms_tsolve, "residual_inf": resid,
+            "lnz": int(e["L"][1].size), "unz": int(e["U"][1].size), **{"lu_" + k: v for k, v in Fn.num.info().items()},
+            "cpu_scipy_superlu_ms": t_splu * 1e3, "cpu_oracle_ms": t_or * 1e3,
+            "x_vs_superlu": float(np.abs(X - xs).max()), "x_vs_oracle": float(np.abs(X - xo).max())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="chol5,chol21,lap3d,lp4a,lp4b")
@@ -143,6 +186,8 @@ def main():
             out = lp_std_case(250, 200)
         elif case == "lp4b":
             out = lp_case(250, 200)
+        elif case == "klu3":
+            out = klu_case(args.steps * 5, args.warmup)
         else:
             raise SystemExit("unknown case " + case)
         print(json.dumps(out), flush=True)

@@ -45,6 +45,7 @@ struct kvx_lu_num {
     std::vector<int32_t> lvl_maxm, lvl_maxk;
     double tol = 1e-3, stol = 1e-3;
     int64_t attempts = 0;
+    bool unblocked = std::getenv("KVX_LU_UNBLOCKED") != nullptr;   // debugging aid: big fronts by one workgroup each
 };
 
 namespace {
@@ -135,7 +136,7 @@ LuDev dev_view(const kvx_lu_num *N)
 
 int lds_class(int m)
 {
-    static const int cls[] = {16, 32, 48, 64, KVX_LU_LDS_M};
+    static const int cls[] = {16, 32, 48, 64, 88, 112, KVX_LU_LDS_M};
     for (int c : cls) if (m <= c) return c;
     return KVX_LU_LDS_M;
 }
@@ -151,14 +152,19 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     for (int32_t l = P.nlevels - 1; l >= 0; l--) {
         const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nl = P.nlds[l];
         int64_t q = b;
-        while (q < b + nl) {                                  // runs of one LDS size class (list sorted by m descending)
-            const int c = lds_class(P.fr[P.levellist[q]].m);
+        while (q < b + nl) {                                  // runs of one LDS size class (list sorted by m descending);
+            const int c = lds_class(P.fr[P.levellist[q]].m);  // a thin level goes out as ONE launch sized for its largest front
             int64_t q2 = q;
-            while (q2 < b + nl && lds_class(P.fr[P.levellist[q2]].m) == c) q2++;
+            while (q2 < b + nl && (nl <= 256 || lds_class(P.fr[P.levellist[q2]].m) == c)) q2++;
             launch_lu_fronts(d, N->d_lists + q, (int)(q2 - q), c, 0, Ax_dev, N->tol, N->stol, reuse, N->st);
             q = q2;
         }
-        if (e > b + nl) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, N->lvl_maxk[l], Ax_dev, N->tol, N->stol, reuse, N->st);
+        if (e > b + nl) {
+            int bm = 0, bk = 0;                                // big fronts of the level: blocked multi-launch path
+            for (int64_t qq = b + nl; qq < e; qq++) { bm = std::max(bm, P.fr[P.levellist[qq]].m); bk = std::max(bk, P.fr[P.levellist[qq]].k); }
+            if (N->unblocked) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, bk, Ax_dev, N->tol, N->stol, reuse, N->st);
+            else launch_lu_big_level(d, N->d_lists + b + nl, (int)(e - b - nl), bm, bk, Ax_dev, N->tol, N->stol, reuse, N->st);
+        }
     }
     HIPCHK(hipGetLastError());
     fail_host.resize((size_t)P.nfront);

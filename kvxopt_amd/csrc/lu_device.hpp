@@ -35,6 +35,9 @@ struct LuDev {           // all device pointers
 // Factor the fronts list[0..cnt) (one workgroup each).  lds_m > 0: fronts of order <= lds_m held in LDS; 0: in HBM.
 void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, int max_k, const double *Ax,
                       double tol, double stol, int reuse, hipStream_t st);
+// All fronts of a level that do not fit in LDS (blocked: lu_kernels.hip k_lub_*).
+void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, const double *Ax, double tol,
+                         double stol, int reuse, hipStream_t st);
 // Triangular sweeps over one level.  unit = 1: the L panels (unit diagonal, in-front row permutation);
 // unit = 0: the U' panels.  W: update vectors, wsize doubles per right-hand side.
 void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx,

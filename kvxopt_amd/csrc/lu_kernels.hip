@@ -5,9 +5,11 @@
 // One workgroup per front and one launch per (level, size class).  A front is a dense m x m matrix: k pivot rows /
 // columns first, then u = m - k update rows / columns.  Small fronts live in LDS for the whole assemble-factor-store
 // sequence; larger ones in their own m x m region of the arena in HBM (their update matrix is read from there by
-// the parent).  These are byte/latency-bound kernels -- no MFMA here (fronts of circuit / power-flow matrices are
-// tens of rows; a blocked MFMA path for large LU fronts is future work).
+// the parent) and are factored by column blocks of 32 pivots with three launches per block (panel, row interchanges +
+// triangular solve, rank-32 update on 64 x 64 tiles).  Byte/latency-bound work on plain FP64 FMAs: fronts of circuit /
+// power-flow matrices are tens to hundreds of rows (an MFMA update for fronts of thousands of rows is future work).
 #include "lu_device.hpp"
+#include <algorithm>
 
 namespace kvx {
 
@@ -24,37 +26,40 @@ constexpr int LU_NT_SOLVE = 256;
 // the whole front column): the host then merges this front into its parent and factors again.
 template <int NT>
 __device__ void lu_factor_front(double *Fm, const int ld, const int m, const int k, int32_t *ipiv, int32_t *fail_slot,
-                                const double tol, const double stol, const int reuse, int *sh_i, double *sh_d)
+                                const double tol, const double stol, const int reuse, int *sh_i, double *sh_d, int32_t *sh_piv)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int tx = tid & 63, ty = tid >> 6;
     constexpr int NW = NT / 64;
     bool failed = false;
+    double lmax = 0.0;                                           // largest multiplier seen by this thread (acceptance test below)
+    if (reuse) {                                                 // the recorded pivot sequence: one coalesced load, not one per step
+        for (int t = tid; t < k; t += NT) sh_piv[t] = ipiv[t];
+        __syncthreads();
+    }
     for (int j = 0; j < k; j++) {
-        if (tid < 64) {
-            double bmax = -1.0, amax = 0.0;
+        if (tid < 64) {                                          // search among the rows of the pivot block only
+            double bmax = -1.0;
             int bidx = j;
-            for (int i = j + lane; i < m; i += 64) {
+            for (int i = j + lane; i < k; i += 64) {
                 const double a = fabs(Fm[i + (int64_t)j * ld]);
-                if (i < k && a > bmax) { bmax = a; bidx = i; }
-                amax = fmax(amax, a);
+                if (a > bmax) { bmax = a; bidx = i; }
             }
             for (int off = 32; off; off >>= 1) {
-                const double ob = __shfl_xor(bmax, off), oa = __shfl_xor(amax, off);
+                const double ob = __shfl_xor(bmax, off);
                 const int oi = __shfl_xor(bidx, off);
                 if (ob > bmax || (ob == bmax && oi < bidx)) { bmax = ob; bidx = oi; }
-                amax = fmax(amax, oa);
             }
             if (lane == 0) {
                 const double diag = fabs(Fm[j + (int64_t)j * ld]);
                 int r = (diag > 0.0 && diag >= tol * bmax) ? j : bidx;
-                if (reuse) r = j + ipiv[j];
+                if (reuse) r = j + sh_piv[j];
                 double pv = Fm[r + (int64_t)j * ld];
                 const double ap = fabs(pv);
-                const bool bad = !(ap > 0.0) || !(ap <= 1.7e308) || ap < stol * amax;
+                const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);
                 if (bad && !failed) { failed = true; *fail_slot = j + 1; }
-                if (!(ap > 0.0) || !(ap <= 1.7e308)) pv = 1.0;          // keep going with finite numbers; the result is discarded
-                if (!reuse) ipiv[j] = r - j;
+                if (bad) pv = 1.0;                                // keep going with finite numbers; the result is discarded
+                sh_piv[j] = r - j;
                 sh_i[0] = r;
                 sh_d[0] = pv;
             }
@@ -62,22 +67,79 @@ __device__ void lu_factor_front(double *Fm, const int ld, const int m, const int
         __syncthreads();
         const int r = sh_i[0];
         const double pv = sh_d[0];
-        if (r != j)
+        if (r != j) {                                            // uniform
             for (int c = tid; c < m; c += NT) {
                 const double a = Fm[j + (int64_t)c * ld], b = Fm[r + (int64_t)c * ld];
                 Fm[j + (int64_t)c * ld] = b;
                 Fm[r + (int64_t)c * ld] = a;
             }
+            __syncthreads();
+        }
+        // scale and rank-1 update in one pass: every wave forms the multipliers of its rows itself
+        for (int i = j + 1 + tx; i < m; i += 64) {
+            const double l = Fm[i + (int64_t)j * ld] / pv;
+            lmax = fmax(lmax, fabs(l));
+            for (int c = j + 1 + ty; c < m; c += NW) Fm[i + (int64_t)c * ld] -= l * Fm[j + (int64_t)c * ld];
+        }
         __syncthreads();
-        for (int i = j + 1 + tid; i < m; i += NT) Fm[i + (int64_t)j * ld] /= pv;
-        __syncthreads();
-        for (int c = j + 1 + ty; c < m; c += NW) {
-            const double ujc = Fm[j + (int64_t)c * ld];
-            if (ujc != 0.0)
-                for (int i = j + 1 + tx; i < m; i += 64) Fm[i + (int64_t)c * ld] -= Fm[i + (int64_t)j * ld] * ujc;
+        if (ty == 0)
+            for (int i = j + 1 + tx; i < m; i += 64) Fm[i + (int64_t)j * ld] /= pv;
+    }
+    // |pivot| >= stol * max|column|  <=>  max|multiplier| <= 1 / stol : one test per front instead of one per pivot
+    if (!(lmax * stol <= 1.0)) atomicMax(fail_slot, 1);
+    __syncthreads();
+    if (!reuse)
+        for (int t = tid; t < k; t += NT) ipiv[t] = sh_piv[t];
+}
+
+// Assemble a front: zero, scatter the (row-scaled) entries of A, extend-add the children's update matrices
+// (the parent pulls: no atomics, reproducible).
+template <int NT>
+__device__ void lu_assemble_front(const LuDev &d, const LuFrontD &F, double *Fm, const int ld, const double *__restrict__ Ax)
+{
+    const int tid = threadIdx.x;
+    const int m = F.m;
+    for (int64_t idx = tid; idx < (int64_t)m * m; idx += NT) Fm[idx] = 0.0;
+    __syncthreads();
+    for (int64_t e = tid; e < F.acnt; e += NT) {                 // every entry has its own slot
+        const int64_t src = d.a_src[F.aptr + e];
+        Fm[d.a_dst[F.aptr + e]] += Ax[src] * d.rinv[d.ai32[src]];
+    }
+    __syncthreads();
+    for (int c = 0; c < F.nchild; c++) {
+        const LuFrontD C = d.fr[d.children[F.childptr + c]];
+        const int uc = C.m - C.k, ldc = C.upd_ld;
+        const int32_t *__restrict__ relc = d.rel + C.rowptr + C.k;
+        const double *__restrict__ Uc = d.arena + C.upd_off;
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int jc = ty; jc < uc; jc += NT / 64) {
+            const int64_t cj = (int64_t)relc[jc] * ld;
+            for (int ic = tx; ic < uc; ic += 64) Fm[relc[ic] + cj] += Uc[ic + (int64_t)jc * ldc];
         }
         __syncthreads();
     }
+}
+
+// Panels and in-front permutation of a factored front: L(:, 0:k) as is, U(0:k, :) transposed, both m x k column-major.
+template <int NT>
+__device__ void lu_store_front(const LuDev &d, const LuFrontD &F, const double *Fm, const int ld, int32_t *sh_lp, int32_t *sh_piv)
+{
+    const int tid = threadIdx.x;
+    const int m = F.m, k = F.k;
+    for (int t = tid; t < k; t += NT) { sh_lp[t] = t; sh_piv[t] = d.ipiv[F.p0 + t]; }
+    __syncthreads();
+    if (tid == 0)
+        for (int j = 0; j < k; j++) {
+            const int r = j + sh_piv[j];
+            if (r != j) { const int a = sh_lp[j]; sh_lp[j] = sh_lp[r]; sh_lp[r] = a; }
+        }
+    __syncthreads();
+    for (int t = tid; t < k; t += NT) d.lperm[F.p0 + t] = sh_lp[t];
+    double *__restrict__ Lp = d.Lx + F.px, *__restrict__ Up = d.Ux + F.px;
+    for (int64_t idx = tid; idx < (int64_t)m * k; idx += NT) Lp[idx] = Fm[idx];
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int t = ty; t < k; t += NT / 64)
+        for (int c = tx; c < m; c += 64) Up[c + (int64_t)t * m] = Fm[t + (int64_t)c * ld];
 }
 
 template <bool LDS, int NT>
@@ -93,48 +155,13 @@ __global__ __launch_bounds__(NT) void k_lu_front(const LuDev d, const int32_t *_
     const int m = F.m, k = F.k, u = m - k;
     double *Fm = LDS ? smem : d.arena + (F.upd_off - k - (int64_t)k * m);
     int32_t *sh_lp = (int32_t *)(LDS ? smem + (int64_t)lds_m * lds_m : smem);
+    int32_t *sh_piv = sh_lp + (LDS ? lds_m : k);
     const int ld = m;
     if (tid == 0) d.fail[f] = 0;
-    for (int64_t idx = tid; idx < (int64_t)m * m; idx += NT) Fm[idx] = 0.0;
+    lu_assemble_front<NT>(d, F, Fm, ld, Ax);
+    lu_factor_front<NT>(Fm, ld, m, k, d.ipiv + F.p0, d.fail + f, tol, stol, reuse, sh_i, sh_d, sh_piv);
     __syncthreads();
-    // entries of A (scaled rows); every entry has its own slot
-    for (int64_t e = tid; e < F.acnt; e += NT) {
-        const int64_t src = d.a_src[F.aptr + e];
-        Fm[d.a_dst[F.aptr + e]] += Ax[src] * d.rinv[d.ai32[src]];
-    }
-    __syncthreads();
-    // extend-add the children's update matrices (parent pulls: no atomics, reproducible)
-    for (int c = 0; c < F.nchild; c++) {
-        const LuFrontD C = d.fr[d.children[F.childptr + c]];
-        const int uc = C.m - C.k, ldc = C.upd_ld;
-        const int32_t *__restrict__ relc = d.rel + C.rowptr + C.k;
-        const double *__restrict__ Uc = d.arena + C.upd_off;
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int jc = ty; jc < uc; jc += NT / 64) {
-            const int64_t cj = (int64_t)relc[jc] * ld;
-            for (int ic = tx; ic < uc; ic += 64) Fm[relc[ic] + cj] += Uc[ic + (int64_t)jc * ldc];
-        }
-        __syncthreads();
-    }
-    lu_factor_front<NT>(Fm, ld, m, k, d.ipiv + F.p0, d.fail + f, tol, stol, reuse, sh_i, sh_d);
-    // which front row ended in each pivot slot
-    for (int t = tid; t < k; t += NT) sh_lp[t] = t;
-    __syncthreads();
-    if (tid == 0)
-        for (int j = 0; j < k; j++) {
-            const int r = j + d.ipiv[F.p0 + j];
-            if (r != j) { const int a = sh_lp[j]; sh_lp[j] = sh_lp[r]; sh_lp[r] = a; }
-        }
-    __syncthreads();
-    for (int t = tid; t < k; t += NT) d.lperm[F.p0 + t] = sh_lp[t];
-    // panels: L(:, 0:k) as is, U(0:k, :) transposed, both m x k column-major
-    double *__restrict__ Lp = d.Lx + F.px, *__restrict__ Up = d.Ux + F.px;
-    for (int64_t idx = tid; idx < (int64_t)m * k; idx += NT) Lp[idx] = Fm[idx];
-    {
-        const int tx = tid & 63, ty = tid >> 6;
-        for (int t = ty; t < k; t += NT / 64)
-            for (int c = tx; c < m; c += 64) Up[c + (int64_t)t * m] = Fm[t + (int64_t)c * ld];
-    }
+    lu_store_front<NT>(d, F, Fm, ld, sh_lp, sh_piv);
     if (LDS) {
         double *__restrict__ Uo = d.arena + F.upd_off;
         const int tx = tid & 63, ty = tid >> 6;
@@ -260,19 +287,428 @@ __global__ void k_lu_udiag(const LuDev d, const int nfront, double *__restrict__
     for (int t = threadIdx.x; t < F.k; t += blockDim.x) out[F.p0 + t] = d.Ux[F.px + t + (int64_t)t * F.m];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked path for fronts that do not fit in LDS: the front stays in its m x m region of the arena and is factored
+// by column blocks of LU_NB pivots, three launches per block over ALL big fronts of the level:
+//   k_lub_panel  one workgroup per front: the (m - jb) x nb panel (staged in LDS when it fits) with pivoting,
+//   k_lub_trsm   one thread per remaining column: the block's row interchanges, then U12 = L11^-1 A12,
+//   k_lub_gemm   64 x 64 tiles: A22 -= L21 U12.
+constexpr int LU_NB = 32;
+constexpr int LU_PANEL_LDS_DOUBLES = 19456;       // 152 KB of the 160 KB a gfx950 workgroup may use: the panel is staged in LDS when (m - jb) * nb fits
+
+// Assembly of a big front, one workgroup per 16 columns: zero them, scatter the entries of A that land there, pull
+// the children's update-matrix columns that map there (children one after the other: their targets overlap).
+constexpr int LU_ASM_COLS = 16;
+__global__ __launch_bounds__(256) void k_lub_assemble(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ Ax)
+{
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const int f = list[blockIdx.y];
+    const LuFrontD F = d.fr[f];
+    const int m = F.m;
+    const int c0 = blockIdx.x * LU_ASM_COLS;
+    if (c0 >= m) return;
+    const int c1 = min(m, c0 + LU_ASM_COLS);
+    double *Fm = d.arena + (F.upd_off - F.k - (int64_t)F.k * m);
+    if (blockIdx.x == 0 && tid == 0) d.fail[f] = 0;
+    for (int64_t idx = (int64_t)c0 * m + tid; idx < (int64_t)c1 * m; idx += 256) Fm[idx] = 0.0;
+    __syncthreads();
+    for (int64_t e = tid; e < F.acnt; e += 256) {
+        const int dst = d.a_dst[F.aptr + e];
+        if (dst >= c0 * m && dst < c1 * m) {
+            const int64_t src = d.a_src[F.aptr + e];
+            Fm[dst] += Ax[src] * d.rinv[d.ai32[src]];
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < F.nchild; c++) {
+        const LuFrontD C = d.fr[d.children[F.childptr + c]];
+        const int uc = C.m - C.k, ldc = C.upd_ld;
+        const int32_t *__restrict__ relc = d.rel + C.rowptr + C.k;
+        const double *__restrict__ Uc = d.arena + C.upd_off;
+        for (int jc = ty; jc < uc; jc += 4) {
+            const int pc = relc[jc];
+            if (pc < c0 || pc >= c1) continue;                // wave-uniform
+            for (int ic = tx; ic < uc; ic += 64) Fm[relc[ic] + (int64_t)pc * m] += Uc[ic + (int64_t)jc * ldc];
+        }
+        __syncthreads();
+    }
+}
+
+// Panels of a factored big front, one workgroup per 64 front columns; the first workgroup also turns the interchange
+// sequence into the in-front permutation.
+__global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t *__restrict__ list)
+{
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const LuFrontD F = d.fr[list[blockIdx.y]];
+    const int m = F.m, k = F.k;
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= m) return;
+    const double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
+    double *__restrict__ Lp = d.Lx + F.px, *__restrict__ Up = d.Ux + F.px;
+    const int c = c0 + tx;
+    if (c < m)
+        for (int t = ty; t < k; t += 4) Up[c + (int64_t)t * m] = Fm[t + (int64_t)c * m];
+    for (int cc = c0 + ty; cc < min(k, c0 + 64); cc += 4)
+        for (int i = tx; i < m; i += 64) Lp[i + (int64_t)cc * m] = Fm[i + (int64_t)cc * m];
+    if (blockIdx.x == 0) {
+        int32_t *sh_lp = (int32_t *)smem, *sh_piv = sh_lp + k;
+        for (int t = tid; t < k; t += 256) { sh_lp[t] = t; sh_piv[t] = d.ipiv[F.p0 + t]; }
+        __syncthreads();
+        if (tid == 0)
+            for (int j = 0; j < k; j++) {
+                const int r = j + sh_piv[j];
+                if (r != j) { const int a = sh_lp[j]; sh_lp[j] = sh_lp[r]; sh_lp[r] = a; }
+            }
+        __syncthreads();
+        for (int t = tid; t < k; t += 256) d.lperm[F.p0 + t] = sh_lp[t];
+    }
+}
+
+__global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
+                                                          const double stol, const int reuse)
+{
+    extern __shared__ double smem[];
+    __shared__ int sh_i[2];
+    __shared__ double sh_d[2];
+    constexpr int NT = LU_NT_LDS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = list[blockIdx.x];
+    const LuFrontD F = d.fr[f];
+    const int m = F.m, k = F.k;
+    if (jb >= k) return;
+    const int nbk = min(LU_NB, k - jb), rows = m - jb, cand = k - jb;
+    if (rows <= 1024) return;                                // handled by k_lub_panel_reg
+    double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
+    double *G = Fm + jb + (int64_t)jb * m;                   // panel in the front, ld = m
+    const bool staged = (int64_t)rows * nbk <= LU_PANEL_LDS_DOUBLES;
+    double *Pm = staged ? smem : G;
+    const int pld = staged ? rows : m;
+    if (staged) {
+        for (int idx = tid; idx < rows * nbk; idx += NT) { const int i = idx % rows, c = idx / rows; Pm[i + c * pld] = G[i + (int64_t)c * m]; }
+        __syncthreads();
+    }
+    int32_t *ipiv = d.ipiv + F.p0 + jb;
+    __shared__ int32_t sh_piv[LU_NB];
+    if (reuse && tid < nbk) sh_piv[tid] = ipiv[tid];
+    if (reuse) __syncthreads();
+    bool failed = false;
+    for (int j = 0; j < nbk; j++) {
+        if (tid < 64) {
+            double bmax = -1.0, amax = 0.0;
+            int bidx = j;
+            for (int i = j + lane; i < rows; i += 64) {
+                const double a = fabs(Pm[i + (int64_t)j * pld]);
+                if (i < cand && a > bmax) { bmax = a; bidx = i; }
+                amax = fmax(amax, a);
+            }
+            for (int off = 32; off; off >>= 1) {
+                const double ob = __shfl_xor(bmax, off), oa = __shfl_xor(amax, off);
+                const int oi = __shfl_xor(bidx, off);
+                if (ob > bmax || (ob == bmax && oi < bidx)) { bmax = ob; bidx = oi; }
+                amax = fmax(amax, oa);
+            }
+            if (lane == 0) {
+                const double diag = fabs(Pm[j + (int64_t)j * pld]);
+                int r = (diag > 0.0 && diag >= tol * bmax) ? j : bidx;
+                if (reuse) r = j + sh_piv[j];
+                double pv = Pm[r + (int64_t)j * pld];
+                const double ap = fabs(pv);
+                const bool bad = !(ap > 0.0) || !(ap <= 1.7e308) || ap < stol * amax;
+                if (bad && !failed && d.fail[f] == 0) { failed = true; d.fail[f] = jb + j + 1; }
+                if (!(ap > 0.0) || !(ap <= 1.7e308)) pv = 1.0;
+                sh_piv[j] = r - j;
+                sh_i[0] = r;
+                sh_d[0] = pv;
+            }
+        }
+        __syncthreads();
+        const int r = sh_i[0];
+        const double pv = sh_d[0];
+        if (r != j && tid < nbk) {
+            const double a = Pm[j + (int64_t)tid * pld], b = Pm[r + (int64_t)tid * pld];
+            Pm[j + (int64_t)tid * pld] = b;
+            Pm[r + (int64_t)tid * pld] = a;
+        }
+        __syncthreads();
+        for (int i = j + 1 + tid; i < rows; i += NT) Pm[i + (int64_t)j * pld] /= pv;
+        __syncthreads();
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int c = j + 1 + ty; c < nbk; c += NT / 64) {
+            const double ujc = Pm[j + (int64_t)c * pld];
+            if (ujc != 0.0)
+                for (int i = j + 1 + tx; i < rows; i += 64) Pm[i + (int64_t)c * pld] -= Pm[i + (int64_t)j * pld] * ujc;
+        }
+        __syncthreads();
+    }
+    if (!reuse && tid < nbk) ipiv[tid] = sh_piv[tid];
+    if (staged)
+        for (int idx = tid; idx < rows * nbk; idx += NT) { const int i = idx % rows, c = idx / rows; G[i + (int64_t)c * m] = Pm[i + c * pld]; }
+}
+
+
+// Register panel: ONE THREAD PER PANEL ROW (rows <= 1024), the row's nb entries in registers.  No data moves when a
+// pivot is chosen: every thread carries the logical position (`slot`) its row currently has under the LAPACK-style
+// interchange sequence; the pivot row publishes itself in LDS, everyone below eliminates with it.  Two barriers per
+// pivot; the row lands at its logical position when the panel is written back (identical to applying the
+// interchanges, which k_lub_trsm does for the other columns).  The pivot steps are expanded by template recursion so
+// that every index into the row is a compile-time constant (a `#pragma unroll` loop left the row in scratch memory).
+struct PanelCtx {
+    double *sh_b, *urow, *sh_diag;
+    int *sh_s, *sh_piv;
+    int32_t *fail_slot;
+    double tol, lmax;
+    int lane, wave, ncw, nbk, cand, reuse, jb, slot;
+    bool has, failed;
+};
+
+template <int J>
+__device__ __forceinline__ void panel_step(double (&a)[LU_NB], PanelCtx &x)
+{
+    if constexpr (J < LU_NB) {
+        if (J < x.nbk) {                                          // uniform
+            const double av = fabs(a[J]);
+            if (x.wave < x.ncw) {                                 // only the waves that hold candidate rows search
+                const bool c = x.has && x.slot >= J && x.slot < x.cand;
+                double bmax = c ? av : -1.0;
+                int bslot = c ? x.slot : 0x7fffffff;
+#pragma unroll
+                for (int off = 32; off; off >>= 1) {
+                    const double ob = __shfl_xor(bmax, off);
+                    const int os = __shfl_xor(bslot, off);
+                    if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
+                }
+                if (x.lane == 0) { x.sh_b[x.wave] = bmax; x.sh_s[x.wave] = bslot; }
+                if (x.has && x.slot == J) x.sh_diag[0] = av;
+            }
+            __syncthreads();
+            double bmax = -1.0;
+            int bslot = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < 16; w++) {
+                if (w < x.ncw) {
+                    const double ob = x.sh_b[w];
+                    const int os = x.sh_s[w];
+                    if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
+                }
+            }
+            const double dg = x.sh_diag[0];
+            int r = (dg > 0.0 && dg >= x.tol * bmax) ? J : bslot;
+            if (x.reuse) r = J + x.sh_piv[J];
+            if (r == 0x7fffffff) r = J;                           // nothing but NaNs: keep the diagonal, the step is flagged below
+            if (x.has && x.slot == r) {                           // the pivot row: publish, take position J
+#pragma unroll
+                for (int c = 0; c < LU_NB; c++) x.urow[c] = a[c];
+                x.slot = J;
+            } else if (x.has && x.slot == J) x.slot = r;
+            __syncthreads();
+            double pv = x.urow[J];
+            const double ap = fabs(pv);
+            const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);
+            if (bad) pv = 1.0;
+            if (threadIdx.x == 0) {
+                if (bad && !x.failed && *x.fail_slot == 0) { x.failed = true; *x.fail_slot = x.jb + J + 1; }
+                x.sh_piv[J] = r - J;
+            }
+            if (x.has && x.slot > J) {
+                const double l = a[J] / pv;
+                a[J] = l;
+                x.lmax = fmax(x.lmax, fabs(l));
+#pragma unroll
+                for (int c = J + 1; c < LU_NB; c++) a[c] -= l * x.urow[c];
+            }
+        }
+        panel_step<J + 1>(a, x);
+    }
+}
+
+// The acceptance test |pivot| >= stol * max|column| of lu_factor_front is applied afterwards in its equivalent form
+// max|multiplier| <= 1 / stol (one reduction per panel instead of one per pivot).
+__global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
+                                                         const double stol, const int reuse)
+{
+    __shared__ double sh_b[16], sh_diag[2], urow[LU_NB];
+    __shared__ int sh_s[16], sh_piv[LU_NB];
+    const int tid = threadIdx.x;
+    const int f = list[blockIdx.x];
+    const LuFrontD F = d.fr[f];
+    const int m = F.m, k = F.k;
+    if (jb >= k) return;
+    const int nbk = min(LU_NB, k - jb), rows = m - jb;
+    if (rows > 1024) return;                                  // handled by k_lub_panel
+    double *G = d.arena + (F.upd_off - k - (int64_t)k * m) + jb + (int64_t)jb * m;
+    int32_t *ipiv = d.ipiv + F.p0 + jb;
+    if (reuse && tid < nbk) sh_piv[tid] = ipiv[tid];
+    PanelCtx x;
+    x.sh_b = sh_b; x.sh_diag = sh_diag; x.urow = urow; x.sh_s = sh_s; x.sh_piv = sh_piv;
+    x.fail_slot = d.fail + f; x.tol = tol; x.lmax = 0.0;
+    x.lane = tid & 63; x.wave = tid >> 6; x.nbk = nbk; x.cand = k - jb; x.ncw = (min(x.cand, rows) + 63) >> 6; x.reuse = reuse; x.jb = jb;
+    x.has = tid < rows; x.slot = x.has ? tid : 0x7fffffff; x.failed = false;
+    double a[LU_NB];
+#pragma unroll
+    for (int c = 0; c < LU_NB; c++) a[c] = (x.has && c < nbk) ? G[tid + (int64_t)c * m] : 0.0;
+    __syncthreads();
+    panel_step<0>(a, x);
+    double lm = x.lmax;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) lm = fmax(lm, __shfl_xor(lm, off));
+    __syncthreads();
+    if (x.lane == 0) sh_b[x.wave] = lm;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) lm = fmax(lm, sh_b[w]);
+        if (!(lm * stol <= 1.0) && d.fail[f] == 0) d.fail[f] = jb + 1;
+    }
+    if (!reuse && tid < nbk) ipiv[tid] = sh_piv[tid];
+    if (x.has) {
+#pragma unroll
+        for (int c = 0; c < LU_NB; c++)
+            if (c < nbk) G[x.slot + (int64_t)c * m] = a[c];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *__restrict__ list, const int jb)
+{
+    __shared__ double L11[LU_NB * LU_NB];
+    __shared__ double T[LU_NB][65];                           // 32 block rows x 64 columns, padded: conflict-free by column
+    __shared__ int sw[LU_NB];
+    const int tid = threadIdx.x;
+    const LuFrontD F = d.fr[list[blockIdx.y]];
+    const int m = F.m, k = F.k;
+    const int c0 = blockIdx.x * 64;
+    if (jb >= k || c0 >= m) return;
+    const int nbk = min(LU_NB, k - jb);
+    double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
+    for (int idx = tid; idx < LU_NB * LU_NB; idx += 64) {
+        const int i = idx % LU_NB, t = idx / LU_NB;
+        L11[idx] = (i < nbk && t < nbk && i > t) ? Fm[(jb + i) + (int64_t)(jb + t) * m] : 0.0;
+    }
+    if (tid < LU_NB) sw[tid] = tid < nbk ? tid + d.ipiv[F.p0 + jb + tid] : tid;
+    __syncthreads();
+    const int c = c0 + tid;
+    const bool inpanel = c >= jb && c < jb + nbk;
+    if (c < m && !inpanel) {                                  // the block's row interchanges, every column outside the panel
+        double *col = Fm + jb + (int64_t)c * m;
+        for (int j = 0; j < nbk; j++) {
+            const int r = sw[j];
+            if (r != j) { const double a = col[j], b = col[r]; col[j] = b; col[r] = a; }
+        }
+    }
+    if (c0 + 64 <= jb + nbk) return;                          // nothing right of the panel in this block of columns
+    __syncthreads();
+    const int lr = tid & 31, lc = tid >> 5;                   // coalesced tile load: 32 consecutive rows of two columns per instruction
+    for (int cc = 0; cc < 64; cc += 2) {
+        const int col = c0 + cc + lc;
+        T[lr][cc + lc] = (lr < nbk && col < m) ? Fm[(jb + lr) + (int64_t)col * m] : 0.0;
+    }
+    __syncthreads();
+    if (c < m && c >= jb + nbk) {                             // U12(:, c) = L11^-1 A12(:, c)
+        double v[LU_NB];
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) v[t] = T[t][tid];
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) {
+#pragma unroll
+            for (int s2 = t + 1; s2 < LU_NB; s2++) v[s2] -= L11[s2 + t * LU_NB] * v[t];
+        }
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) T[t][tid] = v[t];
+    }
+    __syncthreads();
+    for (int cc = 0; cc < 64; cc += 2) {
+        const int col = c0 + cc + lc;
+        if (lr < nbk && col < m && col >= jb + nbk) Fm[(jb + lr) + (int64_t)col * m] = T[lr][cc + lc];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *__restrict__ list, const int jb)
+{
+    __shared__ double Ls[LU_NB * 64], Us[LU_NB * 64];
+    const int tid = threadIdx.x;
+    const LuFrontD F = d.fr[list[blockIdx.z]];
+    const int m = F.m, k = F.k;
+    if (jb >= k) return;
+    const int nbk = min(LU_NB, k - jb), t0 = jb + nbk;
+    const int r0 = t0 + blockIdx.x * 64, c0 = t0 + blockIdx.y * 64;
+    if (r0 >= m || c0 >= m) return;
+    double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
+    for (int idx = tid; idx < LU_NB * 64; idx += 256) {
+        const int i = idx & 63, t = idx >> 6;                 // L21 tile: rows r0.., block column t
+        Ls[idx] = (t < nbk && r0 + i < m) ? Fm[(r0 + i) + (int64_t)(jb + t) * m] : 0.0;
+    }
+    for (int idx = tid; idx < LU_NB * 64; idx += 256) {
+        const int t = idx % LU_NB, c = idx / LU_NB;           // U12 tile: block row t, columns c0..
+        Us[t * 64 + c] = (t < nbk && c0 + c < m) ? Fm[(jb + t) + (int64_t)(c0 + c) * m] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double acc[4][4] = {};
+    for (int t = 0; t < nbk; t++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { a[q] = Ls[t * 64 + tx + 16 * q]; b[q] = Us[t * 64 + ty + 16 * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int p = 0; p < 4; p++) acc[q][p] += a[q] * b[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int c = c0 + ty + 16 * p;
+        if (c >= m) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = r0 + tx + 16 * q;
+            if (i < m) Fm[i + (int64_t)c * m] -= acc[q][p];
+        }
+    }
+}
+
 }  // namespace
+
+// gfx950: a workgroup may use all 160 KB of a CU's LDS; beyond 64 KB the kernel must be told so once.
+static void allow_large_lds()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front<true, LU_NT_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lub_panel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+}
 
 void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, int max_k, const double *Ax, double tol,
                       double stol, int reuse, hipStream_t st)
 {
     if (cnt <= 0) return;
+    allow_large_lds();
     if (lds_m > 0) {
-        const size_t sm = (size_t)lds_m * lds_m * sizeof(double) + (size_t)lds_m * sizeof(int32_t);
+        const size_t sm = (size_t)lds_m * lds_m * sizeof(double) + 2 * (size_t)lds_m * sizeof(int32_t);
         hipLaunchKernelGGL((k_lu_front<true, LU_NT_LDS>), dim3(cnt), dim3(LU_NT_LDS), sm, st, d, list, Ax, tol, stol, reuse, lds_m);
     } else {
-        const size_t sm = (size_t)max_k * sizeof(int32_t) + 16;
+        const size_t sm = 2 * (size_t)max_k * sizeof(int32_t) + 16;
         hipLaunchKernelGGL((k_lu_front<false, LU_NT_BIG>), dim3(cnt), dim3(LU_NT_BIG), sm, st, d, list, Ax, tol, stol, reuse, 0);
     }
+}
+
+
+void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, const double *Ax, double tol,
+                         double stol, int reuse, hipStream_t st)
+{
+    if (cnt <= 0) return;
+    allow_large_lds();
+    hipLaunchKernelGGL(k_lub_assemble, dim3((max_m + LU_ASM_COLS - 1) / LU_ASM_COLS, cnt), dim3(256), 0, st, d, list, Ax);
+    const int tiles = (max_m + 63) / 64;
+    for (int jb = 0; jb < max_k; jb += LU_NB) {
+        hipLaunchKernelGGL(k_lub_panel_reg, dim3(cnt), dim3(std::min(1024, (max_m - jb + 63) / 64 * 64)), 0, st, d, list, jb, tol, stol, reuse);
+        if (max_m - jb > 1024)
+            hipLaunchKernelGGL(k_lub_panel, dim3(cnt), dim3(LU_NT_LDS), (size_t)LU_PANEL_LDS_DOUBLES * sizeof(double), st, d, list, jb, tol,
+                               stol, reuse);
+        hipLaunchKernelGGL(k_lub_trsm, dim3(tiles, cnt), dim3(64), 0, st, d, list, jb);
+        if (max_m - jb - 1 > 0) hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb);
+    }
+    hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list);
 }
 
 void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,

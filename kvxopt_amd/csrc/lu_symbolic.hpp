@@ -65,7 +65,7 @@ struct LuPlan {
     int64_t lnz_bound = 0, unz_bound = 0;
 };
 
-constexpr int KVX_LU_LDS_M = 88;         // fronts of order <= this are factored inside LDS (88*88*8 = 60.5 KB, under the 64 KB a workgroup gets by default)
+constexpr int KVX_LU_LDS_M = 136;        // fronts of order <= this are factored inside LDS (136*136*8 = 144.5 KB of the 160 KB a gfx950 workgroup may use)
 
 // values may be nullptr (pattern-only: plain maximum transversal).  Throws std::runtime_error on invalid input.
 void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, LuSymbolic &Y);
