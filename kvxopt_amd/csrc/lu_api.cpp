@@ -34,7 +34,9 @@ struct kvx_lu_num {
     LuPlan P;
     int64_t n = 0, nnz = 0;
     bool dev = false, factored = false;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr;      // st2: the blocked big-front chain of a level runs beside its LDS fronts
+    std::vector<hipEvent_t> evA, evB;
+    hipEvent_t ev0 = nullptr;
     LuFrontD *d_fr = nullptr;
     int32_t *d_rowidx = nullptr, *d_rel = nullptr, *d_children = nullptr, *d_adst = nullptr, *d_ai32 = nullptr;
     int32_t *d_ipiv = nullptr, *d_lperm = nullptr, *d_fail = nullptr, *d_lists = nullptr;
@@ -149,8 +151,21 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     HIPCHK(hipMemsetAsync(N->d_rmax, 0, (size_t)N->n * sizeof(double), N->st));
     launch_lu_rowmax(N->nnz, N->d_ai32, Ax_dev, N->d_rmax, N->st);
     launch_lu_rinv(N->n, N->d_rmax, N->d_rinv, N->st);
+    while ((int32_t)N->evA.size() < P.nlevels) {
+        hipEvent_t a, b2;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b2, hipEventDisableTiming));
+        N->evA.push_back(a); N->evB.push_back(b2);
+    }
+    HIPCHK(hipEventRecord(N->ev0, N->st));
+    HIPCHK(hipStreamWaitEvent(N->st2, N->ev0, 0));
+    int32_t lastA = -1, lastB = -1;                            // deepest-so-far levels with work recorded on st / st2
     for (int32_t l = P.nlevels - 1; l >= 0; l--) {
         const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nl = P.nlds[l];
+        const bool hasA = nl > 0, hasB = e > b + nl;
+        // everything of the levels below must be complete: each stream waits for the other's latest record
+        if (hasA && lastB >= 0) HIPCHK(hipStreamWaitEvent(N->st, N->evB[lastB], 0));
+        if (hasB && lastA >= 0) HIPCHK(hipStreamWaitEvent(N->st2, N->evA[lastA], 0));
         int64_t q = b;
         while (q < b + nl) {                                  // runs of one LDS size class (list sorted by m descending);
             const int c = lds_class(P.fr[P.levellist[q]].m);  // a thin level goes out as ONE launch sized for its largest front
@@ -159,13 +174,16 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
             launch_lu_fronts(d, N->d_lists + q, (int)(q2 - q), c, 0, Ax_dev, N->tol, N->stol, reuse, N->st);
             q = q2;
         }
-        if (e > b + nl) {
+        if (hasB) {
             int bm = 0, bk = 0;                                // big fronts of the level: blocked multi-launch path
             for (int64_t qq = b + nl; qq < e; qq++) { bm = std::max(bm, P.fr[P.levellist[qq]].m); bk = std::max(bk, P.fr[P.levellist[qq]].k); }
-            if (N->unblocked) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, bk, Ax_dev, N->tol, N->stol, reuse, N->st);
-            else launch_lu_big_level(d, N->d_lists + b + nl, (int)(e - b - nl), bm, bk, Ax_dev, N->tol, N->stol, reuse, N->st);
+            if (N->unblocked) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, bk, Ax_dev, N->tol, N->stol, reuse, N->st2);
+            else launch_lu_big_level(d, N->d_lists + b + nl, (int)(e - b - nl), bm, bk, Ax_dev, N->tol, N->stol, reuse, N->st2);
         }
+        if (hasA) { HIPCHK(hipEventRecord(N->evA[l], N->st)); lastA = l; }
+        if (hasB) { HIPCHK(hipEventRecord(N->evB[l], N->st2)); lastB = l; }
     }
+    if (lastB >= 0) HIPCHK(hipStreamWaitEvent(N->st, N->evB[lastB], 0));
     HIPCHK(hipGetLastError());
     fail_host.resize((size_t)P.nfront);
     HIPCHK(hipMemcpyAsync(fail_host.data(), N->d_fail, (size_t)P.nfront * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
@@ -215,6 +233,8 @@ int ensure_device(kvx_lu_num *N)
         return KVX_EDEVICE;
     }
     HIPCHK(hipStreamCreateWithFlags(&N->st, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&N->st2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&N->ev0, hipEventDisableTiming));
     std::vector<int32_t> ai32((size_t)N->nnz);
     for (int64_t p = 0; p < N->nnz; p++) ai32[p] = (int32_t)N->sym->Y.Ai[p];
     int rc;
@@ -318,6 +338,10 @@ void kvx_lu_free_numeric(kvx_lu_num *N)
     free_structure(N);
     void *ptrs[] = {N->d_ai32, N->d_rinv, N->d_rmax, N->d_Ax};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : N->evA) (void)hipEventDestroy(e);
+    for (hipEvent_t e : N->evB) (void)hipEventDestroy(e);
+    if (N->ev0) (void)hipEventDestroy(N->ev0);
+    if (N->st2) (void)hipStreamDestroy(N->st2);
     if (N->st) (void)hipStreamDestroy(N->st);
     delete N;
 }
