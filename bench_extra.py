@@ -15,6 +15,8 @@
   klu3    : BASELINE.json configs[2]: klu.linsolve on the ACTIVSg2000 power-flow Jacobian (4000 x 4000, 29 336 entries,
             tests/golden/ACTIVSg2000.npz), nrhs = 3: symbolic, first numeric, steady-state refactorisation and solve times,
             next to the CPU oracle and SciPy's SuperLU on the host.
+  lu2d    : unsymmetric counterpart of config 2 for the LU path: convection-diffusion 5-point operator on a 600 x 600 grid
+            (n = 360 000, workloads.convdiff_2d): refactorisation + solve on the GPU next to SciPy's SuperLU on the host.
 
 The headline line the driver reads is bench.py's; this script documents the rest (results in DESIGN.md section 5).
 """
@@ -164,6 +166,38 @@ def klu_case(steps, warmup):
             "x_vs_superlu": float(np.abs(X - xs).max()), "x_vs_oracle": float(np.abs(X - xo).max())}
 
 
+def lu2d_case(g, steps):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from kvxopt_amd import klu, _lib, workloads
+    from kvxopt_amd.base import spmatrix
+    n, cp, ri, v = workloads.convdiff_2d(g)
+    A = spmatrix.from_ccs(n, n, cp, ri, v)
+    As = sp.csc_matrix((v, ri, cp), shape=(n, n))
+    t0 = time.perf_counter(); Fs = klu.symbolic(A); t_sym = time.perf_counter() - t0
+    t0 = time.perf_counter(); Fn = klu.numeric(A, Fs); t_first = time.perf_counter() - t0
+    vals_d = _lib.DeviceBuffer.from_array(v)
+    b = np.random.default_rng(1).standard_normal(n)
+    b_d = _lib.DeviceBuffer.from_array(b)
+    Fn.num.refactor_dev(vals_d.ptr, v.size)
+    t0 = time.perf_counter()
+    for _ in range(steps): Fn.num.refactor_dev(vals_d.ptr, v.size)
+    ms_ref = (time.perf_counter() - t0) / steps * 1e3
+    Fn.num.solve_dev(b_d.ptr, "N", 1)
+    t0 = time.perf_counter()
+    for _ in range(steps): b_d.upload(b); Fn.num.solve_dev(b_d.ptr, "N", 1)
+    ms_solve = (time.perf_counter() - t0) / steps * 1e3
+    x = b_d.download(np.float64, n)
+    t0 = time.perf_counter(); lu = spla.splu(As); xs = lu.solve(b); t_splu = time.perf_counter() - t0
+    e = Fn.num.extract()
+    return {"case": "lu2d convection-diffusion %dx%d" % (g, g), "metric": "LU refactor+solve ms", "value": ms_ref + ms_solve, "unit": "ms",
+            "n": n, "nnz": int(v.size), "ms_symbolic_host": t_sym * 1e3, "ms_first_numeric": t_first * 1e3, "ms_refactor_dev": ms_ref,
+            "ms_solve_dev_incl_upload": ms_solve, "lnz": int(e["L"][1].size), "unz": int(e["U"][1].size),
+            "rel_residual": float(np.linalg.norm(As @ x - b) / np.linalg.norm(b)), "merges": Fs.sym.info()["merges"],
+            **{"lu_" + k: val for k, val in Fn.num.info().items()}, "cpu_scipy_superlu_ms": t_splu * 1e3,
+            "x_vs_superlu": float(np.abs(x - xs).max())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default="chol5,chol21,lap3d,lp4a,lp4b")
@@ -186,6 +220,8 @@ def main():
             out = lp_std_case(250, 200)
         elif case == "lp4b":
             out = lp_case(250, 200)
+        elif case == "lu2d":
+            out = lu2d_case(600, max(3, args.steps // 2))
         elif case == "klu3":
             out = klu_case(args.steps * 5, args.warmup)
         else:

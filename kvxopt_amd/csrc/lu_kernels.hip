@@ -18,6 +18,14 @@ namespace {
 constexpr int LU_NT_LDS = 256;
 constexpr int LU_NT_BIG = 1024;
 constexpr int LU_NT_SOLVE = 256;
+constexpr int LU_SB = 32;                        // pivots per block in the triangular sweeps
+
+__device__ __forceinline__ double readlane_d(const double v, const int lane)      // lane must be wave-uniform
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 
 // Right-looking elimination of the k pivot columns of the m x m front Fm (leading dimension ld).
 // KLU's pivot rule (klu.h: Common.tol = 0.001, "partial pivoting with diagonal preference"): keep the diagonal
@@ -202,13 +210,35 @@ __global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_fwd(const LuDev d, const int
         for (int t = tid; t < k; t += NT) fv[t] = g[t];
         __syncthreads();
     }
-    for (int t = 0; t < k; t++) {
-        double y = fv[t];
-        if (!UNIT) y /= panel[t + (int64_t)t * m];
-        for (int i = t + 1 + tid; i < m; i += NT) fv[i] -= panel[i + (int64_t)t * m] * y;
+    // blocks of 32 pivots: the first wavefront solves the 32 x 32 triangle in registers (pivot values travel by
+    // v_readlane, no barrier inside), then every thread applies the block to its rows below: two barriers per block
+    __shared__ double ysh[LU_SB];
+    for (int t0 = 0; t0 < k; t0 += LU_SB) {
+        const int nbk = min(LU_SB, k - t0);
+        if (tid < 64) {
+            const bool on = tid < nbk;
+            double fi = on ? fv[t0 + tid] : 0.0, rd = 1.0;
+            double lb[LU_SB];
+#pragma unroll
+            for (int t = 0; t < LU_SB; t++) lb[t] = (on && t < tid) ? panel[(t0 + tid) + (int64_t)(t0 + t) * m] : 0.0;
+            if (!UNIT && on) rd = 1.0 / panel[(t0 + tid) + (int64_t)(t0 + tid) * m];
+#pragma unroll
+            for (int t = 0; t < LU_SB; t++) {
+                double yt = readlane_d(fi, t);
+                if (!UNIT) yt *= readlane_d(rd, t);
+                fi -= lb[t] * yt;
+            }
+            if (on) { const double y = UNIT ? fi : fi * rd; ysh[tid] = y; fv[t0 + tid] = y; }
+        }
+        __syncthreads();
+        for (int i = t0 + nbk + tid; i < m; i += NT) {
+            double acc = 0.0;
+            for (int t = 0; t < nbk; t++) acc += panel[i + (int64_t)(t0 + t) * m] * ysh[t];
+            fv[i] -= acc;
+        }
         __syncthreads();
     }
-    for (int t = tid; t < k; t += NT) x[F.p0 + t] = UNIT ? fv[t] : fv[t] / panel[t + (int64_t)t * m];
+    for (int t = tid; t < k; t += NT) x[F.p0 + t] = fv[t];
     double *__restrict__ ws = w + F.wx;
     for (int i = k + tid; i < m; i += NT) ws[i - k] = fv[i];
 }
@@ -238,11 +268,31 @@ __global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_bwd(const LuDev d, const int
         if (lane == 0) fv[t] -= s;
     }
     __syncthreads();
-    for (int t = k - 1; t >= 0; t--) {
-        double y = fv[t];
-        if (!UNIT) y /= panel[t + (int64_t)t * m];
-        if (tid == 0) g[t] = y;
-        for (int s = tid; s < t; s += NT) fv[s] -= panel[t + (int64_t)s * m] * y;
+    __shared__ double ysh[LU_SB];
+    for (int t0 = ((k - 1) / LU_SB) * LU_SB; t0 >= 0; t0 -= LU_SB) {      // blocks of 32 pivots, last block first (see k_lu_fwd)
+        const int nbk = min(LU_SB, k - t0);
+        if (tid < 64) {
+            const bool on = tid < nbk;
+            double ws = on ? fv[t0 + tid] : 0.0, rd = 1.0;
+            double cb[LU_SB];
+#pragma unroll
+            for (int t = 0; t < LU_SB; t++) cb[t] = (on && t > tid && t < nbk) ? panel[(t0 + t) + (int64_t)(t0 + tid) * m] : 0.0;
+            if (!UNIT && on) rd = 1.0 / panel[(t0 + tid) + (int64_t)(t0 + tid) * m];
+#pragma unroll
+            for (int t = LU_SB - 1; t >= 0; t--) {
+                double yt = readlane_d(ws, t);
+                if (!UNIT) yt *= readlane_d(rd, t);
+                ws -= cb[t] * yt;
+            }
+            if (on) { const double y = UNIT ? ws : ws * rd; ysh[tid] = y; g[t0 + tid] = y; }
+        }
+        __syncthreads();
+        for (int s2 = tid; s2 < t0; s2 += NT) {
+            const double *__restrict__ colp = panel + t0 + (int64_t)s2 * m;
+            double acc = 0.0;
+            for (int t = 0; t < nbk; t++) acc += colp[t] * ysh[t];
+            fv[s2] -= acc;
+        }
         __syncthreads();
     }
     for (int t = tid; t < k; t += NT) x[F.p0 + (UNIT ? d.lperm[F.p0 + t] : t)] = g[t];
@@ -366,8 +416,8 @@ __global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t 
     }
 }
 
-__global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
-                                                          const double stol, const int reuse)
+__global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs,
+                                                          const double tol, const double stol, const int reuse)
 {
     extern __shared__ double smem[];
     __shared__ int sh_i[2];
@@ -378,8 +428,8 @@ __global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const in
     const LuFrontD F = d.fr[f];
     const int m = F.m, k = F.k;
     if (jb >= k) return;
-    const int nbk = min(LU_NB, k - jb), rows = m - jb, cand = k - jb;
-    if (rows <= 1024) return;                                // handled by k_lub_panel_reg
+    const int nbk = min(nbs, k - jb), rows = m - jb, cand = k - jb;
+    if (rows <= 4096) return;                                // handled by k_lub_panel_reg
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
     double *G = Fm + jb + (int64_t)jb * m;                   // panel in the front, ld = m
     const bool staged = (int64_t)rows * nbk <= LU_PANEL_LDS_DOUBLES;
@@ -454,25 +504,32 @@ __global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const in
 // pivot; the row lands at its logical position when the panel is written back (identical to applying the
 // interchanges, which k_lub_trsm does for the other columns).  The pivot steps are expanded by template recursion so
 // that every index into the row is a compile-time constant (a `#pragma unroll` loop left the row in scratch memory).
+template <int RPT>
 struct PanelCtx {
     double *sh_b, *urow, *sh_diag;
     int *sh_s, *sh_piv;
     int32_t *fail_slot;
     double tol, lmax;
-    int lane, wave, ncw, nbk, cand, reuse, jb, slot;
-    bool has, failed;
+    int lane, wave, ncw, nbk, cand, reuse, jb;
+    int slot[RPT];
+    bool has[RPT], failed;
 };
 
-template <int J>
-__device__ __forceinline__ void panel_step(double (&a)[LU_NB], PanelCtx &x)
+template <int J, int NB, int RPT>
+__device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &x)
 {
-    if constexpr (J < LU_NB) {
+    if constexpr (J < NB) {
         if (J < x.nbk) {                                          // uniform
-            const double av = fabs(a[J]);
             if (x.wave < x.ncw) {                                 // only the waves that hold candidate rows search
-                const bool c = x.has && x.slot >= J && x.slot < x.cand;
-                double bmax = c ? av : -1.0;
-                int bslot = c ? x.slot : 0x7fffffff;
+                double bmax = -1.0;
+                int bslot = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < RPT; q++) {
+                    const bool c = x.has[q] && x.slot[q] >= J && x.slot[q] < x.cand;
+                    const double av = fabs(a[q][J]);
+                    if (c && (av > bmax || (av == bmax && x.slot[q] < bslot))) { bmax = av; bslot = x.slot[q]; }
+                    if (x.has[q] && x.slot[q] == J) x.sh_diag[0] = av;
+                }
 #pragma unroll
                 for (int off = 32; off; off >>= 1) {
                     const double ob = __shfl_xor(bmax, off);
@@ -480,7 +537,6 @@ __device__ __forceinline__ void panel_step(double (&a)[LU_NB], PanelCtx &x)
                     if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
                 }
                 if (x.lane == 0) { x.sh_b[x.wave] = bmax; x.sh_s[x.wave] = bslot; }
-                if (x.has && x.slot == J) x.sh_diag[0] = av;
             }
             __syncthreads();
             double bmax = -1.0;
@@ -497,11 +553,14 @@ __device__ __forceinline__ void panel_step(double (&a)[LU_NB], PanelCtx &x)
             int r = (dg > 0.0 && dg >= x.tol * bmax) ? J : bslot;
             if (x.reuse) r = J + x.sh_piv[J];
             if (r == 0x7fffffff) r = J;                           // nothing but NaNs: keep the diagonal, the step is flagged below
-            if (x.has && x.slot == r) {                           // the pivot row: publish, take position J
 #pragma unroll
-                for (int c = 0; c < LU_NB; c++) x.urow[c] = a[c];
-                x.slot = J;
-            } else if (x.has && x.slot == J) x.slot = r;
+            for (int q = 0; q < RPT; q++) {
+                if (x.has[q] && x.slot[q] == r) {                 // the pivot row: publish, take position J
+#pragma unroll
+                    for (int c = 0; c < NB; c++) x.urow[c] = a[q][c];
+                    x.slot[q] = J;
+                } else if (x.has[q] && x.slot[q] == J) x.slot[q] = r;
+            }
             __syncthreads();
             double pv = x.urow[J];
             const double ap = fabs(pv);
@@ -511,45 +570,57 @@ __device__ __forceinline__ void panel_step(double (&a)[LU_NB], PanelCtx &x)
                 if (bad && !x.failed && *x.fail_slot == 0) { x.failed = true; *x.fail_slot = x.jb + J + 1; }
                 x.sh_piv[J] = r - J;
             }
-            if (x.has && x.slot > J) {
-                const double l = a[J] / pv;
-                a[J] = l;
-                x.lmax = fmax(x.lmax, fabs(l));
 #pragma unroll
-                for (int c = J + 1; c < LU_NB; c++) a[c] -= l * x.urow[c];
+            for (int q = 0; q < RPT; q++) {
+                if (x.has[q] && x.slot[q] > J) {
+                    const double l = a[q][J] / pv;
+                    a[q][J] = l;
+                    x.lmax = fmax(x.lmax, fabs(l));
+#pragma unroll
+                    for (int c = J + 1; c < NB; c++) a[q][c] -= l * x.urow[c];
+                }
             }
         }
-        panel_step<J + 1>(a, x);
+        panel_step<J + 1, NB, RPT>(a, x);
     }
 }
 
 // The acceptance test |pivot| >= stol * max|column| of lu_factor_front is applied afterwards in its equivalent form
-// max|multiplier| <= 1 / stol (one reduction per panel instead of one per pivot).
+// max|multiplier| <= 1 / stol (one reduction per panel instead of one per pivot).  NB pivots per panel, RPT rows per
+// thread: <32, 1> up to 1024 rows, <16, 2> up to 2048, <8, 4> up to 4096 (the register budget of a 1024-thread workgroup).
+template <int NB, int RPT>
 __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
                                                          const double stol, const int reuse)
 {
-    __shared__ double sh_b[16], sh_diag[2], urow[LU_NB];
-    __shared__ int sh_s[16], sh_piv[LU_NB];
-    const int tid = threadIdx.x;
+    __shared__ double sh_b[16], sh_diag[2], urow[NB];
+    __shared__ int sh_s[16], sh_piv[NB];
+    const int tid = threadIdx.x, nth = blockDim.x;
     const int f = list[blockIdx.x];
     const LuFrontD F = d.fr[f];
     const int m = F.m, k = F.k;
     if (jb >= k) return;
-    const int nbk = min(LU_NB, k - jb), rows = m - jb;
-    if (rows > 1024) return;                                  // handled by k_lub_panel
+    const int nbk = min(NB, k - jb), rows = m - jb;
+    if (rows > RPT * nth) return;                             // handled by k_lub_panel
     double *G = d.arena + (F.upd_off - k - (int64_t)k * m) + jb + (int64_t)jb * m;
     int32_t *ipiv = d.ipiv + F.p0 + jb;
     if (reuse && tid < nbk) sh_piv[tid] = ipiv[tid];
-    PanelCtx x;
+    PanelCtx<RPT> x;
     x.sh_b = sh_b; x.sh_diag = sh_diag; x.urow = urow; x.sh_s = sh_s; x.sh_piv = sh_piv;
     x.fail_slot = d.fail + f; x.tol = tol; x.lmax = 0.0;
-    x.lane = tid & 63; x.wave = tid >> 6; x.nbk = nbk; x.cand = k - jb; x.ncw = (min(x.cand, rows) + 63) >> 6; x.reuse = reuse; x.jb = jb;
-    x.has = tid < rows; x.slot = x.has ? tid : 0x7fffffff; x.failed = false;
-    double a[LU_NB];
+    x.lane = tid & 63; x.wave = tid >> 6; x.nbk = nbk; x.cand = k - jb; x.reuse = reuse; x.jb = jb;
+    x.ncw = RPT > 1 ? (nth >> 6) : (min(x.cand, rows) + 63) >> 6;     // with several rows per thread every wave may hold candidates
+    x.failed = false;
+    double a[RPT][NB];
 #pragma unroll
-    for (int c = 0; c < LU_NB; c++) a[c] = (x.has && c < nbk) ? G[tid + (int64_t)c * m] : 0.0;
+    for (int q = 0; q < RPT; q++) {
+        const int row = tid + q * nth;
+        x.has[q] = row < rows;
+        x.slot[q] = x.has[q] ? row : 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[q][c] = (x.has[q] && c < nbk) ? G[row + (int64_t)c * m] : 0.0;
+    }
     __syncthreads();
-    panel_step<0>(a, x);
+    panel_step<0, NB, RPT>(a, x);
     double lm = x.lmax;
 #pragma unroll
     for (int off = 32; off; off >>= 1) lm = fmax(lm, __shfl_xor(lm, off));
@@ -557,18 +628,20 @@ __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int
     if (x.lane == 0) sh_b[x.wave] = lm;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) lm = fmax(lm, sh_b[w]);
+        for (int w = 1; w < (nth >> 6); w++) lm = fmax(lm, sh_b[w]);
         if (!(lm * stol <= 1.0) && d.fail[f] == 0) d.fail[f] = jb + 1;
     }
     if (!reuse && tid < nbk) ipiv[tid] = sh_piv[tid];
-    if (x.has) {
 #pragma unroll
-        for (int c = 0; c < LU_NB; c++)
-            if (c < nbk) G[x.slot + (int64_t)c * m] = a[c];
-    }
+    for (int q = 0; q < RPT; q++)
+        if (x.has[q]) {
+#pragma unroll
+            for (int c = 0; c < NB; c++)
+                if (c < nbk) G[x.slot[q] + (int64_t)c * m] = a[q][c];
+        }
 }
 
-__global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *__restrict__ list, const int jb)
+__global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs)
 {
     __shared__ double L11[LU_NB * LU_NB];
     __shared__ double T[LU_NB][65];                           // 32 block rows x 64 columns, padded: conflict-free by column
@@ -578,7 +651,7 @@ __global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *_
     const int m = F.m, k = F.k;
     const int c0 = blockIdx.x * 64;
     if (jb >= k || c0 >= m) return;
-    const int nbk = min(LU_NB, k - jb);
+    const int nbk = min(nbs, k - jb);
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
     for (int idx = tid; idx < LU_NB * LU_NB; idx += 64) {
         const int i = idx % LU_NB, t = idx / LU_NB;
@@ -622,14 +695,14 @@ __global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *_
     }
 }
 
-__global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *__restrict__ list, const int jb)
+__global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs)
 {
     __shared__ double Ls[LU_NB * 64], Us[LU_NB * 64];
     const int tid = threadIdx.x;
     const LuFrontD F = d.fr[list[blockIdx.z]];
     const int m = F.m, k = F.k;
     if (jb >= k) return;
-    const int nbk = min(LU_NB, k - jb), t0 = jb + nbk;
+    const int nbk = min(nbs, k - jb), t0 = jb + nbk;
     const int r0 = t0 + blockIdx.x * 64, c0 = t0 + blockIdx.y * 64;
     if (r0 >= m || c0 >= m) return;
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
@@ -700,13 +773,22 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
     allow_large_lds();
     hipLaunchKernelGGL(k_lub_assemble, dim3((max_m + LU_ASM_COLS - 1) / LU_ASM_COLS, cnt), dim3(256), 0, st, d, list, Ax);
     const int tiles = (max_m + 63) / 64;
-    for (int jb = 0; jb < max_k; jb += LU_NB) {
-        hipLaunchKernelGGL(k_lub_panel_reg, dim3(cnt), dim3(std::min(1024, (max_m - jb + 63) / 64 * 64)), 0, st, d, list, jb, tol, stol, reuse);
-        if (max_m - jb > 1024)
-            hipLaunchKernelGGL(k_lub_panel, dim3(cnt), dim3(LU_NT_LDS), (size_t)LU_PANEL_LDS_DOUBLES * sizeof(double), st, d, list, jb, tol,
-                               stol, reuse);
-        hipLaunchKernelGGL(k_lub_trsm, dim3(tiles, cnt), dim3(64), 0, st, d, list, jb);
-        if (max_m - jb - 1 > 0) hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb);
+    for (int jb = 0; jb < max_k;) {
+        const int rows = max_m - jb;                          // tallest panel of this step
+        const int nth = std::min(1024, (rows + 63) / 64 * 64);
+        int nbs = LU_NB;
+        if (rows <= 1024) hipLaunchKernelGGL((k_lub_panel_reg<32, 1>), dim3(cnt), dim3(nth), 0, st, d, list, jb, tol, stol, reuse);
+        else if (rows <= 2048) { nbs = 16; hipLaunchKernelGGL((k_lub_panel_reg<16, 2>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol, reuse); }
+        else {
+            nbs = 8;
+            hipLaunchKernelGGL((k_lub_panel_reg<8, 4>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol, reuse);
+            if (rows > 4096)
+                hipLaunchKernelGGL(k_lub_panel, dim3(cnt), dim3(LU_NT_LDS), (size_t)LU_PANEL_LDS_DOUBLES * sizeof(double), st, d, list, jb, nbs,
+                                   tol, stol, reuse);
+        }
+        hipLaunchKernelGGL(k_lub_trsm, dim3(tiles, cnt), dim3(64), 0, st, d, list, jb, nbs);
+        hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb, nbs);
+        jb += nbs;
     }
     hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list);
 }

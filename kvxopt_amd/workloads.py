@@ -157,3 +157,22 @@ def lp_grid_std(gx, gy):
     Gp = np.arange(nv + 1, dtype=np.int64)
     return {"p": p, "n": nv, "ml": nv, "Ap": Ap, "Ai": Ai.astype(np.int64), "Ax": Ax, "b": b, "c": c,
             "Gp": Gp, "Gi": np.arange(nv, dtype=np.int64), "Gx": -np.ones(nv), "h": np.zeros(nv)}
+
+
+def convdiff_2d(g, seed=0):
+    """Unsymmetric 5-point convection-diffusion operator on a g x g grid with a random local wind (full CCS, int64):
+    the LU counterpart of laplacian_2d -- structurally symmetric, numerically unsymmetric, not diagonally dominant."""
+    rng = np.random.default_rng(seed)
+    n = g * g
+    idx = np.arange(n, dtype=np.int64).reshape(g, g)
+    I, J, V = [idx.ravel()], [idx.ravel()], [4.0 + 0.1 * rng.random(n)]
+    for a, b, s in ((idx[1:, :], idx[:-1, :], 1.0), (idx[:-1, :], idx[1:, :], -1.0), (idx[:, 1:], idx[:, :-1], 1.0), (idx[:, :-1], idx[:, 1:], -1.0)):
+        w = rng.standard_normal(a.size) * 0.8
+        I.append(a.ravel()); J.append(b.ravel()); V.append(-1.0 + s * w)
+    I, J, V = np.concatenate(I), np.concatenate(J), np.concatenate(V)
+    order = np.lexsort((I, J))
+    I, J, V = I[order], J[order], V[order]
+    colptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(colptr, J + 1, 1)
+    np.cumsum(colptr, out=colptr)
+    return n, colptr, I.astype(np.int64), V

@@ -215,6 +215,31 @@ def test_refactorisation_reuses_and_falls_back(golden_dir):
     assert np.allclose(D2 @ x, np.ones(3), atol=1e-12)
 
 
+def test_unsymmetric_grid_uses_the_blocked_big_front_path():
+    """Convection-diffusion on a 150 x 150 grid (n = 22 500): fronts of several hundred rows go through the blocked
+    HBM path (panel / trsm / update); solution against SciPy's SuperLU and residual to the north-star bar."""
+    import scipy.sparse.linalg as spla
+    from kvxopt_amd import workloads
+    n, cp, ri, v = workloads.convdiff_2d(150, seed=1)
+    A = spmatrix.from_ccs(n, n, cp, ri, v)
+    As = to_sp(A)
+    Fs = klu.symbolic(A)
+    Fn = klu.numeric(A, Fs)
+    assert Fn.num.info()["max_front"] > 136                              # beyond the LDS-resident class
+    b = np.random.default_rng(8).standard_normal((n, 2))
+    lu = spla.splu(As)
+    for tran in "NT":
+        x = np.asfortranarray(b.copy())
+        klu.solve(A, Fs, Fn, x, trans=tran)
+        M = As if tran == "N" else As.T
+        assert np.linalg.norm(M @ x - b) <= 1e-10 * np.linalg.norm(b)
+        xs = lu.solve(b, trans=tran)
+        assert np.abs(x - xs).max() <= 1e-7 * max(1.0, np.abs(xs).max())
+    L, U, P, Q, R, F, r = klu.get_numeric(A, Fs, Fn)
+    rho = abs(to_sp(R) @ to_sp(P) @ As @ to_sp(Q) - to_sp(L) @ to_sp(U)).sum(axis=0).max()
+    assert rho < 1e-12
+
+
 def test_ldb_offset_and_nrhs_arguments():
     """klu.c:619-628: nrhs / ldB / offsetB follow the BLAS conventions."""
     A = spmatrix(DOC_V, DOC_I, DOC_J)
