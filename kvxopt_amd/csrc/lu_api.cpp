@@ -44,7 +44,7 @@ struct kvx_lu_num {
     double *d_rinv = nullptr, *d_rmax = nullptr, *d_Lx = nullptr, *d_Ux = nullptr, *d_arena = nullptr, *d_Ax = nullptr;
     double *d_W = nullptr, *d_X = nullptr, *d_B = nullptr;
     int64_t cap_rhs = 0;
-    std::vector<int32_t> lvl_maxm, lvl_maxk;
+    std::vector<int32_t> lvl_maxm, lvl_maxk, lvl_smallm, lvl_smallk;   // per level: all fronts / those swept by one workgroup
     double tol = 1e-3, stol = 1e-3;
     int64_t attempts = 0;
     bool unblocked = std::getenv("KVX_LU_UNBLOCKED") != nullptr;   // debugging aid: big fronts by one workgroup each
@@ -90,8 +90,8 @@ int upload_structure(kvx_lu_num *N)
         return KVX_EINVAL;
     }
     const LuPlan &P = N->P;
-    if ((int64_t)P.max_m + P.max_k > 8000) {
-        set_last_error("LU front of order " + std::to_string(P.max_m) + " exceeds what the solve kernels hold in LDS");
+    if ((int64_t)P.max_k > 8000) {                              // k_lu_fwd_big_init keeps the permuted pivot part in LDS
+        set_last_error("LU pivot block of " + std::to_string(P.max_k) + " columns exceeds what the solve kernels hold in LDS");
         return KVX_EINVAL;
     }
     std::vector<LuFrontD> fd((size_t)P.nfront);
@@ -119,10 +119,17 @@ int upload_structure(kvx_lu_num *N)
     if ((rc = dalloc(&N->d_arena, P.arena))) return rc;
     N->lvl_maxm.assign((size_t)P.nlevels, 0);
     N->lvl_maxk.assign((size_t)P.nlevels, 0);
+    N->lvl_smallm.assign((size_t)P.nlevels, 0);
+    N->lvl_smallk.assign((size_t)P.nlevels, 0);
     for (int32_t l = 0; l < P.nlevels; l++)
         for (int64_t q = P.levelptr[l]; q < P.levelptr[l + 1]; q++) {
-            N->lvl_maxm[l] = std::max(N->lvl_maxm[l], P.fr[P.levellist[q]].m);
-            N->lvl_maxk[l] = std::max(N->lvl_maxk[l], P.fr[P.levellist[q]].k);
+            const LuFrontH &fh = P.fr[P.levellist[q]];
+            N->lvl_maxm[l] = std::max(N->lvl_maxm[l], fh.m);
+            N->lvl_maxk[l] = std::max(N->lvl_maxk[l], fh.k);
+            if (fh.m <= KVX_LU_SOLVE_BIG_M) {
+                N->lvl_smallm[l] = std::max(N->lvl_smallm[l], fh.m);
+                N->lvl_smallk[l] = std::max(N->lvl_smallk[l], fh.k);
+            }
         }
     return KVX_OK;
 }
@@ -270,12 +277,19 @@ int solve_on_device(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64
     // A x = b:  L U (Q' x) = R P b         A' x = b:  U' L' (R^-1 P x) = Q' b
     if (!trans) launch_lu_gather(n, (int)nrhs, N->d_prow, N->d_rinv, B_dev, ldB, N->d_X, n, N->st);
     else launch_lu_gather(n, (int)nrhs, N->d_qcol, nullptr, B_dev, ldB, N->d_X, n, N->st);
-    for (int32_t l = P.nlevels - 1; l >= 0; l--)
-        launch_lu_fwd(d, N->d_lists + P.levelptr[l], (int)(P.levelptr[l + 1] - P.levelptr[l]), N->lvl_maxm[l], N->lvl_maxk[l],
-                      trans ? 0 : 1, N->d_X, n, (int)nrhs, N->d_W, P.wsize, N->st);
-    for (int32_t l = 0; l < P.nlevels; l++)
-        launch_lu_bwd(d, N->d_lists + P.levelptr[l], (int)(P.levelptr[l + 1] - P.levelptr[l]), N->lvl_maxm[l], N->lvl_maxk[l],
-                      trans ? 1 : 0, N->d_X, n, (int)nrhs, N->st);
+    for (int32_t l = P.nlevels - 1; l >= 0; l--) {
+        const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nb = P.nsbig[l];
+        launch_lu_fwd(d, N->d_lists + b, (int)(e - nb - b), N->lvl_smallm[l], N->lvl_smallk[l], trans ? 0 : 1, N->d_X, n, (int)nrhs,
+                      N->d_W, P.wsize, N->st);
+        launch_lu_fwd_big(d, N->d_lists + e - nb, (int)nb, N->lvl_maxm[l], N->lvl_maxk[l], trans ? 0 : 1, N->d_X, n, (int)nrhs, N->d_W,
+                          P.wsize, N->st);
+    }
+    for (int32_t l = 0; l < P.nlevels; l++) {
+        const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nb = P.nsbig[l];
+        launch_lu_bwd(d, N->d_lists + b, (int)(e - nb - b), N->lvl_smallm[l], N->lvl_smallk[l], trans ? 1 : 0, N->d_X, n, (int)nrhs, N->st);
+        launch_lu_bwd_big(d, N->d_lists + e - nb, (int)nb, N->lvl_maxm[l], N->lvl_maxk[l], trans ? 1 : 0, N->d_X, n, (int)nrhs, N->d_W,
+                          P.wsize, N->st);
+    }
     if (!trans) launch_lu_scatter(n, (int)nrhs, N->d_qcol, nullptr, N->d_X, n, B_dev, ldB, N->st);
     else launch_lu_scatter(n, (int)nrhs, N->d_prow, N->d_rinv, N->d_X, n, B_dev, ldB, N->st);
     HIPCHK(hipGetLastError());

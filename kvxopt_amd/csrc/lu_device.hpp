@@ -44,6 +44,11 @@ void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int 
                    int nrhs, double *W, int64_t wsize, hipStream_t st);
 void launch_lu_bwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx,
                    int nrhs, hipStream_t st);
+// The same sweeps for fronts of order > KVX_LU_SOLVE_BIG_M: many workgroups, one launch per 32 pivots.
+void launch_lu_fwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,
+                       double *W, int64_t wsize, hipStream_t st);
+void launch_lu_bwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,
+                       double *W, int64_t wsize, hipStream_t st);
 void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double *rmax, hipStream_t st);   // rmax zeroed by the caller
 void launch_lu_rinv(int64_t n, const double *rmax, double *rinv, hipStream_t st);
 // X[p] = B[idx[p]] * (scale ? scale[idx[p]] : 1)   /   B[idx[p]] = X[p] * (scale ? scale[idx[p]] : 1)

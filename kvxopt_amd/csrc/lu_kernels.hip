@@ -738,6 +738,155 @@ __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Triangular sweeps of fronts too large for one workgroup (m > KVX_LU_SOLVE_BIG_M): a single workgroup streams the
+// panel at ~10 GB/s.  The front's work vector (m doubles, at W + wx - k) lives in HBM; one launch per block of 32
+// pivots, every workgroup solves the 32 x 32 triangle redundantly in its first wavefront and applies the block to
+// its own 1024 rows (forward) / columns (backward).
+constexpr int LU_BIG_CHUNK = 1024;
+
+template <bool UNIT>
+__device__ __forceinline__ void wave_tri_fwd(const double *__restrict__ panel, const int m, const int t0, const int nbk, const double *fvec,
+                                             double *ysh)
+{
+    const int tid = threadIdx.x;
+    const bool on = tid < nbk;
+    double fi = on ? fvec[t0 + tid] : 0.0, rd = 1.0;
+    double lb[LU_SB];
+#pragma unroll
+    for (int t = 0; t < LU_SB; t++) lb[t] = (on && t < tid) ? panel[(t0 + tid) + (int64_t)(t0 + t) * m] : 0.0;
+    if (!UNIT && on) rd = 1.0 / panel[(t0 + tid) + (int64_t)(t0 + tid) * m];
+#pragma unroll
+    for (int t = 0; t < LU_SB; t++) {
+        double yt = readlane_d(fi, t);
+        if (!UNIT) yt *= readlane_d(rd, t);
+        fi -= lb[t] * yt;
+    }
+    if (on) ysh[tid] = UNIT ? fi : fi * rd;
+}
+
+template <bool UNIT>
+__device__ __forceinline__ void wave_tri_bwd(const double *__restrict__ panel, const int m, const int t0, const int nbk, const double *fvec,
+                                             double *ysh)
+{
+    const int tid = threadIdx.x;
+    const bool on = tid < nbk;
+    double ws = on ? fvec[t0 + tid] : 0.0, rd = 1.0;
+    double cb[LU_SB];
+#pragma unroll
+    for (int t = 0; t < LU_SB; t++) cb[t] = (on && t > tid && t < nbk) ? panel[(t0 + t) + (int64_t)(t0 + tid) * m] : 0.0;
+    if (!UNIT && on) rd = 1.0 / panel[(t0 + tid) + (int64_t)(t0 + tid) * m];
+#pragma unroll
+    for (int t = LU_SB - 1; t >= 0; t--) {
+        double yt = readlane_d(ws, t);
+        if (!UNIT) yt *= readlane_d(rd, t);
+        ws -= cb[t] * yt;
+    }
+    if (on) ysh[tid] = UNIT ? ws : ws * rd;
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_fwd_big_init(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ X,
+                                                                  const int64_t ldx, double *__restrict__ W, const int64_t wsize)
+{
+    extern __shared__ double smem[];
+    constexpr int NT = LU_NT_SOLVE;
+    const int tid = threadIdx.x;
+    const LuFrontD F = d.fr[list[blockIdx.x]];
+    const int m = F.m, k = F.k;
+    const double *x = X + (int64_t)blockIdx.y * ldx;
+    double *w = W + (int64_t)blockIdx.y * wsize;
+    double *fvec = w + F.wx - k;
+    for (int t = tid; t < m; t += NT) fvec[t] = t < k ? x[F.p0 + t] : 0.0;
+    __syncthreads();
+    for (int c = 0; c < F.nchild; c++) {
+        const LuFrontD C = d.fr[d.children[F.childptr + c]];
+        const int uc = C.m - C.k;
+        const int32_t *__restrict__ relc = d.rel + C.rowptr + C.k;
+        const double *__restrict__ wc = w + C.wx;
+        for (int i = tid; i < uc; i += NT) fvec[relc[i]] += wc[i];
+        __syncthreads();
+    }
+    if (UNIT) {
+        for (int t = tid; t < k; t += NT) smem[t] = fvec[d.lperm[F.p0 + t]];
+        __syncthreads();
+        for (int t = tid; t < k; t += NT) fvec[t] = smem[t];
+    }
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_fwd_big_step(const LuDev d, const int32_t *__restrict__ list, double *__restrict__ X,
+                                                                  const int64_t ldx, double *__restrict__ W, const int64_t wsize, const int t0)
+{
+    __shared__ double ysh[LU_SB];
+    constexpr int NT = LU_NT_SOLVE;
+    const int tid = threadIdx.x;
+    const LuFrontD F = d.fr[list[blockIdx.y]];
+    const int m = F.m, k = F.k;
+    if (t0 >= k) return;
+    const int nbk = min(LU_SB, k - t0), t1 = t0 + nbk;
+    const int r0 = max(t1, (int)blockIdx.x * LU_BIG_CHUNK), r1 = min(m, ((int)blockIdx.x + 1) * LU_BIG_CHUNK);
+    if (r0 >= r1 && blockIdx.x != 0) return;
+    double *fvec = W + (int64_t)blockIdx.z * wsize + F.wx - k;
+    const double *__restrict__ panel = (UNIT ? d.Lx : d.Ux) + F.px;
+    if (tid < 64) wave_tri_fwd<UNIT>(panel, m, t0, nbk, fvec, ysh);
+    __syncthreads();
+    for (int i = r0 + tid; i < r1; i += NT) {
+        double acc = 0.0;
+        for (int t = 0; t < nbk; t++) acc += panel[i + (int64_t)(t0 + t) * m] * ysh[t];
+        fvec[i] -= acc;
+    }
+    if (blockIdx.x == 0 && tid < nbk) X[(int64_t)blockIdx.z * ldx + F.p0 + t0 + tid] = ysh[tid];
+}
+
+// w(t) = x(p0 + t) - panel21(:, t)' * x(update rows): one wavefront per pivot column
+template <bool UNIT>
+__global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_bwd_big_init(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ X,
+                                                                  const int64_t ldx, double *__restrict__ W, const int64_t wsize)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LuFrontD F = d.fr[list[blockIdx.y]];
+    const int m = F.m, k = F.k;
+    const int t = blockIdx.x * (LU_NT_SOLVE / 64) + wave;
+    if (t >= k) return;
+    const double *x = X + (int64_t)blockIdx.z * ldx;
+    double *fvec = W + (int64_t)blockIdx.z * wsize + F.wx - k;
+    const double *__restrict__ panel = (UNIT ? d.Lx : d.Ux) + F.px;
+    const int32_t *__restrict__ rows = d.rowidx + F.rowptr;
+    double s = 0.0;
+    for (int i = k + lane; i < m; i += 64) s += panel[i + (int64_t)t * m] * x[rows[i]];
+    for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) fvec[t] = x[F.p0 + t] - s;
+}
+
+template <bool UNIT>
+__global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_bwd_big_step(const LuDev d, const int32_t *__restrict__ list, double *__restrict__ X,
+                                                                  const int64_t ldx, double *__restrict__ W, const int64_t wsize, const int t0)
+{
+    __shared__ double ysh[LU_SB];
+    constexpr int NT = LU_NT_SOLVE;
+    const int tid = threadIdx.x;
+    const LuFrontD F = d.fr[list[blockIdx.y]];
+    const int m = F.m, k = F.k;
+    if (t0 >= k) return;
+    const int nbk = min(LU_SB, k - t0);
+    const int s0 = blockIdx.x * LU_BIG_CHUNK, s1 = min(t0, ((int)blockIdx.x + 1) * LU_BIG_CHUNK);
+    if (s0 >= s1 && blockIdx.x != 0) return;
+    double *fvec = W + (int64_t)blockIdx.z * wsize + F.wx - k;
+    const double *__restrict__ panel = (UNIT ? d.Lx : d.Ux) + F.px;
+    if (tid < 64) wave_tri_bwd<UNIT>(panel, m, t0, nbk, fvec, ysh);
+    __syncthreads();
+    for (int s2 = s0 + tid; s2 < s1; s2 += NT) {
+        const double *__restrict__ colp = panel + t0 + (int64_t)s2 * m;
+        double acc = 0.0;
+        for (int t = 0; t < nbk; t++) acc += colp[t] * ysh[t];
+        fvec[s2] -= acc;
+    }
+    if (blockIdx.x == 0 && tid < nbk)
+        X[(int64_t)blockIdx.z * ldx + F.p0 + (UNIT ? d.lperm[F.p0 + t0 + tid] : t0 + tid)] = ysh[tid];
+}
+
 }  // namespace
 
 // gfx950: a workgroup may use all 160 KB of a CU's LDS; beyond 64 KB the kernel must be told so once.
@@ -809,6 +958,33 @@ void launch_lu_bwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int 
     const size_t sm = (size_t)(max_m + max_k) * sizeof(double);
     if (unit) hipLaunchKernelGGL(k_lu_bwd<true>, dim3(cnt, nrhs), dim3(LU_NT_SOLVE), sm, st, d, list, X, ldx, max_m);
     else hipLaunchKernelGGL(k_lu_bwd<false>, dim3(cnt, nrhs), dim3(LU_NT_SOLVE), sm, st, d, list, X, ldx, max_m);
+}
+
+
+void launch_lu_fwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,
+                       double *W, int64_t wsize, hipStream_t st)
+{
+    if (cnt <= 0 || nrhs <= 0) return;
+    const int chunks = (max_m + LU_BIG_CHUNK - 1) / LU_BIG_CHUNK;
+    if (unit) hipLaunchKernelGGL(k_lu_fwd_big_init<true>, dim3(cnt, nrhs), dim3(LU_NT_SOLVE), (size_t)max_k * sizeof(double), st, d, list, X, ldx, W, wsize);
+    else hipLaunchKernelGGL(k_lu_fwd_big_init<false>, dim3(cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize);
+    for (int t0 = 0; t0 < max_k; t0 += LU_SB) {
+        if (unit) hipLaunchKernelGGL(k_lu_fwd_big_step<true>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
+        else hipLaunchKernelGGL(k_lu_fwd_big_step<false>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
+    }
+}
+
+void launch_lu_bwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,
+                       double *W, int64_t wsize, hipStream_t st)
+{
+    if (cnt <= 0 || nrhs <= 0) return;
+    const int chunks = (max_k + LU_BIG_CHUNK - 1) / LU_BIG_CHUNK, colwg = (max_k + LU_NT_SOLVE / 64 - 1) / (LU_NT_SOLVE / 64);
+    if (unit) hipLaunchKernelGGL(k_lu_bwd_big_init<true>, dim3(colwg, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize);
+    else hipLaunchKernelGGL(k_lu_bwd_big_init<false>, dim3(colwg, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize);
+    for (int t0 = (max_k - 1) / LU_SB * LU_SB; t0 >= 0; t0 -= LU_SB) {
+        if (unit) hipLaunchKernelGGL(k_lu_bwd_big_step<true>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
+        else hipLaunchKernelGGL(k_lu_bwd_big_step<false>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
+    }
 }
 
 void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double *rmax, hipStream_t st)

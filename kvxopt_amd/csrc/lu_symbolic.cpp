@@ -300,8 +300,8 @@ void lu_build_plan(const LuSymbolic &Y, LuPlan &P)
         P.px[f + 1] = P.px[f] + m * k;
         if (m <= KVX_LU_LDS_M) { P.upd_off[f] = P.arena; P.upd_ld[f] = (int32_t)u; P.arena += u * u; }
         else { P.upd_off[f] = P.arena + k + k * m; P.upd_ld[f] = (int32_t)m; P.arena += m * m; }
-        P.wx[f] = P.wsize;
-        P.wsize += u;
+        if (m > KVX_LU_SOLVE_BIG_M) { P.wx[f] = P.wsize + k; P.wsize += m; }     // whole work vector; update part at offset k
+        else { P.wx[f] = P.wsize; P.wsize += u; }
         P.max_m = std::max(P.max_m, (int32_t)m);
         P.max_k = std::max(P.max_k, (int32_t)k);
         P.lnz_bound += k * m - k * (k - 1) / 2;
@@ -323,13 +323,18 @@ void lu_build_plan(const LuSymbolic &Y, LuPlan &P)
         for (int64_t f = 0; f < nf; f++) P.levellist[(size_t)cur[P.fr[f].depth]++] = (int32_t)f;
     }
     P.nlds.assign((size_t)P.nlevels, 0);
+    P.nsbig.assign((size_t)P.nlevels, 0);
     for (int32_t l = 0; l < P.nlevels; l++) {
         std::stable_sort(P.levellist.begin() + P.levelptr[l], P.levellist.begin() + P.levelptr[l + 1],
                          [&](int32_t a, int32_t b) {
                              const bool la = P.fr[a].m <= KVX_LU_LDS_M, lb = P.fr[b].m <= KVX_LU_LDS_M;
-                             return la != lb ? la : P.fr[a].m > P.fr[b].m;
+                             if (la != lb) return la;
+                             return la ? P.fr[a].m > P.fr[b].m : P.fr[a].m < P.fr[b].m;
                          });
-        for (int64_t q = P.levelptr[l]; q < P.levelptr[l + 1]; q++) P.nlds[l] += P.fr[P.levellist[q]].m <= KVX_LU_LDS_M;
+        for (int64_t q = P.levelptr[l]; q < P.levelptr[l + 1]; q++) {
+            P.nlds[l] += P.fr[P.levellist[q]].m <= KVX_LU_LDS_M;
+            P.nsbig[l] += P.fr[P.levellist[q]].m > KVX_LU_SOLVE_BIG_M;
+        }
     }
     // scatter map of the caller's entries
     std::vector<int32_t> posrow((size_t)n), poscol((size_t)n);

@@ -58,13 +58,16 @@ struct LuPlan {
     std::vector<int32_t> a_dst;           // r + c*m inside the front
     int32_t nlevels = 0;
     std::vector<int64_t> levelptr;        // level L = fronts at depth L (roots: 0)
-    std::vector<int32_t> levellist;       // inside a level: LDS-resident fronts first, then the big ones
+    std::vector<int32_t> levellist;       // inside a level: LDS-resident fronts first (largest first), then the big ones (smallest first)
     std::vector<int32_t> nlds;            // [nlevels] how many fronts of the level are LDS resident (m <= lds_m)
+    std::vector<int32_t> nsbig;           // [nlevels] how many fronts (the LAST of the level's list) take the multi-workgroup solve path
     int64_t arena = 0, wsize = 0, lsize = 0;
     int32_t max_m = 0, max_k = 0;
     int64_t lnz_bound = 0, unz_bound = 0;
 };
 
+constexpr int KVX_LU_SOLVE_BIG_M = 384;   // fronts of order > this are swept by many workgroups (one launch per 32 pivots); their solve
+                                          // work vector holds all m entries (the update part at offset k)
 constexpr int KVX_LU_LDS_M = 136;        // fronts of order <= this are factored inside LDS (136*136*8 = 144.5 KB of the 160 KB a gfx950 workgroup may use)
 
 // values may be nullptr (pattern-only: plain maximum transversal).  Throws std::runtime_error on invalid input.
