@@ -34,8 +34,9 @@ struct kvx_lu_num {
     LuPlan P;
     int64_t n = 0, nnz = 0;
     bool dev = false, factored = false;
-    hipStream_t st = nullptr, st2 = nullptr;      // st2: the blocked big-front chain of a level runs beside its LDS fronts
-    std::vector<hipEvent_t> evA, evB;
+    hipStream_t st = nullptr, st2 = nullptr, st3 = nullptr;   // st2: the blocked big-front chain of a level runs beside its LDS fronts;
+                                                              // st3: every other size class of a wide level
+    std::vector<hipEvent_t> evA, evB, evC, evD;
     hipEvent_t ev0 = nullptr;
     LuFrontD *d_fr = nullptr;
     int32_t *d_rowidx = nullptr, *d_rel = nullptr, *d_children = nullptr, *d_adst = nullptr, *d_ai32 = nullptr;
@@ -159,10 +160,12 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     launch_lu_rowmax(N->nnz, N->d_ai32, Ax_dev, N->d_rmax, N->st);
     launch_lu_rinv(N->n, N->d_rmax, N->d_rinv, N->st);
     while ((int32_t)N->evA.size() < P.nlevels) {
-        hipEvent_t a, b2;
+        hipEvent_t a, b2, c2, d2;
         HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&b2, hipEventDisableTiming));
-        N->evA.push_back(a); N->evB.push_back(b2);
+        HIPCHK(hipEventCreateWithFlags(&c2, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d2, hipEventDisableTiming));
+        N->evA.push_back(a); N->evB.push_back(b2); N->evC.push_back(c2); N->evD.push_back(d2);
     }
     HIPCHK(hipEventRecord(N->ev0, N->st));
     HIPCHK(hipStreamWaitEvent(N->st2, N->ev0, 0));
@@ -174,12 +177,28 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
         if (hasA && lastB >= 0) HIPCHK(hipStreamWaitEvent(N->st, N->evB[lastB], 0));
         if (hasB && lastA >= 0) HIPCHK(hipStreamWaitEvent(N->st2, N->evA[lastA], 0));
         int64_t q = b;
+        int run = 0;
+        bool forked = false;
         while (q < b + nl) {                                  // runs of one LDS size class (list sorted by m descending);
             const int c = lds_class(P.fr[P.levellist[q]].m);  // a thin level goes out as ONE launch sized for its largest front
             int64_t q2 = q;
             while (q2 < b + nl && (nl <= 256 || lds_class(P.fr[P.levellist[q2]].m) == c)) q2++;
-            launch_lu_fronts(d, N->d_lists + q, (int)(q2 - q), c, 0, Ax_dev, N->tol, N->stol, reuse, N->st);
+            hipStream_t s = N->st;
+            if (run & 1) {                                    // independent launches, each as long as its slowest front: alternate streams
+                if (!forked) {
+                    HIPCHK(hipEventRecord(N->evC[l], N->st));
+                    HIPCHK(hipStreamWaitEvent(N->st3, N->evC[l], 0));
+                    forked = true;
+                }
+                s = N->st3;
+            }
+            launch_lu_fronts(d, N->d_lists + q, (int)(q2 - q), c, 0, Ax_dev, N->tol, N->stol, reuse, s);
             q = q2;
+            run++;
+        }
+        if (forked) {
+            HIPCHK(hipEventRecord(N->evD[l], N->st3));
+            HIPCHK(hipStreamWaitEvent(N->st, N->evD[l], 0));
         }
         if (hasB) {
             int bm = 0, bk = 0;                                // big fronts of the level: blocked multi-launch path
@@ -241,6 +260,7 @@ int ensure_device(kvx_lu_num *N)
     }
     HIPCHK(hipStreamCreateWithFlags(&N->st, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&N->st2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&N->st3, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&N->ev0, hipEventDisableTiming));
     std::vector<int32_t> ai32((size_t)N->nnz);
     for (int64_t p = 0; p < N->nnz; p++) ai32[p] = (int32_t)N->sym->Y.Ai[p];
@@ -354,7 +374,10 @@ void kvx_lu_free_numeric(kvx_lu_num *N)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : N->evA) (void)hipEventDestroy(e);
     for (hipEvent_t e : N->evB) (void)hipEventDestroy(e);
+    for (hipEvent_t e : N->evC) (void)hipEventDestroy(e);
+    for (hipEvent_t e : N->evD) (void)hipEventDestroy(e);
     if (N->ev0) (void)hipEventDestroy(N->ev0);
+    if (N->st3) (void)hipStreamDestroy(N->st3);
     if (N->st2) (void)hipStreamDestroy(N->st2);
     if (N->st) (void)hipStreamDestroy(N->st);
     delete N;
