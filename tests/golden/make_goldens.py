@@ -302,6 +302,29 @@ def g6_conelp_std():
                "cases": meta}, open(os.path.join(HERE, "g6_conelp_std.json"), "w"), indent=1, default=float)
 
 
+def g7_mps():
+    """modeling.op.fromfile + solve on the reference's own fixture tests/boeing2.mps (tests/test_modeling.py:59-63):
+    the parsed problem (objective, inequality / equality counts) and the solution of the reference's default LP path
+    (solvers.lp -> conelp, dense LAPACK kkt 'chol': pure reference).  The MPS file itself is DATA (Netlib LP) and is
+    kept next to the goldens as tests/golden/boeing2.mps."""
+    import shutil
+    from kvxopt import solvers
+    from kvxopt.modeling import op
+    solvers.options["show_progress"] = False
+    src = os.path.join(REF, "tests", "boeing2.mps")
+    shutil.copyfile(src, os.path.join(HERE, "boeing2.mps"))
+    lp = op()
+    lp.fromfile(src)
+    lp.solve()
+    assert lp.status == "optimal"
+    xs = {v.name: float(v.value[0]) for v in lp.variables()}
+    meta = {"via": "reference (modeling.op.fromfile, solvers.lp with the dense kkt solver)", "status": lp.status,
+            "objective": float(lp.objective.value()[0]), "n_variables": len(lp.variables()),
+            "n_inequalities": len(lp.inequalities()), "n_equalities": len(lp.equalities()), "x": xs}
+    json.dump(meta, open(os.path.join(HERE, "g7_boeing2.json"), "w"), indent=1)
+    print("boeing2: objective", meta["objective"], "vars", meta["n_variables"], "ineq", meta["n_inequalities"], "eq", meta["n_equalities"])
+
+
 if __name__ == "__main__":
     stage()
     import kvxopt
@@ -312,4 +335,5 @@ if __name__ == "__main__":
     g4_conelp()
     g5_coneqp()
     g6_conelp_std()
+    g7_mps()
     print("goldens written to", HERE)
