@@ -43,8 +43,9 @@ typedef struct {
     double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .05)     */
     double  relax_z2;
     double  relax_z3;
-    double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off                     */
-    int32_t reserved[8];
+    double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off: a pivot d <= 0 fails.  > 0: CHOLMOD's rule,
+                             * L_kk < dbound is replaced by dbound; with reserved[3] = 1 by 1e64 (the row drops out of the solves) */
+    int32_t reserved[8];    /* [0] nd_leaf, [1] leaf_cols, [2] leaf_rows, [3] dbound mode                                       */
 } kvx_chol_opts;
 
 void kvx_chol_default_opts(kvx_chol_opts *o);

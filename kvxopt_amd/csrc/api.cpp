@@ -391,7 +391,14 @@ int ensure_device(kvx_chol *F)
         if ((rc = upload(&F->d_tiles, tiles))) return rc;
     }
     F->ds = DevSym{F->d_k, F->d_m, F->d_first, F->d_px, F->d_rowptr, F->d_rowidx, F->d_rel,
-                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
+                   F->d_ux, F->d_wx, F->d_childptr, F->d_children, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles, 0.0, 0.0};
+    if (F->opts.dbound > 0.0) {
+        // cholmod.options['dbound'] (cholmod.c:116-117; CHOLMOD: "entries of L_kk smaller than dbound are replaced by dbound").
+        // reserved[3] = 1: replace by 1e64 instead -- the row drops out of the solves (the customary cure for normal equations
+        // A D A' that lose rank numerically near the end of an interior-point run; used by lp.KKTDiagEqDev).
+        F->ds.piv_floor = F->opts.dbound * F->opts.dbound;
+        F->ds.piv_repl = F->opts.reserved[3] == 1 ? 1e128 : F->ds.piv_floor;
+    }
     F->lists_host = S.levellist;
     F->lptr_host = S.levelptr;
     build_plan(F);

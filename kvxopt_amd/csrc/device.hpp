@@ -26,6 +26,9 @@ struct DevSym {
     const struct FrontDesc *fd;
     const struct ChildDesc *cd;
     const int32_t *tiles;     // per child of a big front: first child column landing in each 16-column parent tile
+    // Pivot rule (cholmod.options['dbound'], cholmod.c:116-117): a pivot d <= piv_floor is replaced by piv_repl
+    // (piv_repl > 0) instead of ending the factorisation.  0 / 0 = the plain rule: d <= 0 (or NaN) fails.
+    double piv_floor, piv_repl;
 };
 
 struct FrontDesc {            // 64 bytes
@@ -87,18 +90,27 @@ __device__ __forceinline__ void kvx_sqrt_rsqrt(double d, double &root, double &i
 // ~40 cycles per use, an LDS broadcast read + fma ~10), and the loads of the buffer overlap the
 // rsqrt chain because the UNSCALED column is published and scaled by 1/d on the consumer side.
 // cb2: LDS double[2][64] (double-buffered by J parity); dinv: optional output of 1/l_jj.
+// floor: pivots d <= floor (or NaN) are replaced by sub; flag_all: 1 = such a pivot also ends the factorisation (the plain
+// rule; sub = 1 only keeps the arithmetic finite), 0 = it does not (dbound mode: no failure is reported, NaN included).
+struct PivRule { double floor, sub; int flag_all; };
+__device__ __forceinline__ PivRule make_piv_rule(const DevSym &ds)
+{
+    return PivRule{ds.piv_floor, ds.piv_repl > 0.0 ? ds.piv_repl : 1.0, ds.piv_repl > 0.0 ? 0 : 1};
+}
 template <int KMAX, int J>
 __device__ __forceinline__ void kvx_col_step(double (&a)[KMAX], int k, int r, int *status, int col0,
-                                             double *dinv, double *cb2)
+                                             double *dinv, double *cb2, const PivRule pr)
 {
     if (J < k) {                                   // wave-uniform
         double *cb = cb2 + (J & 1) * 64;
         const double aj = a[J];
         cb[r] = aj;
         double d = kvx_readlane(aj, J);
-        if (!(d > 0.0)) {
-            if (r == 0) atomicMin(status, col0 + J);
-            d = 1.0;
+        if (!(d > pr.floor)) {
+            if (pr.flag_all) {
+                if (r == 0) atomicMin(status, col0 + J);
+            }
+            d = pr.sub;
         }
         double ljj, inv;
         kvx_sqrt_rsqrt(d, ljj, inv);
@@ -111,9 +123,9 @@ __device__ __forceinline__ void kvx_col_step(double (&a)[KMAX], int k, int r, in
 }
 template <int KMAX, int... Js>
 __device__ __forceinline__ void kvx_col_steps(double (&a)[KMAX], int k, int r, int *status, int col0, double *dinv,
-                                              double *cb2, std::integer_sequence<int, Js...>)
+                                              double *cb2, const PivRule pr, std::integer_sequence<int, Js...>)
 {
-    (kvx_col_step<KMAX, Js>(a, k, r, status, col0, dinv, cb2), ...);
+    (kvx_col_step<KMAX, Js>(a, k, r, status, col0, dinv, cb2, pr), ...);
 }
 #endif
 

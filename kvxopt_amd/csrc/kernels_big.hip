@@ -55,15 +55,15 @@ __device__ __forceinline__ int y_idx(int i, int c) { return blk_slot(i >> 4, c >
 // interleave: every lane stores (the non-factor lanes into a dump slot), a failed pivot is only
 // recorded in `bad`, and the diagonal is d * rsqrt(d) like every other entry of the column.
 template <int J>
-__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad)
+__device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad, const PivRule pr)
 {
     double *cb = colbuf + (J & 1) * 80;
     const double aj = acc[J];
     cb[wslot] = aj;
     double d = kvx_readlane(aj, J);
-    const bool neg = !(d > 0.0);
-    bad = (neg && bad > J) ? J : bad;
-    d = neg ? 1.0 : d;
+    const bool neg = !(d > pr.floor);                           // same instruction count as the plain rule (floor = 0, sub = 1):
+    bad = (neg && bad > J) ? J : bad;                           // whether a recorded step counts is decided after the sweep
+    d = neg ? pr.sub : d;
     double inv = __builtin_amdgcn_rsq(d);          // 1/sqrt(d): hardware seed + two Newton steps
     const double hd = 0.5 * d;
     inv = inv * __builtin_fma(-hd * inv, inv, 1.5);
@@ -75,10 +75,10 @@ __device__ __forceinline__ void diag16_step(double (&acc)[16], double *colbuf, i
     acc[J] = (rr < J) ? 0.0 : lj;
 }
 template <int... Js>
-__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad,
+__device__ __forceinline__ void diag16_steps(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad, const PivRule pr,
                                              std::integer_sequence<int, Js...>)
 {
-    (diag16_step<Js>(acc, colbuf, wslot, rr, bad), ...);
+    (diag16_step<Js>(acc, colbuf, wslot, rr, bad, pr), ...);
 }
 
 struct PotrfLds {
@@ -90,7 +90,7 @@ struct PotrfLds {
 
 // Factor + invert the block held in lds.S (lower triangle, identity padding beyond nbk; the caller has
 // filled it and passed a barrier).  256 threads.  Ends with a barrier: S = L, Yl = L^{-1}.
-__device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *status, int col0)
+__device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *status, int col0, const PivRule pr)
 {
     const int nblk = (nbk + 15) >> 4;
     const int i = tid & 63;
@@ -110,8 +110,8 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
                 acc[c] = fac ? lv : ((i < 32 && c == lr) ? 1.0 : 0.0);
             }
             int bad = 16;
-            diag16_steps(acc, lds.colbuf, fac ? lr : i, fac ? lr : 1000, bad, std::make_integer_sequence<int, 16>());
-            if (bad < 16 && i == 0) atomicMin(status, col0 + 16 * s + bad);
+            diag16_steps(acc, lds.colbuf, fac ? lr : i, fac ? lr : 1000, bad, pr, std::make_integer_sequence<int, 16>());
+            if (bad < 16 && i == 0 && pr.flag_all) atomicMin(status, col0 + 16 * s + bad);
             if (fac) {
 #pragma unroll
                 for (int c = 0; c < 16; c++) Sd[lr + 16 * c] = acc[c];                 // zeros above the diagonal
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__r
         }
     }
     __syncthreads();
-    potrf_lds(lds, nbk, tid, status, fd.first + jb);
+    potrf_lds(lds, nbk, tid, status, fd.first + jb, make_piv_rule(ds));
     potrf_store(lds, nbk, tid, P, m, jb, Linv + fd.linv + (int64_t)(jb / NB) * NB * NB);
 }
 
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
                 if (t <= w) lds.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? old[t][q] - acc[t][q] : (cc == i ? 1.0 : 0.0);
             }
         __syncthreads();
-        potrf_lds(lds, nb2, threadIdx.x, status, fd.first + t0);
+        potrf_lds(lds, nb2, threadIdx.x, status, fd.first + t0, make_piv_rule(ds));
         potrf_store(lds, nb2, threadIdx.x, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
     }
 }
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
     }
     if (fuse) {
         __syncthreads();
-        potrf_lds(lds.po, nb2, tid, status, fd.first + t0);         // (waves 4-7 only keep its barriers company)
+        potrf_lds(lds.po, nb2, tid, status, fd.first + t0, make_piv_rule(ds));   // (waves 4-7 only keep its barriers company)
         if (tid < 256) potrf_store(lds.po, nb2, tid, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
     }
 }

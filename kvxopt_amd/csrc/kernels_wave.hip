@@ -32,7 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // its own columns; double buffering makes the one barrier per column sufficient.
 template <int KMAX, int J>
 __device__ __forceinline__ void quad_col_step(double (&a)[KMAX / 2], int k, int row, int p, int *status, int col0,
-                                              double *cb2)
+                                              double *cb2, const PivRule pr)
 {
     if (J < k) {                                   // workgroup-uniform
         double *cb = cb2 + (J & 1) * 128;
@@ -41,9 +41,11 @@ __device__ __forceinline__ void quad_col_step(double (&a)[KMAX / 2], int k, int 
         __syncthreads();
         const double aj = cb[row];
         double d = cb[J];
-        if (!(d > 0.0)) {
-            if (row == 0 && p == 0) atomicMin(status, col0 + J);
-            d = 1.0;
+        if (!(d > pr.floor)) {
+            if (pr.flag_all) {
+                if (row == 0 && p == 0) atomicMin(status, col0 + J);
+            }
+            d = pr.sub;
         }
         double ljj, inv;
         kvx_sqrt_rsqrt(d, ljj, inv);
@@ -60,9 +62,9 @@ __device__ __forceinline__ void quad_col_step(double (&a)[KMAX / 2], int k, int 
 }
 template <int KMAX, int... Js>
 __device__ __forceinline__ void quad_col_steps(double (&a)[KMAX / 2], int k, int row, int p, int *status, int col0,
-                                               double *cb2, std::integer_sequence<int, Js...>)
+                                               double *cb2, const PivRule pr, std::integer_sequence<int, Js...>)
 {
-    (quad_col_step<KMAX, Js>(a, k, row, p, status, col0, cb2), ...);
+    (quad_col_step<KMAX, Js>(a, k, row, p, status, col0, cb2, pr), ...);
 }
 
 // Extend-add of one child's update matrix (lower triangle, uc x uc, ld = uc) into the LDS image F.
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
 #pragma unroll
         for (int j = 0; j < KMAX; j++) a[j] += kvx_ld0(F, r + j * m, j < k && r < m);
     }
-    kvx_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, cb2, std::make_integer_sequence<int, KMAX>());
+    kvx_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, cb2, make_piv_rule(ds), std::make_integer_sequence<int, KMAX>());
     if (r < m) {
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
 #pragma unroll
         for (int t = 0; t < KMAX / 2; t++) a[t] += kvx_ld0(F, row + (2 * t + p) * m, 2 * t + p < k && row < m);
     }
-    quad_col_steps<KMAX>(a, k, row, p, status, fd.first, cb2, std::make_integer_sequence<int, KMAX>());
+    quad_col_steps<KMAX>(a, k, row, p, status, fd.first, cb2, make_piv_rule(ds), std::make_integer_sequence<int, KMAX>());
     if (row < m) {
 #pragma unroll
         for (int t = 0; t < KMAX / 2; t++)

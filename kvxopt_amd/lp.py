@@ -235,13 +235,22 @@ class KKTDiagEqDev:
         h = ctypes.c_void_p()
         raise_for(lib().kvx_atda_plan(n, p, _lib.pi(ATp), _lib.pi(np.ascontiguousarray(ATi)), None, None, ctypes.byref(h)))
         self._plan = h
+        self.A2 = SpMatDev(p, n, Ap, Ai, Ax ** 2)                     # diag(K) = (A o A) S^-1
+        self.kd = DVec(max(p, 1))
+        self.kscale = 1.0
         knz = ctypes.c_int64()
         raise_for(lib().kvx_atda_pattern(h, ctypes.byref(knz), None, None))
         self.Kp = np.empty(p + 1, dtype=np.int64)
         Ki = np.empty(max(knz.value, 1), dtype=np.int64)
         raise_for(lib().kvx_atda_pattern(h, ctypes.byref(knz), _lib.pi(self.Kp), _lib.pi(Ki)))
         self.Ki = Ki[:knz.value].copy()
-        self.fac = Factor(p, self.Kp, self.Ki, "L", None, chol_opts)
+        # K is factored after scaling to max(diag K) = 1 with the pivot rule "d <= 1e-30 -> 1e128" (cholmod's dbound in its
+        # drop-the-row form): near the solution S^-1 = diag(x ./ z) spans twenty orders of magnitude and K = A S^-1 A' loses
+        # rank in floating point; the reference stops there with status 'unknown' (coneprog.py:1078-1109), interior-point
+        # codes built on normal equations zero the affected multipliers instead.
+        ko = {"dbound": 1e-15, "dbound_drop": 1}
+        ko.update(chol_opts or {})
+        self.fac = Factor(p, self.Kp, self.Ki, "L", None, ko)
         self.ATx = DVec(max(ATx.size, 1), ATx if ATx.size else None)
         self.Kx = DVec(self.Ki.size)
         self.w, self.t = DVec(ml), DVec(ml)
@@ -258,10 +267,15 @@ class KKTDiagEqDev:
     def factor(self, di, sync=True):
         self.w.sqr_of(di)
         self.G2.gemv(self.w, self.sdiag, trans="T")                   # S_kk = sum_i di_i^2 G_ik^2
-        if -self.sdiag.max_step() <= 0.0:                             # min_k S_kk <= 0: S is singular
-            raise ArithmeticError(0)
         self.sinv.fill(1.0).div(self.sdiag)
+        self.A2.gemv(self.sinv, self.kd, trans="N", alpha=-1.0)       # -diag(K)
+        smin, kmax = reduce_multi([("max", self.sdiag), ("max", self.kd)])   # one host round trip: -min S_kk, max diag K
+        if -smin <= 0.0 or not (kmax > 0.0) or not np.isfinite(kmax):  # S singular / K = 0
+            raise ArithmeticError(0)
+        self.kscale = 1.0 / kmax
+        self.sinv.scal(self.kscale)                                   # K' = A (S^-1 / max diag K) A'
         raise_for(lib().kvx_atda_assemble_dev(self._plan, self.ATx.ptr, self.sinv.ptr, None, self.Kx.ptr))
+        self.sinv.scal(kmax)
         self.fac.factorize_dev(self.Kx.ptr, sync=sync)
         self.di = di
         self.nfactor += 1
@@ -277,7 +291,8 @@ class KKTDiagEqDev:
         self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)        # x := bx + G' W^-1 W^-T bz
         self.u.xmy(1.0, self.sinv, x)                                 # u := S^-1 x
         self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)       # y := A S^-1 x - by
-        self.fac.solve_dev(y.ptr, 0, 1, max(1, self.p), sync=not self.async_solves)   # y := K^-1 y = uy
+        self.fac.solve_dev(y.ptr, 0, 1, max(1, self.p), sync=not self.async_solves)   # y := K'^-1 y
+        y.scal(self.kscale)                                           # K^-1 = K'^-1 / max diag K: uy
         self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)
         x.mul(self.sinv)                                              # x := S^-1 (x - A' uy) = ux
         self.G.gemv(x, self.t, trans="N")
@@ -296,6 +311,7 @@ class KKTDiagEqDev:
             self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)
             raise_for(lib().kvx_vec_copy_dev(p, y.ptr, self._y2.ptr + 8 * p * k))
         self.fac.solve_dev(self._y2.ptr, 0, 2, max(1, p), sync=not self.async_solves)
+        self._y2.scal(self.kscale)
         for k, (x, y, z) in enumerate(((xa, ya, za), (xb, yb, zb))):
             raise_for(lib().kvx_vec_copy_dev(p, self._y2.ptr + 8 * p * k, y.ptr))
             self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)

@@ -297,3 +297,39 @@ def test_full_size_properties():
     assert np.array_equal(d1, F.diag())                        # bitwise reproducible refactor
     x2 = b.copy(); F.solve(x2)
     assert np.array_equal(x, x2)
+
+
+def test_dbound_replaces_small_pivots():
+    """cholmod.options['dbound'] (cholmod.c:116-117; CHOLMOD: diagonal entries of L below dbound are replaced by dbound),
+    in every kernel class (wave, LDS, blocked), and the drop-the-row form used by the interior-point driver."""
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import spmatrix, matrix
+    A = spmatrix([4.0, 1e-12, 9.0], [0, 1, 2], [0, 1, 2])
+    cholmod.options["dbound"] = 1e-3
+    try:
+        F = cholmod.symbolic(A)
+        cholmod.numeric(A, F)
+        assert sorted(np.array(cholmod.diag(F)._a).ravel()) == pytest.approx([1e-3, 2.0, 3.0], rel=1e-12)
+    finally:
+        cholmod.options.clear()
+    # a singular Laplacian (pure Neumann problem): the last pivot of every kernel class is ~ 0 or slightly negative
+    for g in (6, 11, 30):                       # fronts of the wave, LDS and blocked classes
+        n, cp, ri, vx = workloads.laplacian_2d(g)
+        vx = vx.copy()
+        # subtract the coupling from the diagonal: A = graph Laplacian, A 1 = 0
+        import scipy.sparse as sp
+        L = sp.csc_matrix((vx, ri, cp), shape=(n, n))
+        Lf = L + sp.tril(L, -1).T
+        off = np.asarray(abs(Lf - sp.diags(Lf.diagonal())).sum(axis=1)).ravel()
+        Lg = sp.tril(Lf - sp.diags(Lf.diagonal()) + sp.diags(off)).tocsc(); Lg.sort_indices()
+        with pytest.raises(ArithmeticError):
+            F0 = Factor(n, Lg.indptr, Lg.indices); F0.factorize(Lg.data * 1.0 - 0.0)
+            if F0.info()["minor"] == n:          # rounding may leave the last pivot tiny but positive
+                raise ArithmeticError("positive by rounding")
+        F1 = Factor(n, Lg.indptr, Lg.indices, opts={"dbound": 1e-6, "dbound_drop": 1})
+        F1.factorize(Lg.data)                    # no exception: the pivot is replaced, its row drops out
+        Afull = Lg + sp.tril(Lg, -1).T
+        rng = np.random.default_rng(g)
+        b = rng.standard_normal(n); b -= b.mean()            # consistent right-hand side
+        x = b.copy(); F1.solve(x)
+        assert np.abs(Afull @ x - b).max() < 1e-8 * max(1.0, np.abs(x).max())
