@@ -108,3 +108,29 @@ def test_ordering_quality_on_grid():
     nat = Factor(n, cp, ri, opts={"ordering": 1}).info()
     assert nd["lnz"] < 0.5 * nat["lnz"] and nd["flops"] < 0.3 * nat["flops"]
     assert nd["nlevels"] < 40
+
+
+def test_amd_order_mirror(golden_dir):
+    """kvxopt.amd.order (amd.c:131-223): an 'i' matrix holding a fill-reducing permutation of the `uplo` triangle."""
+    import os
+    from kvxopt_amd import amd
+    from kvxopt_amd.base import spmatrix, matrix
+    from kvxopt_amd.chol import Factor
+    z = np.load(os.path.join(golden_dir, "bcsstk13.npz"))
+    n = int(z["n"])
+    A = spmatrix.from_ccs(n, n, z["colptr"], z["rowind"], z["values"])
+    p = amd.order(A)
+    assert p.typecode == "i" and p.size == (n, 1) and sorted(p._a) == list(range(n))
+    nat = Factor(n, z["colptr"], z["rowind"], "L", np.arange(n)).info()["lnz"]
+    got = Factor(n, z["colptr"], z["rowind"], "L", np.asarray(p._a)).info()["lnz"]
+    assert got < 0.8 * nat                                           # bcsstk13: 3.1e5 against 4.3e5 in the stored order
+    n2, cp2, ri2, _ = workloads.laplacian_2d(60)
+    A2 = spmatrix.from_ccs(n2, n2, cp2, ri2, np.ones(ri2.size))
+    p2 = np.asarray(amd.order(A2)._a)
+    assert Factor(n2, cp2, ri2, "L", p2).info()["lnz"] < 0.4 * Factor(n2, cp2, ri2, "L", np.arange(n2)).info()["lnz"]
+    with pytest.raises(TypeError):
+        amd.order(spmatrix([1.0], [0], [0], (1, 2)))
+    with pytest.raises(ValueError):
+        amd.order(A, uplo="X")
+    with pytest.raises(TypeError):
+        amd.order(matrix(np.eye(2)))
