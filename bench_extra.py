@@ -5,6 +5,7 @@
   chol21  : the "~20 nnz/row" north-star variant, 21-point stencil on the 1000 x 1000 grid (workloads.stencil21_2d)
   lap3d   : 7-point Laplacian on a 100^3 grid (n = 1e6; one eighth of config 5's unknowns): the flop-bound regime
             (nnz(L) = 5.4e8, 2.7e12 flops, top front of order 14 082)
+  lap3d200: BASELINE.json configs[4] (7-point Laplacian 200^3, n = 8e6) on ONE GPU -- not part of the default run
   lp4a    : BASELINE.json configs[3] literally: standard form, 50 000 equality rows, 200 000
             variables, G = -I; the equality branch of misc.kkt_chol2 (K = A S^-1 A' refactored every iteration)
   lp4b    : BASELINE.json configs[3] in inequality form: the device-resident
@@ -216,6 +217,8 @@ def main():
             out = chol_case("chol21 (21-point stencil)", *workloads.stencil21_2d(args.grid), 1, args.steps, args.warmup)
         elif case == "lap3d":
             out = chol_case("lap3d 100^3", *workloads.laplacian_3d(100), 1, max(2, args.steps // 3), 1)
+        elif case == "lap3d200":                  # BASELINE configs[4] on ONE GPU: the whole factor (nnz(L) ~ 9e9) sits in HBM
+            out = chol_case("lap3d 200^3 (config 5, 1 GPU)", *workloads.laplacian_3d(200), 1, 2, 1)
         elif case == "lp4a":
             out = lp_std_case(250, 200)
         elif case == "lp4b":
