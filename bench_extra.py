@@ -13,6 +13,7 @@
             metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
             plus the per-iteration cost of one KKT factor (assembly + numeric Cholesky) and one KKT solve.
 
+  lp4c    : lp4b plus 200 random equality rows: general G and A together (dense K = A S^-1 A', lp.KKTGenEqDev)
   klu3    : BASELINE.json configs[2]: klu.linsolve on the ACTIVSg2000 power-flow Jacobian (4000 x 4000, 29 336 entries,
             tests/golden/ACTIVSg2000.npz), nrhs = 3: symbolic, first numeric, steady-state refactorisation and solve times,
             next to the CPU oracle and SciPy's SuperLU on the host.
@@ -128,6 +129,24 @@ def lp_std_case(gx, gy):
             "factorizations": sol["factorizations"]}
 
 
+def lp_eq_case(gx, gy, p):
+    """Config-4b grid LP plus p equality rows: general G AND A (lp.KKTGenEqDev: dense K = A S^-1 A')."""
+    from kvxopt_amd import lp, workloads
+    from kvxopt_amd.base import spmatrix
+    L = workloads.lp_grid_eq(gx, gy, p)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    lp.conelp(L["c"], G, L["h"], A=A, b=L["b"], options={"maxiters": 2})
+    t0 = time.perf_counter()
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    dt = time.perf_counter() - t0
+    return {"case": "lp4c grid %dx%d + %d equalities (general G)" % (gx, gy, p), "metric": "IPM iterations/s", "value": sol["iterations"] / dt,
+            "unit": "iterations/s", "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "loop_s": sol.get("loop seconds"),
+            "iterations_per_s_loop_only": sol["iterations"] / sol["loop seconds"] if sol.get("loop seconds") else None,
+            "ml": L["ml"], "n": L["n"], "p": p, "gap": sol["gap"], "primal_infeasibility": sol["primal infeasibility"],
+            "dual_infeasibility": sol["dual infeasibility"]}
+
+
 def klu_case(steps, warmup):
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
@@ -223,6 +242,8 @@ def main():
             out = lp_std_case(250, 200)
         elif case == "lp4b":
             out = lp_case(250, 200)
+        elif case == "lp4c":
+            out = lp_eq_case(250, 200, 200)
         elif case == "lu2d":
             out = lu2d_case(600, max(3, args.steps // 2))
         elif case == "klu3":

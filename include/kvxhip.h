@@ -207,12 +207,24 @@ int kvx_vec_scal_dev(int64_t n, double alpha, double *x);                       
 int kvx_vec_addc_dev(int64_t n, double c, double *x);                           /* x += c              */
 int kvx_vec_fill_dev(int64_t n, double c, double *x);                           /* x := c              */
 int kvx_vec_copy_dev(int64_t n, const double *x, double *y);                    /* y := x              */
+int kvx_vec_copy_strided_dev(int64_t n, const double *x, int64_t incx, double *y);   /* y[i] := x[i * incx] (e.g. a dense diagonal) */
 int kvx_vec_xmy_dev(int64_t n, double a, const double *x, const double *y, double b, double *z); /* z := a x.*y + b z */
 
 /* ---- sparse mat-vec: replaces base.gemv on spmatrix (sparse.c:1073-1104) ----------------- */
 /* y := alpha*op(A)*x + beta*y, A m x n CCS with int64 indices on the device. trans 'N'/'T'. */
 int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap_dev, const int64_t *Ai_dev,
                  const double *Ax_dev, double alpha, const double *x_dev, double beta, double *y_dev);
+
+/* ---- dense helpers of the equality-constrained KKT solve with a general S (misc.py:1476-1487, 1545): K = A S^-1 A' formed
+ * as a dense p x p matrix from X = S^-1 A' (kvx_chol_solve_dev with nrhs = p) when p is moderate ------------------------- */
+/* Y(j, c) = sum_i A(i, j) X(i, c) for the CCS matrix A with n columns and every column c < ncols of the dense X */
+int kvx_spmm_t_dev(int64_t n, int64_t ncols, const int64_t *Ap_dev, const int64_t *Ai_dev, const double *Ax_dev,
+                   const double *X_dev, int64_t ldx, double *Y_dev, int64_t ldy);
+/* D (m x n dense, leading dimension ld) := the CCS matrix */
+int kvx_dense_from_ccs_dev(int64_t m, int64_t n, const int64_t *Ap_dev, const int64_t *Ai_dev, const double *Ax_dev,
+                           double *D_dev, int64_t ld);
+/* out := lower triangle of the dense p x p matrix K, column by column (the value array of a dense lower CCS pattern) */
+int kvx_pack_lower_dev(int64_t p, const double *K_dev, int64_t ld, double *out_dev);
 
 /* ---- device memory plumbing for hosts without their own allocator ------------------------ */
 int kvx_dev_malloc(void **p, int64_t bytes);

@@ -85,6 +85,7 @@ _SIGS = {
     "kvx_vec_addc_dev": (ctypes.c_int, [i64, f64, vp]),
     "kvx_vec_fill_dev": (ctypes.c_int, [i64, f64, vp]),
     "kvx_vec_copy_dev": (ctypes.c_int, [i64, vp, vp]),
+    "kvx_vec_copy_strided_dev": (ctypes.c_int, [i64, vp, i64, vp]),
     "kvx_vec_xmy_dev": (ctypes.c_int, [i64, f64, vp, vp, f64, vp]),
     "kvx_spmv_dev": (ctypes.c_int, [ctypes.c_int, i64, i64, vp, vp, vp, f64, vp, f64, vp]),
     "kvx_lu_analyze": (ctypes.c_int, [i64, i64p, i64p, f64p, ctypes.POINTER(vp)]),
@@ -104,6 +105,9 @@ _SIGS = {
                                       i64p, ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p),
                                       i64p, i64p, f64p, i64p, ctypes.POINTER(i64p)]),
     "kvx_lu_det": (ctypes.c_int, [vp, f64p]),
+    "kvx_spmm_t_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, i64, vp, i64]),
+    "kvx_dense_from_ccs_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, i64]),
+    "kvx_pack_lower_dev": (ctypes.c_int, [i64, vp, i64, vp]),
     "kvx_dev_malloc": (ctypes.c_int, [ctypes.POINTER(vp), i64]),
     "kvx_dev_free": (ctypes.c_int, [vp]),
     "kvx_dev_upload": (ctypes.c_int, [vp, vp, i64]),

@@ -8,6 +8,7 @@
 // All of it is HBM/latency-bound streaming work: coalesced grid-stride loops, wavefront (64-lane)
 // shuffles for the reductions, no MFMA.
 #include "kkt.hpp"
+#include <algorithm>
 
 namespace kvx {
 
@@ -268,6 +269,57 @@ void launch_spmv(hipStream_t st, int trans, int64_t m, int64_t n, const int64_t 
         if (m > 0 && beta != 1.0) hipLaunchKernelGGL(k_beta, dim3(grid_for(m)), dim3(256), 0, st, m, beta, y);
         if (n > 0) hipLaunchKernelGGL(k_spmv_n, dim3(grid_for(n)), dim3(256), 0, st, n, Ap, Ai, Ax, alpha, x, y);
     }
+}
+
+// ---- dense helpers of the equality-constrained KKT path with a general S (misc.py:1476-1487): K = A S^-1 A' is formed
+// as a dense p x p matrix from X = S^-1 A' (n x p, multi-right-hand-side solve) when p is moderate ------------------
+// Y(j, c) = sum_i A(i, j) X(i, c): the gather ('T') form of the mat-vec on every column of X
+__global__ __launch_bounds__(256) void k_spmm_t(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                                                const double *__restrict__ Ax, const double *__restrict__ X, int64_t ldx,
+                                                double *__restrict__ Y, int64_t ldy)
+{
+    const int sub = threadIdx.x & 15;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const double *__restrict__ x = X + (int64_t)blockIdx.y * ldx;
+    double *__restrict__ y = Y + (int64_t)blockIdx.y * ldy;
+    for (; j < n; j += stride) {
+        double acc = 0.0;
+        for (int64_t p = Ap[j] + sub; p < Ap[j + 1]; p += 16) acc += Ax[p] * x[Ai[p]];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) y[j] = acc;
+    }
+}
+// D (m x n, leading dimension ld, zeroed by the caller) := the CCS matrix
+__global__ void k_dense_from_ccs(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                                 const double *__restrict__ Ax, double *__restrict__ D, int64_t ld)
+{
+    GS_LOOP(j, n) {
+        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) D[Ai[p] + j * ld] = Ax[p];
+    }
+}
+// out := lower triangle of the dense p x p matrix K by columns (the value array of a dense lower CCS pattern)
+__global__ void k_pack_lower(int64_t p, const double *__restrict__ K, int64_t ld, double *__restrict__ out)
+{
+    const int64_t j = blockIdx.y;
+    const int64_t off = j * p - j * (j - 1) / 2;
+    for (int64_t i = j + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p; i += (int64_t)gridDim.x * blockDim.x)
+        out[off + (i - j)] = K[i + j * ld];
+}
+void launch_spmm_t(hipStream_t st, int64_t n, int64_t ncols, const int64_t *Ap, const int64_t *Ai, const double *Ax, const double *X,
+                   int64_t ldx, double *Y, int64_t ldy)
+{
+    if (n > 0 && ncols > 0)
+        hipLaunchKernelGGL(k_spmm_t, dim3(std::min<unsigned>(grid_for(n * 16), 4096u), (unsigned)ncols), dim3(256), 0, st, n, Ap, Ai, Ax, X, ldx, Y, ldy);
+}
+void launch_dense_from_ccs(hipStream_t st, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *D, int64_t ld)
+{
+    if (n > 0) hipLaunchKernelGGL(k_dense_from_ccs, dim3(grid_for(n)), dim3(256), 0, st, n, Ap, Ai, Ax, D, ld);
+}
+void launch_pack_lower(hipStream_t st, int64_t p, const double *K, int64_t ld, double *out)
+{
+    if (p > 0) hipLaunchKernelGGL(k_pack_lower, dim3((unsigned)std::min<int64_t>((p + 255) / 256, 64), (unsigned)p), dim3(256), 0, st, p, K, ld, out);
 }
 
 }  // namespace kvx

@@ -25,6 +25,10 @@ int reduce_scratch_doubles();
 void launch_atda(hipStream_t st, int64_t snz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
                  const int32_t *gi, const double *gx, const double *w, double *sx);
 void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx);
+void launch_spmm_t(hipStream_t st, int64_t n, int64_t ncols, const int64_t *Ap, const int64_t *Ai, const double *Ax, const double *X,
+                   int64_t ldx, double *Y, int64_t ldy);
+void launch_dense_from_ccs(hipStream_t st, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *D, int64_t ld);
+void launch_pack_lower(hipStream_t st, int64_t p, const double *K, int64_t ld, double *out);
 void launch_spmv(hipStream_t st, int trans, int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax,
                  double alpha, const double *x, double beta, double *y);
 }  // namespace kvx

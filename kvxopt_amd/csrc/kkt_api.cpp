@@ -312,6 +312,12 @@ int kvx_vec_fill_dev(int64_t n, double c, double *x)
 { launch_fill(nullptr, n, c, x); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_vec_copy_dev(int64_t n, const double *x, double *y)
 { if (n > 0) HIPCHK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, nullptr)); return KVX_OK; }
+int kvx_vec_copy_strided_dev(int64_t n, const double *x, int64_t incx, double *y)     /* y[i] := x[i * incx] */
+{
+    if (n > 0 && incx > 0)
+        HIPCHK(hipMemcpy2DAsync(y, sizeof(double), x, (size_t)incx * sizeof(double), sizeof(double), (size_t)n, hipMemcpyDeviceToDevice, nullptr));
+    return KVX_OK;
+}
 int kvx_vec_xmy_dev(int64_t n, double a, const double *x, const double *y, double b, double *z)
 { launch_xmy(nullptr, n, a, x, y, b, z); HIPCHK(hipGetLastError()); return KVX_OK; }
 
@@ -320,6 +326,32 @@ int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap, const int64
 {
     if (trans != 'N' && trans != 'T') return KVX_EINVAL;
     launch_spmv(nullptr, trans, m, n, Ap, Ai, Ax, alpha, x, beta, y);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int kvx_spmm_t_dev(int64_t n, int64_t ncols, const int64_t *Ap, const int64_t *Ai, const double *Ax, const double *X, int64_t ldx,
+                   double *Y, int64_t ldy)
+{
+    if (n < 0 || ncols < 0 || ncols > 65535) return KVX_EINVAL;
+    launch_spmm_t(nullptr, n, ncols, Ap, Ai, Ax, X, ldx, Y, ldy);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int kvx_dense_from_ccs_dev(int64_t m, int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, double *D, int64_t ld)
+{
+    if (m < 0 || n < 0 || ld < std::max<int64_t>(1, m)) return KVX_EINVAL;
+    if (m > 0 && n > 0) HIPCHK(hipMemset2DAsync(D, (size_t)ld * sizeof(double), 0, (size_t)m * sizeof(double), (size_t)n, nullptr));
+    launch_dense_from_ccs(nullptr, n, Ap, Ai, Ax, D, ld);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int kvx_pack_lower_dev(int64_t p, const double *K, int64_t ld, double *out)
+{
+    if (p < 0 || p > 65535 || ld < std::max<int64_t>(1, p)) return KVX_EINVAL;
+    launch_pack_lower(nullptr, p, K, ld, out);
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }

@@ -320,10 +320,106 @@ class KKTDiagEqDev:
             z.xmy(1.0, di, self.t, -1.0)
 
 
+class KKTGenEqDev:
+    """Device-resident `misc.kkt_chol2` with equality constraints and a GENERAL sparse G (S not diagonal), for a moderate
+    number p of equality rows.  The reference forms Asct = L^-1 P A' by sparse triangular solves, K = Asct' Asct by a sparse
+    syrk and re-analyses K at every call (misc.py:1476-1487).  Here X = S^-1 A' is one multi-right-hand-side solve with the
+    factor of S (n x p dense), K = A X a dense p x p matrix (one gather mat-mat), factored as a single dense front by the
+    same Cholesky (dense lower pattern, analysed once).  KKT solve (misc.py:1489-1563 written with S^-1):
+    u = S^-1 (bx + G' W^-1 W^-T bz), uy = K^-1 (A u - by), ux = S^-1 (bx + G'.. - A' uy), uz = W^-T (G ux - bz)."""
+
+    MAX_P = 2048
+
+    def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts=None):
+        if p > self.MAX_P:
+            raise NotImplementedError("device-resident conelp with a general G handles up to %d equality constraints "
+                                      "(dense K); use kvxopt_amd.misc.kkt_chol2 (host arrays) beyond" % self.MAX_P)
+        self.ml, self.n, self.p = ml, n, p
+        self.S = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+        self.G = self.S.G
+        self.A = SpMatDev(p, n, Ap, Ai, Ax)
+        # CCS of A' (n x p) = CSR of A
+        Ap = np.asarray(Ap, dtype=np.int64); Ai = np.asarray(Ai, dtype=np.int64); Ax = np.asarray(Ax, dtype=np.float64)
+        cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
+        order = np.lexsort((cols, Ai))
+        ATp = np.zeros(p + 1, dtype=np.int64)
+        np.add.at(ATp, Ai + 1, 1)
+        np.cumsum(ATp, out=ATp)
+        self.AT = SpMatDev(n, p, ATp, cols[order], Ax[order])
+        self.X = DVec(max(n * p, 1))
+        self.Kd = DVec(max(p * p, 1))
+        self.Kx = DVec(max(p * (p + 1) // 2, 1))
+        Kp = np.zeros(p + 1, dtype=np.int64)
+        Kp[1:] = np.cumsum(np.arange(p, 0, -1))
+        Ki = np.concatenate([np.arange(j, p, dtype=np.int64) for j in range(p)]) if p else np.zeros(0, np.int64)
+        # K is dense: natural order, one front; scaled to max diag = 1 with the pivot floor of KKTDiagEqDev
+        self.fac = Factor(p, Kp, Ki, "L", None, {"ordering": 1, "dbound": 1e-15, "dbound_drop": 1})
+        self.kdiag = DVec(max(p, 1))
+        self.u, self.r = DVec(n), DVec(n)
+        self.t = self.S.t
+        self.kscale = 1.0
+        self.di = None
+        self.nfactor = 0
+        self._async = False
+
+    @property
+    def async_solves(self):
+        return self._async
+
+    @async_solves.setter
+    def async_solves(self, v):
+        self._async = v
+        self.S.async_solves = v
+
+    def factor(self, di, sync=True):
+        n, p = self.n, self.p
+        self.S.factor(di, sync=False)                                  # S = G' W^-1 W^-T G: assembly + numeric refactorisation
+        raise_for(lib().kvx_dense_from_ccs_dev(n, p, self.AT.cp.ptr, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n))   # X := A'
+        self.S.fac.solve_dev(self.X.ptr, 0, p, n, sync=False)          # X := S^-1 A'   (a failed S surfaces in check())
+        raise_for(lib().kvx_spmm_t_dev(p, p, self.AT.cp.ptr, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n, self.Kd.ptr, p))  # K := A X
+        raise_for(lib().kvx_pack_lower_dev(p, self.Kd.ptr, p, self.Kx.ptr))
+        # scale to max diag K = 1 (one host round trip; it also surfaces a failed factorisation of S)
+        raise_for(lib().kvx_vec_copy_strided_dev(p, self.Kd.ptr, p + 1, self.kdiag.ptr))
+        self.kdiag.scal(-1.0)
+        kmax = self.kdiag.max_step()
+        self.S.check()
+        if not (kmax > 0.0) or not np.isfinite(kmax):
+            raise ArithmeticError(0)
+        self.kscale = 1.0 / kmax
+        self.Kx.scal(self.kscale)
+        self.fac.factorize_dev(self.Kx.ptr, sync=sync)
+        self.di = di
+        self.nfactor += 1
+
+    def check(self):
+        self.S.check()
+        self.fac.status()
+
+    def solve(self, x, y, z):
+        """Overwrites (x, y, z) = (bx, by, bz) with (ux, uy, uz)."""
+        di, n, p = self.di, self.n, self.p
+        z.mul(di)
+        self.t.xmy(1.0, di, z)
+        self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)        # x := bx + G' W^-1 W^-T bz
+        self.u.copy_from(x)
+        self.S.fac.solve_dev(self.u.ptr, 0, 1, max(1, n), sync=not self._async)       # u := S^-1 x
+        self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)       # y := A u - by
+        self.fac.solve_dev(y.ptr, 0, 1, max(1, p), sync=not self._async)
+        y.scal(self.kscale)                                           # uy = K^-1 (A u - by)
+        self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)            # x := x - A' uy
+        self.S.fac.solve_dev(x.ptr, 0, 1, max(1, n), sync=not self._async)            # ux = S^-1 (...)
+        self.G.gemv(x, self.t, trans="N")
+        z.xmy(1.0, di, self.t, -1.0)                                  # uz = W^-T (G ux - bz)
+
+    def solve2(self, xa, ya, za, xb, yb, zb):
+        self.solve(xa, ya, za)
+        self.solve(xb, yb, zb)
+
+
 def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
-    (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints G must have at most one
-    entry per row (KKTDiagEqDev).  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
+    (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints either G has at most one entry per
+    row (standard form: KKTDiagEqDev, any p) or p <= 2048 (general G: KKTGenEqDev, dense K).  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
     _lib.require_device()
     opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
     opts.update(options or {})
@@ -358,7 +454,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             return np.zeros(0)
 
     if p > 0:
-        kkt = KKTDiagEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts)
+        Gi64 = np.asarray(Gi, dtype=np.int64)
+        diag_s = not (Gi64.size and np.bincount(Gi64, minlength=ml).max() > 1)
+        kkt = (KKTDiagEqDev if diag_s else KKTGenEqDev)(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts)
         Ad = kkt.A
         bv = DVec(p, b_h)
         y, dy, y1, ry, hry = (DVec(p) for _ in range(5))

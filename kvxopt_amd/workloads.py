@@ -119,7 +119,28 @@ def lp_grid(gx, gy, seed=4):
     h = Gx0 + s0
     cvec = np.zeros(n)
     np.add.at(cvec, c, -v * z0[r])
-    return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h}
+    return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h, "x0": x0}
+
+
+def lp_grid_eq(gx, gy, p, seed=9):
+    """lp_grid plus p equality constraints A x = b (goldens G8): general G AND equality rows, the branch of
+    misc.kkt_chol2 with K = A S^-1 A' and a non-diagonal S (misc.py:1476-1487).  Row i of A has three entries N(0, 1) in
+    random columns; b = A x0 with lp_grid's interior point x0, so the problem stays strictly feasible."""
+    L = lp_grid(gx, gy)
+    n = L["n"]
+    rng = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(p, dtype=np.int64), 3)
+    cols = np.concatenate([rng.choice(n, 3, replace=False) for _ in range(p)]).astype(np.int64)
+    vals = rng.standard_normal(3 * p)
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(Ap, cols + 1, 1)
+    np.cumsum(Ap, out=Ap)
+    b = np.zeros(p)
+    np.add.at(b, rows, vals * L["x0"][cols])
+    L.update({"p": p, "Ap": Ap, "Ai": rows, "Ax": vals, "b": b})
+    return L
 
 
 def qp_grid(gx, gy):

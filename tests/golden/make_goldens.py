@@ -302,6 +302,36 @@ def g6_conelp_std():
                "cases": meta}, open(os.path.join(HERE, "g6_conelp_std.json"), "w"), indent=1, default=float)
 
 
+def g8_conelp_eq():
+    """conelp with a general sparse G AND equality constraints (workloads.lp_grid_eq): the branch of misc.kkt_chol2 that
+    forms K = A S^-1 A' with a non-diagonal S (misc.py:1476-1487, 1545)."""
+    from kvxopt import matrix, solvers, spmatrix
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    out, meta = {}, {}
+    for name, gx, gy, p in [("eq6x5p4", 6, 5, 4), ("eq15x12p20", 15, 12, 20)]:
+        L = workloads.lp_grid_eq(gx, gy, p)
+        ml, n = L["ml"], L["n"]
+        gcols = np.repeat(np.arange(n), np.diff(L["Gp"]))
+        acols = np.repeat(np.arange(n), np.diff(L["Ap"]))
+        G = spmatrix(L["Gx"].tolist(), L["Gi"].tolist(), gcols.tolist(), (ml, n))
+        A = spmatrix(L["Ax"].tolist(), L["Ai"].tolist(), acols.tolist(), (p, n))
+        c, h, b = matrix(L["c"]), matrix(L["h"]), matrix(L["b"])
+        sol_d = solvers.conelp(c, matrix(G), h, A=matrix(A), b=b, kktsolver="chol2")   # pure reference (dense LAPACK branch)
+        sol_s = solvers.conelp(c, G, h, A=A, b=b)                                      # reference python + oracle cholesky
+        assert sol_d["status"] == sol_s["status"] == "optimal", (sol_d["status"], sol_s["status"])
+        assert sol_d["iterations"] == sol_s["iterations"]
+        assert np.allclose(tolist(sol_d["x"]), tolist(sol_s["x"]), rtol=1e-6, atol=1e-8)
+        for k in "xysz":
+            out[name + "_" + k] = tolist(sol_d[k])
+        meta[name] = {k: sol_d[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective",
+                                           "dual objective", "primal infeasibility", "dual infeasibility")}
+    np.savez_compressed(os.path.join(HERE, "g8_conelp_eq.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch of misc.kkt_chol2), cross-checked against reference python + "
+                      "oracle cholesky (sparse branch); generator kvxopt_amd.workloads.lp_grid_eq",
+               "cases": meta}, open(os.path.join(HERE, "g8_conelp_eq.json"), "w"), indent=1, default=float)
+
+
 def g7_mps():
     """modeling.op.fromfile + solve on the reference's own fixture tests/boeing2.mps (tests/test_modeling.py:59-63):
     the parsed problem (objective, inequality / equality counts) and the solution of the reference's default LP path
@@ -336,4 +366,5 @@ if __name__ == "__main__":
     g5_coneqp()
     g6_conelp_std()
     g7_mps()
+    g8_conelp_eq()
     print("goldens written to", HERE)

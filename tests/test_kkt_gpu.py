@@ -231,17 +231,55 @@ def test_conelp_standard_form_golden(golden_dir, name, gx, gy):
     assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * np.linalg.norm(L["b"]) and sol["x"].min() > -1e-7
 
 
+@pytest.mark.parametrize("name,gx,gy,p", [("eq6x5p4", 6, 5, 4), ("eq15x12p20", 15, 12, 20)])
+def test_conelp_general_g_with_equalities_golden(golden_dir, name, gx, gy, p):
+    """G8: the reference's conelp with a general sparse G and equality constraints: the branch of misc.kkt_chol2 with
+    K = A S^-1 A' for a non-diagonal S (misc.py:1476-1487) -- on the device K is a dense p x p front (lp.KKTGenEqDev)."""
+    g = np.load(os.path.join(golden_dir, "g8_conelp_eq.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g8_conelp_eq.json")))["cases"][name]
+    L = workloads.lp_grid_eq(gx, gy, p)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    for k, tol in (("x", 1e-6), ("y", 1e-6), ("s", 1e-6), ("z", 1e-6)):
+        assert rel(sol[k], g[name + "_" + k]) < tol, k
+    assert abs(sol["primal objective"] - meta["primal objective"]) < 1e-8 * abs(meta["primal objective"])
+    acols = np.repeat(np.arange(L["n"]), np.diff(L["Ap"]))
+    Ax_ = np.zeros(L["p"]); np.add.at(Ax_, L["Ai"], L["Ax"] * sol["x"][acols])
+    assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * max(1.0, np.linalg.norm(L["b"]))
+
+
+def test_conelp_general_g_with_equalities_at_scale():
+    """Config-4b grid (ml = 200 000, n = 50 000) with 200 equality rows: optimal, feasible, duality gap closed."""
+    L = workloads.lp_grid_eq(250, 200, 200)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    assert sol["status"] == "optimal"
+    assert sol["relative gap"] < 1e-6 and sol["primal infeasibility"] < 1e-7 and sol["dual infeasibility"] < 1e-7
+    acols = np.repeat(np.arange(L["n"]), np.diff(L["Ap"]))
+    Ax_ = np.zeros(L["p"]); np.add.at(Ax_, L["Ai"], L["Ax"] * sol["x"][acols])
+    assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * max(1.0, np.linalg.norm(L["b"]))
+
+
 def test_conelp_equality_errors():
     L = workloads.lp_grid_std(6, 5)
     G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
     A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
     with pytest.raises(TypeError):
         lp.conelp(L["c"], G, L["h"], A=A, b=L["b"][:-1])
-    with pytest.raises(NotImplementedError):                            # S not diagonal: host-array kkt_chol2 only
-        P = workloads.lp_grid(6, 5)
-        G2 = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
-        A2 = spmatrix([1.0] * P["n"], [0] * P["n"], list(range(P["n"])), (1, P["n"]))
-        lp.conelp(P["c"], G2, P["h"], A=A2, b=np.ones(1))
+    old = lp.KKTGenEqDev.MAX_P
+    lp.KKTGenEqDev.MAX_P = 0
+    try:
+        with pytest.raises(NotImplementedError):                        # S not diagonal and more equality rows than the dense-K path takes
+            P = workloads.lp_grid(6, 5)
+            G2 = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+            A2 = spmatrix([1.0] * P["n"], [0] * P["n"], list(range(P["n"])), (1, P["n"]))
+            lp.conelp(P["c"], G2, P["h"], A=A2, b=np.ones(1))
+    finally:
+        lp.KKTGenEqDev.MAX_P = old
     with pytest.raises(NotImplementedError):
         lp.conelp(L["c"], G, L["h"], dims={"l": 0, "q": [L["ml"]], "s": []})
 
