@@ -252,10 +252,77 @@ def standard_form(P):
     return c, A, np.array(b, dtype=np.float64), c0, recover
 
 
-def solve(filename, options=None):
+def natural_form(P):
+    """The reference's own formulation (modeling.py:2962-3007, then op._inmatrixform): min c'x + c0 s.t. G x <= h, A x = b
+    over the file's variables -- inequality rows, range rows and finite bounds in G, 'E' rows and FX bounds in A.
+    Returns (c, G, h, A or None, b, c0)."""
+    cols = {k: j for j, k in enumerate(P.cols)}
+    n = len(P.cols)
+    GI, GJ, GV, h, AI, AJ, AV, b = [], [], [], [], [], [], [], []
+
+    def add_ineq(coeffs, sign, rhs):                      # sign * a'x <= rhs
+        r = len(h)
+        for k, a in coeffs.items():
+            GI.append(r); GJ.append(cols[k]); GV.append(sign * a)
+        h.append(rhs)
+
+    def add_eq(coeffs, rhs):
+        r = len(b)
+        for k, a in coeffs.items():
+            AI.append(r); AJ.append(cols[k]); AV.append(a)
+        b.append(rhs)
+
+    for label in P.rows:
+        co, t, rhs, rng = P.coeff[label], P.rowtype[label], P.rhs.get(label, 0.0), P.ranges.get(label)
+        if not co:
+            continue                                       # rows without variables: checked by standard_form's rule, dropped
+        if t == "L":
+            add_ineq(co, 1.0, rhs)
+            if rng is not None:
+                add_ineq(co, -1.0, -(rhs - abs(rng)))
+        elif t == "G":
+            add_ineq(co, -1.0, -rhs)
+            if rng is not None:
+                add_ineq(co, 1.0, rhs + abs(rng))
+        elif not rng:
+            add_eq(co, rhs)
+        elif rng > 0:
+            add_ineq(co, -1.0, -rhs); add_ineq(co, 1.0, rhs + rng)
+        else:
+            add_ineq(co, 1.0, rhs); add_ineq(co, -1.0, -(rhs + rng))
+    for k in P.cols:
+        lo, up = P.bounds[k]
+        if lo is not None and up is not None and lo == up:
+            add_eq({k: 1.0}, lo)
+            continue
+        if lo is not None:
+            add_ineq({k: 1.0}, -1.0, -lo)
+        if up is not None:
+            add_ineq({k: 1.0}, 1.0, up)
+    c = np.zeros(n)
+    for k, a in P.coeff[P.objective_row].items():
+        c[cols[k]] = a
+    G = spmatrix(GV, GI, GJ, (len(h), n))
+    A = spmatrix(AV, AI, AJ, (len(b), n)) if b else None
+    return c, G, np.array(h), A, np.array(b), P.c0
+
+
+def solve(filename, options=None, form="standard"):
     """Read, convert and solve on the GPU.  Returns status / objective / x (by column label) / iterations as
-    `modeling.op.solve` exposes them (op.status, op.objective.value(), variable.value)."""
+    `modeling.op.solve` exposes them (op.status, op.objective.value(), variable.value).
+    form = "standard": min c'y, A y = b, y >= 0 (any size; K = A S^-1 A' sparse, S diagonal);
+    form = "natural": the reference's own G x <= h, A x = b (general G; needs at most 2048 equality rows)."""
     P = read_mps(filename)
+    if form == "natural":
+        c, G, h, A, b, c0 = natural_form(P)
+        sol = _lp.conelp(c, G, h, A=A, b=b if A is not None else None, options=options)
+        out = {"status": sol["status"], "iterations": sol["iterations"], "sol": sol, "problem": P,
+               "natural_form": {"inequalities": int(G.size[0]), "equalities": 0 if A is None else int(A.size[0]), "cols": int(c.size)}}
+        if sol["x"] is not None:
+            x = np.asarray(sol["x"]).reshape(-1)
+            out["x"] = dict(zip(P.cols, x.tolist()))
+            out["objective"] = float(c @ x + c0)
+        return out
     c, A, b, c0, recover = standard_form(P)
     ny = c.size
     ar = np.arange(ny, dtype=np.int64)

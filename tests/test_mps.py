@@ -103,6 +103,29 @@ def test_boeing2_reader_and_standard_form_against_reference(golden_dir):
     assert np.linalg.matrix_rank(_sp(A).toarray()) == A.size[0]                      # K = A S^-1 A' is nonsingular
 
 
+def test_boeing2_natural_form_has_the_reference_shape(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "g7_boeing2.json")))
+    P = mps.read_mps(os.path.join(golden_dir, "boeing2.mps"))
+    c, G, h, A, b, c0 = mps.natural_form(P)
+    assert c.size == g["n_variables"] and A.size[0] == g["n_equalities"]
+    assert G.size[0] == g["n_inequalities"]            # after the reference dropped its 26 constraints without variables
+    r = linprog(c, A_ub=_sp(G), b_ub=h, A_eq=_sp(A), b_eq=b, bounds=(None, None), method="highs")
+    assert r.status == 0 and abs(r.fun + c0 - g["objective"]) < 1e-5 * abs(g["objective"])
+
+
+@pytest.mark.gpu
+def test_boeing2_natural_form_on_the_gpu(golden_dir):
+    """The reference's own formulation (general G + 4 equality rows) on the device: lp.KKTGenEqDev."""
+    from kvxopt_amd import _lib
+    _lib.require_device()
+    g = json.load(open(os.path.join(golden_dir, "g7_boeing2.json")))
+    out = mps.solve(os.path.join(golden_dir, "boeing2.mps"), form="natural")
+    assert out["status"] == "optimal", out["iterations"]
+    assert abs(out["objective"] - g["objective"]) <= 1e-5 * abs(g["objective"])
+    xr = g["x"]
+    assert max(abs(out["x"][k] - xr[k]) for k in xr) <= 1e-3 * max(1.0, max(abs(v) for v in xr.values()))   # the optimum is not unique to more
+
+
 @pytest.mark.gpu
 def test_boeing2_on_the_gpu_matches_the_reference(golden_dir):
     """tests/test_modeling.py:59-63 asserts status == 'optimal'; the golden adds the reference's objective value."""
