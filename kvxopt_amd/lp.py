@@ -330,12 +330,13 @@ class KKTGenEqDev:
 
     MAX_P = 2048
 
-    def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts=None):
+    def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts=None, Pp=None, Pi=None, Px=None):
+        """Pp, Pi, Px: optional lower-triangular CCS of the QP Hessian (coneqp): S = P + G' W^-1 W^-T G."""
         if p > self.MAX_P:
             raise NotImplementedError("device-resident conelp with a general G handles up to %d equality constraints "
                                       "(dense K); use kvxopt_amd.misc.kkt_chol2 (host arrays) beyond" % self.MAX_P)
         self.ml, self.n, self.p = ml, n, p
-        self.S = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+        self.S = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
         self.G = self.S.G
         self.A = SpMatDev(p, n, Ap, Ai, Ax)
         # CCS of A' (n x p) = CSR of A
@@ -703,9 +704,9 @@ def _lower_ccs(P, n):
     return cp, Pi[keep].copy(), Px[keep].copy()
 
 
-def coneqp(P, q, G, h, options=None, chol_opts=None):
-    """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h  on the GPU (orthant cone, no equality
-    constraints): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
+def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None):
+    """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h, Ax = b  on the GPU (orthant cone; at most
+    KKTGenEqDev.MAX_P equality rows): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
     misc.kkt_chol2 with H = P.  P: spmatrix-like, its lower triangle is used.  Returns the reference's result
     dictionary (coneprog.py:2216-2221) with numpy arrays, plus "factorizations"."""
     _lib.require_device()
@@ -722,7 +723,29 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
     if ml == 0:
         raise ValueError("coneqp on the GPU needs at least one inequality (dims['l'] > 0)")
     Pp, Pi, Px = _lower_ccs(P, n)
-    kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
+    p = 0
+    if A is not None:
+        p, na, Ap, Ai, Ax = base._as_ccs(A)
+        if na != n:
+            raise TypeError("'A' must have %d columns" % n)
+        b_h = np.asarray(b._a if isinstance(b, base.matrix) else b, dtype=np.float64).reshape(-1)
+        if b_h.size != p:
+            raise TypeError("'b' must have length %d" % p)
+    if p > 0:
+        kkt = KKTGenEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts, Pp, Pi, Px)
+        Ad = kkt.A
+        bv = DVec(p, b_h)
+        y, dy, ry = DVec(p), DVec(p), DVec(p)
+        if refinement:
+            wy, wy2 = DVec(p), DVec(p)
+        resy0 = max(1.0, bv.nrm2())
+        ksolve = kkt.solve
+    else:
+        kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
+        y = dy = ry = wy = wy2 = None
+        resy0 = 1.0
+        def ksolve(xx, yy, zz):
+            kkt.solve(xx, zz)
     Gd, Pd = kkt.G, SymSpMatDev(n, Pp, Pi, Px)
     qv, hv = DVec(n, q_h), DVec(ml, h_h)
     x, dx, rx, tmpx = (DVec(n) for _ in range(4))
@@ -734,7 +757,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
     resz0 = max(1.0, hv.nrm2())
 
     def result(status, iters, gap, relgap, pcost, dcost, pres, dres):
-        return {"x": x.get(), "y": np.zeros(0), "s": s.get(), "z": z.get(), "status": status, "gap": gap,
+        return {"x": x.get(), "y": y.get() if p else np.zeros(0), "s": s.get(), "z": z.get(), "status": status, "gap": gap,
                 "relative gap": relgap, "primal objective": pcost, "dual objective": dcost,
                 "primal infeasibility": pres, "dual infeasibility": dres,
                 "primal slack": -s.max_step(), "dual slack": -z.max_step(), "iterations": iters,
@@ -747,8 +770,15 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
     except ArithmeticError:
         raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
     x.copy_from(qv).scal(-1.0)
+    if p:
+        y.copy_from(bv)
     z.copy_from(hv)
-    kkt.solve(x, z)
+    try:
+        ksolve(x, y, z)
+        if p:
+            kkt.check()
+    except ArithmeticError:
+        raise ValueError("Rank(A) < p or Rank([P; G; A]) < n")
     s.copy_from(z).scal(-1.0)
     ts = s.max_step()
     if ts >= -1e-8 * max(s.nrm2(), 1.0):
@@ -758,17 +788,20 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
         z.addc(1.0 + tz)
     gap = s.dot(z)
 
-    def f4_no_ir(bx, bz, bs):
-        # [P G'; G -W'W][ux; W^-1 uz] = [bx; bz - W'(lmbda o\ bs)],  us = lmbda o\ bs - uz   (coneprog.py:2283-2313)
+    def f4_no_ir(bx, by, bz, bs):
+        # [P A' G'; A 0 0; G 0 -W'W][ux; uy; W^-1 uz] = [bx; by; bz - W'(lmbda o\ bs)],  us = lmbda o\ bs - uz   (coneprog.py:2283-2313)
         bs.div(lmbda)
         tmp.xmy(1.0, bs, d)
         bz.axpy(tmp, -1.0)
-        kkt.solve(bx, bz)
+        ksolve(bx, by, bz)
         bs.axpy(bz, -1.0)
 
-    def res(ux, uz, us, vx, vz, vs):
-        # residual of the Newton equations (coneprog.py:1929-1960) with p = 0
+    def res(ux, uy, uz, us, vx, vy, vz, vs):
+        # residual of the Newton equations (coneprog.py:1929-1960)
         Pd.symv(ux, vx, alpha=-1.0, beta=1.0)
+        if p:
+            Ad.gemv(uy, vx, trans="T", alpha=-1.0, beta=1.0)
+            Ad.gemv(ux, vy, trans="N", alpha=-1.0, beta=1.0)
         tmp.xmy(1.0, uz, di)
         Gd.gemv(tmp, vx, trans="T", alpha=-1.0, beta=1.0)
         Gd.gemv(ux, vz, trans="N", alpha=-1.0, beta=1.0)
@@ -778,31 +811,42 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
         tmp.mul(lmbda)
         vs.axpy(tmp, -1.0)
 
-    def f4(bx, bz, bs):
+    def f4(bx, by, bz, bs):
         if refinement:
             wx.copy_from(bx); wz.copy_from(bz); ws.copy_from(bs)
-        f4_no_ir(bx, bz, bs)
+            if p:
+                wy.copy_from(by)
+        f4_no_ir(bx, by, bz, bs)
         for _ in range(refinement):
             wx2.copy_from(wx); wz2.copy_from(wz); ws2.copy_from(ws)
-            res(bx, bz, bs, wx2, wz2, ws2)
-            f4_no_ir(wx2, wz2, ws2)
+            if p:
+                wy2.copy_from(wy)
+            res(bx, by, bz, bs, wx2, wy2, wz2, ws2)
+            f4_no_ir(wx2, wy2, wz2, ws2)
             bx.axpy(wx2); bz.axpy(wz2); bs.axpy(ws2)
+            if p:
+                by.axpy(wy2)
 
     for iters in range(MAXITERS + 1):
         # residuals and objectives (coneprog.py:2167-2203): one reduction call for the five inner products
         rx.copy_from(qv)
         Pd.symv(x, rx, alpha=1.0, beta=1.0)
         tmpx.copy_from(rx)                               # P x + q, for f0
+        if p:
+            Ad.gemv(y, rx, trans="T", alpha=1.0, beta=1.0)
+            ry.copy_from(bv)
+            Ad.gemv(x, ry, trans="N", alpha=1.0, beta=-1.0)      # ry = A x - b
         Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
         rz.copy_from(s).axpy(hv, -1.0)
         Gd.gemv(x, rz, trans="N", alpha=1.0, beta=1.0)
-        xPq, xq, v_rx, v_rz, zrz = reduce_multi([("dot", x, tmpx), ("dot", x, qv), ("dot", rx, rx), ("dot", rz, rz), ("dot", z, rz)])
+        xPq, xq, v_rx, v_rz, zrz, v_ry, yry = reduce_multi([("dot", x, tmpx), ("dot", x, qv), ("dot", rx, rx), ("dot", rz, rz),
+                                                             ("dot", z, rz), ("dot", ry, ry), ("dot", y, ry)])
         f0 = 0.5 * (xPq + xq)
-        resx, resz = math.sqrt(v_rx), math.sqrt(v_rz)
+        resx, resz, resy = math.sqrt(v_rx), math.sqrt(v_rz), math.sqrt(v_ry)
         pcost = f0
-        dcost = f0 + zrz - gap
+        dcost = f0 + yry + zrz - gap
         relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
-        pres, dres = resz / resz0, resx / resx0
+        pres, dres = max(resy / resy0, resz / resz0), resx / resx0
         if show:
             if iters == 0:
                 print("% 10s% 12s% 10s% 8s% 7s" % ("pcost", "dcost", "gap", "pres", "dres"))
@@ -817,6 +861,8 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
         lmbdasq.sqr_of(lmbda)
         try:
             kkt.factor(di)
+            if p:
+                kkt.check()
         except ArithmeticError:
             if iters == 0:
                 raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
@@ -831,8 +877,10 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
                 ds.axpy(ws3, -1.0)
             ds.axpy(lmbdasq, -1.0).addc(sigma * mu)
             dx.copy_from(rx).scal(-1.0 + eta)
+            if p:
+                dy.copy_from(ry).scal(-1.0 + eta)
             dz.copy_from(rz).scal(-1.0 + eta)
-            f4(dx, dz, ds)
+            f4(dx, dy, dz, ds)
             dsdz = ds.dot(dz)
             if correction and i == 0:
                 ws3.xmy(1.0, ds, dz)
@@ -849,6 +897,8 @@ def coneqp(P, q, G, h, options=None, chol_opts=None):
 
         # update iterates and scaling (coneprog.py:2454-2545)
         x.axpy(dx, step)
+        if p:
+            y.axpy(dy, step)
         ds.scal(step).addc(1.0); dz.scal(step).addc(1.0)
         ds.mul(lmbda); dz.mul(lmbda)
         raise_for(lib().kvx_nt_update_scaling_dev(ml, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr))

@@ -332,6 +332,39 @@ def g8_conelp_eq():
                "cases": meta}, open(os.path.join(HERE, "g8_conelp_eq.json"), "w"), indent=1, default=float)
 
 
+def g9_coneqp_eq():
+    """coneqp with equality constraints: the grid QP of G5 plus the equality rows of G8 (misc.kkt_chol2 with H = P and
+    K = A S^-1 A', misc.py:1425-1426, 1476-1487)."""
+    from kvxopt import matrix, solvers, spmatrix
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    out, meta = {}, {}
+    for name, gx, gy, p in [("qpeq6x5p4", 6, 5, 4), ("qpeq15x12p20", 15, 12, 20)]:
+        Q = qp_grid(gx, gy)
+        L = workloads.lp_grid_eq(gx, gy, p)
+        ml, n = Q["ml"], Q["n"]
+        cols = np.repeat(np.arange(n), np.diff(Q["Gp"]))
+        G = spmatrix(Q["Gx"].tolist(), Q["Gi"].tolist(), cols.tolist(), (ml, n))
+        pcols = np.repeat(np.arange(n), np.diff(Q["Pp"]))
+        P = spmatrix(Q["Px"].tolist(), Q["Pi"].tolist(), pcols.tolist(), (n, n))
+        acols = np.repeat(np.arange(n), np.diff(L["Ap"]))
+        A = spmatrix(L["Ax"].tolist(), L["Ai"].tolist(), acols.tolist(), (p, n))
+        q, h, b = matrix(Q["q"]), matrix(Q["h"]), matrix(L["b"])
+        sol_d = solvers.coneqp(P, q, matrix(G), h, A=matrix(A), b=b, kktsolver="chol2")   # pure reference (dense LAPACK branch)
+        sol_s = solvers.coneqp(P, q, G, h, A=A, b=b)                                      # reference python + oracle cholesky
+        assert sol_d["status"] == sol_s["status"] == "optimal", (sol_d["status"], sol_s["status"])
+        assert sol_d["iterations"] == sol_s["iterations"]
+        assert np.allclose(tolist(sol_d["x"]), tolist(sol_s["x"]), rtol=1e-6, atol=1e-8)
+        for k in "xysz":
+            out[name + "_" + k] = tolist(sol_d[k])
+        meta[name] = {k: sol_d[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective",
+                                           "dual objective", "primal infeasibility", "dual infeasibility")}
+    np.savez_compressed(os.path.join(HERE, "g9_coneqp_eq.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch of misc.kkt_chol2), cross-checked against reference python + "
+                      "oracle cholesky (sparse branch); generators make_goldens.qp_grid + kvxopt_amd.workloads.lp_grid_eq",
+               "cases": meta}, open(os.path.join(HERE, "g9_coneqp_eq.json"), "w"), indent=1, default=float)
+
+
 def g7_mps():
     """modeling.op.fromfile + solve on the reference's own fixture tests/boeing2.mps (tests/test_modeling.py:59-63):
     the parsed problem (objective, inequality / equality counts) and the solution of the reference's default LP path
@@ -367,4 +400,5 @@ if __name__ == "__main__":
     g6_conelp_std()
     g7_mps()
     g8_conelp_eq()
+    g9_coneqp_eq()
     print("goldens written to", HERE)

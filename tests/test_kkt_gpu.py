@@ -199,6 +199,31 @@ def test_coneqp_golden(golden_dir, name, gx, gy):
     assert sol["s"].min() > 0 and sol["z"].min() > 0 and sol["s"] @ sol["z"] < 1e-4
 
 
+@pytest.mark.parametrize("name,gx,gy,p", [("qpeq6x5p4", 6, 5, 4), ("qpeq15x12p20", 15, 12, 20)])
+def test_coneqp_with_equalities_golden(golden_dir, name, gx, gy, p):
+    """G9: the reference's coneqp with equality constraints (misc.kkt_chol2 with H = P and K = A S^-1 A'): same
+    iteration count, same x, y, s, z and objectives; with and without iterative refinement."""
+    g = np.load(os.path.join(golden_dir, "g9_coneqp_eq.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g9_coneqp_eq.json")))["cases"][name]
+    Q = workloads.qp_grid(gx, gy)
+    L = workloads.lp_grid_eq(gx, gy, p)
+    G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
+    P = spmatrix.from_ccs(Q["n"], Q["n"], Q["Pp"], Q["Pi"], Q["Px"])
+    A = spmatrix.from_ccs(p, Q["n"], L["Ap"], L["Ai"], L["Ax"])
+    sol = lp.coneqp(P, Q["q"], G, Q["h"], A=A, b=L["b"])
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    for k, tol in (("x", 1e-6), ("y", 1e-5), ("s", 1e-5), ("z", 1e-5)):
+        assert rel(sol[k], g[name + "_" + k]) < tol, k
+    for key in ("primal objective", "dual objective"):
+        assert abs(sol[key] - meta[key]) < 1e-7 * max(1.0, abs(meta[key]))
+    sol2 = lp.coneqp(P, Q["q"], G, Q["h"], {"refinement": 1}, A=A, b=L["b"])
+    assert sol2["status"] == "optimal" and rel(sol2["x"], g[name + "_x"]) < 1e-6
+    acols = np.repeat(np.arange(Q["n"]), np.diff(L["Ap"]))
+    Ax_ = np.zeros(p); np.add.at(Ax_, L["Ai"], L["Ax"] * sol["x"][acols])
+    assert np.linalg.norm(Ax_ - L["b"]) < 1e-7 * max(1.0, np.linalg.norm(L["b"]))
+
+
 def test_coneqp_errors():
     Q = workloads.qp_grid(6, 5)
     G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
