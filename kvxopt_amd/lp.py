@@ -111,18 +111,36 @@ def reduce_multi(items):
 
 
 class SpMatDev:
-    """CCS matrix resident in HBM (int64 indices as in the reference, kvxopt.h:46)."""
+    """CCS matrix resident in HBM (int64 indices as in the reference, kvxopt.h:46), together with the CCS of its
+    transpose: both directions of the mat-vec then run as row gathers (kvx_spmv_dev 'T') -- the column-scatter form of
+    'N' needs FP64 atomics, whose rounding depends on the order of arrival: with it two runs of the interior-point loop
+    differ in the last bits, without it they are bitwise identical (like the factorisation and the solves)."""
 
     def __init__(self, m, n, colptr, rowind, values):
         self.m, self.n = int(m), int(n)
-        self.cp = DeviceBuffer.from_array(np.ascontiguousarray(colptr, dtype=np.int64))
-        self.ri = DeviceBuffer.from_array(np.ascontiguousarray(rowind, dtype=np.int64)) if len(rowind) else DeviceBuffer(8)
-        self.vx = DeviceBuffer.from_array(np.ascontiguousarray(values, dtype=np.float64)) if len(values) else DeviceBuffer(8)
+        colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+        rowind = np.ascontiguousarray(rowind, dtype=np.int64)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        self.cp = DeviceBuffer.from_array(colptr)
+        self.ri = DeviceBuffer.from_array(rowind) if len(rowind) else DeviceBuffer(8)
+        self.vx = DeviceBuffer.from_array(values) if len(values) else DeviceBuffer(8)
+        cols = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(colptr))
+        order = np.lexsort((cols, rowind))
+        tp = np.zeros(self.m + 1, dtype=np.int64)
+        np.add.at(tp, rowind + 1, 1)
+        np.cumsum(tp, out=tp)
+        self.tcp = DeviceBuffer.from_array(tp)
+        self.tri = DeviceBuffer.from_array(cols[order]) if len(rowind) else DeviceBuffer(8)
+        self.tvx = DeviceBuffer.from_array(values[order]) if len(values) else DeviceBuffer(8)
 
     def gemv(self, x, y, trans="N", alpha=1.0, beta=0.0):
         """y := alpha*op(A)*x + beta*y  (base.gemv -> sparse.c:1073-1104)."""
-        raise_for(lib().kvx_spmv_dev(ord(trans), self.m, self.n, self.cp.ptr, self.ri.ptr, self.vx.ptr,
-                                     float(alpha), x.ptr, float(beta), y.ptr))
+        if trans == "N":                                  # A x = (A')' x: gather over the rows of A
+            raise_for(lib().kvx_spmv_dev(ord("T"), self.n, self.m, self.tcp.ptr, self.tri.ptr, self.tvx.ptr,
+                                         float(alpha), x.ptr, float(beta), y.ptr))
+        else:
+            raise_for(lib().kvx_spmv_dev(ord("T"), self.m, self.n, self.cp.ptr, self.ri.ptr, self.vx.ptr,
+                                         float(alpha), x.ptr, float(beta), y.ptr))
 
 
 class KKTChol2Dev:

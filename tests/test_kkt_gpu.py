@@ -289,6 +289,22 @@ def test_conelp_general_g_with_equalities_at_scale():
     assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * max(1.0, np.linalg.norm(L["b"]))
 
 
+def test_interior_point_runs_are_bitwise_reproducible():
+    """No atomics anywhere on the path (mat-vecs are row gathers, reductions fixed trees, extend-add parent-pull):
+    two runs of the same problem give identical bits."""
+    L = workloads.lp_grid_eq(15, 12, 20)
+    G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
+    a = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    b = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    for k in "xysz":
+        assert np.array_equal(a[k], b[k]), k
+    P = workloads.lp_grid(25, 20)
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    a = lp.conelp(P["c"], G, P["h"]); b = lp.conelp(P["c"], G, P["h"])
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["z"], b["z"]) and a["gap"] == b["gap"]
+
+
 def test_conelp_equality_errors():
     L = workloads.lp_grid_std(6, 5)
     G = spmatrix.from_ccs(L["ml"], L["n"], L["Gp"], L["Gi"], L["Gx"])
