@@ -237,8 +237,10 @@ int kvx_dev_sync(void);
  * Sparse LU (the kvxopt.klu API, src/C/klu.c; SURVEY 8(f)1, BASELINE configs[2]).  Real 'd' matrices, square,
  * CCS with int64 indices.  Static-structure multifrontal LU with threshold partial pivoting inside the pivot
  * block of each front; fronts without an acceptable pivot are merged into their parents and the factorisation
- * repeats (kvxopt_amd/csrc/lu_symbolic.hpp).  Factorisation:  R P A Q = L U + F  with F = 0 (one diagonal
- * block; no block-triangular form yet), L unit lower, R = diag(1 / Rs).
+ * repeats (kvxopt_amd/csrc/lu_symbolic.hpp).  Factorisation:  R P A Q = L U + F  as in KLU: P, Q bring A to block upper
+ * triangular form (strongly connected components after the matching), L U are the factors of the diagonal blocks, F the
+ * off-diagonal blocks (never eliminated), L unit lower, R = diag(1 / Rs).  (Chains of more than 64 dependent block levels
+ * are factored as one block instead: they would serialise the solves.)
  * --------------------------------------------------------------------------------------------------------- */
 typedef struct kvx_lu_sym kvx_lu_sym;      /* replaces the "KLU SYM D FACTOR" capsule (klu.c:36,276-279)   */
 typedef struct kvx_lu_num kvx_lu_num;      /* replaces the "KLU NUM D FACTOR" capsule (klu.c:38,336-339)   */
@@ -253,6 +255,9 @@ void kvx_lu_free_symbolic(kvx_lu_sym *S);
  * symmetrised pattern, levels, largest base front */
 int kvx_lu_sym_info(kvx_lu_sym *S, int64_t info[8]);
 int kvx_lu_sym_matching(kvx_lu_sym *S, int64_t *rowfor /* n: row on the diagonal of column j */);
+/* block triangular form (KLU's BTF): number of diagonal blocks, number of block levels of the back substitution, and (blk
+ * may be NULL) the block of every column j -- row rowfor[j] is in the same block; entries satisfy blk[row] <= blk[col] */
+int kvx_lu_sym_btf(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *blk);
 
 /* numeric(A, Fs) -- klu.c:310-379 (klu_factor :336).  nnz must equal the analysed pattern's.  The symbolic
  * object is updated when fronts are merged (it must outlive the numeric object).

@@ -92,6 +92,7 @@ _SIGS = {
     "kvx_lu_free_symbolic": (None, [vp]),
     "kvx_lu_sym_info": (ctypes.c_int, [vp, i64p]),
     "kvx_lu_sym_matching": (ctypes.c_int, [vp, i64p]),
+    "kvx_lu_sym_btf": (ctypes.c_int, [vp, i64p, i64p, i64p]),
     "kvx_lu_factor": (ctypes.c_int, [vp, i64, f64p, ctypes.POINTER(vp)]),
     "kvx_lu_factor_dev": (ctypes.c_int, [vp, i64, vp, ctypes.POINTER(vp)]),
     "kvx_lu_refactor": (ctypes.c_int, [vp, i64, f64p]),

@@ -40,7 +40,10 @@ struct kvx_lu_num {
     hipEvent_t ev0 = nullptr;
     LuFrontD *d_fr = nullptr;
     int32_t *d_rowidx = nullptr, *d_rel = nullptr, *d_children = nullptr, *d_adst = nullptr, *d_ai32 = nullptr;
-    int32_t *d_ipiv = nullptr, *d_lperm = nullptr, *d_fail = nullptr, *d_lists = nullptr;
+    int32_t *d_ipiv = nullptr, *d_lperm = nullptr, *d_fail = nullptr, *d_lists = nullptr, *d_slists = nullptr;
+    int32_t *d_fcol = nullptr, *d_frow = nullptr, *d_flevpos = nullptr;          // block triangular form: F by rows / by columns
+    int64_t *d_fptr_r = nullptr, *d_fptr_c = nullptr, *d_fsrc_r = nullptr, *d_fsrc_c = nullptr;
+    double *d_fval_r = nullptr, *d_fval_c = nullptr;
     int64_t *d_asrc = nullptr, *d_prow = nullptr, *d_qcol = nullptr;
     double *d_rinv = nullptr, *d_rmax = nullptr, *d_Lx = nullptr, *d_Ux = nullptr, *d_arena = nullptr, *d_Ax = nullptr;
     double *d_W = nullptr, *d_X = nullptr, *d_B = nullptr;
@@ -70,8 +73,12 @@ int dalloc(T **dst, int64_t count)
 void free_structure(kvx_lu_num *N)
 {
     void *ptrs[] = {N->d_fr, N->d_rowidx, N->d_rel, N->d_children, N->d_adst, N->d_ipiv, N->d_lperm, N->d_fail, N->d_lists,
-                    N->d_asrc, N->d_prow, N->d_qcol, N->d_Lx, N->d_Ux, N->d_arena, N->d_W, N->d_X, N->d_B};
+                    N->d_asrc, N->d_prow, N->d_qcol, N->d_Lx, N->d_Ux, N->d_arena, N->d_W, N->d_X, N->d_B, N->d_slists, N->d_fcol,
+                    N->d_frow, N->d_flevpos, N->d_fptr_r, N->d_fptr_c, N->d_fsrc_r, N->d_fsrc_c, N->d_fval_r, N->d_fval_c};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    N->d_slists = N->d_fcol = N->d_frow = N->d_flevpos = nullptr;
+    N->d_fptr_r = N->d_fptr_c = N->d_fsrc_r = N->d_fsrc_c = nullptr;
+    N->d_fval_r = N->d_fval_c = nullptr;
     N->d_fr = nullptr; N->d_rowidx = N->d_rel = N->d_children = N->d_adst = N->d_ipiv = N->d_lperm = N->d_fail = N->d_lists = nullptr;
     N->d_asrc = N->d_prow = N->d_qcol = nullptr;
     N->d_Lx = N->d_Ux = N->d_arena = N->d_W = N->d_X = N->d_B = nullptr;
@@ -112,6 +119,16 @@ int upload_structure(kvx_lu_num *N)
     if ((rc = up(&N->d_prow, P.prow))) return rc;
     if ((rc = up(&N->d_qcol, P.qcol))) return rc;
     if ((rc = up(&N->d_lists, P.levellist))) return rc;
+    if ((rc = up(&N->d_slists, P.stagelist))) return rc;
+    if ((rc = up(&N->d_fcol, P.fcol))) return rc;
+    if ((rc = up(&N->d_frow, P.frow))) return rc;
+    if ((rc = up(&N->d_flevpos, P.flevpos))) return rc;
+    if ((rc = up(&N->d_fptr_r, P.fptr_r))) return rc;
+    if ((rc = up(&N->d_fptr_c, P.fptr_c))) return rc;
+    if ((rc = up(&N->d_fsrc_r, P.fsrc_r))) return rc;
+    if ((rc = up(&N->d_fsrc_c, P.fsrc_c))) return rc;
+    if ((rc = dalloc(&N->d_fval_r, (int64_t)P.fcol.size()))) return rc;
+    if ((rc = dalloc(&N->d_fval_c, (int64_t)P.fcol.size()))) return rc;
     if ((rc = dalloc(&N->d_ipiv, N->n))) return rc;
     if ((rc = dalloc(&N->d_lperm, N->n))) return rc;
     if ((rc = dalloc(&N->d_fail, P.nfront))) return rc;
@@ -159,6 +176,8 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     HIPCHK(hipMemsetAsync(N->d_rmax, 0, (size_t)N->n * sizeof(double), N->st));
     launch_lu_rowmax(N->nnz, N->d_ai32, Ax_dev, N->d_rmax, N->st);
     launch_lu_rinv(N->n, N->d_rmax, N->d_rinv, N->st);
+    launch_lu_fvals((int64_t)P.fcol.size(), N->d_fsrc_r, Ax_dev, N->d_rinv, N->d_ai32, N->d_fval_r, N->st);
+    launch_lu_fvals((int64_t)P.fcol.size(), N->d_fsrc_c, Ax_dev, N->d_rinv, N->d_ai32, N->d_fval_c, N->st);
     while ((int32_t)N->evA.size() < P.nlevels) {
         hipEvent_t a, b2, c2, d2;
         HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -297,18 +316,31 @@ int solve_on_device(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64
     // A x = b:  L U (Q' x) = R P b         A' x = b:  U' L' (R^-1 P x) = Q' b
     if (!trans) launch_lu_gather(n, (int)nrhs, N->d_prow, N->d_rinv, B_dev, ldB, N->d_X, n, N->st);
     else launch_lu_gather(n, (int)nrhs, N->d_qcol, nullptr, B_dev, ldB, N->d_X, n, N->st);
-    for (int32_t l = P.nlevels - 1; l >= 0; l--) {
-        const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nb = P.nsbig[l];
-        launch_lu_fwd(d, N->d_lists + b, (int)(e - nb - b), N->lvl_smallm[l], N->lvl_smallk[l], trans ? 0 : 1, N->d_X, n, (int)nrhs,
-                      N->d_W, P.wsize, N->st);
-        launch_lu_fwd_big(d, N->d_lists + e - nb, (int)nb, N->lvl_maxm[l], N->lvl_maxk[l], trans ? 0 : 1, N->d_X, n, (int)nrhs, N->d_W,
+    // block levels (one without BTF); inside a level the stages are the tree depths of its blocks: forward sweep leaves ->
+    // roots, backward sweep roots -> leaves.  A x = b walks the block levels upwards (a block after the later blocks its rows
+    // touch), A' x = b downwards; the products with the off-diagonal blocks F come first.
+    auto sweep = [&](int32_t t, bool fwd, int unit) {
+        const int64_t sb = P.stageptr[t], se = P.stageptr[t + 1], nb = P.stage_nbig[t];
+        if (fwd) {
+            launch_lu_fwd(d, N->d_slists + sb, (int)(se - nb - sb), P.stage_smallm[t], P.stage_smallk[t], unit, N->d_X, n, (int)nrhs, N->d_W,
                           P.wsize, N->st);
-    }
-    for (int32_t l = 0; l < P.nlevels; l++) {
-        const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nb = P.nsbig[l];
-        launch_lu_bwd(d, N->d_lists + b, (int)(e - nb - b), N->lvl_smallm[l], N->lvl_smallk[l], trans ? 1 : 0, N->d_X, n, (int)nrhs, N->st);
-        launch_lu_bwd_big(d, N->d_lists + e - nb, (int)nb, N->lvl_maxm[l], N->lvl_maxk[l], trans ? 1 : 0, N->d_X, n, (int)nrhs, N->d_W,
-                          P.wsize, N->st);
+            launch_lu_fwd_big(d, N->d_slists + se - nb, (int)nb, P.stage_bigm[t], P.stage_bigk[t], unit, N->d_X, n, (int)nrhs, N->d_W, P.wsize,
+                              N->st);
+        } else {
+            launch_lu_bwd(d, N->d_slists + sb, (int)(se - nb - sb), P.stage_smallm[t], P.stage_smallk[t], unit, N->d_X, n, (int)nrhs, N->st);
+            launch_lu_bwd_big(d, N->d_slists + se - nb, (int)nb, P.stage_bigm[t], P.stage_bigk[t], unit, N->d_X, n, (int)nrhs, N->d_W, P.wsize,
+                              N->st);
+        }
+    };
+    for (int32_t li = 0; li < P.nblev; li++) {
+        const int32_t l = trans ? P.nblev - 1 - li : li;
+        if (P.nblev > 1 && !P.fcol.empty()) {
+            const int64_t cnt = P.flevptr[l + 1] - P.flevptr[l];
+            if (!trans) launch_lu_fterm(cnt, (int)nrhs, N->d_flevpos + P.flevptr[l], N->d_fptr_r, N->d_fcol, N->d_fval_r, N->d_X, n, N->st);
+            else launch_lu_fterm(cnt, (int)nrhs, N->d_flevpos + P.flevptr[l], N->d_fptr_c, N->d_frow, N->d_fval_c, N->d_X, n, N->st);
+        }
+        for (int32_t t = P.levstage[l + 1] - 1; t >= P.levstage[l]; t--) sweep(t, true, trans ? 0 : 1);
+        for (int32_t t = P.levstage[l]; t < P.levstage[l + 1]; t++) sweep(t, false, trans ? 1 : 0);
     }
     if (!trans) launch_lu_scatter(n, (int)nrhs, N->d_qcol, nullptr, N->d_X, n, B_dev, ldB, N->st);
     else launch_lu_scatter(n, (int)nrhs, N->d_prow, N->d_rinv, N->d_X, n, B_dev, ldB, N->st);
@@ -388,6 +420,15 @@ int kvx_lu_sym_info(kvx_lu_sym *S, int64_t info[8])
     if (!S || !info) return KVX_EINVAL;
     info[0] = S->Y.n; info[1] = S->Y.nnz; info[2] = S->Y.S.nsuper; info[3] = S->Y.nmerges;
     info[4] = S->Y.structurally_singular ? 1 : 0; info[5] = S->Y.S.lnz; info[6] = S->Y.S.nlevels; info[7] = S->Y.S.max_m;
+    return KVX_OK;
+}
+
+int kvx_lu_sym_btf(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *blk)
+{
+    if (!S || !nblocks || !nlevels) return KVX_EINVAL;
+    *nblocks = S->Y.nblocks;
+    *nlevels = S->Y.nblev;
+    if (blk) for (int64_t j = 0; j < S->Y.n; j++) blk[j] = S->Y.blk[(size_t)j];
     return KVX_OK;
 }
 
@@ -532,12 +573,24 @@ int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, doub
     to_ccs(n, tu, up_, ui_, ux_);
     *lnz = (int64_t)li_.size();
     *unz = (int64_t)ui_.size();
-    *fnz = 0;                                   // one diagonal block: no off-diagonal part F (klu_extract's F, r)
-    *nblocks = 1;
+    // F: the off-diagonal blocks, rows in final pivotal order (the in-front interchanges permute them with their rows)
+    std::vector<Trip> tf;
+    {
+        std::vector<double> hF(P.fcol.size());
+        if (!hF.empty()) HIPCHK(hipMemcpy(hF.data(), N->d_fval_r, hF.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int64_t pr = 0; pr < n; pr++)
+            for (int64_t e = P.fptr_r[pr]; e < P.fptr_r[pr + 1]; e++)
+                if (hF[(size_t)e] != 0.0) tf.push_back({finalpos[pr], (int64_t)P.fcol[(size_t)e], hF[(size_t)e]});
+    }
+    std::vector<int64_t> fp_, fi_;
+    std::vector<double> fx_;
+    to_ccs(n, tf, fp_, fi_, fx_);
+    *fnz = (int64_t)fi_.size();
+    *nblocks = (int64_t)P.rblocks.size() - 1;
     *Lp = mdup(lp_); *Li = mdup(li_); *Lx = mdup(lx_);
     *Up = mdup(up_); *Ui = mdup(ui_); *Ux = mdup(ux_);
-    *Fp = mdup(std::vector<int64_t>((size_t)n + 1, 0)); *Fi = mdup(std::vector<int64_t>()); *Fx = mdup(std::vector<double>());
-    *r_out = mdup(std::vector<int64_t>{0, n});
+    *Fp = mdup(fp_); *Fi = mdup(fi_); *Fx = mdup(fx_);
+    *r_out = mdup(P.rblocks);
     if (!*Lp || !*Li || !*Lx || !*Up || !*Ui || !*Ux || !*Fp || !*Fi || !*Fx || !*r_out) return KVX_ENOMEM;
     return KVX_OK;
 }

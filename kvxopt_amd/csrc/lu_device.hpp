@@ -49,6 +49,10 @@ void launch_lu_fwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, 
                        double *W, int64_t wsize, hipStream_t st);
 void launch_lu_bwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,
                        double *W, int64_t wsize, hipStream_t st);
+// Off-diagonal blocks of the block triangular form: values (scaled entries of A) and the update X[pos] -= F(pos, :) X.
+void launch_lu_fvals(int64_t nf, const int64_t *src, const double *Ax, const double *rinv, const int32_t *ai32, double *out, hipStream_t st);
+void launch_lu_fterm(int64_t cnt, int nrhs, const int32_t *poslist, const int64_t *ptr, const int32_t *idx, const double *val, double *X,
+                     int64_t ldx, hipStream_t st);
 void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double *rmax, hipStream_t st);   // rmax zeroed by the caller
 void launch_lu_rinv(int64_t n, const double *rmax, double *rinv, hipStream_t st);
 // X[p] = B[idx[p]] * (scale ? scale[idx[p]] : 1)   /   B[idx[p]] = X[p] * (scale ? scale[idx[p]] : 1)

@@ -887,6 +887,30 @@ __global__ __launch_bounds__(LU_NT_SOLVE) void k_lu_bwd_big_step(const LuDev d, 
         X[(int64_t)blockIdx.z * ldx + F.p0 + (UNIT ? d.lperm[F.p0 + t0 + tid] : t0 + tid)] = ysh[tid];
 }
 
+
+// ---- block triangular form: the off-diagonal blocks F of R P A Q are never eliminated; a block level subtracts their
+// products with the parts of the solution already known before its own sweeps (KLU's block back substitution) ----------
+__global__ void k_lu_fvals(const int64_t nf, const int64_t *__restrict__ src, const double *__restrict__ Ax, const double *__restrict__ rinv,
+                           const int32_t *__restrict__ ai32, double *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nf) return;
+    const int64_t p = src[e];
+    out[e] = Ax[p] * rinv[ai32[p]];
+}
+// X[pos] -= sum_e val[e] * X[idx[e]] over the entries ptr[pos] .. ptr[pos + 1) for every listed position
+__global__ void k_lu_fterm(const int64_t cnt, const int32_t *__restrict__ poslist, const int64_t *__restrict__ ptr,
+                           const int32_t *__restrict__ idx, const double *__restrict__ val, double *__restrict__ X, const int64_t ldx)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= cnt) return;
+    const int32_t pos = poslist[q];
+    double *x = X + (int64_t)blockIdx.y * ldx;
+    double acc = 0.0;
+    for (int64_t e = ptr[pos]; e < ptr[pos + 1]; e++) acc += val[e] * x[idx[e]];
+    if (ptr[pos + 1] > ptr[pos]) x[pos] -= acc;
+}
+
 }  // namespace
 
 // gfx950: a workgroup may use all 160 KB of a CU's LDS; beyond 64 KB the kernel must be told so once.
@@ -985,6 +1009,17 @@ void launch_lu_bwd_big(const LuDev &d, const int32_t *list, int cnt, int max_m, 
         if (unit) hipLaunchKernelGGL(k_lu_bwd_big_step<true>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
         else hipLaunchKernelGGL(k_lu_bwd_big_step<false>, dim3(chunks, cnt, nrhs), dim3(LU_NT_SOLVE), 0, st, d, list, X, ldx, W, wsize, t0);
     }
+}
+
+void launch_lu_fvals(int64_t nf, const int64_t *src, const double *Ax, const double *rinv, const int32_t *ai32, double *out, hipStream_t st)
+{
+    if (nf > 0) hipLaunchKernelGGL(k_lu_fvals, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, nf, src, Ax, rinv, ai32, out);
+}
+void launch_lu_fterm(int64_t cnt, int nrhs, const int32_t *poslist, const int64_t *ptr, const int32_t *idx, const double *val, double *X,
+                     int64_t ldx, hipStream_t st)
+{
+    if (cnt > 0 && nrhs > 0)
+        hipLaunchKernelGGL(k_lu_fterm, dim3((unsigned)((cnt + 255) / 256), nrhs), dim3(256), 0, st, cnt, poslist, ptr, idx, val, X, ldx);
 }
 
 void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double *rmax, hipStream_t st)

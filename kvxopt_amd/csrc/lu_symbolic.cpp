@@ -2,6 +2,7 @@
 #include "lu_symbolic.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <numeric>
 #include <queue>
@@ -124,15 +125,83 @@ void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *A
     }
     const int64_t matched = lu_matching(n, Ap, Ai, Ax, rinv.data(), Y.rowfor);
     Y.structurally_singular = matched < n;
-    // pattern of tril(M + M') with the diagonal, M(colof[i], j) = A(i, j)
+    // M(colof[i], j) = A(i, j)
     std::vector<int64_t> colof((size_t)n);
     for (int64_t j = 0; j < n; j++) colof[Y.rowfor[j]] = j;
+    // ---- block triangular form: strongly connected components of the graph r -> c for every M(r, c) != 0 (Tarjan,
+    // iterative).  Components come out sinks first; numbering them backwards makes every entry satisfy blk[r] <= blk[c].
+    Y.blk.assign((size_t)n, 0);
+    Y.nblocks = 1; Y.nblev = 1;
+    Y.blev.assign(1, 0);
+    {
+        // CSR of M (rows = M row labels)
+        std::vector<int64_t> rp((size_t)n + 1, 0);
+        for (int64_t p = 0; p < Y.nnz; p++) rp[colof[Ai[p]] + 1]++;
+        for (int64_t i = 0; i < n; i++) rp[i + 1] += rp[i];
+        std::vector<int32_t> rc((size_t)Y.nnz);
+        {
+            std::vector<int64_t> cur(rp.begin(), rp.end() - 1);
+            for (int64_t j = 0; j < n; j++)
+                for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) rc[(size_t)cur[colof[Ai[p]]]++] = (int32_t)j;
+        }
+        std::vector<int32_t> index((size_t)n, -1), low((size_t)n, 0), comp((size_t)n, -1), stack, callv;
+        std::vector<int64_t> callp;
+        std::vector<char> onstack((size_t)n, 0);
+        int32_t counter = 0, ncomp = 0;
+        for (int64_t root = 0; root < n; root++) {
+            if (index[root] >= 0) continue;
+            callv.push_back((int32_t)root); callp.push_back(rp[root]);
+            index[root] = low[root] = counter++; stack.push_back((int32_t)root); onstack[root] = 1;
+            while (!callv.empty()) {
+                const int32_t v = callv.back();
+                int64_t &pp = callp.back();
+                if (pp < rp[v + 1]) {
+                    const int32_t w = rc[(size_t)pp++];
+                    if (index[w] < 0) {
+                        index[w] = low[w] = counter++; stack.push_back(w); onstack[w] = 1;
+                        callv.push_back(w); callp.push_back(rp[w]);
+                    } else if (onstack[w]) low[v] = std::min(low[v], index[w]);
+                } else {
+                    if (low[v] == index[v]) {
+                        for (;;) { const int32_t w = stack.back(); stack.pop_back(); onstack[w] = 0; comp[w] = ncomp; if (w == v) break; }
+                        ncomp++;
+                    }
+                    callv.pop_back(); callp.pop_back();
+                    if (!callv.empty()) low[callv.back()] = std::min(low[callv.back()], low[v]);
+                }
+            }
+        }
+        const char *env = std::getenv("KVX_LU_NO_BTF");
+        if (ncomp > 1 && !(env && env[0] == '1') && !Y.structurally_singular) {
+            std::vector<int32_t> blk((size_t)n);
+            for (int64_t v = 0; v < n; v++) blk[v] = ncomp - 1 - comp[v];
+            // block levels for the back substitution: block k waits for the later blocks its rows touch
+            std::vector<int32_t> blev((size_t)ncomp, 0);
+            std::vector<std::vector<int32_t>> rows((size_t)ncomp);
+            for (int64_t v = 0; v < n; v++) rows[blk[v]].push_back((int32_t)v);
+            int32_t maxlev = 0;
+            for (int32_t k = ncomp - 1; k >= 0; k--) {
+                int32_t lv = 0;
+                for (int32_t r : rows[k])
+                    for (int64_t q = rp[r]; q < rp[r + 1]; q++) {
+                        const int32_t j = blk[rc[(size_t)q]];
+                        if (j != k) lv = std::max(lv, blev[j] + 1);
+                    }
+                blev[k] = lv;
+                maxlev = std::max(maxlev, lv);
+            }
+            if (maxlev < 64) {                  // deep chains of tiny blocks are a sequential sparse triangular solve: one block then
+                Y.blk = blk; Y.blev = blev; Y.nblocks = ncomp; Y.nblev = maxlev + 1;
+            }
+        }
+    }
+    // pattern of tril(D + D') with the diagonal, D = the diagonal blocks of M
     std::vector<int64_t> cnt((size_t)n + 1, 0);
     for (int64_t j = 0; j < n; j++) {
         cnt[j + 1]++;                                                  // diagonal
         for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
             const int64_t r = colof[Ai[p]];
-            if (r != j) cnt[std::min(r, j) + 1]++;
+            if (r != j && Y.blk[r] == Y.blk[j]) cnt[std::min(r, j) + 1]++;
         }
     }
     for (int64_t j = 0; j < n; j++) cnt[j + 1] += cnt[j];
@@ -141,7 +210,7 @@ void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *A
         idx[(size_t)cur[j]++] = j;
         for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
             const int64_t r = colof[Ai[p]];
-            if (r != j) idx[(size_t)cur[std::min(r, j)]++] = std::max(r, j);
+            if (r != j && Y.blk[r] == Y.blk[j]) idx[(size_t)cur[std::min(r, j)]++] = std::max(r, j);
         }
     }
     std::vector<int64_t> ptr((size_t)n + 1, 0), uniq;
@@ -194,6 +263,9 @@ void lu_build_plan(const LuSymbolic &Y, LuPlan &P)
         if (gparent[g] >= 0) kids[gparent[g]].push_back(g);
         else roots.push_back(g);
     }
+    // block triangular form: the trees (one per diagonal block) follow each other in block order
+    auto block_of_group = [&](int32_t g) { return Y.blk[(size_t)S.perm[S.super[top[g]]]]; };
+    std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return block_of_group(a) < block_of_group(b); });
     // postorder of the contracted forest
     std::vector<int32_t> order;
     order.reserve(glist.size());
@@ -336,26 +408,99 @@ void lu_build_plan(const LuSymbolic &Y, LuPlan &P)
             P.nsbig[l] += P.fr[P.levellist[q]].m > KVX_LU_SOLVE_BIG_M;
         }
     }
-    // scatter map of the caller's entries
+    // ---- position blocks, solve stages ----------------------------------------------------------------------
+    std::vector<int32_t> pblk((size_t)n);
+    for (int64_t p = 0; p < n; p++) pblk[p] = Y.blk[(size_t)P.qcol[p]];
+    P.rblocks.clear();
+    for (int64_t p = 0; p < n; p++) {
+        if (p == 0 || pblk[p] != pblk[p - 1]) {
+            if (p > 0 && pblk[p] < pblk[p - 1]) throw std::runtime_error("internal: blocks out of order");
+            P.rblocks.push_back(p);
+        }
+    }
+    P.rblocks.push_back(n);
+    if ((int64_t)P.rblocks.size() != Y.nblocks + 1) throw std::runtime_error("internal: a diagonal block is not contiguous");
+    P.nblev = (int32_t)Y.nblev;
+    {
+        std::vector<int32_t> flev((size_t)nf), maxdep((size_t)P.nblev, -1);
+        for (int64_t f = 0; f < nf; f++) {
+            flev[f] = Y.blev[(size_t)pblk[P.fr[f].p0]];
+            maxdep[flev[f]] = std::max(maxdep[flev[f]], P.fr[f].depth);
+        }
+        P.levstage.assign((size_t)P.nblev + 1, 0);
+        for (int32_t l = 0; l < P.nblev; l++) P.levstage[l + 1] = P.levstage[l] + maxdep[l] + 1;
+        P.nstage = P.levstage[P.nblev];
+        P.stageptr.assign((size_t)P.nstage + 1, 0);
+        for (int64_t f = 0; f < nf; f++) P.stageptr[P.levstage[flev[f]] + P.fr[f].depth + 1]++;
+        for (int32_t t = 0; t < P.nstage; t++) P.stageptr[t + 1] += P.stageptr[t];
+        P.stagelist.resize((size_t)nf);
+        std::vector<int64_t> cur(P.stageptr.begin(), P.stageptr.end() - 1);
+        for (int64_t f = 0; f < nf; f++) P.stagelist[(size_t)cur[P.levstage[flev[f]] + P.fr[f].depth]++] = (int32_t)f;
+        P.stage_nbig.assign((size_t)P.nstage, 0);
+        P.stage_smallm.assign((size_t)P.nstage, 0); P.stage_smallk.assign((size_t)P.nstage, 0);
+        P.stage_bigm.assign((size_t)P.nstage, 0); P.stage_bigk.assign((size_t)P.nstage, 0);
+        for (int32_t t = 0; t < P.nstage; t++) {
+            std::stable_sort(P.stagelist.begin() + P.stageptr[t], P.stagelist.begin() + P.stageptr[t + 1],
+                             [&](int32_t x, int32_t y) {
+                                 const bool bx = P.fr[x].m > KVX_LU_SOLVE_BIG_M, by = P.fr[y].m > KVX_LU_SOLVE_BIG_M;
+                                 return bx != by ? !bx : P.fr[x].m < P.fr[y].m;
+                             });
+            for (int64_t q = P.stageptr[t]; q < P.stageptr[t + 1]; q++) {
+                const LuFrontH &fh = P.fr[P.stagelist[q]];
+                if (fh.m > KVX_LU_SOLVE_BIG_M) {
+                    P.stage_nbig[t]++;
+                    P.stage_bigm[t] = std::max(P.stage_bigm[t], fh.m); P.stage_bigk[t] = std::max(P.stage_bigk[t], fh.k);
+                } else {
+                    P.stage_smallm[t] = std::max(P.stage_smallm[t], fh.m); P.stage_smallk[t] = std::max(P.stage_smallk[t], fh.k);
+                }
+            }
+        }
+        P.flevptr.assign((size_t)P.nblev + 1, 0);
+        for (int64_t p = 0; p < n; p++) P.flevptr[Y.blev[(size_t)pblk[p]] + 1]++;
+        for (int32_t l = 0; l < P.nblev; l++) P.flevptr[l + 1] += P.flevptr[l];
+        P.flevpos.resize((size_t)n);
+        std::vector<int64_t> cur2(P.flevptr.begin(), P.flevptr.end() - 1);
+        for (int64_t p = 0; p < n; p++) P.flevpos[(size_t)cur2[Y.blev[(size_t)pblk[p]]]++] = (int32_t)p;
+    }
+    // ---- scatter map of the caller's entries (diagonal blocks) and the off-diagonal part F ------------------------
     std::vector<int32_t> posrow((size_t)n), poscol((size_t)n);
     for (int64_t p = 0; p < n; p++) { posrow[P.prow[p]] = (int32_t)p; poscol[P.qcol[p]] = (int32_t)p; }
     P.aptr.assign((size_t)nf + 1, 0);
+    P.fptr_r.assign((size_t)n + 1, 0);
+    P.fptr_c.assign((size_t)n + 1, 0);
     std::vector<int32_t> ef((size_t)Y.nnz);
+    int64_t nF = 0;
     for (int64_t j = 0; j < n; j++)
         for (int64_t p = Y.Ap[j]; p < Y.Ap[j + 1]; p++) {
-            const int32_t f = col2front[std::min(posrow[Y.Ai[p]], poscol[j])];
+            const int32_t pr = posrow[Y.Ai[p]], pc = poscol[j];
+            if (pblk[pr] != pblk[pc]) {
+                if (pblk[pr] > pblk[pc]) throw std::runtime_error("internal: entry below the block diagonal");
+                ef[p] = -1; nF++;
+                P.fptr_r[pr + 1]++; P.fptr_c[pc + 1]++;
+                continue;
+            }
+            const int32_t f = col2front[std::min(pr, pc)];
             ef[p] = f;
             P.aptr[f + 1]++;
         }
     for (int64_t f = 0; f < nf; f++) P.aptr[f + 1] += P.aptr[f];
-    P.a_src.resize((size_t)Y.nnz);
-    P.a_dst.resize((size_t)Y.nnz);
+    for (int64_t p = 0; p < n; p++) { P.fptr_r[p + 1] += P.fptr_r[p]; P.fptr_c[p + 1] += P.fptr_c[p]; }
+    P.a_src.resize((size_t)(Y.nnz - nF));
+    P.a_dst.resize((size_t)(Y.nnz - nF));
+    P.fcol.resize((size_t)nF); P.frow.resize((size_t)nF); P.fsrc_r.resize((size_t)nF); P.fsrc_c.resize((size_t)nF);
     {
-        std::vector<int64_t> cur(P.aptr.begin(), P.aptr.end() - 1);
+        std::vector<int64_t> cur(P.aptr.begin(), P.aptr.end() - 1), cr(P.fptr_r.begin(), P.fptr_r.end() - 1), cc(P.fptr_c.begin(), P.fptr_c.end() - 1);
         for (int64_t j = 0; j < n; j++)
             for (int64_t p = Y.Ap[j]; p < Y.Ap[j + 1]; p++) {
                 const int32_t f = ef[p];
-                const int32_t lr = local_index(f, posrow[Y.Ai[p]]), lc = local_index(f, poscol[j]);
+                const int32_t pr = posrow[Y.Ai[p]], pc = poscol[j];
+                if (f < 0) {
+                    const int64_t a1 = cr[pr]++, a2 = cc[pc]++;
+                    P.fcol[(size_t)a1] = pc; P.fsrc_r[(size_t)a1] = p;
+                    P.frow[(size_t)a2] = pr; P.fsrc_c[(size_t)a2] = p;
+                    continue;
+                }
+                const int32_t lr = local_index(f, pr), lc = local_index(f, pc);
                 if (lr < 0 || lc < 0) throw std::runtime_error("internal: entry outside the front structure");
                 const int64_t q = cur[f]++;
                 P.a_src[q] = p;

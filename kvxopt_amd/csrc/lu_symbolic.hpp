@@ -27,6 +27,11 @@ struct LuSymbolic {
     std::vector<int64_t> rowfor;          // matching: row rowfor[j] sits on the diagonal of column j
     bool structurally_singular = false;
     Symbolic S;                           // analysis of pattern(M + M'), M = A(rowfor, :)
+    // block triangular form (KLU's BTF, klu_analyze): strongly connected components of M, numbered so that every entry
+    // M(r, c) has blk[r] <= blk[c] (block UPPER triangular).  nblocks == 1: not used (one block, F empty).
+    int64_t nblocks = 1, nblev = 1;
+    std::vector<int32_t> blk;             // [n] block of every M label (row and column share it: the diagonal is matched)
+    std::vector<int32_t> blev;            // [nblocks] solve level: 1 + max level of the later blocks this one's rows touch (0: none)
     std::vector<int32_t> uf;              // union-find over S's supernodes: learned merges (uf[s] = representative link)
     int64_t nmerges = 0;
 };
@@ -61,6 +66,20 @@ struct LuPlan {
     std::vector<int32_t> levellist;       // inside a level: LDS-resident fronts first (largest first), then the big ones (smallest first)
     std::vector<int32_t> nlds;            // [nlevels] how many fronts of the level are LDS resident (m <= lds_m)
     std::vector<int32_t> nsbig;           // [nlevels] how many fronts (the LAST of the level's list) take the multi-workgroup solve path
+    // triangular solves: stages = (block level, tree depth) pairs; without BTF one block level, stages = tree levels
+    int32_t nblev = 1, nstage = 0;
+    std::vector<int32_t> levstage;        // [nblev+1] stage range of every block level (stage = levstage[l] + depth)
+    std::vector<int64_t> stageptr;        // [nstage+1] into stagelist
+    std::vector<int32_t> stagelist;       // fronts of a stage: one-workgroup fronts first, then the multi-workgroup ones (m ascending)
+    std::vector<int32_t> stage_nbig, stage_smallm, stage_smallk, stage_bigm, stage_bigk;   // [nstage]
+    // F = off-diagonal blocks of R P A Q (never eliminated, klu_extract's F): by row position (CSR, for A x = b) and by
+    // column position (CSC, for A' x = b); fsrc = index of the entry in the caller's value array
+    std::vector<int64_t> fptr_r, fptr_c;  // [n+1]
+    std::vector<int32_t> fcol, frow;      // column position of a CSR entry / row position of a CSC entry
+    std::vector<int64_t> fsrc_r, fsrc_c;
+    std::vector<int64_t> flevptr;         // [nblev+1] into flevpos
+    std::vector<int32_t> flevpos;         // positions of the block level (all of them: rows and columns share positions)
+    std::vector<int64_t> rblocks;         // [nblocks+1] block boundaries in pivotal positions (klu_extract's r)
     int64_t arena = 0, wsize = 0, lsize = 0;
     int32_t max_m = 0, max_k = 0;
     int64_t lnz_bound = 0, unz_bound = 0;

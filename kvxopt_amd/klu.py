@@ -9,9 +9,10 @@ No CPU fallback: numeric calls raise RuntimeError without a GPU.
     get_numeric(A, Fs, Fn) -> L, U, P, Q, R, F, r                klu.c:392-566   (R P A Q = L U + F)
     get_det(A, Fs, Fn) -> float                                  klu.c:707-828
 
-Real ('d') matrices only; complex ('z') raises TypeError (out of scope).  The factorisation is not
-KLU's: no block-triangular form (F is empty, r = [0, n]), static fronts with in-front threshold pivoting -- the
-identities the reference's tests check (tests/test_sparse_solvers.py:214-323) hold all the same.
+Real ('d') matrices only; complex ('z') raises TypeError (out of scope).  The factorisation has KLU's form
+(block triangular permutation, L U of the diagonal blocks, off-diagonal part F, row scaling R) but not its algorithm:
+static multifrontal fronts with in-front threshold pivoting -- the identities the reference's tests check
+(tests/test_sparse_solvers.py:214-323) hold all the same.
 """
 import numpy as np
 

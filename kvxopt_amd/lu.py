@@ -36,6 +36,13 @@ class LuSymbolic:
         keys = ("n", "nnz", "nsuper", "merges", "structurally_singular", "lnz_sym", "nlevels", "max_front")
         return dict(zip(keys, (int(x) for x in a)))
 
+    def btf(self):
+        """(number of diagonal blocks, number of block levels, block of every column)."""
+        nb, nl = i64(), i64()
+        blk = np.empty(self.n, dtype=np.int64)
+        raise_for(lib().kvx_lu_sym_btf(self._h, ctypes.byref(nb), ctypes.byref(nl), pi(blk)))
+        return nb.value, nl.value, blk
+
     def matching(self):
         r = np.empty(self.n, dtype=np.int64)
         raise_for(lib().kvx_lu_sym_matching(self._h, pi(r)))

@@ -116,6 +116,28 @@ def test_matching_is_optimal_on_small_random_matrices():
         assert got >= best * (1 - 1e-12)
 
 
+@pytest.mark.parametrize("name,nblocks", [("bp_800", 492), ("ACTIVSg2000", 1)])      # (ACTIVSg2000 stores explicit zeros: with them it is irreducible)
+def test_block_triangular_form(golden_dir, name, nblocks):
+    """KLU's BTF: strongly connected components of the matched matrix, numbered so that R P A Q is block UPPER triangular;
+    the count is checked against SciPy's strongly connected components of the same matched matrix."""
+    from scipy.sparse.csgraph import connected_components
+    n, cp, ri, v, A = load(golden_dir, name)
+    S = LuSymbolic(n, cp, ri, v)
+    nb, nlev, blk = S.btf()
+    rowfor = S.matching()
+    M = A.tocsr()[rowfor, :].tocoo()                       # M(j, j) = A(rowfor[j], j)
+    assert nb == nblocks == connected_components(M.tocsr(), directed=True, connection="strong")[0]
+    assert np.all(blk[M.row] <= blk[M.col])                 # nothing below the block diagonal
+    assert 1 <= nlev <= 64 and sorted(set(blk)) == list(range(nb))
+
+
+def test_deep_block_chains_fall_back_to_one_block(golden_dir):
+    """A triangular matrix is n singleton blocks in one dependency chain: factoring it as one block keeps the solves parallel."""
+    n, cp, ri, v, A = load(golden_dir, "bcsstk13")          # stored lower triangle, read as a general matrix
+    nb, nlev, blk = LuSymbolic(n, cp, ri, v).btf()
+    assert nb == 1 and nlev == 1 and not blk.any()
+
+
 def test_structurally_singular_pattern_is_flagged():
     A = sp.csc_matrix(np.array([[1.0, 1.0, 0], [1.0, 1.0, 0], [1.0, 1.0, 0]]))       # column 2 empty
     S = LuSymbolic(3, A.indptr, A.indices, A.data)

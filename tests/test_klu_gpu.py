@@ -99,6 +99,26 @@ def test_parity_with_oracle(golden_dir, name):
         assert np.abs(x - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
 
 
+def test_block_triangular_form_of_bp_800(golden_dir):
+    """KLU's R P A Q = L U + F with a non-trivial F: bp_800 has 492 diagonal blocks (471 singletons); L U is block
+    diagonal, F strictly block upper triangular, r the block boundaries."""
+    A = load(golden_dir, "bp_800")
+    n = A.size[0]
+    Fs = klu.symbolic(A)
+    nb, nlev, blk = Fs.sym.btf()
+    assert nb == 492 and 1 < nlev <= 64
+    Fn = klu.numeric(A, Fs)
+    L, U, P, Q, R, F, r = klu.get_numeric(A, Fs, Fn)
+    assert len(r) == nb + 1 and r[0] == 0 and r[-1] == n and all(a < b for a, b in zip(r, r[1:]))
+    bo = np.searchsorted(np.array(r), np.arange(n), side="right") - 1        # block of every pivotal position
+    for Msp, name in ((to_sp(L), "L"), (to_sp(U), "U")):
+        C = Msp.tocoo()
+        assert np.all(bo[C.row] == bo[C.col]), name                           # factors of the diagonal blocks only
+    C = to_sp(F).tocoo()
+    assert C.nnz > 0 and np.all(bo[C.row] < bo[C.col])                        # F strictly above the block diagonal
+    assert (to_sp(L).nnz - n) + to_sp(U).nnz + C.nnz < 1.6 * A.values.size    # 6 969 entries for 4 534 in A (9 574 + without BTF)
+
+
 def test_doc_known_answers():
     A = spmatrix(DOC_V, DOC_I, DOC_J)
     B = matrix(np.arange(5.0))
@@ -185,7 +205,7 @@ def test_zero_diagonal_random_matrices_force_pivoting_and_merges():
             xo = OracleKLU(n, M.colptr, M.rowind, M.values).solve(b, tran)
             assert np.abs(x - xo).max() <= 1e-8 * max(1.0, np.abs(xo).max())
         L, U, P, Q, R, F, r = klu.get_numeric(M, Fs, Fn)
-        rho = abs(to_sp(R) @ to_sp(P) @ to_sp(M) @ to_sp(Q) - to_sp(L) @ to_sp(U)).sum(axis=0).max()
+        rho = abs(to_sp(R) @ to_sp(P) @ to_sp(M) @ to_sp(Q) - to_sp(L) @ to_sp(U) - to_sp(F)).sum(axis=0).max()
         assert rho < 1e-10
     assert merges > 0            # the merge path was exercised
 
@@ -236,7 +256,7 @@ def test_unsymmetric_grid_uses_the_blocked_big_front_path():
         xs = lu.solve(b, trans=tran)
         assert np.abs(x - xs).max() <= 1e-7 * max(1.0, np.abs(xs).max())
     L, U, P, Q, R, F, r = klu.get_numeric(A, Fs, Fn)
-    rho = abs(to_sp(R) @ to_sp(P) @ As @ to_sp(Q) - to_sp(L) @ to_sp(U)).sum(axis=0).max()
+    rho = abs(to_sp(R) @ to_sp(P) @ As @ to_sp(Q) - to_sp(L) @ to_sp(U) - to_sp(F)).sum(axis=0).max()
     assert rho < 1e-12
 
 
