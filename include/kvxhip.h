@@ -197,6 +197,12 @@ int kvx_lp_step_post_dev(int64_t ml, double dtau, const double *z1, const double
 int kvx_lp_update_dev(int64_t ml, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s, double *z);
 /* count <= 32 reductions with one host synchronisation: kind[i] = 0 sdot(x_i, y_i), 1 max_step(x_i) -- bitwise the
  * values of the single calls (the per-iteration residual norms / objectives of coneprog.py:861-896 in one go). */
+/* second half of f6_no_ir + step bounds (coneprog.py:1162-1195, 1303-1321) in one host round trip: dtau is formed on the
+ * device from c'dx + b'dy + th'dz (and z1'z1 when z1z1 < 0) and consumed there by dx += dtau x1, dy += dtau y1,
+ * dz += dtau z1, ds -= dz, [ws3 = ds.*dz], ds ./= lmbda, dz ./= lmbda.  out_host = {dtau, z1'z1, max(-ds), max(-dz)}. */
+int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, const double *b, const double *th, const double *x1,
+                           const double *y1, const double *z1, const double *lmbda, double *dx, double *dy, double *dz, double *ds,
+                           double *ws3, double dgi, double dtau0, double z1z1, double out_host[4]);
 int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, const double *const *x,
                             const double *const *y, double *out_host);
 

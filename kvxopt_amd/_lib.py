@@ -77,6 +77,7 @@ _SIGS = {
     "kvx_lp_newton_rhs_dev": (ctypes.c_int, [i64, vp, vp, f64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_step_post_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_update_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp, vp, vp]),
+    "kvx_lp_second_half_dev": (ctypes.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64p]),
     "kvx_nt_reduce_multi_dev": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), i64p, ctypes.POINTER(vp),
                                                 ctypes.POINTER(vp), f64p]),
     "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),

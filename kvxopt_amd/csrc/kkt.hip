@@ -98,6 +98,46 @@ __global__ void k_lp_update(int64_t n, double step, double *__restrict__ ds, dou
         z[i] = ln * dinv;
     }
 }
+
+// ---- second half of f6_no_ir with dtau kept on the device (coneprog.py:1162-1195, 1303-1316): the host used to fetch the
+// three inner products, form dtau, launch the updates and fetch the two step bounds -- two round trips; here dtau is formed
+// by a one-thread kernel from the reduction results and the dependent kernels read it from memory: one round trip.
+//   r[0..2] = c'dx, b'dy, th'dz ; r[3] = z1'z1 (or the host value when r3_host >= 0)
+//   out[0] = dtau = dgi (dtau0 + r0 + r1 + r2) / (1 + z1z1) ; out[1] = z1z1
+__global__ void k_lp_dtau(const double *__restrict__ r, double dgi, double dtau0, double z1z1_host, int use_host, double *__restrict__ out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const double zz = use_host ? z1z1_host : r[3];
+        out[0] = dgi * (dtau0 + r[0] + r[1] + r[2]) / (1.0 + zz);
+        out[1] = zz;
+    }
+}
+__global__ void k_axpy_devalpha(int64_t n, const double *__restrict__ alpha, const double *__restrict__ x, double *__restrict__ y)
+{
+    const double a = alpha[0];
+    GS_LOOP(i, n) y[i] += a * x[i];
+}
+__global__ void k_lp_step_post_dev(int64_t n, const double *__restrict__ dtau_p, const double *__restrict__ z1, const double *__restrict__ lm,
+                                   double *__restrict__ ds, double *__restrict__ dz, double *__restrict__ ws3)
+{
+    const double dtau = dtau_p[0];
+    GS_LOOP(i, n) {
+        const double zz = dz[i] + dtau * z1[i];
+        const double ss = ds[i] - zz;
+        if (ws3) ws3[i] = ss * zz;
+        const double l = lm[i];
+        ds[i] = ss / l;
+        dz[i] = zz / l;
+    }
+}
+void launch_lp_dtau(hipStream_t st, const double *r, double dgi, double dtau0, double z1z1_host, int use_host, double *out)
+{ hipLaunchKernelGGL(k_lp_dtau, dim3(1), dim3(64), 0, st, r, dgi, dtau0, z1z1_host, use_host, out); }
+void launch_axpy_devalpha(hipStream_t st, int64_t n, const double *alpha, const double *x, double *y)
+{ if (n > 0) hipLaunchKernelGGL(k_axpy_devalpha, dim3(grid_for(n)), dim3(256), 0, st, n, alpha, x, y); }
+void launch_lp_step_post_devalpha(hipStream_t st, int64_t n, const double *dtau, const double *z1, const double *lm, double *ds, double *dz,
+                                  double *ws3)
+{ if (n > 0) hipLaunchKernelGGL(k_lp_step_post_dev, dim3(grid_for(n)), dim3(256), 0, st, n, dtau, z1, lm, ds, dz, ws3); }
+
 void launch_lp_newton_rhs(hipStream_t st, int64_t n, const double *lsq, const double *ws3, double shift, double scale,
                           const double *rz, const double *lm, const double *d, double *ds, double *dz)
 { if (n > 0) hipLaunchKernelGGL(k_lp_newton_rhs, dim3(grid_for(n)), dim3(256), 0, st, n, lsq, ws3, shift, scale, rz, lm, d, ds, dz); }

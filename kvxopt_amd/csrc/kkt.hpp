@@ -8,6 +8,10 @@ void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const do
 void launch_update_scaling(hipStream_t st, int64_t n, double *s, double *z, double *d, double *di, double *lm);
 void launch_lp_newton_rhs(hipStream_t st, int64_t n, const double *lsq, const double *ws3, double shift, double scale,
                           const double *rz, const double *lm, const double *d, double *ds, double *dz);
+void launch_lp_dtau(hipStream_t st, const double *r, double dgi, double dtau0, double z1z1_host, int use_host, double *out);
+void launch_axpy_devalpha(hipStream_t st, int64_t n, const double *alpha, const double *x, double *y);
+void launch_lp_step_post_devalpha(hipStream_t st, int64_t n, const double *dtau, const double *z1, const double *lm, double *ds, double *dz,
+                                  double *ws3);
 void launch_lp_step_post(hipStream_t st, int64_t n, double dtau, const double *z1, const double *lm, double *ds, double *dz, double *ws3);
 void launch_lp_update(hipStream_t st, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lm, double *s, double *z);
 void launch_scale(hipStream_t st, int64_t n, int64_t ncols, int64_t ldx, double *x, const double *w);

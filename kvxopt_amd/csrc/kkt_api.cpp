@@ -301,6 +301,35 @@ int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, co
     return KVX_OK;
 }
 
+// Second half of f6_no_ir for the orthant cone in ONE host round trip (kkt.hip, k_lp_dtau): returns dtau, z1'z1 and the
+// step bounds max(-ds ./ lmbda), max(-dz ./ lmbda) of coneprog.py:1316-1321.  y-blocks may be empty (p = 0: b, dy, y1 NULL).
+// z1z1 < 0: compute z1'z1 in the same reduction (first call of an iteration), else the value of that call.
+int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, const double *b, const double *th, const double *x1,
+                           const double *y1, const double *z1, const double *lmbda, double *dx, double *dy, double *dz, double *ds,
+                           double *ws3, double dgi, double dtau0, double z1z1, double out_host[4])
+{
+    if (ml < 0 || n < 0 || p < 0 || !out_host) return KVX_EINVAL;
+    int rc = ensure_scratch();
+    if (rc) return rc;
+    Scratch &s = scratch();
+    double *r = s.multi, *sc = s.multi + 8, *mx = s.multi + 16;
+    launch_dot(nullptr, n, c, dx, s.part, r + 0);
+    if (p > 0) launch_dot(nullptr, p, b, dy, s.part, r + 1);
+    else HIPCHK(hipMemsetAsync(r + 1, 0, sizeof(double), nullptr));
+    launch_dot(nullptr, ml, th, dz, s.part, r + 2);
+    if (z1z1 < 0.0) launch_dot(nullptr, ml, z1, z1, s.part, r + 3);
+    launch_lp_dtau(nullptr, r, dgi, dtau0, z1z1, z1z1 < 0.0 ? 0 : 1, sc);
+    launch_axpy_devalpha(nullptr, n, sc, x1, dx);
+    if (p > 0) launch_axpy_devalpha(nullptr, p, sc, y1, dy);
+    launch_lp_step_post_devalpha(nullptr, ml, sc, z1, lmbda, ds, dz, ws3);
+    launch_maxneg(nullptr, ml, ds, s.part, mx + 0);
+    launch_maxneg(nullptr, ml, dz, s.part, mx + 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(s.host, s.multi, 18 * sizeof(double), hipMemcpyDeviceToHost));
+    out_host[0] = s.host[8]; out_host[1] = s.host[9]; out_host[2] = s.host[16]; out_host[3] = s.host[17];
+    return KVX_OK;
+}
+
 // ---- BLAS-1 glue of the interior-point loop on device vectors (blas.axpy/scal/copy/dot calls of coneprog.py) ----
 int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y)
 { launch_axpy(nullptr, n, alpha, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }

@@ -636,31 +636,36 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
             ksolve2(x1, y1, z1, dx, dy, dz)
             x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
             th.copy_from(hv).mul(di)                     # th = W^{-T} h      (coneprog.py:1126-1128)
-            z1z1 = z1.dot(z1)                            # (first host synchronisation after the factorisation)
-            kkt.check()
         except ArithmeticError:
             kkt.async_solves = False
             x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
             return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
 
+        z1z1 = -1.0                                      # computed on the device with the first direction
+        out4 = (ctypes.c_double * 4)()
         for i in (0, 1):
             if i == 1:
                 newton_rhs(1)
                 ksolve(dx, dy, dz)
-            # second half of f6_no_ir (coneprog.py:1162-1195)
+            # second half of f6_no_ir (coneprog.py:1162-1195), dz += dtau z1, ds -= dz, [ws3 := ds o dz for the corrector
+            # (coneprog.py:1303-1306)], the scaling by lmbda and the step bounds (coneprog.py:1314-1321): dtau is formed on the
+            # device from the inner products, ONE host round trip per direction (the first one after the factorisation)
             dkappa = -st8["dkappa"] / lmbda_g
-            dtau = st8["dtau"] + dkappa / dgi
-            cdx, bdy, thdz = reduce_multi([("dot", cv, dx), ("dot", bv, dy), ("dot", th, dz)])
-            dtau = dgi * (dtau + cdx + bdy + thdz) / (1.0 + z1z1)
-            dx.axpy(x1, dtau)
-            dy.axpy(y1, dtau)
+            dtau0 = st8["dtau"] + dkappa / dgi
+            raise_for(lib().kvx_lp_second_half_dev(ml, n, p, cv.ptr, bv.ptr if p else None, th.ptr, x1.ptr, y1.ptr if p else None,
+                                                   z1.ptr, lmbda.ptr, dx.ptr, dy.ptr if p else None, dz.ptr, ds.ptr,
+                                                   ws3.ptr if i == 0 else None, dgi, dtau0, z1z1, out4))
+            dtau, z1z1, ts, tz = out4[0], out4[1], out4[2], out4[3]
+            if i == 0:
+                try:
+                    kkt.check()                          # the stream is idle by now: no extra wait
+                except ArithmeticError:
+                    kkt.async_solves = False
+                    x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+                    return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
             dkappa -= dtau
-            # dz += dtau z1, ds -= dz, [ws3 := ds o dz for the corrector (coneprog.py:1303-1306)], then the scaling by
-            # lmbda for the step length (coneprog.py:1314-1316): one fused kernel
-            raise_for(lib().kvx_lp_step_post_dev(ml, dtau, z1.ptr, lmbda.ptr, ds.ptr, dz.ptr, ws3.ptr if i == 0 else None))
             if i == 0:
                 wkappa3 = dtau * dkappa
-            ts, tz = reduce_multi([("max", ds), ("max", dz)])
             tt = -dtau / lmbda_g
             tk = -dkappa / lmbda_g
             t = max(0.0, ts, tz, tt, tk)
