@@ -333,3 +333,60 @@ def test_dbound_replaces_small_pivots():
         b = rng.standard_normal(n); b -= b.mean()            # consistent right-hand side
         x = b.copy(); F1.solve(x)
         assert np.abs(Afull @ x - b).max() < 1e-8 * max(1.0, np.abs(x).max())
+
+
+def test_covariance_selection_example_drives_the_mirror():
+    """The reference's own user script for this API, examples/doc/chap7/covsel.py (SURVEY 8(b) "what calls it"), restated with
+    numpy for its dense algebra and kvxopt_amd.cholmod for everything it asks of CHOLMOD: symbolic once, numeric per Newton
+    step and per line-search trial (ArithmeticError on a non-positive-definite trial, cholmod.c:308-310), diag for log det,
+    solve with an n-column identity.  At the solution inv(K) agrees with Y on the sparsity pattern."""
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import spmatrix, matrix
+    import scipy.sparse as sp
+    rng = np.random.default_rng(17)
+    n = 40
+    Bm = sp.random(n, n, density=0.06, random_state=3, data_rvs=lambda k: rng.standard_normal(k))
+    K0 = (Bm @ Bm.T + 4.0 * sp.identity(n)).tocsc()               # a sparse SPD "true" precision matrix
+    Sig = np.linalg.inv(K0.toarray())
+    pat = sp.tril(K0).tocoo()
+    order = np.lexsort((pat.row, pat.col))
+    I, J = pat.row[order], pat.col[order]
+    Yv = Sig[I, J]                                                  # Y: sample covariance on the pattern of K
+    m = len(I)
+    D = np.nonzero(I == J)[0]
+    Kv = np.where(I == J, 1.0, 0.0)
+    K = spmatrix(Kv, I, J, (n, n))
+    F = cholmod.symbolic(K)
+    failures = 0
+    for iters in range(100):
+        cholmod.numeric(K, F)
+        d = np.array(cholmod.diag(F)._a).ravel()
+        Kinv = np.asfortranarray(np.eye(n))
+        cholmod.solve(F, Kinv)
+        grad = 2 * (Yv - Kinv[I, J])
+        hess = 2 * (Kinv[np.ix_(I, J)] * Kinv[np.ix_(J, I)] + Kinv[np.ix_(I, I)] * Kinv[np.ix_(J, J)])
+        v = np.linalg.solve(hess, -grad)
+        sqntdecr = -grad @ v
+        if sqntdecr < 1e-12:
+            break
+        dx = v.copy(); dx[D] *= 2
+        f = -2.0 * np.log(d).sum()
+        s_ = 1.0
+        for _ in range(50):
+            Kn = spmatrix(np.array(K.values) + s_ * dx, I, J, (n, n))
+            try:
+                cholmod.numeric(Kn, F)
+            except ArithmeticError:
+                failures += 1
+                s_ *= 0.5
+                continue
+            dn = np.array(cholmod.diag(F)._a).ravel()
+            fn = -2.0 * np.log(dn).sum() + 2 * s_ * (v @ Yv)
+            if fn < f - 0.01 * s_ * sqntdecr:
+                break
+            s_ *= 0.5
+        K = spmatrix(np.array(K.values) + s_ * dx, I, J, (n, n))
+    assert iters < 40
+    Kd = np.zeros((n, n)); Kd[I, J] = K.values; Kd = Kd + np.tril(Kd, -1).T
+    assert np.abs(np.linalg.inv(Kd)[I, J] - Yv).max() < 1e-7       # optimality: inv(K) = Y on the pattern
+    assert np.abs(Kd - K0.toarray()).max() < 1e-5                  # and here the maximiser is the true precision matrix
