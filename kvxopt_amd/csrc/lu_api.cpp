@@ -163,7 +163,7 @@ LuDev dev_view(const kvx_lu_num *N)
 
 int lds_class(int m)
 {
-    static const int cls[] = {16, 32, 48, 64, 88, 112, KVX_LU_LDS_M};
+    static const int cls[] = {16, 32, 48, 64, 88, KVX_LU_LDS_M};
     for (int c : cls) if (m <= c) return c;
     return KVX_LU_LDS_M;
 }

@@ -10,6 +10,7 @@
 // power-flow matrices are tens to hundreds of rows (an MFMA update for fronts of thousands of rows is future work).
 #include "lu_device.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace kvx {
 
@@ -176,6 +177,187 @@ __global__ __launch_bounds__(NT) void k_lu_front(const LuDev d, const int32_t *_
         for (int j = ty; j < u; j += NT / 64)
             for (int i = tx; i < u; i += 64) Uo[i + (int64_t)j * u] = Fm[(k + i) + (int64_t)(k + j) * ld];
     }
+}
+
+
+// Register-tiled elimination of an LDS-resident front (m <= 16 T).  The LDS version above moves 24 bytes through LDS per
+// multiply-add of the rank-1 update and is LDS-bandwidth bound (a front of order 136 with 100 pivots: ~90 us).  Here the
+// 256 threads form a 16 x 16 grid, thread (tx, ty) keeps the entries (tx + 16 a, ty + 16 b), a, b < T, in registers; per
+// pivot the pivot row and the multiplier column travel through LDS once (2 T reads per thread instead of 2 T^2) and the
+// update is T^2 register FMAs.  Rows are never moved: each thread carries the logical position (`slot`) of its rows under
+// the LAPACK-style interchange sequence, the tile is written back to the logical positions at the end.  Pivot steps are
+// unrolled over the column-block index so that every register index is a compile-time constant.
+template <int T>
+struct TileCtx {
+    double *lcol, *urow, *sh_pv;
+    int *sh_r, *sh_piv;
+    int32_t *fail_slot;
+    double tol, lmax;
+    int m, k, tx, ty, reuse;
+    int slot[T];
+    bool failed;
+};
+
+template <int T, int BJ>
+__device__ __forceinline__ void tile_block(double (&a)[T][T], TileCtx<T> &x)
+{
+    if constexpr (BJ < T) {
+        for (int jj = 0; jj < 16; jj++) {
+            const int j = 16 * BJ + jj;
+            if (j >= x.k) break;                                  // uniform
+            // (1) the 16 threads holding column j (ty == jj: 16 consecutive lanes of one wavefront) choose the pivot
+            if (x.ty == jj) {
+                double bmax = -1.0, bval = 0.0, dval = 0.0;
+                int brow = -1, bslot = 0x7fffffff, qrow = -1;
+#pragma unroll
+                for (int ar = 0; ar < T; ar++) {
+                    const int i = x.tx + 16 * ar;
+                    const int sl = x.slot[ar];
+                    const double v = a[ar][BJ], av = fabs(v);
+                    const bool cand = i < x.k && sl >= j;         // rows of the pivot block not yet used
+                    if (x.reuse) {
+                        if (cand && sl == j + x.sh_piv[j]) { bmax = av; bval = v; brow = i; bslot = sl; }
+                    } else if (cand && (av > bmax || (av == bmax && sl < bslot))) { bmax = av; bval = v; brow = i; bslot = sl; }
+                    if (i < x.k && sl == j) { qrow = i; dval = v; }
+                }
+#pragma unroll
+                for (int off = 8; off; off >>= 1) {
+                    const double ob = __shfl_xor(bmax, off), ov = __shfl_xor(bval, off), od = __shfl_xor(dval, off);
+                    const int orow = __shfl_xor(brow, off), osl = __shfl_xor(bslot, off), oq = __shfl_xor(qrow, off);
+                    if (ob > bmax || (ob == bmax && osl < bslot)) { bmax = ob; bval = ov; brow = orow; bslot = osl; }
+                    if (oq >= 0) { qrow = oq; dval = od; }
+                }
+                if (x.tx == 0) {
+                    // KLU's rule: keep the diagonal (the row at logical position j) when |d| >= tol * max
+                    if (!x.reuse && qrow >= 0 && fabs(dval) > 0.0 && fabs(dval) >= x.tol * bmax) { brow = qrow; bval = dval; bslot = j; }
+                    const double ap = fabs(bval);
+                    const bool bad = brow < 0 || !(ap > 0.0) || !(ap <= 1.7e308);
+                    if (bad && !x.failed) { x.failed = true; *x.fail_slot = j + 1; }
+                    if (bad) { bval = 1.0; if (brow < 0) { brow = qrow; bslot = j; } }
+                    x.sh_r[0] = brow; x.sh_r[1] = qrow; x.sh_r[2] = bslot;
+                    x.sh_pv[0] = bval;
+                    x.sh_piv[j] = bslot - j;
+                }
+            }
+            __syncthreads();
+            const int r = x.sh_r[0], q = x.sh_r[1], sr = x.sh_r[2];
+            const double pv = x.sh_pv[0];
+            // (2) interchange = relabel; the owners of the pivot row publish it, the owners of column j the multipliers
+#pragma unroll
+            for (int ar = 0; ar < T; ar++) {
+                const int i = x.tx + 16 * ar;
+                if (i == r) x.slot[ar] = j;
+                else if (i == q) x.slot[ar] = sr;
+            }
+#pragma unroll
+            for (int ar = 0; ar < T; ar++)
+                if (x.tx + 16 * ar == r) {                        // (tested on the row number, not on `ar`: a comparison of the
+#pragma unroll                                                    //  index itself lets LLVM index the tile dynamically -> scratch)
+                    for (int bc = 0; bc < T; bc++) x.urow[x.ty + 16 * bc] = a[ar][bc];
+                }
+            if (x.ty == jj) {
+#pragma unroll
+                for (int ar = 0; ar < T; ar++) {
+                    const int i = x.tx + 16 * ar;
+                    double l = 0.0;
+                    if (i < x.m && x.slot[ar] > j) {
+                        l = a[ar][BJ] / pv;
+                        a[ar][BJ] = l;
+                        x.lmax = fmax(x.lmax, fabs(l));
+                    }
+                    x.lcol[i] = l;
+                }
+            }
+            __syncthreads();
+            // (3) rank-1 update of the columns right of j, in registers
+            double lr[T];
+#pragma unroll
+            for (int ar = 0; ar < T; ar++) lr[ar] = x.lcol[x.tx + 16 * ar];
+            if (x.ty > jj) {
+                const double u0 = x.urow[x.ty + 16 * BJ];
+#pragma unroll
+                for (int ar = 0; ar < T; ar++) a[ar][BJ] -= lr[ar] * u0;
+            }
+#pragma unroll
+            for (int bc = BJ + 1; bc < T; bc++) {
+                const double uc = x.urow[x.ty + 16 * bc];
+#pragma unroll
+                for (int ar = 0; ar < T; ar++) a[ar][bc] -= lr[ar] * uc;
+            }
+        }
+        tile_block<T, BJ + 1>(a, x);
+    }
+}
+
+template <int T>
+__device__ void lu_factor_front_tiled(double *Fm, const int ld, const int m, const int k, int32_t *ipiv, int32_t *fail_slot,
+                                      const double tol, const double stol, const int reuse, double *lcol, double *urow, int *sh_r,
+                                      double *sh_pv, int32_t *sh_piv)
+{
+    const int tid = threadIdx.x;
+    TileCtx<T> x;
+    x.lcol = lcol; x.urow = urow; x.sh_pv = sh_pv; x.sh_r = sh_r; x.sh_piv = sh_piv; x.fail_slot = fail_slot;
+    x.tol = tol; x.lmax = 0.0; x.m = m; x.k = k; x.tx = tid & 15; x.ty = tid >> 4; x.reuse = reuse; x.failed = false;
+    if (reuse) {
+        for (int t = tid; t < k; t += 256) sh_piv[t] = ipiv[t];
+    }
+    double a[T][T];
+#pragma unroll
+    for (int ar = 0; ar < T; ar++) {
+        const int i = x.tx + 16 * ar;
+        x.slot[ar] = i;
+#pragma unroll
+        for (int bc = 0; bc < T; bc++) {
+            const int c = x.ty + 16 * bc;
+            a[ar][bc] = (i < m && c < m) ? Fm[i + (int64_t)c * ld] : 0.0;
+        }
+    }
+    __syncthreads();
+    tile_block<T, 0>(a, x);
+    __syncthreads();
+    // back to LDS, every row at its logical position
+#pragma unroll
+    for (int ar = 0; ar < T; ar++) {
+        const int i = x.tx + 16 * ar;
+        if (i < m) {
+#pragma unroll
+            for (int bc = 0; bc < T; bc++) {
+                const int c = x.ty + 16 * bc;
+                if (c < m) Fm[x.slot[ar] + (int64_t)c * ld] = a[ar][bc];
+            }
+        }
+    }
+    if (!(x.lmax * stol <= 1.0)) atomicMax(fail_slot, 1);        // |pivot| >= stol * max|column|  <=>  max|multiplier| <= 1 / stol
+    __syncthreads();
+    if (!reuse)
+        for (int t = tid; t < k; t += 256) ipiv[t] = sh_piv[t];
+}
+
+template <int T>
+__global__ __launch_bounds__(256, 1) void k_lu_front_tiled(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ Ax,
+                                                         const double tol, const double stol, const int reuse, const int lds_m)
+{
+    extern __shared__ double smem[];
+    __shared__ int sh_r[4];
+    __shared__ double sh_pv[2];
+    __shared__ double lcol[16 * T], urow[16 * T];
+    const int tid = threadIdx.x;
+    const int f = list[blockIdx.x];
+    const LuFrontD F = d.fr[f];
+    const int m = F.m, k = F.k, u = m - k;
+    double *Fm = smem;
+    int32_t *sh_lp = (int32_t *)(smem + (int64_t)lds_m * lds_m);
+    int32_t *sh_piv = sh_lp + lds_m;
+    const int ld = m;
+    if (tid == 0) d.fail[f] = 0;
+    lu_assemble_front<256>(d, F, Fm, ld, Ax);
+    lu_factor_front_tiled<T>(Fm, ld, m, k, d.ipiv + F.p0, d.fail + f, tol, stol, reuse, lcol, urow, sh_r, sh_pv, sh_piv);
+    __syncthreads();
+    lu_store_front<256>(d, F, Fm, ld, sh_lp, sh_piv);
+    double *__restrict__ Uo = d.arena + F.upd_off;
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int j = ty; j < u; j += 4)
+        for (int i = tx; i < u; i += 64) Uo[i + (int64_t)j * u] = Fm[(k + i) + (int64_t)(k + j) * ld];
 }
 
 // Forward sweep of one front: f = [x(pivots); 0] + children's update vectors; (row permutation); solve with the
@@ -920,6 +1102,7 @@ static void allow_large_lds()
     if (done) return;
     done = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front<true, LU_NT_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front_tiled<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lub_panel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
 }
@@ -931,7 +1114,19 @@ void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, i
     allow_large_lds();
     if (lds_m > 0) {
         const size_t sm = (size_t)lds_m * lds_m * sizeof(double) + 2 * (size_t)lds_m * sizeof(int32_t);
-        hipLaunchKernelGGL((k_lu_front<true, LU_NT_LDS>), dim3(cnt), dim3(LU_NT_LDS), sm, st, d, list, Ax, tol, stol, reuse, lds_m);
+        static const bool legacy = getenv("KVX_LU_LDS_LEGACY") != nullptr;       // the LDS-resident elimination (debugging aid)
+        if (legacy) {
+            hipLaunchKernelGGL((k_lu_front<true, LU_NT_LDS>), dim3(cnt), dim3(LU_NT_LDS), sm, st, d, list, Ax, tol, stol, reuse, lds_m);
+            return;
+        }
+        switch ((lds_m + 15) / 16) {
+        case 1: hipLaunchKernelGGL((k_lu_front_tiled<1>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        case 2: hipLaunchKernelGGL((k_lu_front_tiled<2>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        case 3: hipLaunchKernelGGL((k_lu_front_tiled<3>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        case 4: hipLaunchKernelGGL((k_lu_front_tiled<4>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        case 5: case 6: hipLaunchKernelGGL((k_lu_front_tiled<6>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        default: hipLaunchKernelGGL((k_lu_front_tiled<7>), dim3(cnt), dim3(256), sm, st, d, list, Ax, tol, stol, reuse, lds_m); break;
+        }
     } else {
         const size_t sm = 2 * (size_t)max_k * sizeof(int32_t) + 16;
         hipLaunchKernelGGL((k_lu_front<false, LU_NT_BIG>), dim3(cnt), dim3(LU_NT_BIG), sm, st, d, list, Ax, tol, stol, reuse, 0);

@@ -87,7 +87,7 @@ struct LuPlan {
 
 constexpr int KVX_LU_SOLVE_BIG_M = 384;   // fronts of order > this are swept by many workgroups (one launch per 32 pivots); their solve
                                           // work vector holds all m entries (the update part at offset k)
-constexpr int KVX_LU_LDS_M = 136;        // fronts of order <= this are factored inside LDS (136*136*8 = 144.5 KB of the 160 KB a gfx950 workgroup may use)
+constexpr int KVX_LU_LDS_M = 112;        // fronts of order <= this are assembled in LDS and eliminated in registers (7 x 7 tile per thread)
 
 // values may be nullptr (pattern-only: plain maximum transversal).  Throws std::runtime_error on invalid input.
 void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *Ax, LuSymbolic &Y);
