@@ -702,15 +702,22 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
 {
     if constexpr (J < NB) {
         if (J < x.nbk) {                                          // uniform
-            if (x.wave < x.ncw) {                                 // only the waves that hold candidate rows search
-                double bmax = -1.0;
+            double *sh_b = x.sh_b + (J & 1) * 16, *sh_diag = x.sh_diag + (J & 1);
+            int *sh_s = x.sh_s + (J & 1) * 16;                    // (the search results are double-buffered for the same reason)
+            double *uspec = x.urow + (J & 1) * NB;                // the row at position J publishes itself SPECULATIVELY (two
+            if (x.wave < x.ncw) {                                 // buffers, by parity of J): when the diagonal is kept -- the
+                double bmax = -1.0;                               // common case -- the step needs one barrier, not two
                 int bslot = 0x7fffffff;
 #pragma unroll
                 for (int q = 0; q < RPT; q++) {
                     const bool c = x.has[q] && x.slot[q] >= J && x.slot[q] < x.cand;
                     const double av = fabs(a[q][J]);
                     if (c && (av > bmax || (av == bmax && x.slot[q] < bslot))) { bmax = av; bslot = x.slot[q]; }
-                    if (x.has[q] && x.slot[q] == J) x.sh_diag[0] = av;
+                    if (x.has[q] && x.slot[q] == J) {
+                        sh_diag[0] = av;
+#pragma unroll
+                        for (int c2 = 0; c2 < NB; c2++) uspec[c2] = a[q][c2];
+                    }
                 }
 #pragma unroll
                 for (int off = 32; off; off >>= 1) {
@@ -718,7 +725,7 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
                     const int os = __shfl_xor(bslot, off);
                     if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
                 }
-                if (x.lane == 0) { x.sh_b[x.wave] = bmax; x.sh_s[x.wave] = bslot; }
+                if (x.lane == 0) { sh_b[x.wave] = bmax; sh_s[x.wave] = bslot; }
             }
             __syncthreads();
             double bmax = -1.0;
@@ -726,25 +733,28 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
 #pragma unroll
             for (int w = 0; w < 16; w++) {
                 if (w < x.ncw) {
-                    const double ob = x.sh_b[w];
-                    const int os = x.sh_s[w];
+                    const double ob = sh_b[w];
+                    const int os = sh_s[w];
                     if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
                 }
             }
-            const double dg = x.sh_diag[0];
+            const double dg = sh_diag[0];
             int r = (dg > 0.0 && dg >= x.tol * bmax) ? J : bslot;
             if (x.reuse) r = J + x.sh_piv[J];
             if (r == 0x7fffffff) r = J;                           // nothing but NaNs: keep the diagonal, the step is flagged below
+            if (r != J) {                                         // uniform: an interchange -- the chosen row replaces the speculation
+                __syncthreads();                                  // (everybody has read sh_b / sh_diag; nobody reads uspec yet)
 #pragma unroll
-            for (int q = 0; q < RPT; q++) {
-                if (x.has[q] && x.slot[q] == r) {                 // the pivot row: publish, take position J
+                for (int q = 0; q < RPT; q++) {
+                    if (x.has[q] && x.slot[q] == r) {
 #pragma unroll
-                    for (int c = 0; c < NB; c++) x.urow[c] = a[q][c];
-                    x.slot[q] = J;
-                } else if (x.has[q] && x.slot[q] == J) x.slot[q] = r;
+                        for (int c = 0; c < NB; c++) uspec[c] = a[q][c];
+                        x.slot[q] = J;
+                    } else if (x.has[q] && x.slot[q] == J) x.slot[q] = r;
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            double pv = x.urow[J];
+            double pv = uspec[J];
             const double ap = fabs(pv);
             const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);
             if (bad) pv = 1.0;
@@ -759,7 +769,7 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
                     a[q][J] = l;
                     x.lmax = fmax(x.lmax, fabs(l));
 #pragma unroll
-                    for (int c = J + 1; c < NB; c++) a[q][c] -= l * x.urow[c];
+                    for (int c = J + 1; c < NB; c++) a[q][c] -= l * uspec[c];
                 }
             }
         }
@@ -774,8 +784,8 @@ template <int NB, int RPT>
 __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
                                                          const double stol, const int reuse)
 {
-    __shared__ double sh_b[16], sh_diag[2], urow[NB];
-    __shared__ int sh_s[16], sh_piv[NB];
+    __shared__ double sh_b[32], sh_diag[2], urow[2 * NB];
+    __shared__ int sh_s[32], sh_piv[NB];
     const int tid = threadIdx.x, nth = blockDim.x;
     const int f = list[blockIdx.x];
     const LuFrontD F = d.fr[f];
