@@ -16,7 +16,7 @@
   lp4c    : lp4b plus 200 random equality rows: general G and A together (dense K = A S^-1 A', lp.KKTGenEqDev)
   klu3    : BASELINE.json configs[2]: klu.linsolve on the ACTIVSg2000 power-flow Jacobian (4000 x 4000, 29 336 entries,
             tests/golden/ACTIVSg2000.npz), nrhs = 3: symbolic, first numeric, steady-state refactorisation and solve times,
-            next to the CPU oracle and SciPy's SuperLU on the host.
+            next to SciPy's SuperLU on the host (the CPU oracle is test infrastructure and is not used here).
   lu2d    : unsymmetric counterpart of config 2 for the LU path: convection-diffusion 5-point operator on a 600 x 600 grid
             (n = 360 000, workloads.convdiff_2d): refactorisation + solve on the GPU next to SciPy's SuperLU on the host.
 
@@ -152,7 +152,6 @@ def klu_case(steps, warmup):
     import scipy.sparse.linalg as spla
     from kvxopt_amd import klu, _lib
     from kvxopt_amd.base import spmatrix
-    from oracle.kvx_oracle import OracleKLU        # cpu_baseline leg only
     z = np.load(os.path.join(ROOT, "tests", "golden", "ACTIVSg2000.npz"))
     n = int(z["n"])
     A = spmatrix.from_ccs(n, n, z["colptr"], z["rowind"], z["values"])
@@ -177,13 +176,11 @@ def klu_case(steps, warmup):
     resid = float(np.abs(As @ X - B).max())
     t0 = time.perf_counter(); lu = spla.splu(As); xs = lu.solve(B); t_splu = time.perf_counter() - t0
     e = Fn.num.extract()
-    t0 = time.perf_counter(); O = OracleKLU(n, A.colptr, A.rowind, A.values, Q=e["Q"]); xo = O.solve(B); t_or = time.perf_counter() - t0
     return {"case": "klu3 ACTIVSg2000", "metric": "klu.linsolve wall ms (symbolic + numeric + solve, host buffers)", "value": ms_linsolve,
             "unit": "ms", "n": n, "nnz": int(A.values.size), "nrhs": 3, "ms_symbolic_host": t_sym * 1e3, "ms_first_numeric": t_first * 1e3,
             "ms_refactor_dev": ms_refactor, "ms_solve_dev": ms_solve, "ms_tsolve_dev": ms_tsolve, "residual_inf": resid,
             "lnz": int(e["L"][1].size), "unz": int(e["U"][1].size), **{"lu_" + k: v for k, v in Fn.num.info().items()},
-            "cpu_scipy_superlu_ms": t_splu * 1e3, "cpu_oracle_ms": t_or * 1e3,
-            "x_vs_superlu": float(np.abs(X - xs).max()), "x_vs_oracle": float(np.abs(X - xo).max())}
+            "cpu_scipy_superlu_ms": t_splu * 1e3, "x_vs_superlu": float(np.abs(X - xs).max())}
 
 
 def lu2d_case(g, steps):
