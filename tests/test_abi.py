@@ -42,3 +42,28 @@ def test_numeric_path_fails_loudly_without_gpu():
         F.factorize(np.array([2.0, 1.0, 2.0]))
     with pytest.raises(ValueError):
         F.solve(np.ones(2))          # symbolic factor (cholmod.c:452-453)
+
+
+def test_lu_abi_argument_checks_need_no_gpu():
+    """Status codes of the kvx_lu_* entry points for bad arguments (mapped to the reference's exceptions by klu.py)."""
+    L = _lib.lib()
+    i64p, f64p, vp = _lib.i64p, _lib.f64p, _lib.vp
+    cp = np.array([0, 1, 2], dtype=np.int64); ri = np.array([0, 1], dtype=np.int64); v = np.array([1.0, 2.0])
+    h = vp()
+    assert L.kvx_lu_analyze(0, _lib.pi(cp), _lib.pi(ri), _lib.pd(v), ctypes.byref(h)) == _lib.KVX_EINVAL          # klu.c:256-260
+    bad = np.array([0, 2, 1], dtype=np.int64)
+    assert L.kvx_lu_analyze(2, _lib.pi(bad), _lib.pi(ri), _lib.pd(v), ctypes.byref(h)) == _lib.KVX_EINVAL
+    assert L.kvx_lu_analyze(2, _lib.pi(cp), _lib.pi(ri), _lib.pd(v), ctypes.byref(h)) == _lib.KVX_OK
+    info = np.zeros(8, dtype=np.int64)
+    assert L.kvx_lu_sym_info(h, _lib.pi(info)) == _lib.KVX_OK and info[0] == 2 and info[1] == 2 and info[4] == 0
+    nb, nl = ctypes.c_int64(), ctypes.c_int64()
+    assert L.kvx_lu_sym_btf(h, ctypes.byref(nb), ctypes.byref(nl), None) == _lib.KVX_OK and nb.value == 2 and nl.value == 1
+    n_ = vp()
+    assert L.kvx_lu_factor(h, 5, _lib.pd(v), ctypes.byref(n_)) == _lib.KVX_EINVAL                                  # other pattern
+    if L.kvx_device_count() == 0:
+        assert L.kvx_lu_factor(h, 2, _lib.pd(v), ctypes.byref(n_)) == _lib.KVX_EDEVICE                             # no CPU fallback
+        assert b"no CPU fallback" in L.kvx_last_error()
+    assert L.kvx_lu_solve(None, 0, _lib.pd(v), 1, 2) == _lib.KVX_EINVAL
+    assert L.kvx_lu_det(None, None) == _lib.KVX_EINVAL
+    L.kvx_lu_free_symbolic(h)
+    L.kvx_lu_free_numeric(None)
