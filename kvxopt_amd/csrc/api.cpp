@@ -81,6 +81,7 @@ struct kvx_chol {
     uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
     std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
     std::vector<int64_t> lptr_host;
+    int outer_block = 1024;    // columns per outer block of the two-level update (KVX_OUTER_BLOCK; a multiple of 64): config 5 runs at 33.3 / 37.5 / 38.6 / 37.4 TF/s with 256 / 512 / 1024 / 2048
     int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
     // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
     SubDesc *d_subs = nullptr;
@@ -407,6 +408,7 @@ int ensure_device(kvx_chol *F)
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
+    { const char *e = getenv("KVX_OUTER_BLOCK"); if (e && atoi(e) >= 64) F->outer_block = atoi(e) / 64 * 64; }
     F->dev_ready = true;
     return KVX_OK;
 }
@@ -514,13 +516,13 @@ int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue 
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             if (bigm >= F->two_level_m) {
-                // 256-column outer blocks, one rank-256 update of the trailing matrix per block (128-tile kernel: 34 TF/s
+                // outer blocks of `outer_block` (1024) columns, one rank-1024 update of the trailing matrix per block (128-tile kernel: 34 TF/s
                 // on a dense trailing matrix; rocBLAS dgemm at K = 256 reaches 48-59).  Measured on MI355X against the
                 // single-level path: dense n = 10240 14.8 vs 16.7 ms, 3-D 80^3 49.6 vs 51.0 ms, but 21-point 1000^2
                 // (fronts <= 5007, many per level) 29.1 vs 24.3 ms -- the outer update is an extra serial launch per
                 // block, so it is used for very large fronts only; look-ahead (outer update of block b beside the panel
                 // chain of block b + 1) is the missing piece
-                constexpr int OB = 256;
+                const int OB = F->outer_block;
                 for (int ob = 0; ob < P.big_maxk; ob += OB) {
                     for (int jb = ob; jb < std::min(ob + OB, P.big_maxk); jb += KVX_NB) {
                         { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }

@@ -206,11 +206,14 @@ def test_syrk128_variant_parity(monkeypatch):
     L = sp.tril(S).tocsc(); L.sort_indices()
     parity(2500, L.indptr, L.indices, L.data, seed=4)
     parity(*workloads.laplacian_2d(150), seed=150)
-    # the opt-in two-level blocking (per panel only the rest of a 256-column outer block, then one rank-256 update)
+    # the two-level blocking of very large fronts, forced on here (per panel only the rest of an outer block of 1024 -- or
+    # KVX_OUTER_BLOCK -- columns, then one rank-1024 update of the trailing matrix)
     monkeypatch.delenv("KVX_SYRK128_TILES")
     monkeypatch.setenv("KVX_TWO_LEVEL_M", "0")
     parity(2500, L.indptr, L.indices, L.data, seed=5)
     parity(*workloads.laplacian_2d(150), seed=151)
+    monkeypatch.setenv("KVX_OUTER_BLOCK", "256")
+    parity(2500, L.indptr, L.indices, L.data, seed=6)
 
 
 def test_async_factor_then_solve_without_host_round_trip():
