@@ -435,10 +435,11 @@ class KKTGenEqDev:
         self.solve(xb, yb, zb)
 
 
-def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
+def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, primalstart=None, dualstart=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
     (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints either G has at most one entry per
-    row (standard form: KKTDiagEqDev, any p) or p <= 2048 (general G: KKTGenEqDev, dense K).  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
+    row (standard form: KKTDiagEqDev, any p) or p <= 2048 (general G: KKTGenEqDev, dense K).  primalstart = {'x', 's'},
+    dualstart = {'y', 'z'} (y optional) as in the reference (coneprog.py:683-737): s and z must be strictly positive.  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
     _lib.require_device()
     opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
     opts.update(options or {})
@@ -524,29 +525,54 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None):
         kkt.factor(di)
     except ArithmeticError:
         raise ValueError("Rank(A) < p or Rank([G; A]) < n")
-    x.fill(0.0); dy.copy_from(bv); s.copy_from(hv)
-    ksolve(x, dy, s)
-    s.scal(-1.0)
+    def _vec(v):
+        return np.ascontiguousarray(np.asarray(v._a if isinstance(v, base.matrix) else v, dtype=np.float64).reshape(-1))
+
+    if primalstart is None:
+        x.fill(0.0); dy.copy_from(bv); s.copy_from(hv)
+        ksolve(x, dy, s)
+        s.scal(-1.0)
+    else:                                                        # coneprog.py:703-705
+        xs0, ss0 = _vec(primalstart["x"]), _vec(primalstart["s"])
+        if xs0.size != n or ss0.size != ml:
+            raise TypeError("primalstart has the wrong dimensions")
+        x.set(xs0); s.set(ss0)
     ts = s.max_step()
-    dx.copy_from(cv).scal(-1.0); y.fill(0.0); z.fill(0.0)
-    ksolve(dx, y, z)
+    if ts >= 0 and primalstart is not None:
+        raise ValueError("initial s is not positive")
+    if dualstart is None:
+        dx.copy_from(cv).scal(-1.0); y.fill(0.0); z.fill(0.0)
+        ksolve(dx, y, z)
+    else:                                                        # coneprog.py:731-733
+        zs0 = _vec(dualstart["z"])
+        if zs0.size != ml:
+            raise TypeError("dualstart has the wrong dimensions")
+        if p and "y" in dualstart:
+            y.set(_vec(dualstart["y"]))
+        elif p:
+            y.fill(0.0)
+        z.set(zs0)
     tz = z.max_step()
+    if tz >= 0 and dualstart is not None:
+        raise ValueError("initial z is not positive")
     nrms, nrmz = s.nrm2(), z.nrm2()
-    gap = s.dot(z)
-    pcost = cv.dot(x)
-    dcost = -bv.dot(y) - hv.dot(z)
-    relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
-    if ts <= 0 and tz <= 0 and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL)):
-        rx.copy_from(cv); Af(y, rx, trans="T", alpha=1.0, beta=1.0); Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
-        resx = rx.nrm2()
-        ry.copy_from(bv); Af(x, ry, trans="N", alpha=1.0, beta=-1.0)
-        resy = ry.nrm2()
-        Gd.gemv(x, rz, trans="N"); rz.axpy(s); rz.axpy(hv, -1.0)
-        resz = rz.nrm2()
-        return result("optimal", 0, gap, relgap, pcost, dcost, max(resy / resy0, resz / resz0), resx / resx0, None, None)
-    if ts >= -1e-8 * max(nrms, 1.0):
+    if primalstart is None and dualstart is None:
+        gap = s.dot(z)
+        pcost = cv.dot(x)
+        dcost = -bv.dot(y) - hv.dot(z)
+        relgap = gap / -pcost if pcost < 0.0 else (gap / dcost if dcost > 0.0 else None)
+        if ts <= 0 and tz <= 0 and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL)):
+            rx.copy_from(cv); Af(y, rx, trans="T", alpha=1.0, beta=1.0); Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
+            resx = rx.nrm2()
+            ry.copy_from(bv); Af(x, ry, trans="N", alpha=1.0, beta=-1.0)
+            resy = ry.nrm2()
+            Gd.gemv(x, rz, trans="N"); rz.axpy(s); rz.axpy(hv, -1.0)
+            resz = rz.nrm2()
+            return result("optimal", 0, gap, relgap, pcost, dcost, max(resy / resy0, resz / resz0), resx / resx0, None, None)
+    # (coneprog.py:806-842: a computed start is pushed into the cone, a given one is taken as it is)
+    if primalstart is None and ts >= -1e-8 * max(nrms, 1.0):
         s.addc(1.0 + ts)
-    if tz >= -1e-8 * max(nrmz, 1.0):
+    if dualstart is None and tz >= -1e-8 * max(nrmz, 1.0):
         z.addc(1.0 + tz)
 
     tau, kappa = 1.0, 1.0

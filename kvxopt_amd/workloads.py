@@ -119,7 +119,7 @@ def lp_grid(gx, gy, seed=4):
     h = Gx0 + s0
     cvec = np.zeros(n)
     np.add.at(cvec, c, -v * z0[r])
-    return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h, "x0": x0}
+    return {"ml": ml, "n": n, "Gp": colptr, "Gi": r.astype(np.int64), "Gx": v, "c": cvec, "h": h, "x0": x0, "s0": s0, "z0": z0}
 
 
 def lp_grid_eq(gx, gy, p, seed=9):

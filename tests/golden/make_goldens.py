@@ -365,6 +365,31 @@ def g9_coneqp_eq():
                "cases": meta}, open(os.path.join(HERE, "g9_coneqp_eq.json"), "w"), indent=1, default=float)
 
 
+def g10_conelp_starts():
+    """conelp with user-supplied starting points (coneprog.py:683-737, 806-842): the strictly feasible primal / dual
+    points the grid-LP generator is built from, all three combinations; pure reference (dense LAPACK branch)."""
+    from kvxopt import matrix, solvers, spmatrix
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    P = workloads.lp_grid(15, 12)
+    ml, n = P["ml"], P["n"]
+    cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
+    G = matrix(spmatrix(P["Gx"].tolist(), P["Gi"].tolist(), cols.tolist(), (ml, n)))
+    c, h = matrix(P["c"]), matrix(P["h"])
+    ps = {"x": matrix(P["x0"]), "s": matrix(P["s0"])}
+    ds = {"z": matrix(P["z0"])}
+    out, meta = {}, {}
+    for name, kw in (("primal", {"primalstart": ps}), ("dual", {"dualstart": ds}), ("both", {"primalstart": ps, "dualstart": ds})):
+        sol = solvers.conelp(c, G, h, kktsolver="chol2", **kw)
+        assert sol["status"] == "optimal"
+        for k in "xsz":
+            out[name + "_" + k] = tolist(sol[k])
+        meta[name] = {k: sol[k] for k in ("status", "iterations", "gap", "primal objective", "dual objective")}
+    np.savez_compressed(os.path.join(HERE, "g10_conelp_starts.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch); generator kvxopt_amd.workloads.lp_grid(15, 12) with its x0, s0, z0",
+               "cases": meta}, open(os.path.join(HERE, "g10_conelp_starts.json"), "w"), indent=1, default=float)
+
+
 def g7_mps():
     """modeling.op.fromfile + solve on the reference's own fixture tests/boeing2.mps (tests/test_modeling.py:59-63):
     the parsed problem (objective, inequality / equality counts) and the solution of the reference's default LP path
@@ -401,4 +426,5 @@ if __name__ == "__main__":
     g7_mps()
     g8_conelp_eq()
     g9_coneqp_eq()
+    g10_conelp_starts()
     print("goldens written to", HERE)

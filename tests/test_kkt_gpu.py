@@ -289,6 +289,30 @@ def test_conelp_general_g_with_equalities_at_scale():
     assert np.linalg.norm(Ax_ - L["b"]) < 1e-6 * max(1.0, np.linalg.norm(L["b"]))
 
 
+@pytest.mark.parametrize("name", ["primal", "dual", "both"])
+def test_conelp_with_user_starting_points_golden(golden_dir, name):
+    """G10: primalstart / dualstart (coneprog.py:683-737, 806-842): same iteration count and solution as the reference;
+    a start outside the cone is refused like there."""
+    g = np.load(os.path.join(golden_dir, "g10_conelp_starts.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g10_conelp_starts.json")))["cases"][name]
+    P = workloads.lp_grid(15, 12)
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    kw = {}
+    if name in ("primal", "both"):
+        kw["primalstart"] = {"x": P["x0"], "s": P["s0"]}
+    if name in ("dual", "both"):
+        kw["dualstart"] = {"z": P["z0"]}
+    sol = lp.conelp(P["c"], G, P["h"], **kw)
+    assert sol["status"] == meta["status"] == "optimal" and sol["iterations"] == meta["iterations"]
+    for k in "xsz":
+        assert rel(sol[k], g[name + "_" + k]) < 1e-6, k
+    assert abs(sol["primal objective"] - meta["primal objective"]) < 1e-8 * abs(meta["primal objective"])
+    with pytest.raises(ValueError):
+        lp.conelp(P["c"], G, P["h"], primalstart={"x": P["x0"], "s": -P["s0"]})
+    with pytest.raises(ValueError):
+        lp.conelp(P["c"], G, P["h"], dualstart={"z": np.zeros(P["ml"])})
+
+
 def test_interior_point_runs_are_bitwise_reproducible():
     """No atomics anywhere on the path (mat-vecs are row gathers, reductions fixed trees, extend-add parent-pull):
     two runs of the same problem give identical bits."""
