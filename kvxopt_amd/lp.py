@@ -753,7 +753,7 @@ def _lower_ccs(P, n):
     return cp, Pi[keep].copy(), Px[keep].copy()
 
 
-def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None):
+def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=None):
     """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h, Ax = b  on the GPU (orthant cone; at most
     KKTGenEqDev.MAX_P equality rows): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
     misc.kkt_chol2 with H = P.  P: spmatrix-like, its lower triangle is used.  Returns the reference's result
@@ -812,29 +812,53 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None):
                 "primal slack": -s.max_step(), "dual slack": -z.max_step(), "iterations": iters,
                 "factorizations": kkt.nfactor}
 
-    # ---- starting point (coneprog.py:2044-2096): factor with W = I, solve [P G'; G -I][x; z] = [-q; h], s = -z
-    d.fill(1.0); di.fill(1.0)
-    try:
-        kkt.factor(di)
-    except ArithmeticError:
-        raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
-    x.copy_from(qv).scal(-1.0)
-    if p:
-        y.copy_from(bv)
-    z.copy_from(hv)
-    try:
-        ksolve(x, y, z)
+    # ---- starting point (coneprog.py:2044-2150)
+    if initvals is None:
+        # factor with W = I, solve [P A' G'; A 0 0; G 0 -I][x; y; z] = [-q; b; h], s = -z, push s and z into the cone
+        d.fill(1.0); di.fill(1.0)
+        try:
+            kkt.factor(di)
+        except ArithmeticError:
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
+        x.copy_from(qv).scal(-1.0)
         if p:
-            kkt.check()
-    except ArithmeticError:
-        raise ValueError("Rank(A) < p or Rank([P; G; A]) < n")
-    s.copy_from(z).scal(-1.0)
-    ts = s.max_step()
-    if ts >= -1e-8 * max(s.nrm2(), 1.0):
-        s.addc(1.0 + ts)
-    tz = z.max_step()
-    if tz >= -1e-8 * max(z.nrm2(), 1.0):
-        z.addc(1.0 + tz)
+            y.copy_from(bv)
+        z.copy_from(hv)
+        try:
+            ksolve(x, y, z)
+            if p:
+                kkt.check()
+        except ArithmeticError:
+            raise ValueError("Rank(A) < p or Rank([P; G; A]) < n")
+        s.copy_from(z).scal(-1.0)
+        ts = s.max_step()
+        if ts >= -1e-8 * max(s.nrm2(), 1.0):
+            s.addc(1.0 + ts)
+        tz = z.max_step()
+        if tz >= -1e-8 * max(z.nrm2(), 1.0):
+            z.addc(1.0 + tz)
+    else:
+        # user-supplied values (coneprog.py:2108-2150): missing x, y default to 0, missing s, z to the cone's identity
+        def _vec(v, length):
+            a = np.ascontiguousarray(np.asarray(v._a if isinstance(v, base.matrix) else v, dtype=np.float64).reshape(-1))
+            if a.size != length:
+                raise TypeError("initvals has the wrong dimensions")
+            return a
+        x.set(_vec(initvals["x"], n)) if "x" in initvals else x.fill(0.0)
+        if "s" in initvals:
+            s.set(_vec(initvals["s"], ml))
+            if s.max_step() >= 0:
+                raise ValueError("initial s is not positive")
+        else:
+            s.fill(1.0)
+        if p:
+            y.set(_vec(initvals["y"], p)) if "y" in initvals else y.fill(0.0)
+        if "z" in initvals:
+            z.set(_vec(initvals["z"], ml))
+            if z.max_step() >= 0:
+                raise ValueError("initial z is not positive")
+        else:
+            z.fill(1.0)
     gap = s.dot(z)
 
     def f4_no_ir(bx, by, bz, bs):

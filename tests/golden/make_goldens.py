@@ -390,6 +390,32 @@ def g10_conelp_starts():
                "cases": meta}, open(os.path.join(HERE, "g10_conelp_starts.json"), "w"), indent=1, default=float)
 
 
+def g11_coneqp_initvals():
+    """coneqp with user-supplied initial values (coneprog.py:2108-2150) on the grid QP: all four given, and x / s only."""
+    from kvxopt import matrix, solvers, spmatrix
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    Q = qp_grid(15, 12)
+    L = workloads.lp_grid(15, 12)
+    ml, n = Q["ml"], Q["n"]
+    cols = np.repeat(np.arange(n), np.diff(Q["Gp"]))
+    G = matrix(spmatrix(Q["Gx"].tolist(), Q["Gi"].tolist(), cols.tolist(), (ml, n)))
+    pcols = np.repeat(np.arange(n), np.diff(Q["Pp"]))
+    P = spmatrix(Q["Px"].tolist(), Q["Pi"].tolist(), pcols.tolist(), (n, n))
+    q, h = matrix(Q["q"]), matrix(Q["h"])
+    out, meta = {}, {}
+    for name, iv in (("all", {"x": matrix(L["x0"]), "s": matrix(L["s0"]), "z": matrix(L["z0"])}),
+                     ("xs", {"x": matrix(L["x0"]), "s": matrix(L["s0"])})):
+        sol = solvers.coneqp(P, q, G, h, initvals=iv, kktsolver="chol2")
+        assert sol["status"] == "optimal"
+        for k in "xsz":
+            out[name + "_" + k] = tolist(sol[k])
+        meta[name] = {k: sol[k] for k in ("status", "iterations", "gap", "primal objective", "dual objective")}
+    np.savez_compressed(os.path.join(HERE, "g11_coneqp_initvals.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch); generators make_goldens.qp_grid(15, 12), workloads.lp_grid(15, 12) x0, s0, z0",
+               "cases": meta}, open(os.path.join(HERE, "g11_coneqp_initvals.json"), "w"), indent=1, default=float)
+
+
 def g7_mps():
     """modeling.op.fromfile + solve on the reference's own fixture tests/boeing2.mps (tests/test_modeling.py:59-63):
     the parsed problem (objective, inequality / equality counts) and the solution of the reference's default LP path
@@ -427,4 +453,5 @@ if __name__ == "__main__":
     g8_conelp_eq()
     g9_coneqp_eq()
     g10_conelp_starts()
+    g11_coneqp_initvals()
     print("goldens written to", HERE)

@@ -224,6 +224,26 @@ def test_coneqp_with_equalities_golden(golden_dir, name, gx, gy, p):
     assert np.linalg.norm(Ax_ - L["b"]) < 1e-7 * max(1.0, np.linalg.norm(L["b"]))
 
 
+@pytest.mark.parametrize("name", ["all", "xs"])
+def test_coneqp_with_initial_values_golden(golden_dir, name):
+    """G11: coneqp(initvals=...) (coneprog.py:2108-2150): same iterations and solution as the reference."""
+    g = np.load(os.path.join(golden_dir, "g11_coneqp_initvals.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g11_coneqp_initvals.json")))["cases"][name]
+    Q = workloads.qp_grid(15, 12)
+    L = workloads.lp_grid(15, 12)
+    G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
+    P = spmatrix.from_ccs(Q["n"], Q["n"], Q["Pp"], Q["Pi"], Q["Px"])
+    iv = {"x": L["x0"], "s": L["s0"]}
+    if name == "all":
+        iv["z"] = L["z0"]
+    sol = lp.coneqp(P, Q["q"], G, Q["h"], initvals=iv)
+    assert sol["status"] == meta["status"] == "optimal" and sol["iterations"] == meta["iterations"]
+    for k in "xsz":
+        assert rel(sol[k], g[name + "_" + k]) < 1e-6, k
+    with pytest.raises(ValueError):
+        lp.coneqp(P, Q["q"], G, Q["h"], initvals={"s": -L["s0"]})
+
+
 def test_coneqp_errors():
     Q = workloads.qp_grid(6, 5)
     G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
