@@ -1,0 +1,47 @@
+"""`kvxopt.solvers` names for the device-resident interior-point drivers of kvxopt_amd.lp (orthant cone only):
+
+    conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None)     coneprog.py:420
+    coneqp(P, q, G, h, dims=None, A=None, b=None, initvals=None)                     coneprog.py:1440
+    lp(c, G, h, A=None, b=None, primalstart=None, dualstart=None)                    coneprog.py:2551 (-> conelp)
+    qp(P, q, G, h, A=None, b=None, initvals=None)                                    coneprog.py:4120 (-> coneqp)
+    options                                                                          the module-level dict of the reference
+
+Like the reference, algorithm parameters come from `solvers.options` ('maxiters', 'abstol', 'reltol', 'feastol',
+'refinement', 'show_progress'); a keyword `options=` overrides it per call.  The reference's `kktsolver=` / `solver=`
+arguments select other KKT solvers or external codes and are not part of this path: passing them raises.
+"""
+from . import lp as _lp
+
+options = {}
+
+
+def _opts(kw):
+    o = dict(options)
+    o.update(kw.pop("options", None) or {})
+    for k in ("kktsolver", "solver"):
+        if kw.pop(k, None) is not None:
+            raise NotImplementedError("kvxopt_amd.solvers runs misc.kkt_chol2 on the GPU; '%s' is not selectable" % k)
+    if kw:
+        raise TypeError("unexpected arguments: %s" % ", ".join(sorted(kw)))
+    return o
+
+
+def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, **kw):
+    return _lp.conelp(c, G, h, dims=dims, A=A, b=b, options=_opts(kw), primalstart=primalstart, dualstart=dualstart)
+
+
+def coneqp(P, q, G, h, dims=None, A=None, b=None, initvals=None, **kw):
+    if dims is not None and (dims.get("q") or dims.get("s")):
+        raise NotImplementedError("only the orthant cone runs on the GPU")
+    return _lp.coneqp(P, q, G, h, _opts(kw), None, A=A, b=b, initvals=initvals)
+
+
+def lp(c, G, h, A=None, b=None, primalstart=None, dualstart=None, **kw):
+    """solvers.lp (coneprog.py:2551-2790): conelp on the orthant, result keys as the reference returns them."""
+    sol = conelp(c, G, h, None, A, b, primalstart, dualstart, **kw)
+    return sol
+
+
+def qp(P, q, G, h, A=None, b=None, initvals=None, **kw):
+    """solvers.qp (coneprog.py:4120-4330): coneqp on the orthant."""
+    return coneqp(P, q, G, h, None, A, b, initvals, **kw)

@@ -244,6 +244,30 @@ def test_coneqp_with_initial_values_golden(golden_dir, name):
         lp.coneqp(P, Q["q"], G, Q["h"], initvals={"s": -L["s0"]})
 
 
+def test_solvers_module_names(golden_dir):
+    """kvxopt.solvers spelling: lp / qp / conelp / coneqp and the module-level options dict."""
+    from kvxopt_amd import solvers
+    meta = json.load(open(os.path.join(golden_dir, "g4_conelp.json")))["cases"]["grid6x5"]
+    P = workloads.lp_grid(6, 5)
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    sol = solvers.lp(P["c"], G, P["h"])
+    assert sol["status"] == "optimal" and sol["iterations"] == meta["iterations"]
+    solvers.options["maxiters"] = 3
+    try:
+        assert solvers.conelp(P["c"], G, P["h"])["status"] == "unknown"          # maxiters reached (coneprog.py:940-960)
+        assert solvers.lp(P["c"], G, P["h"], options={"maxiters": 50})["status"] == "optimal"
+    finally:
+        solvers.options.clear()
+    Q = workloads.qp_grid(6, 5)
+    Gq = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
+    Pq = spmatrix.from_ccs(Q["n"], Q["n"], Q["Pp"], Q["Pi"], Q["Px"])
+    mq = json.load(open(os.path.join(golden_dir, "g5_coneqp.json")))["cases"]["qp6x5"]
+    sq = solvers.qp(Pq, Q["q"], Gq, Q["h"])
+    assert sq["status"] == "optimal" and sq["iterations"] == mq["iterations"]
+    with pytest.raises(NotImplementedError):
+        solvers.lp(P["c"], G, P["h"], kktsolver="ldl")
+
+
 def test_coneqp_errors():
     Q = workloads.qp_grid(6, 5)
     G = spmatrix.from_ccs(Q["ml"], Q["n"], Q["Gp"], Q["Gi"], Q["Gx"])
