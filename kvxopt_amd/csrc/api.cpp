@@ -2,6 +2,7 @@
 // There is NO CPU fallback: every numeric entry point needs a HIP device and returns
 // KVX_EDEVICE otherwise.
 #include "../../include/kvxhip.h"
+#include "abi_guard.hpp"
 #include "device.hpp"
 #include "symbolic.hpp"
 
@@ -845,7 +846,7 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
     return KVX_OK;
 }
 
-int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev)
+static int kvx_chol_factorize_async_dev_impl(kvx_chol *F, const double *values_dev)
 {
     if (!F) return KVX_EINVAL;
     int rc = ensure_device(F);
@@ -854,6 +855,11 @@ int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev)
     if (F->S.nnzA > 0)
         HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, F->S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
     return enqueue_factor(F);
+}
+
+int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev)
+{
+    return guarded([&] { return kvx_chol_factorize_async_dev_impl(F, values_dev); });
 }
 
 int kvx_chol_status(kvx_chol *F, int64_t *minor)
@@ -869,7 +875,7 @@ int kvx_chol_factorize_dev(kvx_chol *F, const double *values_dev, int64_t *minor
     return finish_factor(F, minor);
 }
 
-int kvx_chol_factorize(kvx_chol *F, const double *values, int64_t *minor)
+static int kvx_chol_factorize_impl(kvx_chol *F, const double *values, int64_t *minor)
 {
     if (!F) return KVX_EINVAL;
     int rc = ensure_device(F);
@@ -881,7 +887,12 @@ int kvx_chol_factorize(kvx_chol *F, const double *values, int64_t *minor)
     return finish_factor(F, minor);
 }
 
-int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+int kvx_chol_factorize(kvx_chol *F, const double *values, int64_t *minor)
+{
+    return guarded([&] { return kvx_chol_factorize_impl(F, values, minor); });
+}
+
+static int kvx_chol_solve_dev_impl(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     if (!F) return KVX_EINVAL;
     if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
@@ -890,7 +901,12 @@ int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_
     return solve_dev(F, sys, B_dev, nrhs, ldB);
 }
 
-int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] { return kvx_chol_solve_dev_impl(F, sys, B_dev, nrhs, ldB); });
+}
+
+static int kvx_chol_solve_async_dev_impl(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     if (!F) return KVX_EINVAL;
     if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
@@ -899,7 +915,12 @@ int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, 
     return solve_dev(F, sys, B_dev, nrhs, ldB, true);
 }
 
-int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
+int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] { return kvx_chol_solve_async_dev_impl(F, sys, B_dev, nrhs, ldB); });
+}
+
+static int kvx_chol_solve_impl(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
 {
     if (!F) return KVX_EINVAL;
     if (!F->dev_ready) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
@@ -923,7 +944,12 @@ int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
     return rc;
 }
 
-int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
+int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] { return kvx_chol_solve_impl(F, sys, B, nrhs, ldB); });
+}
+
+static int kvx_chol_spsolve_impl(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
                      int64_t **Xp, int64_t **Xi, double **Xx)
 {
     if (!F || !Xp || !Xi || !Xx || ncol < 0) return KVX_EINVAL;
@@ -965,6 +991,12 @@ int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, cons
     return KVX_OK;
 }
 
+int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
+                     int64_t **Xp, int64_t **Xi, double **Xx)
+{
+    return guarded([&] { return kvx_chol_spsolve_impl(F, sys, ncol, Bp, Bi, Bx, Xp, Xi, Xx); });
+}
+
 int kvx_chol_diag(kvx_chol *F, double *d)
 {
     if (!F || !d) return KVX_EINVAL;
@@ -983,7 +1015,7 @@ int kvx_chol_diag(kvx_chol *F, double *d)
     return KVX_OK;
 }
 
-int kvx_chol_get_factor(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx)
+static int kvx_chol_get_factor_impl(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx)
 {
     if (!F) return KVX_EINVAL;
     Symbolic &S = F->S;
@@ -1017,6 +1049,11 @@ int kvx_chol_get_factor(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, dou
     return KVX_OK;
 }
 
+int kvx_chol_get_factor(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx)
+{
+    return guarded([&] { return kvx_chol_get_factor_impl(F, lnz, Lp, Li, Lx); });
+}
+
 int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info)
 {
     if (!F || !info) return KVX_EINVAL;
@@ -1044,7 +1081,7 @@ int kvx_chol_get_perm(kvx_chol *F, int64_t *perm)
     return KVX_OK;
 }
 
-int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level)
+static int kvx_chol_get_supernodes_impl(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level)
 {
     if (!F) return KVX_EINVAL;
     Symbolic &S = F->S;
@@ -1055,6 +1092,11 @@ int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t
         if (level) level[s] = S.depth[s];
     }
     return KVX_OK;
+}
+
+int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level)
+{
+    return guarded([&] { return kvx_chol_get_supernodes_impl(F, super, nrows, parent, level); });
 }
 
 int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)
@@ -1087,7 +1129,7 @@ int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches)
 }
 
 // ---- subtree-sharded mode ------------------------------------------------------------------------
-int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner, int *cut)
+static int kvx_chol_dist_owner_impl(kvx_chol *F, int nranks, int32_t *owner, int *cut)
 {
     if (!F || nranks < 1 || !owner || !cut) return KVX_EINVAL;
     std::vector<int32_t> ow;
@@ -1098,7 +1140,12 @@ int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner, int *cut)
     return KVX_OK;
 }
 
-int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
+int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner, int *cut)
+{
+    return guarded([&] { return kvx_chol_dist_owner_impl(F, nranks, owner, cut); });
+}
+
+static int kvx_chol_dist_setup_impl(kvx_chol *F, int rank, int nranks, int64_t info[4])
 {
     if (!F || nranks < 1 || rank < 0 || rank >= nranks || !info) return KVX_EINVAL;
     int rc = ensure_device(F);
@@ -1151,7 +1198,12 @@ int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
     return KVX_OK;
 }
 
-int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
+int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
+{
+    return guarded([&] { return kvx_chol_dist_setup_impl(F, rank, nranks, info); });
+}
+
+static int kvx_chol_dist_factor_phase_impl(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
 {
     if (!F || !F->dev_ready || phase < 0 || phase > 1) return KVX_EINVAL;
     Symbolic &S = F->S;
@@ -1185,7 +1237,12 @@ int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev,
     return finish_factor(F, minor);
 }
 
-int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
+int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
+{
+    return guarded([&] { return kvx_chol_dist_factor_phase_impl(F, phase, values_dev, xchg, minor); });
+}
+
+static int kvx_chol_dist_solve_phase_impl(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
 {
     if (!F || !F->dev_ready || phase < 0 || phase > 2 || nrhs < 1 || nrhs > 65535) return KVX_EINVAL;
     if (!F->numeric) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
@@ -1222,6 +1279,11 @@ int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, i
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return KVX_OK;
+}
+
+int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
+{
+    return guarded([&] { return kvx_chol_dist_solve_phase_impl(F, phase, B, nrhs, ldB, xchg); });
 }
 
 void kvx_chol_free(kvx_chol *F)

@@ -1,10 +1,12 @@
 // C-ABI entry points for the NT scaling, normal-equations assembly and sparse mat-vec
 // (include/kvxhip.h).  Device-only: no CPU fallback.
 #include "../../include/kvxhip.h"
+#include "abi_guard.hpp"
 #include "kkt.hpp"
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -81,18 +83,19 @@ int atda_device(kvx_atda *T)
 
 extern "C" {
 
-int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const int64_t *Pp, const int64_t *Pi,
+static int kvx_atda_plan_impl(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const int64_t *Pp, const int64_t *Pi,
                   kvx_atda **out)
 {
     if (!out || ml < 0 || n < 0 || (n > 0 && !Gp)) return KVX_EINVAL;
-    kvx_atda *T = new kvx_atda();
+    std::unique_ptr<kvx_atda> hold(new kvx_atda());
+    kvx_atda *T = hold.get();
     T->ml = ml; T->n = n;
     const int64_t gnz = n ? Gp[n] : 0;
-    if (gnz >= ((int64_t)1 << 31)) { delete T; return KVX_EINVAL; }
+    if (gnz >= ((int64_t)1 << 31)) { return KVX_EINVAL; }
     T->gnz = gnz;
     T->gi32.resize((size_t)gnz);
     for (int64_t p = 0; p < gnz; p++) {
-        if (Gi[p] < 0 || Gi[p] >= ml) { delete T; return KVX_EINVAL; }
+        if (Gi[p] < 0 || Gi[p] >= ml) { return KVX_EINVAL; }
         T->gi32[p] = (int32_t)Gi[p];
     }
     // CSR view of G: for every row the (column, CCS position) pairs, columns ascending
@@ -125,7 +128,7 @@ int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, c
         if (Pp)
             for (int64_t p = Pp[j]; p < Pp[j + 1]; p++) {
                 int64_t i = Pi[p];
-                if (i < 0 || i >= n) { delete T; return KVX_EINVAL; }
+                if (i < 0 || i >= n) { return KVX_EINVAL; }
                 if (i >= j && mark[i] != j) { mark[i] = j; col.push_back(i); }
             }
         std::sort(col.begin(), col.end());
@@ -140,7 +143,7 @@ int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, c
         std::vector<int64_t> cur;
         if (pass == 1) {
             for (int64_t e = 0; e < T->snz; e++) T->pp[e + 1] += T->pp[e];
-            if (T->pp[T->snz] >= ((int64_t)1 << 40)) { delete T; return KVX_ENOMEM; }
+            if (T->pp[T->snz] >= ((int64_t)1 << 40)) { return KVX_ENOMEM; }
             T->pa.resize((size_t)T->pp[T->snz]);
             T->pb.resize((size_t)T->pp[T->snz]);
             cur.assign(T->pp.begin(), T->pp.end() - 1);
@@ -171,17 +174,28 @@ int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, c
         for (int64_t p = 0; p < T->pnz; p++)
             if (T->pslot[p] < 0) T->pslot[p] = 0;   // neutralised below by a zero value
     }
-    *out = T;
+    *out = hold.release();
     return KVX_OK;
 }
 
-int kvx_atda_pattern(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si)
+int kvx_atda_plan(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const int64_t *Pp, const int64_t *Pi,
+                  kvx_atda **out)
+{
+    return guarded([&] { return kvx_atda_plan_impl(ml, n, Gp, Gi, Pp, Pi, out); });
+}
+
+static int kvx_atda_pattern_impl(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si)
 {
     if (!T) return KVX_EINVAL;
     if (snz) *snz = T->snz;
     if (Sp) memcpy(Sp, T->Sp.data(), sizeof(int64_t) * (T->n + 1));
     if (Si && T->snz) memcpy(Si, T->Si.data(), sizeof(int64_t) * T->snz);
     return KVX_OK;
+}
+
+int kvx_atda_pattern(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si)
+{
+    return guarded([&] { return kvx_atda_pattern_impl(T, snz, Sp, Si); });
 }
 
 int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
@@ -195,7 +209,7 @@ int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx, const double *w, const 
     return KVX_OK;
 }
 
-int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
+static int kvx_atda_assemble_impl(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
 {
     if (!T) return KVX_EINVAL;
     int rc = atda_device(T);
@@ -217,6 +231,11 @@ int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const doub
     HIPCHK(hipDeviceSynchronize());
     if (T->snz) HIPCHK(hipMemcpy(Sx, T->d_sx, T->snz * sizeof(double), hipMemcpyDeviceToHost));
     return KVX_OK;
+}
+
+int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
+{
+    return guarded([&] { return kvx_atda_assemble_impl(T, Gx, w, Px, Sx); });
 }
 
 void kvx_atda_free(kvx_atda *T)

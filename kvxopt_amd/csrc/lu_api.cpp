@@ -2,6 +2,7 @@
 // from SuiteSparse KLU (klu_analyze :141, klu_factor :161, klu_solve/klu_tsolve :187-198, klu_extract :444-449,
 // Udiag/Rs/Pnum/Q for the determinant :760-822).  Device-only numeric phase: no CPU fallback.
 #include "../../include/kvxhip.h"
+#include "abi_guard.hpp"
 #include "lu_device.hpp"
 #include "lu_symbolic.hpp"
 
@@ -423,13 +424,18 @@ int kvx_lu_sym_info(kvx_lu_sym *S, int64_t info[8])
     return KVX_OK;
 }
 
-int kvx_lu_sym_btf(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *blk)
+static int kvx_lu_sym_btf_impl(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *blk)
 {
     if (!S || !nblocks || !nlevels) return KVX_EINVAL;
     *nblocks = S->Y.nblocks;
     *nlevels = S->Y.nblev;
     if (blk) for (int64_t j = 0; j < S->Y.n; j++) blk[j] = S->Y.blk[(size_t)j];
     return KVX_OK;
+}
+
+int kvx_lu_sym_btf(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *blk)
+{
+    return guarded([&] { return kvx_lu_sym_btf_impl(S, nblocks, nlevels, blk); });
 }
 
 int kvx_lu_sym_matching(kvx_lu_sym *S, int64_t *rowfor)
@@ -451,7 +457,7 @@ static int new_numeric(kvx_lu_sym *S, int64_t nnz, kvx_lu_num **out)
     return KVX_OK;
 }
 
-int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out)
+static int kvx_lu_factor_dev_impl(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out)
 {
     int rc = new_numeric(S, nnz, out);
     if (rc) return rc;
@@ -460,7 +466,12 @@ int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_
     return KVX_OK;
 }
 
-int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out)
+int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out)
+{
+    return guarded([&] { return kvx_lu_factor_dev_impl(S, nnz, values_dev, out); });
+}
+
+static int kvx_lu_factor_impl(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out)
 {
     int rc = new_numeric(S, nnz, out);
     if (rc) return rc;
@@ -472,21 +483,36 @@ int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num *
     return KVX_OK;
 }
 
-int kvx_lu_refactor_dev(kvx_lu_num *N, int64_t nnz, const double *values_dev)
+int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out)
+{
+    return guarded([&] { return kvx_lu_factor_impl(S, nnz, values, out); });
+}
+
+static int kvx_lu_refactor_dev_impl(kvx_lu_num *N, int64_t nnz, const double *values_dev)
 {
     if (!N || nnz != N->nnz) return KVX_EINVAL;
     if (!N->factored) return factor_loop(N, values_dev, 0);
     return factor_loop(N, values_dev, 1);
 }
 
-int kvx_lu_refactor(kvx_lu_num *N, int64_t nnz, const double *values)
+int kvx_lu_refactor_dev(kvx_lu_num *N, int64_t nnz, const double *values_dev)
+{
+    return guarded([&] { return kvx_lu_refactor_dev_impl(N, nnz, values_dev); });
+}
+
+static int kvx_lu_refactor_impl(kvx_lu_num *N, int64_t nnz, const double *values)
 {
     if (!N || nnz != N->nnz || !values) return KVX_EINVAL;
     HIPCHK(hipMemcpy(N->d_Ax, values, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
     return kvx_lu_refactor_dev(N, nnz, N->d_Ax);
 }
 
-int kvx_lu_solve_dev(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
+int kvx_lu_refactor(kvx_lu_num *N, int64_t nnz, const double *values)
+{
+    return guarded([&] { return kvx_lu_refactor_impl(N, nnz, values); });
+}
+
+static int kvx_lu_solve_dev_impl(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     if (!N || (trans != 0 && trans != 1) || nrhs < 0 || ldB < std::max<int64_t>(1, N ? N->n : 1)) return KVX_EINVAL;
     if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
@@ -498,7 +524,12 @@ int kvx_lu_solve_dev(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int6
     return KVX_OK;
 }
 
-int kvx_lu_solve(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB)
+int kvx_lu_solve_dev(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] { return kvx_lu_solve_dev_impl(N, trans, B_dev, nrhs, ldB); });
+}
+
+static int kvx_lu_solve_impl(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB)
 {
     if (!N || !B || (trans != 0 && trans != 1) || nrhs < 0 || ldB < std::max<int64_t>(1, N->n)) return KVX_EINVAL;
     if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
@@ -515,6 +546,11 @@ int kvx_lu_solve(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB)
     return KVX_OK;
 }
 
+int kvx_lu_solve(kvx_lu_num *N, int trans, double *B, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] { return kvx_lu_solve_impl(N, trans, B, nrhs, ldB); });
+}
+
 int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8])
 {
     if (!N || !info) return KVX_EINVAL;
@@ -523,7 +559,7 @@ int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8])
     return KVX_OK;
 }
 
-int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
+static int kvx_lu_extract_impl(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
                    int64_t **Ui, double **Ux, int64_t *fnz, int64_t **Fp, int64_t **Fi, double **Fx, int64_t *P_out,
                    int64_t *Q_out, double *Rs, int64_t *nblocks, int64_t **r_out)
 {
@@ -595,8 +631,15 @@ int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, doub
     return KVX_OK;
 }
 
+int kvx_lu_extract(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
+                   int64_t **Ui, double **Ux, int64_t *fnz, int64_t **Fp, int64_t **Fi, double **Fx, int64_t *P_out,
+                   int64_t *Q_out, double *Rs, int64_t *nblocks, int64_t **r_out)
+{
+    return guarded([&] { return kvx_lu_extract_impl(N, lnz, Lp, Li, Lx, unz, Up, Ui, Ux, fnz, Fp, Fi, Fx, P_out, Q_out, Rs, nblocks, r_out); });
+}
+
 // Determinant as the reference computes it (klu.c:760-822): prod(Udiag[k] * Rs[k]) times the signs of P and Q.
-int kvx_lu_det(kvx_lu_num *N, double *det)
+static int kvx_lu_det_impl(kvx_lu_num *N, double *det)
 {
     if (!N || !det) return KVX_EINVAL;
     if (!N->factored) { set_last_error("singular matrix"); return KVX_ESINGULAR; }
@@ -625,6 +668,11 @@ int kvx_lu_det(kvx_lu_num *N, double *det)
     }
     *det = (npiv & 1) ? -dd : dd;
     return KVX_OK;
+}
+
+int kvx_lu_det(kvx_lu_num *N, double *det)
+{
+    return guarded([&] { return kvx_lu_det_impl(N, det); });
 }
 
 }  // extern "C"
