@@ -439,10 +439,87 @@ def g7_mps():
     print("boeing2: objective", meta["objective"], "vars", meta["n_variables"], "ineq", meta["n_inequalities"], "eq", meta["n_equalities"])
 
 
+def g12_nonlinear_block():
+    """The nonlinear block of cvxprog on the kkt_chol2 path (mnl > 0): compute_scaling / update_scaling / scale with
+    W['dnl'], and misc.kkt_chol2(G, dims, A, mnl)(W, H, Df) -- dense branch (pure reference, LAPACK) and sparse branch
+    (reference python + oracle cholesky); two factor calls (the second refactors on the fixed pattern with a new Df)."""
+    from kvxopt import matrix, misc, spmatrix
+    out = {}
+    mnl, ml, n = 5, 30, 9
+    dims = {"l": ml, "q": [], "s": []}
+    rng = np.random.default_rng(1212)
+    s, z = rng.uniform(0.1, 3.0, mnl + ml), rng.uniform(0.1, 3.0, mnl + ml)
+    lm = matrix(0.0, (mnl + ml, 1))
+    W = misc.compute_scaling(matrix(s), matrix(z), lm, dims, mnl)
+    out["s"], out["z"] = s, z
+    for k in ("dnl", "dnli", "d", "di"):
+        out["cs_" + k] = tolist(W[k])
+    out["cs_lmbda"] = tolist(lm)
+    xs = rng.standard_normal((mnl + ml, 3))
+    for inv in ("N", "I"):
+        X = matrix(xs.copy())
+        misc.scale(X, W, trans="T", inverse=inv)
+        out["scale_" + inv] = np.array(X).reshape(mnl + ml, 3)
+    out["scale_in"] = xs
+    s2, z2 = rng.uniform(0.5, 2.0, mnl + ml), rng.uniform(0.5, 2.0, mnl + ml)
+    ms, mz = matrix(s2.copy()), matrix(z2.copy())
+    misc.update_scaling(W, lm, ms, mz)
+    out["us_s_in"], out["us_z_in"] = s2, z2
+    out["us_s"], out["us_z"], out["us_lmbda"] = tolist(ms), tolist(mz), tolist(lm)
+    for k in ("dnl", "dnli", "d", "di"):
+        out["us_" + k] = tolist(W[k])
+    for tag, p in (("p0", 0), ("p2", 2)):
+        rng = np.random.default_rng(1213 + p)
+        G = rand_sparse(rng, ml, n, 0.25)
+        Df1 = rand_sparse(rng, mnl, n, 0.5)
+        Df2 = spmatrix(rng.standard_normal(len(Df1)).tolist(), Df1.I, Df1.J, Df1.size)
+        A = rand_sparse(rng, p, n, 0.5) if p else spmatrix([], [], [], (0, n))
+        hI = list(range(n)) + [3, 7]
+        hJ = list(range(n)) + [1, 2]
+        H1 = spmatrix(rng.uniform(0.5, 1.5, n).tolist() + [0.2, -0.1], hI, hJ, (n, n))
+        H2 = spmatrix(rng.uniform(0.5, 1.5, n).tolist() + [-0.3, 0.15], hI, hJ, (n, n))
+        Ws = []
+        for _ in range(2):
+            d, dnl = rng.uniform(0.5, 2.0, ml), rng.uniform(0.5, 2.0, mnl)
+            Ws.append({"dnl": matrix(dnl), "dnli": matrix(1.0 / dnl), "d": matrix(d), "di": matrix(1.0 / d),
+                       "v": [], "beta": [], "r": [], "rti": []})
+        bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(mnl + ml)
+        res = {}
+        for branch in ("dense", "sparse"):
+            dn = branch == "dense"
+            cv = (lambda M: matrix(M)) if dn else (lambda M: M)
+            Am = (matrix(A) if p else matrix(0.0, (0, n))) if dn else A
+            f = misc.kkt_chol2(cv(G), dims, Am, mnl)
+            f(Ws[0], cv(H1), cv(Df1))
+            solve = f(Ws[1], cv(H2), cv(Df2))
+            x, y, zz = matrix(bx.copy()), matrix(by.copy()) if p else matrix(0.0, (0, 1)), matrix(bz.copy())
+            solve(x, y, zz)
+            res[branch] = (tolist(x), tolist(y), tolist(zz))
+        for a, b in zip(res["dense"], res["sparse"]):
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-11), "branches disagree"
+        out[tag + "_G_cp"], out[tag + "_G_ri"], out[tag + "_G_v"] = ccs(G)
+        out[tag + "_Df_cp"], out[tag + "_Df_ri"], out[tag + "_Df1_v"] = ccs(Df1)
+        out[tag + "_Df2_v"] = ccs(Df2)[2]
+        out[tag + "_H_cp"], out[tag + "_H_ri"], out[tag + "_H1_v"] = ccs(H1)
+        out[tag + "_H2_v"] = ccs(H2)[2]
+        if p:
+            out[tag + "_A_cp"], out[tag + "_A_ri"], out[tag + "_A_v"] = ccs(A)
+        for i in range(2):
+            for k in ("dnl", "d"):
+                out["%s_W%d_%s" % (tag, i, k)] = tolist(Ws[i][k])
+        out[tag + "_bx"], out[tag + "_by"], out[tag + "_bz"] = bx, by, bz
+        out[tag + "_x"], out[tag + "_y"], out[tag + "_z"] = res["dense"]          # pure reference result
+    np.savez_compressed(os.path.join(HERE, "g12_nonlinear_block.npz"), **out)
+
+
 if __name__ == "__main__":
     stage()
     import kvxopt
     print("reference kvxopt", kvxopt.__version__)
+    if len(sys.argv) > 1:                     # e.g. `make_goldens.py g12_nonlinear_block`: only the named generators
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_nt_scaling(kvxopt)
     g2_assembly()
     g3_kkt()
@@ -454,4 +531,5 @@ if __name__ == "__main__":
     g9_coneqp_eq()
     g10_conelp_starts()
     g11_coneqp_initvals()
+    g12_nonlinear_block()
     print("goldens written to", HERE)

@@ -107,3 +107,30 @@ def test_lp_generator_is_feasible():
     assert P["ml"] == 120 and P["n"] == 30 and P["Gp"][-1] == len(P["Gx"])
     per_row = np.bincount(P["Gi"], minlength=P["ml"])
     assert per_row.max() <= 2 and per_row.min() >= 1
+
+
+def _dense_of(m, n, cp, ri, v):
+    D = np.zeros((m, n)); D[ri, np.repeat(np.arange(n), np.diff(cp))] = v
+    return D
+
+
+@pytest.mark.parametrize("tag,p", [("p0", 0), ("p2", 2)])
+def test_golden_nonlinear_block_is_the_kkt_solution(golden_dir, tag, p):
+    """G12 pins the mnl > 0 branch of misc.kkt_chol2 (misc.py:1488-1500): the reference's output (ux, uy, W uz) solves
+        [H A' GG'; A 0 0; GG 0 -W'W] [ux; uy; uz] = [bx; by; bz],   GG = [Df; G],  W = diag([dnl; d])
+    -- checked here with a dense numpy solve, so the fixture and the restated system agree before the GPU test uses it."""
+    g = np.load(os.path.join(golden_dir, "g12_nonlinear_block.npz"))
+    mnl, ml, n = 5, 30, 9
+    G = _dense_of(ml, n, g[tag + "_G_cp"], g[tag + "_G_ri"], g[tag + "_G_v"])
+    Df = _dense_of(mnl, n, g[tag + "_Df_cp"], g[tag + "_Df_ri"], g[tag + "_Df2_v"])
+    Hl = _dense_of(n, n, g[tag + "_H_cp"], g[tag + "_H_ri"], g[tag + "_H2_v"])
+    H = Hl + np.tril(Hl, -1).T
+    A = _dense_of(p, n, g[tag + "_A_cp"], g[tag + "_A_ri"], g[tag + "_A_v"]) if p else np.zeros((0, n))
+    w = np.concatenate([g[tag + "_W1_dnl"], g[tag + "_W1_d"]])
+    GG = np.vstack([Df, G])
+    m = mnl + ml
+    K = np.block([[H, A.T, GG.T], [A, np.zeros((p, p)), np.zeros((p, m))], [GG, np.zeros((m, p)), -np.diag(w * w)]])
+    u = np.linalg.solve(K, np.concatenate([g[tag + "_bx"], g[tag + "_by"], g[tag + "_bz"]]))
+    assert np.allclose(u[:n], g[tag + "_x"], rtol=1e-9, atol=1e-11)
+    assert np.allclose(u[n:n + p], g[tag + "_y"], rtol=1e-9, atol=1e-11)
+    assert np.allclose(w * u[n + p:], g[tag + "_z"], rtol=1e-9, atol=1e-11)

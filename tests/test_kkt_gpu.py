@@ -99,6 +99,59 @@ def test_kkt_chol2_golden(golden_dir, tag, p):
         assert rel(y._a, g[tag + "_y"]) < 1e-10
 
 
+def test_nonlinear_block_scaling_golden(golden_dir):
+    """G12: misc.compute_scaling / scale / update_scaling with the nonlinear block of cvxprog (mnl leading entries,
+    W['dnl'], W['dnli']; misc.py:262-270, 48-60, 432-442) against the reference."""
+    g = np.load(os.path.join(golden_dir, "g12_nonlinear_block.npz"))
+    mnl, ml = 5, 30
+    dims = {"l": ml, "q": [], "s": []}
+    lm = matrix(0.0, (mnl + ml, 1))
+    W = misc.compute_scaling(matrix(g["s"]), matrix(g["z"]), lm, dims, mnl)
+    for k in ("dnl", "dnli", "d", "di"):
+        assert W[k].size == (g["cs_" + k].size, 1) and rel(W[k]._a, g["cs_" + k]) < 1e-14, k
+    assert rel(lm._a, g["cs_lmbda"]) < 1e-14
+    for inv in "NI":
+        x = matrix(g["scale_in"].copy(order="F"))
+        misc.scale(x, W, trans="T", inverse=inv)
+        assert rel(x.a, g["scale_" + inv]) < 1e-14
+    ms, mz = matrix(g["us_s_in"].copy()), matrix(g["us_z_in"].copy())
+    misc.update_scaling(W, lm, ms, mz)
+    for got, name in ((ms, "us_s"), (mz, "us_z"), (lm, "us_lmbda"), (W["dnl"], "us_dnl"), (W["dnli"], "us_dnli"),
+                      (W["d"], "us_d"), (W["di"], "us_di")):
+        assert rel(got._a, g[name]) < 1e-14, name
+    # mnl = 0 is not mnl = None: cvxprog passes 0 for problems without nonlinear constraints and still expects the keys
+    W0 = misc.compute_scaling(matrix(g["s"][:ml]), matrix(g["z"][:ml]), matrix(0.0, (ml, 1)), dims, 0)
+    assert W0["dnl"].size == (0, 1) and W0["d"].size == (ml, 1)
+
+
+@pytest.mark.parametrize("tag,p", [("p0", 0), ("p2", 2)])
+def test_kkt_chol2_nonlinear_block_golden(golden_dir, tag, p):
+    """G12: misc.kkt_chol2(G, dims, A, mnl)(W, H, Df) -- the cvxprog form of the path (misc.py:1396-1400, 1413-1415,
+    1423-1424, 1452-1453, 1523, 1560-1561): S = Df' Wnl^-2 Df + G' Wl^-2 G + H.  First call fixes the patterns, the
+    second refactors with new W, H, Df values; the result is compared with the reference's dense LAPACK branch."""
+    g = np.load(os.path.join(golden_dir, "g12_nonlinear_block.npz"))
+    mnl, ml, n = 5, 30, 9
+    G = spmatrix.from_ccs(ml, n, g[tag + "_G_cp"], g[tag + "_G_ri"], g[tag + "_G_v"])
+    A = spmatrix.from_ccs(p, n, g[tag + "_A_cp"], g[tag + "_A_ri"], g[tag + "_A_v"]) if p else spmatrix([], [], [], (0, n))
+    Df = [spmatrix.from_ccs(mnl, n, g[tag + "_Df_cp"], g[tag + "_Df_ri"], g[tag + "_Df%d_v" % i]) for i in (1, 2)]
+    H = [spmatrix.from_ccs(n, n, g[tag + "_H_cp"], g[tag + "_H_ri"], g[tag + "_H%d_v" % i]) for i in (1, 2)]
+    Ws = []
+    for i in range(2):
+        W = W_of(g["%s_W%d_d" % (tag, i)].copy(), 1.0 / g["%s_W%d_d" % (tag, i)])
+        W["dnl"], W["dnli"] = matrix(g["%s_W%d_dnl" % (tag, i)].copy()), matrix(1.0 / g["%s_W%d_dnl" % (tag, i)])
+        Ws.append(W)
+    f = misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, A, mnl)
+    f(Ws[0], H[0], Df[0])
+    solve = f(Ws[1], H[1], Df[1])
+    x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
+    solve(x, y, z)
+    assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
+    if p:
+        assert rel(y._a, g[tag + "_y"]) < 1e-10
+    with pytest.raises(NotImplementedError):                  # dense Df: the reference's LAPACK branch, out of scope
+        misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, A, mnl)(Ws[0], H[0], matrix(Df[0].todense()))
+
+
 def test_kkt_chol2_rejects_other_cones():
     with pytest.raises(ValueError):
         misc.kkt_chol2(spmatrix([1.0], [0], [0], (3, 1)), {"l": 0, "q": [3], "s": []}, spmatrix([], [], [], (0, 1)))
