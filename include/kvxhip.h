@@ -36,7 +36,10 @@ typedef struct kvx_atda kvx_atda;          /* opaque plan for S = G' D G on a fi
 
 /* Options: replaces cholmod.options / set_options() (cholmod.c:87-129). */
 typedef struct {
-    int32_t supernodal;     /* 2 (default): supernodal LL'. Only 2 is implemented; others -> KVX_EINVAL */
+    int32_t supernodal;     /* cholmod.options['supernodal'] (spsolvers.rst:731-736).  2 (default): P A P' = L L'.  0: P A P' = L D L'.
+                             * 1: LL' if flops / nnz(L) >= 40 (CHOLMOD's rule), else LDL'.  One set of kernels computes Lc with
+                             * P A P' = Lc Lc'; the LDL' factor is that result seen as L = Lc diag(Lc)^-1, D = diag(Lc)^2: solve
+                             * sys = 2..6, getfactor (D on the diagonal, unit diagonal of L implicit) and diag (refused) follow it */
     int32_t ordering;       /* 0 = built-in nested-dissection/min-degree (when p == NULL); 1 = natural   */
     int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
     int32_t relax_small;    /* relaxed-amalgamation: always merge if merged width <= this (default 4)    */
@@ -74,7 +77,7 @@ int kvx_chol_factorize_async_dev(kvx_chol *F, const double *values_dev);
 int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the factor's stream */
 
 /* solve(F, B, sys, nrhs, ldB, offsetB) -- cholmod.c:429-499; sys 0..8 = A, LDL', LD, DL', L,
- * L', D, P, P' (:437-439) with D = I.  B (n x nrhs, leading dimension ldB >= max(1,n)) is
+ * L', D, P, P' (:437-439) with D = I for an LL' factor (spsolvers.rst:640-668).  B (n x nrhs, leading dimension ldB >= max(1,n)) is
  * overwritten.  The caller applies offsetB to the pointer.  After kvx_chol_factorize_async_dev the solve
  * is queued behind the factorisation without a host round trip; a failed factorisation is then reported by
  * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456). */
@@ -89,7 +92,8 @@ int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, 
 int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi,
                      const double *Bx, int64_t **Xp, int64_t **Xi, double **Xx);
 
-/* diag(F) -- cholmod.c:900-945: diagonal of L in permuted order, n doubles. */
+/* diag(F) -- cholmod.c:900-945: diagonal of L in permuted order, n doubles.  An LDL' factor is refused (KVX_ESYMBOLIC,
+ * "F must be a nonsingular supernodal Cholesky factor", cholmod.c:919-922): its D comes from solve(sys = 6). */
 int kvx_chol_diag(kvx_chol *F, double *d);
 
 /* getfactor(F) -- cholmod.c:948-985: L as CCS (lower, sorted). Call with Lp=Li=Lx=NULL to
@@ -109,7 +113,8 @@ typedef struct {
     int64_t is_numeric;      /* 1 after a successful factorize                                */
     int64_t minor;
     int64_t solve_rowidx;    /* sum_s m_s: index entries read per triangular sweep           */
-    int64_t reserved[5];
+    int64_t is_ll;           /* 1: LL' factor, 0: LDL' (options['supernodal'] = 0, or 1 on a sparse factor) */
+    int64_t reserved[4];
 } kvx_chol_info;
 int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info);
 int kvx_chol_get_perm(kvx_chol *F, int64_t *perm);     /* final permutation (ordering o postorder) */

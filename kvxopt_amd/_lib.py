@@ -29,7 +29,7 @@ class CholOpts(ctypes.Structure):
 class CholInfo(ctypes.Structure):
     _fields_ = [("n", i64), ("nnz_a", i64), ("lnz", i64), ("flops", f64), ("nsuper", i64), ("lsize", i64),
                 ("nlevels", i64), ("max_front", i64), ("upd_size", i64), ("is_numeric", i64), ("minor", i64),
-                ("solve_rowidx", i64), ("reserved", i64 * 5)]
+                ("solve_rowidx", i64), ("is_ll", i64), ("reserved", i64 * 4)]
 
 
 _SIGS = {

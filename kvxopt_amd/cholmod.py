@@ -15,7 +15,10 @@ Cholesky of libkvxhip.so.  No CPU fallback: numeric calls raise RuntimeError wit
 Differences kept on purpose: `numeric` raises ArithmeticError(minor) on a non-positive-
 definite matrix as DOCUMENTED (cholmod.c:308-310); the reference build tests a stale status there
 (quirk Q1) and only fails at the next solve -- `solve` here raises as well.
-Only options['supernodal'] == 2 (the reference default) is implemented.
+options['supernodal'] (spsolvers.rst:731-736): 2 (default) gives P A P' = L L'; 0 gives P A P' = L D L' and 1 chooses by
+CHOLMOD's flops / nnz(L) >= 40 rule.  One set of HIP kernels computes the LL' factor Lc; the LDL' factor is that result seen
+as L = Lc diag(Lc)^-1, D = diag(Lc)^2 -- `solve`/`spsolve` with sys = 2..6, `getfactor` (D on the diagonal) and `diag`
+(refused, cholmod.c:919-922) follow the reference's behaviour for such a factor.
 """
 import numpy as np
 
@@ -44,8 +47,8 @@ def _check_options():
             opts["dbound"] = v
         else:
             raise ValueError("invalid value for CHOLMOD parameter: %-.20s" % k)
-    if opts.get("supernodal", 2) != 2:
-        raise ValueError("kvxopt_amd.cholmod implements options['supernodal'] = 2 (supernodal LL') only")
+    if opts.get("supernodal", 2) not in (0, 1, 2):
+        raise ValueError("invalid value for CHOLMOD parameter: supernodal")
     opts.pop("nmethods", None)
     return opts
 
@@ -96,7 +99,7 @@ def symbolic(A, p=None, uplo="L"):
     if uplo not in ("L", "U"):
         raise ValueError("possible values of uplo are: 'L', 'U'")
     try:
-        fac = Factor(n, cp, ri, uplo, q, {k: opts[k] for k in ("postorder", "dbound") if k in opts})
+        fac = Factor(n, cp, ri, uplo, q, {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts})
     except ValueError as e:
         if "permutation" in str(e):
             raise ValueError("p is not a valid permutation")
@@ -211,7 +214,7 @@ def diag(F):
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
     inf = F.fac.info()
-    if not inf["is_numeric"] or inf["minor"] < F.fac.n:
+    if not inf["is_numeric"] or inf["minor"] < F.fac.n or not inf["is_ll"]:
         raise ValueError("F must be a nonsingular supernodal Cholesky factor")
     return matrix(F.fac.diag(), (F.fac.n, 1))
 

@@ -50,6 +50,9 @@ struct kvx_chol {
     bool dev_ready = false;
     bool numeric = false;
     bool pending = false;     // a factorisation was enqueued and its status not yet read
+    bool is_ll = true;        // false: the factor is presented as P A P' = L D L' (options['supernodal'] = 0, or 1 on a sparse factor)
+    double *d_diag = nullptr; // diag(Lc) for the LDL' view, extracted after every factorisation
+    bool diag_valid = false;
     int64_t minor = 0;
     hipStream_t stream = nullptr;
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
@@ -569,6 +572,7 @@ int enqueue_factor(kvx_chol *F)
     HIPCHK(hipEventRecord(F->ev[0], st));
     const bool graph_ok = F->use_graph && F->prof_family < 0;
     F->factor_calls++;
+    F->diag_valid = false;
     if (graph_ok && !F->g_factor && F->factor_calls >= 2)
         F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });   // (sharded mode drives the body itself)
     if (graph_ok && F->g_factor) {
@@ -724,8 +728,14 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     }
     if (n == 0 || nrhs == 0) return deferred ? ((rc = finish_factor(F, nullptr)) == KVX_ENOTPOSDEF ? KVX_ESINGULAR : rc) : KVX_OK;
     if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
-    if (sys == 6) return KVX_OK;   // D = I for an LL' factor
+    if (sys == 6 && F->is_ll) return KVX_OK;   // D = I for an LL' factor
     hipStream_t st = F->stream;
+    const bool ldl = !F->is_ll && sys >= 2 && sys <= 6;
+    if (ldl && !F->diag_valid) {
+        if (!F->d_diag) HIPCHK(hipMalloc((void **)&F->d_diag, (size_t)n * sizeof(double)));
+        launch_extract_diag(st, F->ds, S.nsuper, F->d_Lx, F->d_diag);
+        F->diag_valid = true;
+    }
     // wstride: both parity buffers are allocated with wrk_size[p]*x_cap; use a common stride
     const int chunk_max = 65535;
     for (int64_t r0 = 0; r0 < nrhs; r0 += chunk_max) {
@@ -739,6 +749,8 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
         if (sys == 0 || sys == 7) launch_perm_gather(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
         else if (sys == 8) launch_perm_scatter(st, F->d_perm, n, nr, Bc, ldB, F->d_X, n);
         else HIPCHK(hipMemcpy2DAsync(F->d_X, n * sizeof(double), Bc, ldB * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
+        // LDL' view: D L' x = b  ->  Lc' x = diag^-1 b;  L' x = b  ->  Lc' x = diag b;  D x = b  ->  x = diag^-2 b
+        if (ldl && (sys == 3 || sys == 5 || sys == 6)) launch_diag_scale(st, n, nr, F->d_diag, F->d_X, n, sys == 3 ? 1 : (sys == 5 ? 0 : 2));
         if (kind >= 0) {
             auto body = [&]() -> int {
                 if (kind == 0 || kind == 1) {
@@ -763,6 +775,8 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
             if (exec) HIPCHK(hipGraphLaunch(exec, st));
             else if ((rc = body())) return rc;
         }
+        // L D x = b  ->  x = diag^-1 Lc^-1 b;  L x = b  ->  x = diag Lc^-1 b
+        if (ldl && (sys == 2 || sys == 4)) launch_diag_scale(st, n, nr, F->d_diag, F->d_X, n, sys == 2 ? 1 : 0);
         if (sys == 0) launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, Bc, ldB);
         else HIPCHK(hipMemcpy2DAsync(Bc, ldB * sizeof(double), F->d_X, n * sizeof(double), n * sizeof(double), nr, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(F->ev[3], st));
@@ -819,7 +833,7 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
     if (!out || n < 0 || (n > 0 && (!colptr || (!rowind && colptr[n] > 0)))) { set_err("bad arguments"); return KVX_EINVAL; }
     kvx_chol_opts o;
     if (opts) o = *opts; else kvx_chol_default_opts(&o);
-    if (o.supernodal != 2) { set_err("only options['supernodal'] = 2 (supernodal LL') is implemented"); return KVX_EINVAL; }
+    if (o.supernodal < 0 || o.supernodal > 2) { set_err("options['supernodal'] must be 0, 1 or 2"); return KVX_EINVAL; }
     kvx_chol *F = nullptr;
     try {
         F = new kvx_chol();
@@ -834,6 +848,11 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
         if (o.reserved[2] > 0) so.leaf_rows = o.reserved[2];
         static const int64_t zero = 0;
         analyze(n, n ? colptr : &zero, rowind, uplo, perm, so, F->S);
+        // options['supernodal'] (spsolvers.rst:731-736): 2 -> LL'; 0 -> LDL'; 1 -> whichever CHOLMOD would find cheaper,
+        // by its own rule flops / nnz(L) >= 40 -> supernodal LL'.  The arithmetic is the supernodal LL' kernels either
+        // way; an LDL' factor is the same numbers seen as L = Lc diag(Lc)^-1, D = diag(Lc)^2 (solve sys = 2..6,
+        // getfactor and diag follow that form).
+        F->is_ll = o.supernodal == 2 || (o.supernodal == 1 && F->S.lnz > 0 && F->S.flops / (double)F->S.lnz >= 40.0);
         F->minor = n;
     } catch (const std::invalid_argument &e) {
         delete F; set_err(e.what()); return KVX_EPERM;
@@ -1000,7 +1019,7 @@ int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, cons
 int kvx_chol_diag(kvx_chol *F, double *d)
 {
     if (!F || !d) return KVX_EINVAL;
-    if (!F->dev_ready) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESYMBOLIC; }
+    if (!F->dev_ready || !F->is_ll) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESYMBOLIC; }
     int rc = finish_factor(F, nullptr);
     if (rc == KVX_ENOTPOSDEF) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESINGULAR; }
     if (rc) return rc;
@@ -1038,9 +1057,14 @@ static int kvx_chol_get_factor_impl(kvx_chol *F, int64_t *lnz, int64_t *Lp, int6
         const int32_t *rows = S.rowidx.data() + S.rowptr[s];
         for (int64_t j = 0; j < k; j++) {
             if (Lp) Lp[f + j] = q;
+            // LDL' form (as cholmod_factor_to_sparse returns it): D on the diagonal, the unit diagonal of L implicit
+            const double dj = host[(size_t)(S.px[s] + j + j * m)];
             for (int64_t i = j; i < m; i++) {
                 if (Li) Li[q] = rows[i];
-                if (Lx) Lx[q] = host[(size_t)(S.px[s] + i + j * m)];
+                if (Lx) {
+                    const double v = host[(size_t)(S.px[s] + i + j * m)];
+                    Lx[q] = F->is_ll ? v : (i == j ? v * v : v / dj);
+                }
                 q++;
             }
         }
@@ -1071,6 +1095,7 @@ int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info)
     info->is_numeric = (F->numeric && !F->pending) ? 1 : 0;
     info->minor = F->minor;
     info->solve_rowidx = S.sum_m;
+    info->is_ll = F->is_ll ? 1 : 0;
     return KVX_OK;
 }
 
@@ -1293,7 +1318,7 @@ void kvx_chol_free(kvx_chol *F)
         (void)hipStreamSynchronize(F->stream);
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
-                        F->d_Ax, F->d_X, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
+                        F->d_Ax, F->d_X, F->d_X0, F->d_diag, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
         for (void *p : ptrs)
             if (p) (void)hipFree(p);
         if (F->h_status) (void)hipHostFree(F->h_status);

@@ -332,4 +332,20 @@ void launch_extract_diag(hipStream_t st, const DevSym &ds, int64_t nsuper, const
     hipLaunchKernelGGL(k_extract_diag, dim3((unsigned)((nsuper + 255) / 256)), dim3(256), 0, st, ds, nsuper, Lx, d);
 }
 
+// LDL' view of the LL' factor (options['supernodal'] = 0: PAP' = L D L', L = Lc diag(Lc)^-1, D = diag(Lc)^2):
+// X := diag(d) X (mode 0), diag(d)^-1 X (mode 1), diag(d)^-2 X (mode 2) on an n x nrhs block.
+__global__ void k_diag_scale(int64_t n, const double *__restrict__ d, double *__restrict__ X, int64_t ldx, int mode)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double *x = X + (int64_t)blockIdx.y * ldx + i;
+    const double v = d[i];
+    *x = mode == 0 ? *x * v : (mode == 1 ? *x / v : *x / (v * v));
+}
+void launch_diag_scale(hipStream_t st, int64_t n, int nrhs, const double *d, double *X, int64_t ldx, int mode)
+{
+    if (n <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_diag_scale, dim3((unsigned)((n + 255) / 256), (unsigned)nrhs), dim3(256), 0, st, n, d, X, ldx, mode);
+}
+
 }  // namespace kvx

@@ -198,13 +198,20 @@ def kkt_chol2(G, dims, A, mnl=0):
     mnl > 0 (cvxprog, misc.py:1396-1400, 1413-1415, 1423-1424, 1452-1453, 1523, 1560-1561): Df is the mnl x n sparse
     Jacobian of the nonlinear constraints, stacked on top of G:  S = Df' Wnl^-2 Df + G' Wl^-2 G + H; its pattern is
     fixed by the first call like G's.  A dense Df (or dense G, H) sends the reference to its LAPACK branch, which is out
-    of scope here."""
+    of scope here; a dense A (the reference's "mixed" branch, misc.py:1476-1481) is accepted."""
     if dims.get("q") or dims.get("s"):
         raise ValueError("kktsolver option 'kkt_chol2' is implemented only for problems with no "
                          "second-order or semidefinite cone constraints")
-    if isinstance(G, matrix) or isinstance(A, matrix):
-        raise NotImplementedError("kkt_chol2: the dense-G / dense-A LAPACK branches (misc.py:1429,1472-1481) are out of scope")
+    if isinstance(G, matrix):
+        raise NotImplementedError("kkt_chol2: the dense-G LAPACK branch (misc.py:1429,1467-1472) is out of scope")
     p, n = A.size
+    if isinstance(A, matrix):
+        # mixed branch of the reference (sparse S, dense A: misc.py:1476-1481 forms a dense K with LAPACK).  Here a dense A
+        # is A with every entry stored: Asct = L^-1 P A' and K = Asct' Asct come out of the same device kernels as for a
+        # sparse A, K is simply a full p x p pattern (one front).
+        Ad = np.asarray(A.a, dtype=np.float64).reshape(p, n)
+        A = spmatrix.from_ccs(p, n, np.arange(n + 1, dtype=np.int64) * p, np.tile(np.arange(p, dtype=np.int64), n),
+                              np.ascontiguousarray(Ad.T).reshape(-1))
     ml = dims["l"]
     F = {"firstcall": True, "singular": False}
 

@@ -97,6 +97,13 @@ def test_kkt_chol2_golden(golden_dir, tag, p):
     assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
     if p:
         assert rel(y._a, g[tag + "_y"]) < 1e-10
+        # the mixed branch (sparse G, DENSE A; misc.py:1476-1481) gives the same triple
+        f = misc.kkt_chol2(G, dims, matrix(A.todense()))
+        f(W_of(np.ones(ml), np.ones(ml)))
+        solve = f(W_of(g[tag + "_d"].copy(), 1.0 / g[tag + "_d"]))
+        x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
+        solve(x, y, z)
+        assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(y._a, g[tag + "_y"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
 
 
 def test_nonlinear_block_scaling_golden(golden_dir):
@@ -464,10 +471,21 @@ def test_cholmod_module_api():
     p = F.fac.perm()
     Afull = A.todense() + np.tril(A.todense(), -1).T
     assert np.allclose(Ld @ Ld.T, Afull[np.ix_(p, p)], atol=1e-12)
+    # options['supernodal'] = 0: P A P' = L D L'; the documented known answer of spsolvers.rst:766-772
     cholmod.options["supernodal"] = 0
-    with pytest.raises(ValueError):
-        cholmod.symbolic(A)
-    cholmod.options.clear()
+    try:
+        F0 = cholmod.symbolic(A)
+        cholmod.numeric(A, F0)
+        Di = matrix(1.0, (4, 1))
+        cholmod.solve(F0, Di, sys=6)
+        assert abs(-np.sum(np.log(Di._a)) - 5.50533153593) < 1e-10
+        with pytest.raises(ValueError):
+            cholmod.diag(F0)                                   # cholmod.c:919-922: not a supernodal LL' factor
+        cholmod.options["supernodal"] = 3
+        with pytest.raises(ValueError):
+            cholmod.symbolic(A)
+    finally:
+        cholmod.options.clear()
     cholmod.options["bogus"] = 1
     with pytest.raises(ValueError):
         cholmod.symbolic(A)                                    # cholmod.c:118-124
@@ -509,3 +527,40 @@ def test_lp_full_size_properties():
     assert np.linalg.norm(Gx_ - uz / (di * di) - bz) / np.linalg.norm(bz) < 1e-10
     Gtz = np.zeros(n); np.add.at(Gtz, cols, P["Gx"] * uz[P["Gi"]])
     assert np.linalg.norm(Gtz - bx) / np.linalg.norm(bx) < 1e-9   # first block row: G' uz = bx
+
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_cholmod_ldl_factor_semantics(mode):
+    """options['supernodal'] = 0 (and 1 on a sparse factor: flops / nnz(L) < 40): P A P' = L D L' with unit lower L.
+    getfactor returns L with D on its diagonal (what cholmod_factor_to_sparse gives for an LDL' factor); every `sys` code of
+    solve / spsolve follows the table of spsolvers.rst:640-668 with that L and D -- checked against dense numpy solves."""
+    n, cp, ri, v = workloads.laplacian_2d(9, 7)
+    A = spmatrix.from_ccs(n, n, cp, ri, v + 0.01 * np.random.default_rng(1).random(v.size) * (ri == np.repeat(np.arange(n), np.diff(cp))))
+    Afull = A.todense() + np.tril(A.todense(), -1).T
+    cholmod.options["supernodal"] = mode
+    try:
+        F = cholmod.symbolic(A)
+        assert F.fac.info()["is_ll"] == 0
+        cholmod.numeric(A, F)
+        p = F.fac.perm()
+        rng = np.random.default_rng(2)
+        B = rng.standard_normal((n, 3))
+        got = {}
+        for sys in range(9):
+            X = matrix(B.copy(order="F"))
+            cholmod.solve(F, X, sys=sys)
+            got[sys] = X.a.copy()
+        Bs = spmatrix(rng.standard_normal(5), [0, 3, 7, 11, 20], [0, 0, 1, 1, 1], (n, 2))
+        gsp = {sys: cholmod.spsolve(F, Bs, sys=sys).todense() for sys in range(9)}
+        M = cholmod.getfactor(F).todense()                     # (getfactor leaves F symbolic in the reference too)
+    finally:
+        cholmod.options.clear()
+    D = np.diag(np.diag(M))
+    L = np.tril(M, -1) + np.eye(n)
+    assert np.all(np.diag(M) > 0) and np.allclose(L @ D @ L.T, Afull[np.ix_(p, p)], atol=1e-12)
+    P = np.eye(n)[p]                                           # (P x)_i = x_{p_i}
+    ops = {0: Afull, 1: L @ D @ L.T, 2: L @ D, 3: D @ L.T, 4: L, 5: L.T, 6: D, 7: P.T, 8: P}
+    for sys, Mop in ops.items():
+        assert rel(got[sys], np.linalg.solve(Mop, B)) < 1e-11, sys
+        assert rel(gsp[sys], np.linalg.solve(Mop, Bs.todense())) < 1e-11, sys

@@ -64,7 +64,12 @@ def test_user_perm_natural_and_options():
     with pytest.raises(ValueError):
         Factor(n, cp, ri, uplo="X")
     with pytest.raises(ValueError):
-        Factor(n, cp, ri, opts={"supernodal": 0})
+        Factor(n, cp, ri, opts={"supernodal": 3})
+    # options['supernodal']: 2 -> LL', 0 -> LDL', 1 -> CHOLMOD's flops / nnz(L) >= 40 rule (spsolvers.rst:731-736)
+    assert Factor(n, cp, ri).info()["is_ll"] == 1
+    assert Factor(n, cp, ri, opts={"supernodal": 0}).info()["is_ll"] == 0
+    i1 = Factor(n, cp, ri, opts={"supernodal": 1}).info()
+    assert i1["is_ll"] == (1 if i1["flops"] / i1["lnz"] >= 40.0 else 0)
 
 
 def test_edge_cases_empty_diagonal_dense_disconnected():
