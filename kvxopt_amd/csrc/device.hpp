@@ -135,6 +135,30 @@ constexpr int KVX_TILE = 64;         // trailing-update tile
 constexpr int KVX_ASM_TC = 16;       // parent columns owned by one extend-add workgroup (big fronts)
 
 // ---- launchers (kernels.hip) ---------------------------------------------------------------
+
+// Right-hand sides are a grid dimension of the solve kernels.  Workgroups are dispatched in linear order (x fastest), so with the
+// natural (front, rhs) = (blockIdx.x, blockIdx.y) numbering the nrhs workgroups that read one front's panel run far apart and
+// every one of them fetches it from HBM again (n = 1e6, 64 right-hand sides: 1.1 TB/s of panel re-reads).  These helpers renumber
+// the same grid rhs-fastest: the workgroups of one front are dispatched back to back (round-robin over the XCDs), the panel is
+// fetched once per XCD and then hits in its L2.  With one right-hand side the numbering is the natural one.
+__device__ __forceinline__ void kvx_front_rhs(unsigned &fi, unsigned &rh)
+{
+    if (gridDim.y == 1) { fi = blockIdx.x; rh = 0; return; }
+    const unsigned long long L = blockIdx.x + (unsigned long long)gridDim.x * blockIdx.y;
+    fi = __builtin_amdgcn_readfirstlane((unsigned)(L / gridDim.y));
+    rh = __builtin_amdgcn_readfirstlane((unsigned)(L % gridDim.y));
+}
+// 3-D grids (x = part of a front, y = front, z = rhs): rhs fastest, then x, then y
+__device__ __forceinline__ void kvx_part_front_rhs(unsigned &bx, unsigned &by, unsigned &rh)
+{
+    if (gridDim.z == 1) { bx = blockIdx.x; by = blockIdx.y; rh = 0; return; }
+    const unsigned long long L = blockIdx.x + (unsigned long long)gridDim.x * (blockIdx.y + (unsigned long long)gridDim.y * blockIdx.z);
+    const unsigned long long rest = L / gridDim.z;
+    rh = __builtin_amdgcn_readfirstlane((unsigned)(L % gridDim.z));
+    bx = __builtin_amdgcn_readfirstlane((unsigned)(rest % gridDim.x));
+    by = __builtin_amdgcn_readfirstlane((unsigned)(rest / gridDim.x));
+}
+
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx);
 // LDS-front kernel (kernels_wave.hip): m <= mcap (96 or 128), k <= kmax (32 or 64)
 void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,

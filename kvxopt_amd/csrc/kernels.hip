@@ -142,13 +142,15 @@ __global__ __launch_bounds__(NT) void k_fwd_level(DevSym ds, const int32_t *__re
                                                   int64_t ldx, const double *__restrict__ Wc,
                                                   double *__restrict__ Wo, int64_t wstride, int wcap)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     extern __shared__ double sm[];
     double *w = sm, *D = sm + wcap;
-    const int s = list[blockIdx.x];
+    const int s = list[fi];
     const int k = ds.k[s], m = ds.m[s], u = m - k, f = ds.first[s], tid = threadIdx.x;
-    double *x = X + (int64_t)blockIdx.y * ldx;
-    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
-    double *wo = Wo + (int64_t)blockIdx.y * wstride;
+    double *x = X + (int64_t)rh * ldx;
+    const double *wc = Wc + (int64_t)rh * wstride;
+    double *wo = Wo + (int64_t)rh * wstride;
     const double *P = Lx + ds.px[s];
     for (int i = tid; i < m; i += NT) w[i] = (i < k) ? x[f + i] : 0.0;
     __syncthreads();
@@ -199,11 +201,13 @@ __global__ __launch_bounds__(NT) void k_bwd_level(DevSym ds, const int32_t *__re
                                                   const double *__restrict__ Lx, double *__restrict__ X,
                                                   int64_t ldx, int wcap)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     extern __shared__ double sm[];
     double *xf = sm, *D = sm + wcap;
-    const int s = list[blockIdx.x];
+    const int s = list[fi];
     const int k = ds.k[s], m = ds.m[s], f = ds.first[s], tid = threadIdx.x;
-    double *x = X + (int64_t)blockIdx.y * ldx;
+    double *x = X + (int64_t)rh * ldx;
     const double *P = Lx + ds.px[s];
     const int32_t *rows = ds.rowidx + ds.rowptr[s];
     for (int i = tid; i < m; i += NT) xf[i] = (i < k) ? x[f + i] : x[rows[i]];

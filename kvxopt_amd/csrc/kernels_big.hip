@@ -644,23 +644,25 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
                                                            const double *__restrict__ Wc,
                                                            double *__restrict__ Wo, int64_t wstride)
 {
+    unsigned bx, by, rh;
+    kvx_part_front_rhs(bx, by, rh);
     __shared__ double red[3 * 16 * NB];
     __shared__ double own[FIRST ? 256 : 1];
     __shared__ double wsh[SB];
     __shared__ double ysh[SB];
-    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const FrontDesc fd = ds.fd[list[by]];
     const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
     if (jb0 >= k) return;
     const int nb = min(SB, k - jb0);
-    const int rbase = jb0 + nb + blockIdx.x * 256;
-    if (blockIdx.x > 0 && rbase >= m) return;
+    const int rbase = jb0 + nb + bx * 256;
+    if (bx > 0 && rbase >= m) return;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *P = Lx + fd.px;
     const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
-    double *x = X + (int64_t)blockIdx.z * ldx + f;
-    double *wk = WK + (int64_t)blockIdx.z * ldw + f;
-    double *wo = Wo + (int64_t)blockIdx.z * wstride + fd.wx;
+    double *x = X + (int64_t)rh * ldx + f;
+    double *wk = WK + (int64_t)rh * ldw + f;
+    double *wo = Wo + (int64_t)rh * wstride + fd.wx;
     const int nsub = (nb + NB - 1) / NB;
 
     double yI[4][4], lB[6][4];
@@ -680,14 +682,14 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
                 lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
                                              ib * NB + lane < nb);
     if (tid < SB) {
-        const double *x0 = X0 + (int64_t)blockIdx.z * ldx + f;     // rhs as it was before the sweep (x gets y meanwhile)
+        const double *x0 = X0 + (int64_t)rh * ldx + f;     // rhs as it was before the sweep (x gets y meanwhile)
         wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
         ysh[tid] = 0.0;
         if (FIRST) own[tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
     }
     __syncthreads();
     if (FIRST && fd.nchild > 0) {
-        const double *wc = Wc + (int64_t)blockIdx.z * wstride;
+        const double *wc = Wc + (int64_t)rh * wstride;
         ChildDesc cd = ds.cd[fd.childptr];
         for (int c = 0; c < fd.nchild; c++) {
             ChildDesc nx = cd;
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
             }
         }
     }
-    if (blockIdx.x == 0 && tid < nb) x[jb0 + tid] = ysh[tid];
+    if (bx == 0 && tid < nb) x[jb0 + tid] = ysh[tid];
     // rows below the super-block: thread = (row, quarter of the nb columns), partial sums meet in LDS
     const int rr = tid & 255;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
@@ -780,12 +782,14 @@ __global__ __launch_bounds__(256) void k_bwd_big_init(DevSym ds, const int32_t *
                                                       const double *__restrict__ Lx, const double *__restrict__ X,
                                                       int64_t ldx, double *__restrict__ WK, int64_t ldw)
 {
-    const int s = list[blockIdx.y];
+    unsigned bx, by, rh;
+    kvx_part_front_rhs(bx, by, rh);
+    const int s = list[by];
     const int k = ds.k[s], m = ds.m[s], f = ds.first[s];
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+    const int c = bx * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
     if (c >= k) return;
-    const double *x = X + (int64_t)blockIdx.z * ldx;
-    double *wk = WK + (int64_t)blockIdx.z * ldw + f;
+    const double *x = X + (int64_t)rh * ldx;
+    double *wk = WK + (int64_t)rh * ldw + f;
     const double *Pc = Lx + ds.px[s] + (int64_t)c * m;
     const int32_t *rows = ds.rowidx + ds.rowptr[s];
     double acc = 0.0;
@@ -823,21 +827,23 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
                                                            double *__restrict__ X, int64_t ldx,
                                                            double *__restrict__ WK, int64_t ldw)
 {
+    unsigned bx, by, rh;
+    kvx_part_front_rhs(bx, by, rh);
     __shared__ double tsh[SB];
     __shared__ double xsh[SB];
-    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const FrontDesc fd = ds.fd[list[by]];
     const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
     const int jb0 = sidx * SB;
     if (jb0 >= k) return;
     const int nb = min(SB, k - jb0);
-    if (blockIdx.x > 0 && (int)blockIdx.x * NB >= jb0) return;
+    if (bx > 0 && (int)bx * NB >= jb0) return;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int o = 2 * (lane & 1) + ((lane >> 1) & 1);        // the output wave_sum4 leaves in this lane
     const double *P = Lx + fd.px;
     const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
-    double *x = X + (int64_t)blockIdx.z * ldx + f;
-    double *wk = WK + (int64_t)blockIdx.z * ldw + f;
+    double *x = X + (int64_t)rh * ldx + f;
+    double *wk = WK + (int64_t)rh * ldw + f;
     const int nsub = (nb + NB - 1) / NB;
 
     double yI[4][4], lB[6][4];
@@ -880,9 +886,9 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
             }
         }
     }
-    if (blockIdx.x == 0 && tid < nb) x[jb0 + tid] = xsh[tid];
+    if (bx == 0 && tid < nb) x[jb0 + tid] = xsh[tid];
     // earlier pivot columns c0 + 4w .. +3 of the front, rows jb0 + lane + 64 j
-    const int c0 = blockIdx.x * NB + 4 * w;
+    const int c0 = bx * NB + 4 * w;
     if (c0 < jb0) {
         double a[4] = {0.0, 0.0, 0.0, 0.0};
         double v[4][4];

@@ -234,13 +234,15 @@ __global__ __launch_bounds__(64) void k_fwd_wave(DevSym ds, const int32_t *__res
                                                  const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx,
                                                  const double *__restrict__ Wc, double *__restrict__ Wo, int64_t wstride)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     __shared__ double wsh[64];
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, r = threadIdx.x;
     const double *P = Lx + fd.px;
-    double *x = X + (int64_t)blockIdx.y * ldx + fd.first;
-    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
-    double *wo = Wo + (int64_t)blockIdx.y * wstride + fd.wx;
+    double *x = X + (int64_t)rh * ldx + fd.first;
+    const double *wc = Wc + (int64_t)rh * wstride;
+    double *wo = Wo + (int64_t)rh * wstride + fd.wx;
     double a[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
@@ -277,10 +279,12 @@ template <int KMAX, int MMAX>
 __global__ __launch_bounds__(64) void k_bwd_wave(DevSym ds, const int32_t *__restrict__ list,
                                                  const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
 {
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
+    const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, ln = threadIdx.x;
     const double *P = Lx + fd.px;
-    double *xg = X + (int64_t)blockIdx.y * ldx;
+    double *xg = X + (int64_t)rh * ldx;
     const int32_t *rows = ds.rowidx + fd.rowptr;
     // lane ln < k holds column ln: a[r] = L[r][ln]; lane ln also carries x of row ln (rows < m)
     const int col = ln < k ? ln : 0;
@@ -319,15 +323,17 @@ __global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__res
                                                  const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx,
                                                  const double *__restrict__ Wc, double *__restrict__ Wo, int64_t wstride)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     __shared__ double wsh[128];
     __shared__ double ysh[64];
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, r = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(r >> 6);
     const double *P = Lx + fd.px;
-    double *x = X + (int64_t)blockIdx.y * ldx + fd.first;
-    const double *wc = Wc + (int64_t)blockIdx.y * wstride;
-    double *wo = Wo + (int64_t)blockIdx.y * wstride + fd.wx;
+    double *x = X + (int64_t)rh * ldx + fd.first;
+    const double *wc = Wc + (int64_t)rh * wstride;
+    double *wo = Wo + (int64_t)rh * wstride + fd.wx;
     double a[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
@@ -380,14 +386,16 @@ __global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__res
 __global__ __launch_bounds__(128) void k_bwd_lds(DevSym ds, const int32_t *__restrict__ list,
                                                  const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     __shared__ double xf[128];     // y (pivot rows) / solved ancestors (update rows)
     __shared__ double xu[128];     // the same with the pivot rows zeroed
     __shared__ double accsh[64];
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, tid = threadIdx.x, ln = tid & 63;
     const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *P = Lx + fd.px;
-    double *xg = X + (int64_t)blockIdx.y * ldx;
+    double *xg = X + (int64_t)rh * ldx;
     const int32_t *rows = ds.rowidx + fd.rowptr;
     const int col = ln < k ? ln : 0;
     double a[64];
@@ -460,13 +468,15 @@ __global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__
                                                     double *__restrict__ W0, double *__restrict__ W1, int64_t wstride,
                                                     const int32_t *__restrict__ depth)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     constexpr int NC = 4;                          // children handled per batch
     __shared__ double xs[KVX_SUB_MAXCOLS];
     __shared__ double stk[KVX_SUB_STACK];
     __shared__ double wsh[64];
-    const SubDesc sd = subs[blockIdx.x];
+    const SubDesc sd = subs[fi];
     const int r = threadIdx.x;
-    double *x = X + (int64_t)blockIdx.y * ldx + sd.col0;
+    double *x = X + (int64_t)rh * ldx + sd.col0;
     FrontDesc nxt = ds.fd[sd.lo];
     for (int i = r; i < sd.ncols; i += 64) xs[i] = x[i];
     __syncthreads();
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__
         if (r < k) xs[xo + r] = w;
         else if (r < m) {
             if (s == sd.hi) {
-                double *wo = ((depth[s] & 1) ? W1 : W0) + (int64_t)blockIdx.y * wstride + fd.wx;
+                double *wo = ((depth[s] & 1) ? W1 : W0) + (int64_t)rh * wstride + fd.wx;
                 wo[r - k] = w;
             } else {
                 stk[sp + r - k] = w;
@@ -545,10 +555,12 @@ template <int MMAX>
 __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__restrict__ subs,
                                                     const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx)
 {
+    unsigned fi, rh;
+    kvx_front_rhs(fi, rh);
     __shared__ double xs[KVX_SUB_MAXCOLS];
-    const SubDesc sd = subs[blockIdx.x];
+    const SubDesc sd = subs[fi];
     const int ln = threadIdx.x;
-    double *xg = X + (int64_t)blockIdx.y * ldx;
+    double *xg = X + (int64_t)rh * ldx;
     FrontDesc nxt = ds.fd[sd.hi];
     int nrow = (ln < nxt.m && ln >= nxt.k) ? ds.rowidx[nxt.rowptr + ln] : sd.col0;   // global index of update row ln
     for (int i = ln; i < sd.ncols; i += 64) xs[i] = xg[sd.col0 + i];
