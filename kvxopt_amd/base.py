@@ -331,12 +331,12 @@ def gemv(A, x, y, trans="N", alpha=1.0, beta=0.0, m=None, n=None, offsetx=0, off
     xb, _ = _dense_buffer(x)
     yb, _ = _dense_buffer(y)
     if isinstance(A, matrix) or isinstance(A, np.ndarray):
-        Ad = A.a if isinstance(A, matrix) else A
-        lx = Ad.shape[1] if trans == "N" else Ad.shape[0]
-        ly = Ad.shape[0] if trans == "N" else Ad.shape[1]
-        op = Ad if trans == "N" else Ad.T
-        yb[offsety:offsety + ly] = alpha * (op @ xb[offsetx:offsetx + lx]) + beta * yb[offsety:offsety + ly]
-        return
+        # dense operand: every entry stored, same device kernel (no host arithmetic on the product path)
+        Ad = np.asarray(A.a if isinstance(A, matrix) else A, dtype=np.float64)
+        Ad = Ad.reshape(Ad.shape[0], -1)
+        dm, dn = Ad.shape
+        A = spmatrix.from_ccs(dm, dn, np.arange(dn + 1, dtype=np.int64) * dm, np.tile(np.arange(dm, dtype=np.int64), dn),
+                              np.ascontiguousarray(Ad.T).reshape(-1))
     am, an, cp, ri, v = _as_ccs(A)
     lx, ly = (an, am) if trans == "N" else (am, an)
     if ly == 0:

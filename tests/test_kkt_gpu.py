@@ -564,3 +564,22 @@ def test_cholmod_ldl_factor_semantics(mode):
     for sys, Mop in ops.items():
         assert rel(got[sys], np.linalg.solve(Mop, B)) < 1e-11, sys
         assert rel(gsp[sys], np.linalg.solve(Mop, Bs.todense())) < 1e-11, sys
+
+
+def test_base_gemv_sparse_and_dense_with_offsets():
+    """base.gemv (base.c:744 -> sparse.c:1073-1104): y := alpha op(A) x + beta y with offsetx / offsety, sparse A and a dense
+    A (taken as a matrix with every entry stored -- the same device kernel, no host arithmetic)."""
+    rng = np.random.default_rng(21)
+    m, n = 13, 7
+    Ad = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.4)
+    I, J = np.nonzero(Ad)
+    As = spmatrix(Ad[I, J], I, J, (m, n))
+    for A in (As, matrix(Ad)):
+        for trans, lx, ly in (("N", n, m), ("T", m, n)):
+            x = rng.standard_normal(lx + 3); y = rng.standard_normal(ly + 2)
+            yx = matrix(y.copy())
+            base.gemv(A, matrix(x), yx, trans=trans, alpha=-1.5, beta=0.5, offsetx=3, offsety=2)
+            op = Ad if trans == "N" else Ad.T
+            ref = y.copy(); ref[2:] = -1.5 * (op @ x[3:]) + 0.5 * y[2:]
+            assert rel(yx._a, ref) < 1e-14
+
