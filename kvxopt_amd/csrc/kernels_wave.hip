@@ -614,11 +614,205 @@ __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__
     for (int i = ln; i < sd.ncols; i += 64) xg[sd.col0 + i] = xs[i];
 }
 
+// ------------------------------------------------------------------------------------------
+// Subtree walks for a BLOCK of RB right-hand sides per wavefront (used from 4 right-hand sides on).  The walk of
+// k_fwd_subtree / k_bwd_subtree pays, per front, a descriptor, the panel (a column per lane in the backward sweep: uncoalesced)
+// and the relative indices, then one dependent chain of readlane steps; with one right-hand side per wave all of that is paid
+// nrhs times and the chain has no instruction-level parallelism.  Here the panel registers are loaded once per front and the RB
+// substitution chains are independent instruction streams that the compiler interleaves.  Right-hand sides past nrhs (a ragged
+// last block) are computed on a duplicate of the last valid one and not stored.
+template <int KMAX, int RB>
+__global__ __launch_bounds__(64) void k_fwd_subtree_mr(DevSym ds, const SubDesc *__restrict__ subs,
+                                                       const int32_t *__restrict__ edges, const double *__restrict__ Lx,
+                                                       double *__restrict__ X, int64_t ldx, int nrhs,
+                                                       double *__restrict__ W0, double *__restrict__ W1, int64_t wstride,
+                                                       const int32_t *__restrict__ depth)
+{
+    __shared__ double xs[RB][KVX_SUB_MAXCOLS];
+    __shared__ double stk[RB][KVX_SUB_STACK];
+    __shared__ double wsh[RB][64];
+    unsigned fi, rg;
+    kvx_front_rhs(fi, rg);
+    const SubDesc sd = subs[fi];
+    const int r = threadIdx.x;
+    const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
+    int64_t xoff[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) xoff[b] = (int64_t)(r0 + min(b, nv - 1)) * ldx + sd.col0;
+    FrontDesc nxt = ds.fd[sd.lo];
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+        for (int i = r; i < sd.ncols; i += 64) xs[b][i] = X[xoff[b] + i];
+    __syncthreads();
+    int sp = 0;
+    for (int s = sd.lo; s <= sd.hi; s++) {
+        const FrontDesc fd = nxt;
+        if (s < sd.hi) nxt = ds.fd[s + 1];
+        const int k = fd.k, m = fd.m, xo = fd.first - sd.col0;
+        const double *P = Lx + fd.px;
+        double a[KMAX];
+#pragma unroll
+        for (int j0 = 0; j0 < KMAX; j0 += 8) {
+            if (j0 < k) {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+            } else {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; j++) a[j] = 0.0;
+            }
+        }
+        const double dg = kvx_ld0(P, r + (int64_t)r * m, r < k);
+        double w[RB];
+#pragma unroll
+        for (int b = 0; b < RB; b++) w[b] = r < k ? xs[b][xo + r] : 0.0;
+        if (fd.nchild > 0) {
+#pragma unroll
+            for (int b = 0; b < RB; b++) wsh[b][r] = w[b];
+            for (int c = 0; c < fd.nchild; c++) {
+                const int32_t *e = edges + 3 * (fd.childptr + c);
+                const int uc = e[0], rp = e[1], wo = e[2];
+                const bool ok = r < uc;
+                const int t = ds.rel[rp + (ok ? r : 0)];
+                __syncthreads();                   // (one wave: orders the LDS read-modify-writes of successive children)
+#pragma unroll
+                for (int b = 0; b < RB; b++)
+                    if (ok) wsh[b][t] += stk[b][wo + r];
+                sp -= uc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < RB; b++) w[b] = wsh[b][r];
+        }
+        const double rinv = 1.0 / (r < k ? dg : 1.0);
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            if (j < k) {                           // wave-uniform
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    const double yj = kvx_readlane(w[b] * rinv, j);
+                    w[b] = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w[b]) : w[b]);
+                }
+            }
+        }
+        if (r < k) {
+#pragma unroll
+            for (int b = 0; b < RB; b++) xs[b][xo + r] = w[b];
+        } else if (r < m) {
+            if (s == sd.hi) {
+                double *wo = ((depth[s] & 1) ? W1 : W0) + fd.wx + (r - k);
+#pragma unroll
+                for (int b = 0; b < RB; b++)
+                    if (b < nv) wo[(int64_t)(r0 + b) * wstride] = w[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < RB; b++) stk[b][sp + r - k] = w[b];
+            }
+        }
+        sp += m - k;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+        if (b < nv)
+            for (int i = r; i < sd.ncols; i += 64) X[xoff[b] + i] = xs[b][i];
+}
+
+template <int MMAX, int RB>
+__global__ __launch_bounds__(64) void k_bwd_subtree_mr(DevSym ds, const SubDesc *__restrict__ subs,
+                                                       const double *__restrict__ Lx, double *__restrict__ X, int64_t ldx, int nrhs)
+{
+    __shared__ double xs[RB][KVX_SUB_MAXCOLS];
+    unsigned fi, rg;
+    kvx_front_rhs(fi, rg);
+    const SubDesc sd = subs[fi];
+    const int ln = threadIdx.x;
+    const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
+    int64_t xoff[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) xoff[b] = (int64_t)(r0 + min(b, nv - 1)) * ldx;
+    FrontDesc nxt = ds.fd[sd.hi];
+    int nrow = (ln < nxt.m && ln >= nxt.k) ? ds.rowidx[nxt.rowptr + ln] : sd.col0;
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+        for (int i = ln; i < sd.ncols; i += 64) xs[b][i] = X[xoff[b] + sd.col0 + i];
+    __syncthreads();
+    for (int s = sd.hi; s >= sd.lo; s--) {
+        const FrontDesc fd = nxt;
+        const int myrow = nrow;
+        if (s > sd.lo) nxt = ds.fd[s - 1];
+        const int k = fd.k, m = fd.m;
+        const double *P = Lx + fd.px;
+        const int col = ln < k ? ln : 0;
+        double a[MMAX];
+#pragma unroll
+        for (int q0 = 0; q0 < MMAX; q0 += 16) {
+            if (q0 < m) {                          // wave-uniform
+#pragma unroll
+                for (int rr = q0; rr < q0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+            } else {
+#pragma unroll
+                for (int rr = q0; rr < q0 + 16; rr++) a[rr] = 0.0;
+            }
+        }
+        const double dg = kvx_ld0(P, ln + (int64_t)ln * m, ln < k);
+        const int grow = (ln < m) ? (ln < k ? fd.first + ln : myrow) : sd.col0;
+        const int loc = grow - sd.col0;
+        const bool inl = loc >= 0 && loc < sd.ncols;
+        double xv[RB], acc[RB];
+#pragma unroll
+        for (int b = 0; b < RB; b++) xv[b] = kvx_ld0(X + xoff[b], grow, ln < m && !inl);
+        if (s > sd.lo) nrow = (ln < nxt.m && ln >= nxt.k) ? ds.rowidx[nxt.rowptr + ln] : sd.col0;
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            xv[b] = inl ? xs[b][loc] : xv[b];
+            if (ln >= m) xv[b] = 0.0;
+            acc[b] = 0.0;
+        }
+        const double rinv = 1.0 / (ln < k ? dg : 1.0);
+#pragma unroll
+        for (int rr = MMAX - 1; rr >= 0; rr--) {
+            if (rr < m) {                          // wave-uniform
+#pragma unroll
+                for (int b = 0; b < RB; b++) {
+                    double xr;
+                    if (rr < k) {
+                        xr = kvx_readlane((xv[b] - acc[b]) * rinv, rr);
+                        if (ln == rr) xv[b] = xr;
+                    } else {
+                        xr = kvx_readlane(xv[b], rr);
+                    }
+                    acc[b] = (ln < rr) ? __builtin_fma(a[rr], xr, acc[b]) : acc[b];
+                }
+            }
+        }
+        if (ln < k) {
+#pragma unroll
+            for (int b = 0; b < RB; b++) xs[b][fd.first - sd.col0 + ln] = xv[b];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < RB; b++)
+        if (b < nv)
+            for (int i = ln; i < sd.ncols; i += 64) X[xoff[b] + sd.col0 + i] = xs[b][i];
+}
+
+constexpr int KVX_SUB_RB = 4;      // right-hand sides per wavefront in the blocked subtree walks
+// Measured (MI355X, scratch/multirhs.py): the blocked walks win from ~16 right-hand sides on (n = 1e6: 64 rhs 25.4 -> 21.7 ms,
+// 16 rhs 7.8 -> 6.9 ms; n = 50 000: 200 rhs 3.55 -> 3.04 ms) and lose below that on small systems, where the solve is bound by
+// the length of one wave's dependent chain (n = 50 000, 4 rhs: 0.56 -> 0.64 ms).
+constexpr int KVX_SUB_MR_FROM = 16;
+
 void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *edges,
                         const double *Lx, double *X, int64_t ldx, int nrhs, double *W0, double *W1, int64_t wstride,
                         const int32_t *depth)
 {
     if (nsub <= 0 || nrhs <= 0) return;
+    if (nrhs >= KVX_SUB_MR_FROM) {
+        hipLaunchKernelGGL((k_fwd_subtree_mr<32, KVX_SUB_RB>), dim3((unsigned)nsub, (unsigned)((nrhs + KVX_SUB_RB - 1) / KVX_SUB_RB)), dim3(64), 0, st,
+                           ds, subs, edges, Lx, X, ldx, nrhs, W0, W1, wstride, depth);
+        return;
+    }
     hipLaunchKernelGGL(k_fwd_subtree<32>, dim3((unsigned)nsub, (unsigned)nrhs), dim3(64), 0, st, ds, subs, edges, Lx, X, ldx,
                        W0, W1, wstride, depth);
 }
@@ -628,6 +822,14 @@ void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, i
                         int64_t ldx, int nrhs)
 {
     if (nsub <= 0 || nrhs <= 0) return;
+    if (nrhs >= KVX_SUB_MR_FROM) {
+        const unsigned gy = (unsigned)((nrhs + KVX_SUB_RB - 1) / KVX_SUB_RB);
+        if (nsub32 > 0)
+            hipLaunchKernelGGL((k_bwd_subtree_mr<32, KVX_SUB_RB>), dim3((unsigned)nsub32, gy), dim3(64), 0, st, ds, subs, Lx, X, ldx, nrhs);
+        if (nsub > nsub32)
+            hipLaunchKernelGGL((k_bwd_subtree_mr<64, KVX_SUB_RB>), dim3((unsigned)(nsub - nsub32), gy), dim3(64), 0, st, ds, subs + nsub32, Lx, X, ldx, nrhs);
+        return;
+    }
     if (nsub32 > 0)
         hipLaunchKernelGGL(k_bwd_subtree<32>, dim3((unsigned)nsub32, (unsigned)nrhs), dim3(64), 0, st, ds, subs, Lx, X, ldx);
     if (nsub > nsub32)

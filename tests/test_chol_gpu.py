@@ -393,3 +393,26 @@ def test_covariance_selection_example_drives_the_mirror():
     Kd = np.zeros((n, n)); Kd[I, J] = K.values; Kd = Kd + np.tril(Kd, -1).T
     assert np.abs(np.linalg.inv(Kd)[I, J] - Yv).max() < 1e-7       # optimality: inv(K) = Y on the pattern
     assert np.abs(Kd - K0.toarray()).max() < 1e-5                  # and here the maximiser is the true precision matrix
+
+
+@pytest.mark.parametrize("nrhs", [16, 18, 37])
+def test_many_right_hand_sides_blocked_subtree_walks(nrhs):
+    """From 16 right-hand sides on the leaf-subtree walks take blocks of four right-hand sides per wavefront
+    (k_fwd_subtree_mr / k_bwd_subtree_mr); 18 and 37 leave a ragged last block.  Every column must equal the single-rhs
+    solve of the same column bit for bit (same operations in the same order), and match the oracle."""
+    n, cp, ri, v = workloads.laplacian_2d(61, 47)
+    F = Factor(n, cp, ri)
+    F.factorize(v)
+    O = OracleChol(n, cp, ri, "L", F.perm())
+    O.factorize(v)
+    B = np.random.default_rng(nrhs).standard_normal((n, nrhs))
+    for sys in (0, 4, 5):
+        X = np.asfortranarray(B.copy())
+        F.solve(X, sys=sys)
+        Xo = np.asfortranarray(B.copy())
+        O.solve(Xo, sys=sys)
+        assert np.abs(X - Xo).max() / np.abs(Xo).max() < 1e-11
+        for j in (0, nrhs // 2, nrhs - 1):
+            xj = B[:, j].copy()
+            F.solve(xj, sys=sys)
+            assert np.array_equal(xj, X[:, j]), (sys, j)
