@@ -906,11 +906,322 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same three kernels for a BLOCK of RB right-hand sides per workgroup (used from KVX_BIG_MR_FROM right-hand sides on).  With the
+// right-hand sides spread over the grid every workgroup fetches the diagonal inverses, the sub-diagonal blocks, the panel rows
+// and the children's relative indices again; here they are fetched once per block and the right-hand sides of the block follow
+// each other through the dependent part.  Same operations in the same order per right-hand side: every column is bit-identical
+// to its single-rhs solve.  Right-hand sides past nrhs (ragged last block) are skipped.
+template <bool FIRST, int RB>
+__global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const int32_t *__restrict__ list, int jb0,
+                                                              const double *__restrict__ Lx, const double *__restrict__ Linv,
+                                                              double *__restrict__ X, const double *__restrict__ X0, int64_t ldx, int nrhs,
+                                                              double *__restrict__ WK, int64_t ldw,
+                                                              const double *__restrict__ Wc,
+                                                              double *__restrict__ Wo, int64_t wstride)
+{
+    unsigned bx, by, rg;
+    kvx_part_front_rhs(bx, by, rg);
+    __shared__ double red[3 * 16 * NB];
+    __shared__ double own[FIRST ? RB : 1][FIRST ? 256 : 1];
+    __shared__ double wsh[SB];
+    __shared__ double ysh[RB][SB];
+    const FrontDesc fd = ds.fd[list[by]];
+    const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
+    if (jb0 >= k) return;
+    const int nb = min(SB, k - jb0);
+    const int rbase = jb0 + nb + bx * 256;
+    if (bx > 0 && rbase >= m) return;
+    const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double *P = Lx + fd.px;
+    const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
+    const int nsub = (nb + NB - 1) / NB;
+
+    double yI[4][4], lB[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int p = 4 * w + c;
+            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + p * NB, s * NB + lane < nb && p <= lane);
+        }
+#pragma unroll
+    for (int ib = 1; ib < 4; ib++)
+#pragma unroll
+        for (int s = 0; s < ib; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                             ib * NB + lane < nb);
+    for (int b = 0; b < nv; b++) {                 // workgroup-uniform
+        const int rh = r0 + b;
+        double *x = X + (int64_t)rh * ldx + f;
+        double *wk = WK + (int64_t)rh * ldw + f;
+        __syncthreads();                           // wsh / red of the previous right-hand side are free
+        if (tid < SB) {
+            const double *x0 = X0 + (int64_t)rh * ldx + f;
+            wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
+            ysh[b][tid] = 0.0;
+            if (FIRST) own[b][tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
+        }
+        __syncthreads();
+        if (FIRST && fd.nchild > 0) {
+            const double *wc = Wc + (int64_t)rh * wstride;
+            ChildDesc cd = ds.cd[fd.childptr];
+            for (int c = 0; c < fd.nchild; c++) {
+                ChildDesc nx = cd;
+                if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
+                const int32_t *rl = ds.rel + cd.rel;
+                const double *src = wc + cd.wx;
+                for (int i = tid; i < cd.uc; i += SOLVE_NT) {
+                    const int t = rl[i];
+                    const double v = src[i];
+                    if (t < nb) wsh[t] += v;
+                    else if (t >= rbase && t < rbase + 256) own[b][t - rbase] += v;
+                }
+                __syncthreads();
+                cd = nx;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s < nsub) {
+                double part = 0.0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) part = __builtin_fma(yI[s][c], wsh[s * NB + 4 * w + c], part);
+                red[w * NB + lane] = part;
+                __syncthreads();
+                if (tid < NB) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) t += red[q * NB + tid];
+                    ysh[b][s * NB + tid] = t;
+                }
+                __syncthreads();
+                if (s + 1 < nsub) {
+#pragma unroll
+                    for (int ib = s + 1; ib < 4; ib++) {
+                        double pp = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) pp = __builtin_fma(lB[sblk(ib, s)][c], ysh[b][s * NB + 4 * w + c], pp);
+                        red[((ib - s - 1) * 16 + w) * NB + lane] = pp;
+                    }
+                    __syncthreads();
+                    if (tid < (3 - s) * NB) {
+                        const int ib0 = tid >> 6;
+                        double t = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) t += red[(ib0 * 16 + q) * NB + lane];
+                        wsh[(s + 1) * NB + tid] -= t;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (bx == 0 && tid < nb) x[jb0 + tid] = ysh[b][tid];
+    }
+    __syncthreads();
+    // rows below the super-block: the panel entries are loaded once and used for every right-hand side of the block
+    const int rr = tid & 255;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int r = rbase + rr;
+    double acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) acc[b] = 0.0;
+    const int cq = ((nb + 63) >> 6) << 4;
+    if (q * cq < nb && rbase < m) {
+        const bool okr = r < m;
+        const double *Pr = P + (okr ? r : 0) + (int64_t)(jb0 + q * cq) * m;
+        const int nc = min(cq, nb - q * cq);
+#pragma unroll 1
+        for (int j0 = 0; j0 < nc; j0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = kvx_ld0(Pr, (int64_t)(j0 + j) * m, okr && j0 + j < nc);
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const double *yq = ysh[b] + q * cq;
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[b] = __builtin_fma(v[j], yq[j0 + j], acc[b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RB; b++) {
+        if (b < nv) {                              // workgroup-uniform
+            __syncthreads();
+            red[q * 256 + rr] = acc[b];
+            __syncthreads();
+            if (tid < 256 && r < m) {
+                const int rh = r0 + b;
+                double *wk = WK + (int64_t)rh * ldw + f;
+                double *wo = Wo + (int64_t)rh * wstride + fd.wx;
+                const double t = (red[rr] + red[256 + rr]) + (red[512 + rr] + red[768 + rr]);
+                if (FIRST) {
+                    if (r < k) wk[r] = own[b][rr] - t;
+                    else wo[r - k] = own[b][rr] - t;
+                } else {
+                    if (r < k) wk[r] -= t;
+                    else wo[r - k] -= t;
+                }
+            }
+        }
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(256) void k_bwd_big_init_mr(DevSym ds, const int32_t *__restrict__ list,
+                                                         const double *__restrict__ Lx, const double *__restrict__ X,
+                                                         int64_t ldx, int nrhs, double *__restrict__ WK, int64_t ldw)
+{
+    unsigned bx, by, rg;
+    kvx_part_front_rhs(bx, by, rg);
+    const int s = list[by];
+    const int k = ds.k[s], m = ds.m[s], f = ds.first[s];
+    const int c = bx * 4 + (threadIdx.x >> 6), ln = threadIdx.x & 63;
+    if (c >= k) return;
+    const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
+    const double *Pc = Lx + ds.px[s] + (int64_t)c * m;
+    const int32_t *rows = ds.rowidx + ds.rowptr[s];
+    const double *xb[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) xb[b] = X + (int64_t)(r0 + min(b, nv - 1)) * ldx;
+    double acc[RB];
+#pragma unroll
+    for (int b = 0; b < RB; b++) acc[b] = 0.0;
+    for (int i = k + ln; i < m; i += 64) {
+        const double pv = Pc[i];
+        const int ri = rows[i];
+#pragma unroll
+        for (int b = 0; b < RB; b++) acc[b] += pv * xb[b][ri];
+    }
+#pragma unroll
+    for (int b = 0; b < RB; b++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[b] += __shfl_xor(acc[b], o);
+        if (ln == 0 && b < nv) WK[(int64_t)(r0 + b) * ldw + f + c] = xb[b][f + c] - acc[b];
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step_mr(DevSym ds, const int32_t *__restrict__ list, int sidx,
+                                                              const double *__restrict__ Lx, const double *__restrict__ Linv,
+                                                              double *__restrict__ X, int64_t ldx, int nrhs,
+                                                              double *__restrict__ WK, int64_t ldw)
+{
+    unsigned bx, by, rg;
+    kvx_part_front_rhs(bx, by, rg);
+    __shared__ double tsh[SB];
+    __shared__ double xsh[RB][SB];
+    const FrontDesc fd = ds.fd[list[by]];
+    const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
+    const int jb0 = sidx * SB;
+    if (jb0 >= k) return;
+    const int nb = min(SB, k - jb0);
+    if (bx > 0 && (int)bx * NB >= jb0) return;
+    const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int o = 2 * (lane & 1) + ((lane >> 1) & 1);
+    const double *P = Lx + fd.px;
+    const double *Y = Linv + fd.linv + (int64_t)(jb0 / NB) * NB * NB;
+    const int nsub = (nb + NB - 1) / NB;
+
+    double yI[4][4], lB[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int i = 4 * w + c;
+            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + i * NB, s * NB + lane < nb && i <= lane);
+        }
+#pragma unroll
+    for (int ib = 1; ib < 4; ib++)
+#pragma unroll
+        for (int s = 0; s < ib; s++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                             ib * NB + lane < nb);
+    for (int b = 0; b < nv; b++) {                 // workgroup-uniform
+        const int rh = r0 + b;
+        double *x = X + (int64_t)rh * ldx + f;
+        const double *wk = WK + (int64_t)rh * ldw + f;
+        __syncthreads();
+        if (tid < SB) {
+            tsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
+            xsh[b][tid] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 3; s >= 0; s--) {
+            if (s < nsub) {
+                const double tv = tsh[s * NB + lane];
+                const double r = wave_sum4(yI[s][0] * tv, yI[s][1] * tv, yI[s][2] * tv, yI[s][3] * tv, lane);
+                if (lane < 4) xsh[b][s * NB + 4 * w + o] = r;
+                __syncthreads();
+                if (s > 0) {
+                    const double xv = xsh[b][s * NB + lane];
+#pragma unroll
+                    for (int c = 0; c < s; c++) {
+                        const double u = wave_sum4(lB[sblk(s, c)][0] * xv, lB[sblk(s, c)][1] * xv, lB[sblk(s, c)][2] * xv,
+                                                   lB[sblk(s, c)][3] * xv, lane);
+                        if (lane < 4) tsh[c * NB + 4 * w + o] -= u;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (bx == 0 && tid < nb) x[jb0 + tid] = xsh[b][tid];
+    }
+    __syncthreads();
+    const int c0 = bx * NB + 4 * w;
+    if (c0 < jb0) {
+        double v[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[c][j] = kvx_ld0(P, (int64_t)(jb0 + lane + j * NB) + (int64_t)(c0 + c) * m, lane + j * NB < nb && c0 + c < jb0);
+#pragma unroll
+        for (int b = 0; b < RB; b++) {
+            if (b < nv) {                          // workgroup-uniform
+                double a[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) a[c] = __builtin_fma(v[c][j], xsh[b][lane + j * NB], a[c]);
+                const double u = wave_sum4(a[0], a[1], a[2], a[3], lane);
+                if (lane < 4 && c0 + o < jb0) WK[(int64_t)(r0 + b) * ldw + f + c0 + o] -= u;
+            }
+        }
+    }
+}
+
+constexpr int KVX_BIG_RB = 8;          // right-hand sides per workgroup in the blocked big-front steps
+// Measured (MI355X, scratch/multirhs.py): the block makes one workgroup's dependent chain RB times longer, so it pays only once the
+// grid saturates the GPU anyway -- n = 1e6, 64 rhs: 21.7 -> 19.1 ms; n = 50 000, 200 rhs: 3.04 -> 2.90 ms; but 32 rhs at
+// n = 50 000: 0.90 -> 1.24 ms.  Hence the threshold.
+constexpr int KVX_BIG_MR_FROM = 64;    // used from this many right-hand sides on
+
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, const double *X0, int64_t ldx, int nrhs,
                     double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride)
 {
     if (count <= 0 || nrhs <= 0) return;
+    if (nrhs >= KVX_BIG_MR_FROM) {
+        for (int jb = 0; jb < max_k; jb += SB) {
+            int rows = max_m - jb - 1;
+            dim3 grid((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, (unsigned)((nrhs + KVX_BIG_RB - 1) / KVX_BIG_RB));
+            if (jb == 0)
+                hipLaunchKernelGGL((k_fwd_big_step_mr<true, KVX_BIG_RB>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+            else
+                hipLaunchKernelGGL((k_fwd_big_step_mr<false, KVX_BIG_RB>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+        }
+        return;
+    }
     for (int jb = 0; jb < max_k; jb += SB) {
         int rows = max_m - jb - 1;
         dim3 grid((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, (unsigned)nrhs);
@@ -926,6 +1237,17 @@ void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
 {
     if (count <= 0 || nrhs <= 0) return;
     (void)max_m;
+    if (nrhs >= KVX_BIG_MR_FROM) {
+        const unsigned gz = (unsigned)((nrhs + KVX_BIG_RB - 1) / KVX_BIG_RB);
+        hipLaunchKernelGGL((k_bwd_big_init_mr<KVX_BIG_RB>), dim3((unsigned)((max_k + 3) / 4), (unsigned)count, gz), dim3(256), 0, st,
+                           ds, list, Lx, X, ldx, nrhs, WK, ldw);
+        for (int b = (max_k + SB - 1) / SB - 1; b >= 0; b--) {
+            unsigned gx = (unsigned)std::max(1, b * SB / NB);
+            hipLaunchKernelGGL((k_bwd_big_step_mr<KVX_BIG_RB>), dim3(gx, (unsigned)count, gz), dim3(SOLVE_NT), 0, st, ds, list, b, Lx, Linv,
+                               X, ldx, nrhs, WK, ldw);
+        }
+        return;
+    }
     hipLaunchKernelGGL(k_bwd_big_init, dim3((unsigned)((max_k + 3) / 4), (unsigned)count, (unsigned)nrhs), dim3(256), 0, st,
                        ds, list, Lx, X, ldx, WK, ldw);
     for (int b = (max_k + SB - 1) / SB - 1; b >= 0; b--) {

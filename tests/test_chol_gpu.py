@@ -395,12 +395,14 @@ def test_covariance_selection_example_drives_the_mirror():
     assert np.abs(Kd - K0.toarray()).max() < 1e-5                  # and here the maximiser is the true precision matrix
 
 
-@pytest.mark.parametrize("nrhs", [16, 18, 37])
-def test_many_right_hand_sides_blocked_subtree_walks(nrhs):
+@pytest.mark.parametrize("g,h,nrhs", [(61, 47, 16), (61, 47, 18), (61, 47, 37), (300, 280, 18), (300, 280, 67)])
+def test_many_right_hand_sides_blocked_kernels(g, h, nrhs):
     """From 16 right-hand sides on the leaf-subtree walks take blocks of four right-hand sides per wavefront
-    (k_fwd_subtree_mr / k_bwd_subtree_mr); 18 and 37 leave a ragged last block.  Every column must equal the single-rhs
-    solve of the same column bit for bit (same operations in the same order), and match the oracle."""
-    n, cp, ri, v = workloads.laplacian_2d(61, 47)
+    (k_fwd_subtree_mr / k_bwd_subtree_mr) and, from 64 on, the big-front steps blocks of eight per workgroup (k_fwd_big_step_mr,
+    k_bwd_big_init_mr, k_bwd_big_step_mr; the 300 x 280 grid has fronts with more than 256 pivot columns: several super-steps);
+    18, 37 and 67 leave ragged last blocks.  Every column must equal the single-rhs solve of the same column bit for bit
+    (same operations in the same order), and match the oracle."""
+    n, cp, ri, v = workloads.laplacian_2d(g, h)
     F = Factor(n, cp, ri)
     F.factorize(v)
     O = OracleChol(n, cp, ri, "L", F.perm())
