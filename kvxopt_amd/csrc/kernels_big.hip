@@ -912,7 +912,10 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
 // and the children's relative indices again; here they are fetched once per block and the right-hand sides of the block follow
 // each other through the dependent part.  Same operations in the same order per right-hand side: every column is bit-identical
 // to its single-rhs solve.  Right-hand sides past nrhs (ragged last block) are skipped.
-template <bool FIRST, int RB>
+// MODE 1: the diagonal solve only (grid x = 1; writes y into X).  MODE 2: the rows below only (reads y back from X) -- with the GPU
+// saturated by right-hand sides, every row block repeating the diagonal solve (as the single-rhs kernel does to save a launch)
+// would be the bulk of the work.
+template <bool FIRST, int RB, int MODE>
 __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const int32_t *__restrict__ list, int jb0,
                                                               const double *__restrict__ Lx, const double *__restrict__ Linv,
                                                               double *__restrict__ X, const double *__restrict__ X0, int64_t ldx, int nrhs,
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
     if (jb0 >= k) return;
     const int nb = min(SB, k - jb0);
     const int rbase = jb0 + nb + bx * 256;
-    if (bx > 0 && rbase >= m) return;
+    if (MODE == 2 && rbase >= m) return;
     const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -940,21 +943,23 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
     const int nsub = (nb + NB - 1) / NB;
 
     double yI[4][4], lB[6][4];
+    if (MODE == 1) {
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+        for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int p = 4 * w + c;
-            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + p * NB, s * NB + lane < nb && p <= lane);
-        }
+            for (int c = 0; c < 4; c++) {
+                const int p = 4 * w + c;
+                yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + p * NB, s * NB + lane < nb && p <= lane);
+            }
 #pragma unroll
-    for (int ib = 1; ib < 4; ib++)
+        for (int ib = 1; ib < 4; ib++)
 #pragma unroll
-        for (int s = 0; s < ib; s++)
+            for (int s = 0; s < ib; s++)
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
-                                             ib * NB + lane < nb);
+                for (int c = 0; c < 4; c++)
+                    lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                                 ib * NB + lane < nb);
+    }
     for (int b = 0; b < nv; b++) {                 // workgroup-uniform
         const int rh = r0 + b;
         double *x = X + (int64_t)rh * ldx + f;
@@ -962,9 +967,13 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
         __syncthreads();                           // wsh / red of the previous right-hand side are free
         if (tid < SB) {
             const double *x0 = X0 + (int64_t)rh * ldx + f;
-            wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
-            ysh[b][tid] = 0.0;
-            if (FIRST) own[b][tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
+            if (MODE == 1) {
+                wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
+                ysh[b][tid] = 0.0;
+            } else {
+                ysh[b][tid] = kvx_ld0(x, jb0 + tid, tid < nb);      // y of this super-step, written by the MODE 1 launch
+                if (FIRST) own[b][tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
+            }
         }
         __syncthreads();
         if (FIRST && fd.nchild > 0) {
@@ -978,7 +987,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
                 for (int i = tid; i < cd.uc; i += SOLVE_NT) {
                     const int t = rl[i];
                     const double v = src[i];
-                    if (t < nb) wsh[t] += v;
+                    if (MODE == 1) { if (t < nb) wsh[t] += v; }
                     else if (t >= rbase && t < rbase + 256) own[b][t - rbase] += v;
                 }
                 __syncthreads();
@@ -987,7 +996,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            if (s < nsub) {
+            if (MODE == 1 && s < nsub) {
                 double part = 0.0;
 #pragma unroll
                 for (int c = 0; c < 4; c++) part = __builtin_fma(yI[s][c], wsh[s * NB + 4 * w + c], part);
@@ -1020,8 +1029,9 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step_mr(DevSym ds, const i
                 }
             }
         }
-        if (bx == 0 && tid < nb) x[jb0 + tid] = ysh[b][tid];
+        if (MODE == 1 && tid < nb) x[jb0 + tid] = ysh[b][tid];
     }
+    if (MODE == 1) return;
     __syncthreads();
     // rows below the super-block: the panel entries are loaded once and used for every right-hand side of the block
     const int rr = tid & 255;
@@ -1105,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_bwd_big_init_mr(DevSym ds, const int32_
     }
 }
 
-template <int RB>
+template <int RB, int MODE>      // MODE 1: diagonal solve (grid x = 1); MODE 2: the earlier pivot columns (reads x back from X)
 __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step_mr(DevSym ds, const int32_t *__restrict__ list, int sidx,
                                                               const double *__restrict__ Lx, const double *__restrict__ Linv,
                                                               double *__restrict__ X, int64_t ldx, int nrhs,
@@ -1120,7 +1130,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step_mr(DevSym ds, const i
     const int jb0 = sidx * SB;
     if (jb0 >= k) return;
     const int nb = min(SB, k - jb0);
-    if (bx > 0 && (int)bx * NB >= jb0) return;
+    if (MODE == 2 && (int)bx * NB >= jb0) return;
     const int r0 = (int)rg * RB, nv = min(RB, nrhs - r0);
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1130,34 +1140,40 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step_mr(DevSym ds, const i
     const int nsub = (nb + NB - 1) / NB;
 
     double yI[4][4], lB[6][4];
+    if (MODE == 1) {
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+        for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int i = 4 * w + c;
-            yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + i * NB, s * NB + lane < nb && i <= lane);
-        }
+            for (int c = 0; c < 4; c++) {
+                const int i = 4 * w + c;
+                yI[s][c] = kvx_ld0(Y, s * NB * NB + lane + i * NB, s * NB + lane < nb && i <= lane);
+            }
 #pragma unroll
-    for (int ib = 1; ib < 4; ib++)
+        for (int ib = 1; ib < 4; ib++)
 #pragma unroll
-        for (int s = 0; s < ib; s++)
+            for (int s = 0; s < ib; s++)
 #pragma unroll
-            for (int c = 0; c < 4; c++)
-                lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
-                                             ib * NB + lane < nb);
+                for (int c = 0; c < 4; c++)
+                    lB[sblk(ib, s)][c] = kvx_ld0(P, (int64_t)(jb0 + ib * NB + lane) + (int64_t)(jb0 + s * NB + 4 * w + c) * m,
+                                                 ib * NB + lane < nb);
+    }
     for (int b = 0; b < nv; b++) {                 // workgroup-uniform
         const int rh = r0 + b;
         double *x = X + (int64_t)rh * ldx + f;
         const double *wk = WK + (int64_t)rh * ldw + f;
         __syncthreads();
         if (tid < SB) {
-            tsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
-            xsh[b][tid] = 0.0;
+            if (MODE == 1) {
+                tsh[tid] = kvx_ld0(wk, jb0 + tid, tid < nb);
+                xsh[b][tid] = 0.0;
+            } else {
+                xsh[b][tid] = kvx_ld0(x, jb0 + tid, tid < nb);      // x of this super-step, written by the MODE 1 launch
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int s = 3; s >= 0; s--) {
-            if (s < nsub) {
+            if (MODE == 1 && s < nsub) {
                 const double tv = tsh[s * NB + lane];
                 const double r = wave_sum4(yI[s][0] * tv, yI[s][1] * tv, yI[s][2] * tv, yI[s][3] * tv, lane);
                 if (lane < 4) xsh[b][s * NB + 4 * w + o] = r;
@@ -1174,8 +1190,9 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step_mr(DevSym ds, const i
                 }
             }
         }
-        if (bx == 0 && tid < nb) x[jb0 + tid] = xsh[b][tid];
+        if (MODE == 1 && tid < nb) x[jb0 + tid] = xsh[b][tid];
     }
+    if (MODE == 1) return;
     __syncthreads();
     const int c0 = bx * NB + 4 * w;
     if (c0 < jb0) {
@@ -1214,11 +1231,17 @@ void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
     if (nrhs >= KVX_BIG_MR_FROM) {
         for (int jb = 0; jb < max_k; jb += SB) {
             int rows = max_m - jb - 1;
-            dim3 grid((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, (unsigned)((nrhs + KVX_BIG_RB - 1) / KVX_BIG_RB));
-            if (jb == 0)
-                hipLaunchKernelGGL((k_fwd_big_step_mr<true, KVX_BIG_RB>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
-            else
-                hipLaunchKernelGGL((k_fwd_big_step_mr<false, KVX_BIG_RB>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+            const unsigned gz = (unsigned)((nrhs + KVX_BIG_RB - 1) / KVX_BIG_RB);
+            // (blocks of 1 for the diagonal launch -- more, shorter workgroups -- were measured and lost: 18.5 -> 20.4 ms at 64 rhs,
+            // n = 1e6: a 1024-thread workgroup per front and right-hand side is the cost, not the length of its chain)
+            dim3 g1(1, (unsigned)count, gz), g2((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, gz);
+            if (jb == 0) {
+                hipLaunchKernelGGL((k_fwd_big_step_mr<true, KVX_BIG_RB, 1>), g1, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+                hipLaunchKernelGGL((k_fwd_big_step_mr<true, KVX_BIG_RB, 2>), g2, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+            } else {
+                hipLaunchKernelGGL((k_fwd_big_step_mr<false, KVX_BIG_RB, 1>), g1, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+                hipLaunchKernelGGL((k_fwd_big_step_mr<false, KVX_BIG_RB, 2>), g2, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, nrhs, WK, ldw, Wchild, Wout, wstride);
+            }
         }
         return;
     }
@@ -1242,9 +1265,11 @@ void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
         hipLaunchKernelGGL((k_bwd_big_init_mr<KVX_BIG_RB>), dim3((unsigned)((max_k + 3) / 4), (unsigned)count, gz), dim3(256), 0, st,
                            ds, list, Lx, X, ldx, nrhs, WK, ldw);
         for (int b = (max_k + SB - 1) / SB - 1; b >= 0; b--) {
-            unsigned gx = (unsigned)std::max(1, b * SB / NB);
-            hipLaunchKernelGGL((k_bwd_big_step_mr<KVX_BIG_RB>), dim3(gx, (unsigned)count, gz), dim3(SOLVE_NT), 0, st, ds, list, b, Lx, Linv,
+            hipLaunchKernelGGL((k_bwd_big_step_mr<KVX_BIG_RB, 1>), dim3(1, (unsigned)count, gz), dim3(SOLVE_NT), 0, st, ds, list, b, Lx, Linv,
                                X, ldx, nrhs, WK, ldw);
+            if (b > 0)
+                hipLaunchKernelGGL((k_bwd_big_step_mr<KVX_BIG_RB, 2>), dim3((unsigned)(b * SB / NB), (unsigned)count, gz), dim3(SOLVE_NT), 0, st, ds, list, b, Lx, Linv,
+                                   X, ldx, nrhs, WK, ldw);
         }
         return;
     }
