@@ -9,8 +9,13 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <thread>
 
 namespace kvx {
 namespace {
@@ -21,40 +26,52 @@ struct Graph {
     const int32_t *adj;
 };
 
+// Subdomains are dissected by several host threads (order_nd).  A task owns its slice of `verts` and `queue` and writes
+// region / level of its own vertices only, but it READS region / level of neighbours that may belong to another task; those
+// reads can never change a decision (a foreign region id equals neither the task's own id nor the ids it hands out), so the
+// ordering is the same for any thread count.  Relaxed atomics make the concurrent accesses well defined; they are plain moves.
+struct RelaxedI32 {
+    std::atomic<int32_t> v{0};
+    RelaxedI32() = default;
+    RelaxedI32(const RelaxedI32 &o) : v(o.v.load(std::memory_order_relaxed)) {}
+    operator int32_t() const { return v.load(std::memory_order_relaxed); }
+    RelaxedI32 &operator=(int32_t x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
+
 struct NDState {
     Graph g;
-    std::vector<int32_t> verts;    // task ranges are contiguous slices; slice position = final position
-    std::vector<int32_t> region;   // region id of every vertex (-1 = already numbered)
-    std::vector<int32_t> level;    // BFS scratch
-    std::vector<int32_t> queue;    // BFS scratch
-    int32_t next_region = 1;
+    std::vector<int32_t> verts;      // task ranges are contiguous slices; slice position = final position
+    std::vector<RelaxedI32> region;  // region id of every vertex (-1 = already numbered)
+    std::vector<RelaxedI32> level;   // BFS levels (-1 = not visited)
+    std::vector<int32_t> queue;      // BFS scratch: a task uses the slice of its own vertex range
+    std::atomic<int32_t> next_region{1};
 };
 
 // BFS restricted to region `rid` from `root`; fills st.queue[0..cnt) in BFS order and
 // st.level[v]; returns cnt, sets nlev. Levels are reset by the caller through `touched`.
-int64_t bfs(NDState &st, int32_t rid, int32_t root, int32_t &nlev)
+int64_t bfs(NDState &st, int32_t *queue, int32_t rid, int32_t root, int32_t &nlev)
 {
     int64_t head = 0, tail = 0;
-    st.queue[tail++] = root;
+    queue[tail++] = root;
     st.level[root] = 0;
     nlev = 1;
     while (head < tail) {
-        int32_t v = st.queue[head++];
+        int32_t v = queue[head++];
         int32_t lv = st.level[v];
         for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1]; p++) {
             int32_t u = st.g.adj[p];
             if (st.region[u] != rid || st.level[u] >= 0) continue;
             st.level[u] = lv + 1;
             if (lv + 2 > nlev) nlev = lv + 2;
-            st.queue[tail++] = u;
+            queue[tail++] = u;
         }
     }
     return tail;
 }
 
-void reset_levels(NDState &st, int64_t cnt)
+void reset_levels(NDState &st, const int32_t *queue, int64_t cnt)
 {
-    for (int64_t i = 0; i < cnt; i++) st.level[st.queue[i]] = -1;
+    for (int64_t i = 0; i < cnt; i++) st.level[queue[i]] = -1;
 }
 
 // Halo-aware exact minimum degree on a small vertex set (bitset elimination graph).
@@ -117,6 +134,137 @@ void leaf_min_degree(NDState &st, int64_t lo, int64_t hi, std::vector<int32_t> &
     std::copy(order.begin(), order.end(), st.verts.begin() + lo);
 }
 
+struct NDTask { int64_t lo, hi; int32_t rid; };
+
+struct NDWorker {
+    std::vector<int32_t> local_id;   // leaf_min_degree scratch, indexed by vertex (halo vertices are shared between leaves)
+    std::vector<int64_t> levcnt;
+};
+
+// One dissection step on the task's slice; pushes 0..2 child tasks (first pushed = processed last on a LIFO stack).
+void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<NDTask> &out)
+{
+    const int64_t sz = t.hi - t.lo;
+    if (sz <= 0) return;
+    if (sz <= leaf) {
+        if (wk.local_id.empty()) wk.local_id.assign((size_t)st.g.n, -1);
+        leaf_min_degree(st, t.lo, t.hi, wk.local_id);
+        for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
+        return;
+    }
+    int32_t *queue = st.queue.data() + t.lo;       // a connected component of the slice has at most sz vertices
+    // pseudo-peripheral root: repeat BFS from a min-degree vertex of the last level
+    int32_t root = st.verts[t.lo];
+    int32_t nlev = 0;
+    int64_t cnt = 0;
+    for (int iter = 0; iter < 4; iter++) {
+        cnt = bfs(st, queue, t.rid, root, nlev);
+        int32_t cand = -1;
+        int64_t cdeg = INT64_MAX;
+        for (int64_t i = cnt - 1; i >= 0 && st.level[queue[i]] == nlev - 1; i--) {
+            int32_t v = queue[i];
+            int64_t d = st.g.ptr[v + 1] - st.g.ptr[v];
+            if (d < cdeg) { cdeg = d; cand = v; }
+        }
+        if (iter == 3 || cand == root || cand < 0) break;
+        // does the new root give a deeper structure? try it
+        int32_t old_nlev = nlev, old_root = root;
+        reset_levels(st, queue, cnt);
+        root = cand;
+        cnt = bfs(st, queue, t.rid, root, nlev);
+        if (nlev <= old_nlev) {
+            if (nlev < old_nlev) { reset_levels(st, queue, cnt); root = old_root; cnt = bfs(st, queue, t.rid, root, nlev); }
+            break;
+        }
+        reset_levels(st, queue, cnt);
+    }
+    // queue[0..cnt) holds one connected component in BFS order with levels set
+    if (cnt < sz) {
+        // disconnected: peel this component off as its own task, no separator
+        int32_t ra = st.next_region.fetch_add(2, std::memory_order_relaxed), rb = ra + 1;
+        for (int64_t i = 0; i < cnt; i++) st.region[queue[i]] = ra;
+        int64_t a = t.lo, b = t.lo + cnt;
+        std::vector<int32_t> tmp(st.verts.begin() + t.lo, st.verts.begin() + t.hi);
+        reset_levels(st, queue, cnt);              // (before the slice is rewritten: queue aliases nothing in verts)
+        for (int32_t v : tmp) {
+            if (st.region[v] == ra) st.verts[a++] = v;
+            else { st.region[v] = rb; st.verts[b++] = v; }
+        }
+        out.push_back(NDTask{t.lo + cnt, t.hi, rb});
+        out.push_back(NDTask{t.lo, t.lo + cnt, ra});
+        return;
+    }
+    if (nlev < 3) {
+        // diameter too small for a level-set separator (near-clique): number by degree
+        reset_levels(st, queue, cnt);
+        std::sort(st.verts.begin() + t.lo, st.verts.begin() + t.hi, [&](int32_t a, int32_t b) {
+            int64_t da = st.g.ptr[a + 1] - st.g.ptr[a], db = st.g.ptr[b + 1] - st.g.ptr[b];
+            return da != db ? da < db : a < b;
+        });
+        for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
+        return;
+    }
+    std::vector<int64_t> &levcnt = wk.levcnt;
+    levcnt.assign((size_t)nlev, 0);
+    for (int64_t i = 0; i < cnt; i++) levcnt[st.level[queue[i]]]++;
+    // pick the separator level: smallest level among those leaving >= 30% on each side,
+    // else the level where the cumulative count crosses one half
+    int32_t best = -1;
+    int64_t bestcnt = INT64_MAX, cum = 0, half_lev = 1;
+    for (int32_t l = 0; l < nlev; l++) {
+        int64_t below = cum, above = sz - cum - levcnt[l];
+        if (l >= 1 && l <= nlev - 2 && below * 10 >= sz * 3 && above * 10 >= sz * 3 && levcnt[l] < bestcnt) {
+            bestcnt = levcnt[l];
+            best = l;
+        }
+        if (cum * 2 < sz) half_lev = l;
+        cum += levcnt[l];
+    }
+    if (best < 0) best = std::min<int32_t>(std::max<int32_t>((int32_t)half_lev, 1), nlev - 2);
+    // separator = vertices of level `best` with a neighbour in level best+1;
+    // the rest of level `best` joins part A
+    int32_t ra = st.next_region.fetch_add(2, std::memory_order_relaxed), rb = ra + 1;
+    int64_t nA = 0, nB = 0, nS = 0;
+    for (int64_t i = 0; i < cnt; i++) {
+        int32_t v = queue[i];
+        int32_t lv = st.level[v];
+        if (lv < best) { st.region[v] = ra; nA++; }
+        else if (lv > best) { st.region[v] = rb; nB++; }
+        else {
+            bool touches = false;
+            for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1] && !touches; p++) {
+                int32_t u = st.g.adj[p];
+                const int32_t ru = st.region[u];
+                touches = (ru == t.rid || ru == rb) && (st.level[u] == best + 1);
+            }
+            if (touches) { st.region[v] = -1; nS++; }
+            else { st.region[v] = ra; nA++; }
+        }
+    }
+    // lay out verts[lo,hi) as [A | B | S], each in BFS order
+    int64_t a = t.lo, b = t.lo + nA, s = t.lo + nA + nB;
+    for (int64_t i = 0; i < cnt; i++) {
+        int32_t v = queue[i];
+        if (st.region[v] == ra) st.verts[a++] = v;
+        else if (st.region[v] == rb) st.verts[b++] = v;
+        else st.verts[s++] = v;
+    }
+    reset_levels(st, queue, cnt);
+    out.push_back(NDTask{t.lo + nA, t.lo + nA + nB, rb});
+    out.push_back(NDTask{t.lo, t.lo + nA, ra});
+}
+
+// a whole subtree of tasks, depth first, on the calling thread
+void nd_run_local(NDState &st, NDWorker &wk, NDTask t0, int leaf)
+{
+    std::vector<NDTask> stack{t0};
+    while (!stack.empty()) {
+        NDTask t = stack.back();
+        stack.pop_back();
+        nd_step(st, wk, t, leaf, stack);
+    }
+}
+
 }  // namespace
 
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
@@ -128,124 +276,59 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
     st.g = Graph{n, adjptr.data(), adj.data()};
     st.verts.resize((size_t)n);
     std::iota(st.verts.begin(), st.verts.end(), 0);
-    st.region.assign((size_t)n, 0);
-    st.level.assign((size_t)n, -1);
+    st.region = std::vector<RelaxedI32>((size_t)n);            // region 0
+    st.level = std::vector<RelaxedI32>((size_t)n);
+    for (int64_t i = 0; i < n; i++) st.level[(size_t)i] = -1;
     st.queue.resize((size_t)n);
-    std::vector<int32_t> local_id((size_t)n, -1);
-    std::vector<int64_t> levcnt;
     if (leaf < 4) leaf = 4;
 
-    struct Task { int64_t lo, hi; int32_t rid; };
-    std::vector<Task> stack;
-    stack.push_back(Task{0, n, 0});
-
-    while (!stack.empty()) {
-        Task t = stack.back();
-        stack.pop_back();
-        const int64_t sz = t.hi - t.lo;
-        if (sz <= 0) continue;
-        if (sz <= leaf) {
-            leaf_min_degree(st, t.lo, t.hi, local_id);
-            for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
-            continue;
-        }
-        // pseudo-peripheral root: repeat BFS from a min-degree vertex of the last level
-        int32_t root = st.verts[t.lo];
-        int32_t nlev = 0;
-        int64_t cnt = 0;
-        for (int iter = 0; iter < 4; iter++) {
-            cnt = bfs(st, t.rid, root, nlev);
-            int32_t cand = -1;
-            int64_t cdeg = INT64_MAX;
-            for (int64_t i = cnt - 1; i >= 0 && st.level[st.queue[i]] == nlev - 1; i--) {
-                int32_t v = st.queue[i];
-                int64_t d = st.g.ptr[v + 1] - st.g.ptr[v];
-                if (d < cdeg) { cdeg = d; cand = v; }
-            }
-            if (iter == 3 || cand == root || cand < 0) break;
-            // does the new root give a deeper structure? try it
-            int32_t old_nlev = nlev, old_root = root;
-            reset_levels(st, cnt);
-            root = cand;
-            cnt = bfs(st, t.rid, root, nlev);
-            if (nlev <= old_nlev) {
-                if (nlev < old_nlev) { reset_levels(st, cnt); root = old_root; cnt = bfs(st, t.rid, root, nlev); }
-                break;
-            }
-            reset_levels(st, cnt);
-        }
-        // queue[0..cnt) holds one connected component in BFS order with levels set
-        if (cnt < sz) {
-            // disconnected: peel this component off as its own task, no separator
-            int32_t ra = st.next_region++, rb = st.next_region++;
-            for (int64_t i = 0; i < cnt; i++) st.region[st.queue[i]] = ra;
-            int64_t a = t.lo, b = t.lo + cnt;
-            std::vector<int32_t> tmp(st.verts.begin() + t.lo, st.verts.begin() + t.hi);
-            for (int32_t v : tmp) {
-                if (st.region[v] == ra) st.verts[a++] = v;
-                else { st.region[v] = rb; st.verts[b++] = v; }
-            }
-            reset_levels(st, cnt);
-            stack.push_back(Task{t.lo + cnt, t.hi, rb});
-            stack.push_back(Task{t.lo, t.lo + cnt, ra});
-            continue;
-        }
-        if (nlev < 3) {
-            // diameter too small for a level-set separator (near-clique): number by degree
-            reset_levels(st, cnt);
-            std::sort(st.verts.begin() + t.lo, st.verts.begin() + t.hi, [&](int32_t a, int32_t b) {
-                int64_t da = st.g.ptr[a + 1] - st.g.ptr[a], db = st.g.ptr[b + 1] - st.g.ptr[b];
-                return da != db ? da < db : a < b;
-            });
-            for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
-            continue;
-        }
-        levcnt.assign((size_t)nlev, 0);
-        for (int64_t i = 0; i < cnt; i++) levcnt[st.level[st.queue[i]]]++;
-        // pick the separator level: smallest level among those leaving >= 30% on each side,
-        // else the level where the cumulative count crosses one half
-        int32_t best = -1;
-        int64_t bestcnt = INT64_MAX, cum = 0, half_lev = 1;
-        for (int32_t l = 0; l < nlev; l++) {
-            int64_t below = cum, above = sz - cum - levcnt[l];
-            if (l >= 1 && l <= nlev - 2 && below * 10 >= sz * 3 && above * 10 >= sz * 3 && levcnt[l] < bestcnt) {
-                bestcnt = levcnt[l];
-                best = l;
-            }
-            if (cum * 2 < sz) half_lev = l;
-            cum += levcnt[l];
-        }
-        if (best < 0) best = std::min<int32_t>(std::max<int32_t>((int32_t)half_lev, 1), nlev - 2);
-        // separator = vertices of level `best` with a neighbour in level best+1;
-        // the rest of level `best` joins part A
-        int32_t ra = st.next_region++, rb = st.next_region++;
-        int64_t nA = 0, nB = 0, nS = 0;
-        for (int64_t i = 0; i < cnt; i++) {
-            int32_t v = st.queue[i];
-            int32_t lv = st.level[v];
-            if (lv < best) { st.region[v] = ra; nA++; }
-            else if (lv > best) { st.region[v] = rb; nB++; }
-            else {
-                bool touches = false;
-                for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1] && !touches; p++) {
-                    int32_t u = st.g.adj[p];
-                    touches = (st.level[u] == best + 1) && (st.region[u] == t.rid || st.region[u] == rb);
+    // Host threads: subdomains are independent once their separator is numbered.  Tasks of at least `cutoff` vertices go
+    // through a shared pool (their two halves become new pool tasks); smaller ones are finished depth-first by whoever takes
+    // them.  The result does not depend on the thread count (see NDState).  KVX_ND_THREADS = 1 runs the whole tree in place.
+    int nthreads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("KVX_ND_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
+    const int64_t cutoff = 8192;
+    if (n < 4 * cutoff) nthreads = 1;
+    if (nthreads == 1) {
+        NDWorker wk;
+        nd_run_local(st, wk, NDTask{0, n, 0}, leaf);
+    } else {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<NDTask> pool{NDTask{0, n, 0}};
+        int busy = 0;                               // tasks taken and not finished (guarded by mu)
+        auto worker = [&]() {
+            NDWorker wk;
+            std::vector<NDTask> out;
+            for (;;) {
+                NDTask t;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return !pool.empty() || busy == 0; });
+                    if (pool.empty()) return;       // nothing queued and nobody who could queue more
+                    t = pool.back();
+                    pool.pop_back();
+                    busy++;
                 }
-                if (touches) { st.region[v] = -1; nS++; }
-                else { st.region[v] = ra; nA++; }
+                if (t.hi - t.lo < cutoff) {
+                    nd_run_local(st, wk, t, leaf);
+                    out.clear();
+                } else {
+                    out.clear();
+                    nd_step(st, wk, t, leaf, out);
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    for (const NDTask &c : out) pool.push_back(c);
+                    busy--;
+                }
+                cv.notify_all();
             }
-        }
-        // lay out verts[lo,hi) as [A | B | S], each in BFS order
-        int64_t a = t.lo, b = t.lo + nA, s = t.lo + nA + nB;
-        for (int64_t i = 0; i < cnt; i++) {
-            int32_t v = st.queue[i];
-            if (st.region[v] == ra) st.verts[a++] = v;
-            else if (st.region[v] == rb) st.verts[b++] = v;
-            else st.verts[s++] = v;
-        }
-        reset_levels(st, cnt);
-        stack.push_back(Task{t.lo + nA, t.lo + nA + nB, rb});
-        stack.push_back(Task{t.lo, t.lo + nA, ra});
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < nthreads; i++) th.emplace_back(worker);
+        worker();
+        for (auto &x : th) x.join();
     }
     for (int64_t i = 0; i < n; i++) perm[(size_t)i] = st.verts[(size_t)i];
 }
