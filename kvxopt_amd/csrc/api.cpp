@@ -3,10 +3,12 @@
 // KVX_EDEVICE otherwise.
 #include "../../include/kvxhip.h"
 #include "abi_guard.hpp"
+#include "devpool.hpp"
 #include "device.hpp"
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -122,7 +124,7 @@ template <class T>
 int upload(T **dst, const std::vector<T> &src)
 {
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(hipMalloc((void **)dst, bytes));
+    HIPCHK(pool_malloc((void **)dst, bytes));
     if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return KVX_OK;
 }
@@ -137,7 +139,7 @@ struct ProfScope {
         if (F->prof_used + 2 > F->prof_ev.size()) {
             size_t old = F->prof_ev.size();
             F->prof_ev.resize(old + 256, nullptr);
-            for (size_t i = old; i < F->prof_ev.size(); i++) (void)hipEventCreate(&F->prof_ev[i]);
+            for (size_t i = old; i < F->prof_ev.size(); i++) (void)pool_event_get(&F->prof_ev[i], true);
         }
         (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
     }
@@ -296,7 +298,7 @@ int build_subtrees(kvx_chol *F)
         }
     int rc;
     for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
-        if (p) (void)hipFree(p);
+        if (p) (void)pool_free(p);
     F->d_subs = nullptr; F->d_cd_woff = nullptr; F->d_lists_sw = nullptr; F->d_depth = nullptr;
     if ((rc = upload(&F->d_subs, subs))) return rc;
     if ((rc = upload(&F->d_cd_woff, cd_woff))) return rc;
@@ -317,15 +319,15 @@ int ensure_device(kvx_chol *F)
     }
     Symbolic &S = F->S;
     analyze_subtrees(F);
-    HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&F->ev[i]));
+    HIPCHK(pool_stream_get(&F->stream));
+    for (int i = 0; i < 4; i++) HIPCHK(pool_event_get(&F->ev[i], true));
     for (int i = 0; i < 4; i++) {
-        HIPCHK(hipStreamCreateWithFlags(&F->side[i], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&F->ev_join[i], hipEventDisableTiming));
+        HIPCHK(pool_stream_get(&F->side[i]));
+        HIPCHK(pool_event_get(&F->ev_join[i], false));
     }
-    HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&F->ev_in, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&F->ev_out, hipEventDisableTiming));
+    HIPCHK(pool_event_get(&F->ev_fork, false));
+    HIPCHK(pool_event_get(&F->ev_in, false));
+    HIPCHK(pool_event_get(&F->ev_out, false));
     int rc;
     std::vector<int32_t> first((size_t)S.nsuper), perm32((size_t)S.n);
     for (int64_t s = 0; s < S.nsuper; s++) first[s] = (int32_t)S.super[s];
@@ -345,11 +347,11 @@ int ensure_device(kvx_chol *F)
     if ((rc = upload(&F->d_wx, S.wx))) return rc;
     if ((rc = upload(&F->d_childptr, S.childptr))) return rc;
     if ((rc = upload(&F->d_amap, S.amap))) return rc;
-    HIPCHK(hipMalloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
     for (int p = 0; p < 2; p++)
-        HIPCHK(hipMalloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&F->d_status, sizeof(int)));
+        HIPCHK(pool_malloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
     std::vector<int64_t> loff_host;
     {
@@ -360,7 +362,7 @@ int ensure_device(kvx_chol *F)
         for (int64_t s = 0; s < S.nsuper; s++)
             if (front_class(S.sn_m[s], S.sn_k[s]) == KVX_CLS_BIG) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
         if ((rc = upload(&F->d_linv_off, loff))) return rc;
-        HIPCHK(hipMalloc((void **)&F->d_Linv, std::max<int64_t>(tot, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&F->d_Linv, std::max<int64_t>(tot, 1) * sizeof(double)));
     }
     {
         std::vector<FrontDesc> fd((size_t)S.nsuper);
@@ -424,18 +426,18 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
     for (auto &g : F->g_solve)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     F->g_solve.clear();                          // the captured sweeps point into the old workspace
-    if (F->d_X) { (void)hipFree(F->d_X); F->d_X = nullptr; }
-    if (F->d_X0) { (void)hipFree(F->d_X0); F->d_X0 = nullptr; }
-    if (F->d_WK) { (void)hipFree(F->d_WK); F->d_WK = nullptr; }
+    if (F->d_X) { (void)pool_free(F->d_X); F->d_X = nullptr; }
+    if (F->d_X0) { (void)pool_free(F->d_X0); F->d_X0 = nullptr; }
+    if (F->d_WK) { (void)pool_free(F->d_WK); F->d_WK = nullptr; }
     for (int p = 0; p < 2; p++)
-        if (F->d_W[p]) { (void)hipFree(F->d_W[p]); F->d_W[p] = nullptr; }
+        if (F->d_W[p]) { (void)pool_free(F->d_W[p]); F->d_W[p] = nullptr; }
     F->x_cap = 0;
-    HIPCHK(hipMalloc((void **)&F->d_X, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&F->d_X0, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
-    HIPCHK(hipMalloc((void **)&F->d_WK, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_X, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_X0, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_WK, std::max<int64_t>(S.n * nrhs, 1) * sizeof(double)));
     const int64_t wmax = std::max(S.wrk_size[0], S.wrk_size[1]);   // common per-rhs stride of both parity buffers
     for (int p = 0; p < 2; p++)
-        HIPCHK(hipMalloc((void **)&F->d_W[p], std::max<int64_t>(wmax * nrhs, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&F->d_W[p], std::max<int64_t>(wmax * nrhs, 1) * sizeof(double)));
     F->x_cap = nrhs;
     return KVX_OK;
 }
@@ -732,7 +734,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     hipStream_t st = F->stream;
     const bool ldl = !F->is_ll && sys >= 2 && sys <= 6;
     if (ldl && !F->diag_valid) {
-        if (!F->d_diag) HIPCHK(hipMalloc((void **)&F->d_diag, (size_t)n * sizeof(double)));
+        if (!F->d_diag) HIPCHK(pool_malloc((void **)&F->d_diag, (size_t)n * sizeof(double)));
         launch_extract_diag(st, F->ds, S.nsuper, F->d_Lx, F->d_diag);
         F->diag_valid = true;
     }
@@ -951,14 +953,14 @@ static int kvx_chol_solve_impl(kvx_chol *F, int sys, double *B, int64_t nrhs, in
     if (n == 0 || nrhs == 0) return KVX_OK;
     if (ldB < std::max<int64_t>(1, n)) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
     double *d_B = nullptr;
-    HIPCHK(hipMalloc((void **)&d_B, n * nrhs * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&d_B, n * nrhs * sizeof(double)));
     hipError_t e = hipMemcpy2D(d_B, n * sizeof(double), B, ldB * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         rc = solve_dev(F, sys, d_B, nrhs, n);
         if (rc == KVX_OK)
             e = hipMemcpy2D(B, ldB * sizeof(double), d_B, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d_B);
+    (void)pool_free(d_B);
     if (e != hipSuccess) { set_err(hipGetErrorString(e)); return KVX_EDEVICE; }
     return rc;
 }
@@ -1025,11 +1027,11 @@ int kvx_chol_diag(kvx_chol *F, double *d)
     if (rc) return rc;
     if (F->S.n == 0) return KVX_OK;
     double *dd = nullptr;
-    HIPCHK(hipMalloc((void **)&dd, F->S.n * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&dd, F->S.n * sizeof(double)));
     launch_extract_diag(F->stream, F->ds, F->S.nsuper, F->d_Lx, dd);
     hipError_t e = hipStreamSynchronize(F->stream);
     if (e == hipSuccess) e = hipMemcpy(d, dd, F->S.n * sizeof(double), hipMemcpyDeviceToHost);
-    (void)hipFree(dd);
+    (void)pool_free(dd);
     if (e != hipSuccess) { set_err(hipGetErrorString(e)); return KVX_EDEVICE; }
     return KVX_OK;
 }
@@ -1190,7 +1192,7 @@ static int kvx_chol_dist_setup_impl(kvx_chol *F, int rank, int nranks, int64_t i
         }
         F->lptr_host[l + 1] = (int64_t)F->lists_host.size();
     }
-    if (F->d_lists) { HIPCHK(hipFree(F->d_lists)); F->d_lists = nullptr; }
+    if (F->d_lists) { HIPCHK(pool_free(F->d_lists)); F->d_lists = nullptr; }
     if ((rc = upload(&F->d_lists, F->lists_host))) return rc;
     build_plan(F);
     F->dist_nranks = nranks;                         // (sharded mode keeps the subtrees in the level lists)
@@ -1215,7 +1217,7 @@ static int kvx_chol_dist_setup_impl(kvx_chol *F, int rank, int nranks, int64_t i
         if (mine)
             for (int64_t j = S.super[s]; j < S.super[s + 1]; j++) keep[j] = 1;
     }
-    if (F->d_keep) { HIPCHK(hipFree(F->d_keep)); F->d_keep = nullptr; }
+    if (F->d_keep) { HIPCHK(pool_free(F->d_keep)); F->d_keep = nullptr; }
     if ((rc = upload(&F->d_keep, keep))) return rc;
     F->dist_rank = rank; F->dist_nranks = nranks; F->dist_cut = nranks == 1 ? 0 : cut;
     F->dist_ulen = ulen; F->dist_wlen = wlen;
@@ -1314,40 +1316,50 @@ int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, i
 void kvx_chol_free(kvx_chol *F)
 {
     if (!F) return;
+    const bool tim = getenv("KVX_FREE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    auto lap = [&](const char *what) { if (tim) { auto t1 = now(); fprintf(stderr, "  free %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
     if (F->dev_ready) {
         (void)hipStreamSynchronize(F->stream);
+        lap("sync");
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
                         F->d_Ax, F->d_X, F->d_X0, F->d_diag, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
         for (void *p : ptrs)
-            if (p) (void)hipFree(p);
+            if (p) (void)pool_free(p);
+        lap("buffers");
         if (F->h_status) (void)hipHostFree(F->h_status);
+        lap("hostfree");
         for (int i = 0; i < 4; i++)
-            if (F->ev[i]) (void)hipEventDestroy(F->ev[i]);
+            if (F->ev[i]) pool_event_put(F->ev[i], true);
         if (F->g_factor) (void)hipGraphExecDestroy(F->g_factor);
         for (auto &g : F->g_solve)
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        lap("graphs");
         for (hipEvent_t e : F->prof_ev)
-            if (e) (void)hipEventDestroy(e);
+            if (e) pool_event_put(e, true);
         for (int i = 0; i < 4; i++) {
-            if (F->side[i]) (void)hipStreamDestroy(F->side[i]);
-            if (F->ev_join[i]) (void)hipEventDestroy(F->ev_join[i]);
+            if (F->side[i]) pool_stream_put(F->side[i]);
+            if (F->ev_join[i]) pool_event_put(F->ev_join[i], false);
         }
-        if (F->d_keep) (void)hipFree(F->d_keep);
+        if (F->d_keep) (void)pool_free(F->d_keep);
         for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
-            if (p) (void)hipFree(p);
-        if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
-        if (F->ev_in) (void)hipEventDestroy(F->ev_in);
-        if (F->ev_out) (void)hipEventDestroy(F->ev_out);
-        if (F->stream) (void)hipStreamDestroy(F->stream);
+            if (p) (void)pool_free(p);
+        if (F->ev_fork) pool_event_put(F->ev_fork, false);
+        if (F->ev_in) pool_event_put(F->ev_in, false);
+        if (F->ev_out) pool_event_put(F->ev_out, false);
+        if (F->stream) pool_stream_put(F->stream);
+        lap("streams");
     }
     delete F;
+    lap("delete");
 }
 
 void kvx_free(void *p) { free(p); }
 
-int kvx_dev_malloc(void **p, int64_t bytes) { HIPCHK(hipMalloc(p, (size_t)std::max<int64_t>(bytes, 1))); return KVX_OK; }
-int kvx_dev_free(void *p) { HIPCHK(hipFree(p)); return KVX_OK; }
+int kvx_dev_malloc(void **p, int64_t bytes) { HIPCHK(pool_malloc(p, (size_t)std::max<int64_t>(bytes, 1))); return KVX_OK; }
+int kvx_dev_free(void *p) { HIPCHK(pool_free(p)); return KVX_OK; }
 int kvx_dev_upload(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); return KVX_OK; }
 int kvx_dev_download(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return KVX_OK; }
 int kvx_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return KVX_OK; }

@@ -1,0 +1,145 @@
+#include "devpool.hpp"
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace kvx {
+namespace {
+std::mutex g_mu;
+struct Key {
+    int dev; size_t bytes;
+    bool operator<(const Key &o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; }
+};
+std::multimap<Key, void *> g_free;               // cached blocks by (device, size)
+std::unordered_map<void *, Key> g_live;          // blocks handed out -> (device, size)
+size_t g_cached = 0;
+constexpr size_t MAX_BLOCK = (size_t)1 << 30;
+
+std::multimap<int, hipStream_t> g_streams;      // by device
+std::multimap<int, hipEvent_t> g_events[2];      // [timing] by device
+
+size_t cache_cap()
+{
+    static const size_t cap = [] {
+        const char *e = getenv("KVX_POOL_MAX_MB");
+        return (size_t)(e ? atoll(e) : 8192) << 20;
+    }();
+    return cap;
+}
+
+void release_all_locked()
+{
+    for (auto &kv : g_free) (void)hipFree(kv.second);
+    g_free.clear();
+    g_cached = 0;
+}
+}  // namespace
+
+hipError_t pool_malloc(void **p, size_t bytes)
+{
+    if (!p) return hipErrorInvalidValue;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    int dev = 0;
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) return e0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (bytes <= MAX_BLOCK) {
+        auto it = g_free.lower_bound(Key{dev, bytes});
+        if (it != g_free.end() && it->first.dev == dev && it->first.bytes <= bytes + bytes / 8) {
+            *p = it->second;
+            g_live[*p] = it->first;
+            g_cached -= it->first.bytes;
+            g_free.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && !g_free.empty()) {       // out of memory with blocks cached: give them back and retry
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        release_all_locked();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) g_live[*p] = Key{dev, bytes};
+    return e;
+}
+
+hipError_t pool_free(void *p)
+{
+    if (!p) return hipSuccess;
+    std::unique_lock<std::mutex> lk(g_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) { lk.unlock(); return hipFree(p); }      // not ours (never happens inside the library)
+    const Key key = it->second;
+    const size_t bytes = key.bytes;
+    g_live.erase(it);
+    if (bytes > MAX_BLOCK || cache_cap() == 0 || g_cached + bytes > cache_cap()) { lk.unlock(); return hipFree(p); }
+    lk.unlock();
+    hipError_t e = hipDeviceSynchronize();          // what hipFree guarantees: nothing in flight still touches the block
+    lk.lock();
+    g_free.emplace(key, p);
+    g_cached += bytes;
+    return e;
+}
+
+hipError_t pool_stream_get(hipStream_t *s)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_streams.find(dev);
+        if (it != g_streams.end()) { *s = it->second; g_streams.erase(it); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
+void pool_stream_put(hipStream_t s)
+{
+    if (!s) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipStreamDestroy(s); return; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_streams.size() >= 64) { (void)hipStreamDestroy(s); return; }
+    g_streams.emplace(dev, s);
+}
+
+hipError_t pool_event_get(hipEvent_t *ev, bool timing)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto &m = g_events[timing ? 1 : 0];
+        auto it = m.find(dev);
+        if (it != m.end()) { *ev = it->second; m.erase(it); return hipSuccess; }
+    }
+    return timing ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableTiming);
+}
+
+void pool_event_put(hipEvent_t ev, bool timing)
+{
+    if (!ev) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipEventDestroy(ev); return; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &m = g_events[timing ? 1 : 0];
+    if (m.size() >= 4096) { (void)hipEventDestroy(ev); return; }
+    m.emplace(dev, ev);
+}
+
+void pool_release_all()
+{
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_mu);
+    release_all_locked();
+    for (auto &kv : g_streams) (void)hipStreamDestroy(kv.second);
+    g_streams.clear();
+    for (auto &m : g_events) { for (auto &kv : m) (void)hipEventDestroy(kv.second); m.clear(); }
+}
+}  // namespace kvx

@@ -2,6 +2,7 @@
 // (include/kvxhip.h).  Device-only: no CPU fallback.
 #include "../../include/kvxhip.h"
 #include "abi_guard.hpp"
+#include "devpool.hpp"
 #include "kkt.hpp"
 
 #include <algorithm>
@@ -50,16 +51,16 @@ int ensure_scratch()
 {
     Scratch &s = scratch();
     if (s.part) return KVX_OK;
-    HIPCHK(hipMalloc((void **)&s.part, reduce_scratch_doubles() * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&s.part, reduce_scratch_doubles() * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&s.host, 32 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipMalloc((void **)&s.multi, 32 * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&s.multi, 32 * sizeof(double)));
     return KVX_OK;
 }
 
 template <class T>
 int up(T **dst, const std::vector<T> &src)
 {
-    HIPCHK(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    HIPCHK(pool_malloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
     if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return KVX_OK;
 }
@@ -215,10 +216,10 @@ static int kvx_atda_assemble_impl(kvx_atda *T, const double *Gx, const double *w
     int rc = atda_device(T);
     if (rc) return rc;
     if (!T->d_gx) {
-        HIPCHK(hipMalloc((void **)&T->d_gx, std::max<int64_t>(T->gnz, 1) * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&T->d_w, std::max<int64_t>(T->ml, 1) * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&T->d_px, std::max<int64_t>(T->pnz, 1) * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&T->d_sx, std::max<int64_t>(T->snz, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&T->d_gx, std::max<int64_t>(T->gnz, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&T->d_w, std::max<int64_t>(T->ml, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&T->d_px, std::max<int64_t>(T->pnz, 1) * sizeof(double)));
+        HIPCHK(pool_malloc((void **)&T->d_sx, std::max<int64_t>(T->snz, 1) * sizeof(double)));
     }
     if (T->gnz) HIPCHK(hipMemcpy(T->d_gx, Gx, T->gnz * sizeof(double), hipMemcpyHostToDevice));
     if (T->ml) HIPCHK(hipMemcpy(T->d_w, w, T->ml * sizeof(double), hipMemcpyHostToDevice));
@@ -243,7 +244,7 @@ void kvx_atda_free(kvx_atda *T)
     if (!T) return;
     void *ptrs[] = {T->d_pp, T->d_pslot, T->d_pa, T->d_pb, T->d_gi, T->d_gx, T->d_w, T->d_px, T->d_sx};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)pool_free(p);
     delete T;
 }
 

@@ -3,6 +3,7 @@
 // Udiag/Rs/Pnum/Q for the determinant :760-822).  Device-only numeric phase: no CPU fallback.
 #include "../../include/kvxhip.h"
 #include "abi_guard.hpp"
+#include "devpool.hpp"
 #include "lu_device.hpp"
 #include "lu_symbolic.hpp"
 
@@ -60,14 +61,14 @@ namespace {
 template <class T>
 int up(T **dst, const std::vector<T> &src)
 {
-    HIPCHK(hipMalloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    HIPCHK(pool_malloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
     if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return KVX_OK;
 }
 template <class T>
 int dalloc(T **dst, int64_t count)
 {
-    HIPCHK(hipMalloc((void **)dst, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    HIPCHK(pool_malloc((void **)dst, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
     return KVX_OK;
 }
 
@@ -76,7 +77,7 @@ void free_structure(kvx_lu_num *N)
     void *ptrs[] = {N->d_fr, N->d_rowidx, N->d_rel, N->d_children, N->d_adst, N->d_ipiv, N->d_lperm, N->d_fail, N->d_lists,
                     N->d_asrc, N->d_prow, N->d_qcol, N->d_Lx, N->d_Ux, N->d_arena, N->d_W, N->d_X, N->d_B, N->d_slists, N->d_fcol,
                     N->d_frow, N->d_flevpos, N->d_fptr_r, N->d_fptr_c, N->d_fsrc_r, N->d_fsrc_c, N->d_fval_r, N->d_fval_c};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)pool_free(p);
     N->d_slists = N->d_fcol = N->d_frow = N->d_flevpos = nullptr;
     N->d_fptr_r = N->d_fptr_c = N->d_fsrc_r = N->d_fsrc_c = nullptr;
     N->d_fval_r = N->d_fval_c = nullptr;
@@ -181,10 +182,10 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     launch_lu_fvals((int64_t)P.fcol.size(), N->d_fsrc_c, Ax_dev, N->d_rinv, N->d_ai32, N->d_fval_c, N->st);
     while ((int32_t)N->evA.size() < P.nlevels) {
         hipEvent_t a, b2, c2, d2;
-        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&b2, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c2, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&d2, hipEventDisableTiming));
+        HIPCHK(pool_event_get(&a, false));
+        HIPCHK(pool_event_get(&b2, false));
+        HIPCHK(pool_event_get(&c2, false));
+        HIPCHK(pool_event_get(&d2, false));
         N->evA.push_back(a); N->evB.push_back(b2); N->evC.push_back(c2); N->evD.push_back(d2);
     }
     HIPCHK(hipEventRecord(N->ev0, N->st));
@@ -278,10 +279,10 @@ int ensure_device(kvx_lu_num *N)
         set_last_error("no HIP device: the LU numeric phase has no CPU fallback");
         return KVX_EDEVICE;
     }
-    HIPCHK(hipStreamCreateWithFlags(&N->st, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&N->st2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&N->st3, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&N->ev0, hipEventDisableTiming));
+    HIPCHK(pool_stream_get(&N->st));
+    HIPCHK(pool_stream_get(&N->st2));
+    HIPCHK(pool_stream_get(&N->st3));
+    HIPCHK(pool_event_get(&N->ev0, false));
     std::vector<int32_t> ai32((size_t)N->nnz);
     for (int64_t p = 0; p < N->nnz; p++) ai32[p] = (int32_t)N->sym->Y.Ai[p];
     int rc;
@@ -296,9 +297,9 @@ int ensure_device(kvx_lu_num *N)
 int ensure_rhs(kvx_lu_num *N, int64_t nrhs)
 {
     if (nrhs <= N->cap_rhs) return KVX_OK;
-    if (N->d_W) (void)hipFree(N->d_W);
-    if (N->d_X) (void)hipFree(N->d_X);
-    if (N->d_B) (void)hipFree(N->d_B);
+    if (N->d_W) (void)pool_free(N->d_W);
+    if (N->d_X) (void)pool_free(N->d_X);
+    if (N->d_B) (void)pool_free(N->d_B);
     N->d_W = N->d_X = N->d_B = nullptr;
     N->cap_rhs = 0;
     int rc;
@@ -402,17 +403,18 @@ void kvx_lu_free_symbolic(kvx_lu_sym *S) { delete S; }
 void kvx_lu_free_numeric(kvx_lu_num *N)
 {
     if (!N) return;
+    if (N->st) (void)hipDeviceSynchronize();       // streams and events go back to the pool idle
     free_structure(N);
     void *ptrs[] = {N->d_ai32, N->d_rinv, N->d_rmax, N->d_Ax};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (hipEvent_t e : N->evA) (void)hipEventDestroy(e);
-    for (hipEvent_t e : N->evB) (void)hipEventDestroy(e);
-    for (hipEvent_t e : N->evC) (void)hipEventDestroy(e);
-    for (hipEvent_t e : N->evD) (void)hipEventDestroy(e);
-    if (N->ev0) (void)hipEventDestroy(N->ev0);
-    if (N->st3) (void)hipStreamDestroy(N->st3);
-    if (N->st2) (void)hipStreamDestroy(N->st2);
-    if (N->st) (void)hipStreamDestroy(N->st);
+    for (void *p : ptrs) if (p) (void)pool_free(p);
+    for (hipEvent_t e : N->evA) pool_event_put(e, false);
+    for (hipEvent_t e : N->evB) pool_event_put(e, false);
+    for (hipEvent_t e : N->evC) pool_event_put(e, false);
+    for (hipEvent_t e : N->evD) pool_event_put(e, false);
+    if (N->ev0) pool_event_put(N->ev0, false);
+    if (N->st3) pool_stream_put(N->st3);
+    if (N->st2) pool_stream_put(N->st2);
+    if (N->st) pool_stream_put(N->st);
     delete N;
 }
 
