@@ -505,7 +505,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
 
     t_loop = [None]
 
-    def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True):
+    def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True, msg=None):
+        if show:                                         # the reference's closing line (coneprog.py:791,941,961,985,1010,1094)
+            print(msg or {"optimal": "Optimal solution found.", "primal infeasible": "Certificate of primal infeasibility found.",
+                          "dual infeasible": "Certificate of dual infeasibility found."}[status])
         return {"x": x.get() if xs else None, "y": y.get() if zs else None,
                 "s": s.get() if xs else None, "z": z.get() if zs else None,
                 "status": status, "gap": gap, "relative gap": relgap,
@@ -613,7 +616,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 or iters == MAXITERS:
             x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
             if iters == MAXITERS:
-                return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+                return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres,
+                              msg="Terminated (maximum number of iterations reached).")
             return result("optimal", iters, gap, relgap, pcost, dcost, pres, dres, None, None)
         elif pinfres is not None and pinfres <= FEASTOL:
             y.scal(1.0 / (-hz - by)); z.scal(1.0 / (-hz - by))
@@ -665,7 +669,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         except ArithmeticError:
             kkt.async_solves = False
             x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
-            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, msg="Terminated (singular KKT matrix).")
 
         z1z1 = -1.0                                      # computed on the device with the first direction
         out4 = (ctypes.c_double * 4)()
@@ -688,7 +692,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 except ArithmeticError:
                     kkt.async_solves = False
                     x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
-                    return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres)
+                    return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres,
+                                  msg="Terminated (singular KKT matrix).")
             dkappa -= dtau
             if i == 0:
                 wkappa3 = dtau * dkappa
@@ -805,7 +810,9 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
     resx0 = max(1.0, qv.nrm2())
     resz0 = max(1.0, hv.nrm2())
 
-    def result(status, iters, gap, relgap, pcost, dcost, pres, dres):
+    def result(status, iters, gap, relgap, pcost, dcost, pres, dres, msg=None):
+        if show:                                         # coneprog.py:2222-2227, 2269
+            print(msg or "Optimal solution found.")
         return {"x": x.get(), "y": y.get() if p else np.zeros(0), "s": s.get(), "z": z.get(), "status": status, "gap": gap,
                 "relative gap": relgap, "primal objective": pcost, "dual objective": dcost,
                 "primal infeasibility": pres, "dual infeasibility": dres,
@@ -926,7 +933,9 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
             print("%2d: % 8.4e % 8.4e % 4.0e% 7.0e% 7.0e" % (iters, pcost, dcost, gap, pres, dres))
         if (pres <= FEASTOL and dres <= FEASTOL and (gap <= ABSTOL or (relgap is not None and relgap <= RELTOL))) \
                 or iters == MAXITERS:
-            return result("unknown" if iters == MAXITERS else "optimal", iters, gap, relgap, pcost, dcost, pres, dres)
+            if iters == MAXITERS:
+                return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, msg="Terminated (maximum number of iterations reached).")
+            return result("optimal", iters, gap, relgap, pcost, dcost, pres, dres)
 
         # scaling (coneprog.py:2230-2231) and KKT factorisation
         if iters == 0:
@@ -939,7 +948,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         except ArithmeticError:
             if iters == 0:
                 raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")
-            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres)
+            return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, msg="Terminated (singular KKT matrix).")
 
         mu = gap / ml
         sigma, eta = 0.0, 0.0

@@ -16,7 +16,8 @@ options = {}
 
 
 def _opts(kw):
-    o = dict(options)
+    o = {"show_progress": True}                          # the reference's default (coneprog.py:456, 1803)
+    o.update(options)
     o.update(kw.pop("options", None) or {})
     for k in ("kktsolver", "solver"):
         if kw.pop(k, None) is not None:

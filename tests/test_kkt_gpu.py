@@ -304,18 +304,25 @@ def test_coneqp_with_initial_values_golden(golden_dir, name):
         lp.coneqp(P, Q["q"], G, Q["h"], initvals={"s": -L["s0"]})
 
 
-def test_solvers_module_names(golden_dir):
-    """kvxopt.solvers spelling: lp / qp / conelp / coneqp and the module-level options dict."""
+def test_solvers_module_names(golden_dir, capsys):
+    """kvxopt.solvers spelling: lp / qp / conelp / coneqp and the module-level options dict; progress output is on by default
+    as in the reference (coneprog.py:456): the iteration table (:917-923) and the closing line (:941, :961)."""
     from kvxopt_amd import solvers
     meta = json.load(open(os.path.join(golden_dir, "g4_conelp.json")))["cases"]["grid6x5"]
     P = workloads.lp_grid(6, 5)
     G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    capsys.readouterr()
     sol = solvers.lp(P["c"], G, P["h"])
+    out = capsys.readouterr().out.splitlines()
     assert sol["status"] == "optimal" and sol["iterations"] == meta["iterations"]
+    assert out[0].split() == ["pcost", "dcost", "gap", "pres", "dres", "k/t"] and out[1].startswith(" 0: ")
+    assert len(out) == sol["iterations"] + 3 and out[-1] == "Optimal solution found."
     solvers.options["maxiters"] = 3
     try:
         assert solvers.conelp(P["c"], G, P["h"])["status"] == "unknown"          # maxiters reached (coneprog.py:940-960)
-        assert solvers.lp(P["c"], G, P["h"], options={"maxiters": 50})["status"] == "optimal"
+        assert capsys.readouterr().out.splitlines()[-1] == "Terminated (maximum number of iterations reached)."
+        assert solvers.lp(P["c"], G, P["h"], options={"maxiters": 50, "show_progress": False})["status"] == "optimal"
+        assert capsys.readouterr().out == ""
     finally:
         solvers.options.clear()
     Q = workloads.qp_grid(6, 5)
