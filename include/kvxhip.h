@@ -243,6 +243,10 @@ int kvx_dev_free(void *p);
 int kvx_dev_upload(void *dst_dev, const void *src_host, int64_t bytes);
 int kvx_dev_download(void *dst_host, const void *src_dev, int64_t bytes);
 int kvx_dev_sync(void);
+/* Device buffers, streams and events released by the library are kept in a caching pool (up to KVX_POOL_MAX_MB, default 8192)
+ * and handed out again; kvx_dev_trim() gives everything cached back to the driver (e.g. before another framework needs the
+ * memory).  No reference counterpart. */
+int kvx_dev_trim(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sparse LU (the kvxopt.klu API, src/C/klu.c; SURVEY 8(f)1, BASELINE configs[2]).  Real 'd' matrices, square,

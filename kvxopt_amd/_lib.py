@@ -115,6 +115,7 @@ _SIGS = {
     "kvx_dev_upload": (ctypes.c_int, [vp, vp, i64]),
     "kvx_dev_download": (ctypes.c_int, [vp, vp, i64]),
     "kvx_dev_sync": (ctypes.c_int, []),
+    "kvx_dev_trim": (ctypes.c_int, []),
 }
 
 _lib = None

@@ -1363,5 +1363,6 @@ int kvx_dev_free(void *p) { HIPCHK(pool_free(p)); return KVX_OK; }
 int kvx_dev_upload(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); return KVX_OK; }
 int kvx_dev_download(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return KVX_OK; }
 int kvx_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return KVX_OK; }
+int kvx_dev_trim(void) { pool_release_all(); return KVX_OK; }
 
 }  // extern "C"

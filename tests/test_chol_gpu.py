@@ -418,3 +418,24 @@ def test_many_right_hand_sides_blocked_kernels(g, h, nrhs):
             xj = B[:, j].copy()
             F.solve(xj, sys=sys)
             assert np.array_equal(xj, X[:, j]), (sys, j)
+
+
+def test_device_pool_recycles_and_trims():
+    """The caching pool behind every device buffer (csrc/devpool.cpp): a factor created after another one of the same shape
+    was freed gets its blocks back (results unchanged), and kvx_dev_trim() returns the cached memory to the driver."""
+    from kvxopt_amd._lib import lib, raise_for
+    n, cp, ri, v = workloads.laplacian_2d(40, 33)
+    b = np.random.default_rng(5).standard_normal(n)
+    xs = []
+    for rep in range(3):
+        F = Factor(n, cp, ri)
+        F.factorize(v * (1.0 + rep))
+        x = b.copy()
+        F.solve(x)
+        xs.append(x * (1.0 + rep))
+        del F
+        if rep == 1:
+            raise_for(lib().kvx_dev_trim())
+    assert np.abs(xs[0] - xs[1]).max() < 1e-12 * np.abs(xs[0]).max() and np.abs(xs[0] - xs[2]).max() < 1e-12 * np.abs(xs[0]).max()
+    r = workloads.sym_matvec(n, cp, ri, v, xs[0]) - b
+    assert np.abs(r).max() < 1e-12 * np.abs(b).max()
