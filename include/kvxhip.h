@@ -131,25 +131,47 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);
  * prof_read returns the summed kernel time and launch count since the last select. */
 int kvx_chol_prof_select(kvx_chol *F, int family);
 int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches);
-/* ---- subtree-sharded mode: ONE system factored and solved by nranks processes, one GPU each ----------
- * (no reference counterpart -- the reference is single-process.)  Every rank analyses the same
- * matrix; kvx_chol_dist_setup cuts the elimination tree at depth `cut`: the subtrees below the cut are owned by
- * one rank each and only that rank factors / solves them, the top of the tree (depth < cut) is replicated.
- * The ONE real exchange step per factorisation is the update (Schur-complement) matrices of the subtree roots;
- * per solve, their update vectors up and the owned pieces of x back.  The library does no communication: each
- * phase leaves / expects the data to be summed over ranks (all-reduce SUM; non-owned parts are zero) in the
- * caller's device buffer `xchg` (kvxopt_amd/dist.py drives it with torch.distributed, RCCL on a real node).
- *   info[0] = cut depth, info[1] = doubles exchanged per factorisation, info[2] = doubles per solve and rhs
- *   (update vectors), info[3] = n;  xchg must hold max(info[1], max(info[2], n) * nrhs) doubles.            */
-int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner /* nsuper */, int *cut);   /* host-only: the partition */
-int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4]);
-/* phase 0: scatter A, factor this rank's subtrees, pack the root update matrices into xchg.  [all-reduce xchg]
- * phase 1: unpack, factor the replicated top; *minor as kvx_chol_factorize_dev (take the MIN over ranks). */
-int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg_dev, int64_t *minor);
-/* A x = b.  phase 0: permute b, forward-solve the owned subtrees, pack the root update vectors. [all-reduce]
- * phase 1: unpack, top forward + backward, owned subtrees backward, pack the owned entries of x.  [all-reduce]
- * phase 2: unpack x, un-permute into B_dev. */
-int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B_dev, int64_t nrhs, int64_t ldB, double *xchg_dev);
+/* ---- sharded mode: ONE system factored and solved by nranks processes, one GPU each ----------------------------
+ * (the reference is single-process: the calls this stands in for are cholmod_l_factorize / cholmod_l_solve,
+ * src/C/cholmod.c:362-364, 483.)  Every rank analyses the same matrix (the analysis is deterministic) and computes the
+ * same map (kvx_chol_dist_map): proportional mapping of the elimination tree gives every front a contiguous range of ranks;
+ *   - a range of one rank owns the front and its whole subtree: factored and solved by that rank alone;
+ *   - small fronts shared by several ranks are replicated on them (identical arithmetic, nothing exchanged inside the front);
+ *   - shared fronts of order >= min_m are block-cyclic: columns dealt out in blocks of `ob` columns round-robin over the
+ *     range; right-looking, the owner of a pivot block factors the panel and broadcasts it (the panel ends up on every rank
+ *     of the range), every rank applies the rank-ob update to the blocks it owns -- pivot columns and update matrix alike.
+ * Exchange steps, all broadcasts inside the range of the receiving front: a child's update matrix (its column blocks, from
+ * their owners) before the parent assembles; each factored panel; a child's update vector per solve.  One all-reduce over
+ * all ranks ends a solve (every rank contributes the entries of x it reports) and one MIN ends a factorisation (failing
+ * column).  No zero padding: only lower trapezoids of the blocks travel.
+ * The library is collective-agnostic: it packs a message into the caller's device buffer (kvx_chol_dist_set_xchg) and calls
+ * `comm` for every collective; kvxopt_amd/dist.py runs them with torch.distributed (backend "nccl" = RCCL over xGMI on a
+ * node, "gloo" in the tests), a C caller would call ncclBroadcast / ncclAllReduce on its stream.  Stream contract of the
+ * callback: the message is complete in null-stream order when `comm` is entered, and the collective's result must be
+ * visible in null-stream order when it returns (no host synchronisation needed).  Return nonzero to abort (KVX_ECOMM). */
+#define KVX_ECOMM         8   /* a collective callback failed -> RuntimeError */
+#define KVX_DIST_BCAST        1   /* buf[0..count) from global rank `root` to the ranks [lo, hi)            */
+#define KVX_DIST_ALLREDUCE    2   /* element-wise SUM over the ranks [lo, hi), result on every one of them   */
+#define KVX_DIST_ALLREDUCE_MIN 3  /* element-wise MIN                                                        */
+typedef struct { int32_t kind, root, lo, hi; int64_t count; double *buf_dev; } kvx_dist_op;
+typedef int (*kvx_dist_comm_fn)(void *ctx, const kvx_dist_op *op);
+/* host-only: the map for nranks ranks.  glo/ghi/mode: nsuper entries each (mode 0 = owned or replicated, 1 = block-cyclic);
+ * rank_flops / panel_flops: nranks doubles -- factorisation flops each rank executes, and the part of them that is panel
+ * factorisation of block-cyclic fronts; totals[0] = flops of all fronts (sum over fronts of sum_{j<k} (m-j)^2: the work executed, amalgamation zeros
+ * included), totals[1] = flops of the replicated shared fronts.
+ * Any output may be NULL.  ob <= 0 / min_m <= 0: defaults (512, 6144). */
+int kvx_chol_dist_map(kvx_chol *F, int nranks, int ob, int min_m, int32_t *glo, int32_t *ghi, uint8_t *mode,
+                      double *rank_flops, double *panel_flops, double totals[2]);
+/* info[0] = n, [1] = smallest exchange buffer (doubles), [2] = recommended, [3] = shared fronts this rank takes part in,
+ * [4] = of which block-cyclic, [5] = number of distinct rank ranges (kvx_chol_dist_groups), [6] = ob, [7] = min_m */
+int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int ob, int min_m, int64_t info[8]);
+int kvx_chol_dist_groups(kvx_chol *F, int32_t *lohi /* 2 * info[5] entries: lo, hi pairs; ranges of >= 2 ranks */);
+int kvx_chol_dist_set_xchg(kvx_chol *F, double *xchg_dev, int64_t count);
+/* numeric factorisation of the sharded factor; values_dev identical on all ranks.  *minor as kvx_chol_factorize_dev,
+ * already the minimum over the ranks (every rank returns the same status). */
+int kvx_chol_dist_factorize(kvx_chol *F, const double *values_dev, kvx_dist_comm_fn comm, void *ctx, int64_t *minor);
+/* A X = B in place: B_dev (n x nrhs, ld = ldB) identical on all ranks on entry, the full solution on every rank on return. */
+int kvx_chol_dist_solve(kvx_chol *F, double *B_dev, int64_t nrhs, int64_t ldB, kvx_dist_comm_fn comm, void *ctx);
 
 void kvx_chol_free(kvx_chol *F);
 void kvx_free(void *p);
@@ -277,6 +299,11 @@ int kvx_lu_sym_btf(kvx_lu_sym *S, int64_t *nblocks, int64_t *nlevels, int64_t *b
 /* numeric(A, Fs) -- klu.c:310-379 (klu_factor :336).  nnz must equal the analysed pattern's.  The symbolic
  * object is updated when fronts are merged (it must outlive the numeric object).
  * KVX_ESINGULAR -> ArithmeticError("singular matrix") (klu.c:370-371); KVX_EDEVICE: no GPU (never a CPU fallback). */
+/* Stream contract of every *_dev entry point of this header (Cholesky, LU, KKT): the library works on its own non-blocking
+ * streams; on entry it orders them behind whatever the caller has already submitted to the legacy null stream (torch's
+ * default stream, the kvx_nt_* / kvx_atda_* / kvx_spmv_* kernels), so a buffer written by a kernel immediately before the
+ * call is read after that kernel.  Synchronous entry points return with their results complete; the *_async_* ones order
+ * the null stream behind their own work instead. */
 int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num **out);
 int kvx_lu_factor_dev(kvx_lu_sym *S, int64_t nnz, const double *values_dev, kvx_lu_num **out);
 /* numeric with a previous factorisation (doc/source/spsolvers.rst:377-388: "a refactorization is performed"):

@@ -11,7 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVX_LIB_PATH") or os.path.join(_HERE, "libkvxhip.so")
 
-KVX_OK, KVX_EINVAL, KVX_ENOMEM, KVX_ENOTPOSDEF, KVX_ESYMBOLIC, KVX_ESINGULAR, KVX_EDEVICE, KVX_EPERM = range(8)
+KVX_OK, KVX_EINVAL, KVX_ENOMEM, KVX_ENOTPOSDEF, KVX_ESYMBOLIC, KVX_ESINGULAR, KVX_EDEVICE, KVX_EPERM, KVX_ECOMM = range(9)
+KVX_DIST_BCAST, KVX_DIST_ALLREDUCE, KVX_DIST_ALLREDUCE_MIN = 1, 2, 3
 
 i64 = ctypes.c_int64
 f64 = ctypes.c_double
@@ -24,6 +25,14 @@ class CholOpts(ctypes.Structure):
     _fields_ = [("supernodal", ctypes.c_int32), ("ordering", ctypes.c_int32), ("postorder", ctypes.c_int32),
                 ("relax_small", ctypes.c_int32), ("relax_z1", f64), ("relax_z2", f64), ("relax_z3", f64),
                 ("dbound", f64), ("reserved", ctypes.c_int32 * 8)]
+
+
+class DistOp(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("root", ctypes.c_int32), ("lo", ctypes.c_int32), ("hi", ctypes.c_int32),
+                ("count", ctypes.c_int64), ("buf_dev", ctypes.c_void_p)]
+
+
+DIST_COMM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(DistOp))
 
 
 class CholInfo(ctypes.Structure):
@@ -55,10 +64,13 @@ _SIGS = {
     "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
     "kvx_chol_prof_select": (ctypes.c_int, [vp, ctypes.c_int]),
     "kvx_chol_prof_read": (ctypes.c_int, [vp, f64p, i64p]),
-    "kvx_chol_dist_owner": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int)]),
-    "kvx_chol_dist_setup": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, i64p]),
-    "kvx_chol_dist_factor_phase": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, i64p]),
-    "kvx_chol_dist_solve_phase": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64, vp]),
+    "kvx_chol_dist_map": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                                         ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint8), f64p, f64p, f64p]),
+    "kvx_chol_dist_setup": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64p]),
+    "kvx_chol_dist_groups": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int32)]),
+    "kvx_chol_dist_set_xchg": (ctypes.c_int, [vp, vp, i64]),
+    "kvx_chol_dist_factorize": (ctypes.c_int, [vp, vp, DIST_COMM_FN, vp, i64p]),
+    "kvx_chol_dist_solve": (ctypes.c_int, [vp, vp, i64, i64, DIST_COMM_FN, vp]),
     "kvx_chol_free": (None, [vp]),
     "kvx_free": (None, [vp]),
     "kvx_atda_plan": (ctypes.c_int, [i64, i64, i64p, i64p, i64p, i64p, ctypes.POINTER(vp)]),

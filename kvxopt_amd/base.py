@@ -263,7 +263,9 @@ def _atda_plan(ml, n, Gp, Gi):
         Si = np.empty(max(snz.value, 1), dtype=np.int64)
         raise_for(lib().kvx_atda_pattern(h, ctypes.byref(snz), _lib.pi(Sp), _lib.pi(Si)))
         P = (h, Sp, Si[:snz.value].copy())
-        if len(_plans) > 16:
+        if len(_plans) > 16:                         # evict everything, releasing the device side of each plan
+            for old in _plans.values():
+                lib().kvx_atda_free(old[0])
             _plans.clear()
         _plans[key] = P
     return P
@@ -307,7 +309,6 @@ def syrk(A, C, uplo="L", trans="N", alpha=1.0, beta=0.0, partial=False):
     if partial:
         # fixed pattern of C: pick the entries of A'A that C stores (sparse.c:2176-2198)
         cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Sp))
-        full = dict()
         key_full = cols * n + Si
         key_c = np.repeat(np.arange(n, dtype=np.int64), np.diff(C.colptr)) * n + C.rowind
         pos = np.searchsorted(key_full, key_c)
@@ -326,10 +327,19 @@ def syrk(A, C, uplo="L", trans="N", alpha=1.0, beta=0.0, partial=False):
         C.size = (n, n)
 
 
-def gemv(A, x, y, trans="N", alpha=1.0, beta=0.0, m=None, n=None, offsetx=0, offsety=0):
-    """y := alpha*op(A)*x + beta*y (base.c:744 -> sparse.c:1073-1104 for sparse A)."""
+def gemv(A, x, y, trans="N", alpha=1.0, beta=0.0, m=None, n=None, incx=1, incy=1, offsetA=0, offsetx=0, offsety=0):
+    """y := alpha*op(A)*x + beta*y (base.c:744-851 -> sparse.c:1073-1104 for sparse A), with the reference's sub-block
+    selection: the product uses the m x n block of A whose top-left entry is A[offsetA % nrows, offsetA // nrows]
+    (m, n default to A's size), x / y are read and written with strides incx / incy from offsetx / offsety
+    (a negative stride walks the vector backwards, as in BLAS)."""
     xb, _ = _dense_buffer(x)
     yb, _ = _dense_buffer(y)
+    if trans not in ("N", "T"):
+        raise ValueError("possible values of trans are: 'N', 'T'")
+    if incx == 0:
+        raise ValueError("incx must be a nonzero integer")
+    if incy == 0:
+        raise ValueError("incy must be a nonzero integer")
     if isinstance(A, matrix) or isinstance(A, np.ndarray):
         # dense operand: every entry stored, same device kernel (no host arithmetic on the product path)
         Ad = np.asarray(A.a if isinstance(A, matrix) else A, dtype=np.float64)
@@ -338,16 +348,49 @@ def gemv(A, x, y, trans="N", alpha=1.0, beta=0.0, m=None, n=None, offsetx=0, off
         A = spmatrix.from_ccs(dm, dn, np.arange(dn + 1, dtype=np.int64) * dm, np.tile(np.arange(dm, dtype=np.int64), dn),
                               np.ascontiguousarray(Ad.T).reshape(-1))
     am, an, cp, ri, v = _as_ccs(A)
-    lx, ly = (an, am) if trans == "N" else (am, an)
+    m = am if m is None or m < 0 else int(m)
+    n = an if n is None or n < 0 else int(n)
+    if offsetA < 0:
+        raise ValueError("offsetA must be a nonnegative integer")
+    if n > 0 and m > 0 and offsetA + (n - 1) * max(1, am) + m > am * an:
+        raise TypeError("length of A is too small")
+    lx, ly = (n, m) if trans == "N" else (m, n)
+    if offsetx < 0 or offsety < 0:
+        raise ValueError("offsetx and offsety must be nonnegative integers")
+    if lx > 0 and offsetx + (lx - 1) * abs(incx) + 1 > xb.size:
+        raise TypeError("length of x is too small")
+    if ly > 0 and offsety + (ly - 1) * abs(incy) + 1 > yb.size:
+        raise TypeError("length of y is too small")
     if ly == 0:
         return
-    if lx == 0 or v.size == 0:
-        yb[offsety:offsety + ly] *= beta
+    ys = yb[offsety:offsety + (ly - 1) * abs(incy) + 1:abs(incy)]
+    if incy < 0:
+        # the reference scales y through BLAS dscal (sparse.c:1079), which returns at once for a non-positive stride:
+        # with incy < 0 beta is NOT applied.  Kept, so that the results agree (golden G13, case 5).
+        ys = ys[::-1]
+        beta = 1.0
+    if (m, n) != (am, an) or offsetA:
+        # the selected block as a CCS matrix of its own (index work only; the product runs on the device)
+        oi, oj = (offsetA % am, offsetA // am) if am else (0, 0)
+        lo, hi = int(cp[oj]), int(cp[oj + n])
+        rsel, vsel = ri[lo:hi], v[lo:hi]
+        keep = (rsel >= oi) & (rsel < oi + m)
+        col = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp[oj:oj + n + 1]))[keep]
+        cp = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(col, minlength=n), out=cp[1:])
+        ri, v = np.ascontiguousarray(rsel[keep] - oi), np.ascontiguousarray(vsel[keep])
+        am, an = m, n
+    if lx == 0 or v.size == 0 or m == 0:
+        # sparse.c:1079: y is scaled by beta and nothing is added (beta = 0 clears y, NaNs included)
+        ys[:] = 0.0 if beta == 0.0 else beta * ys
         return
+    xs = xb[offsetx:offsetx + (lx - 1) * abs(incx) + 1:abs(incx)]
+    if incx < 0:
+        xs = xs[::-1]
     _lib.require_device()
     d_cp, d_ri, d_v = DeviceBuffer.from_array(cp), DeviceBuffer.from_array(ri), DeviceBuffer.from_array(v)
-    d_x = DeviceBuffer.from_array(np.ascontiguousarray(xb[offsetx:offsetx + lx]))
-    d_y = DeviceBuffer.from_array(np.ascontiguousarray(yb[offsety:offsety + ly]))
+    d_x = DeviceBuffer.from_array(np.ascontiguousarray(xs))
+    d_y = DeviceBuffer.from_array(np.zeros(ly) if beta == 0.0 else np.ascontiguousarray(ys))
     raise_for(lib().kvx_spmv_dev(ord(trans), am, an, d_cp.ptr, d_ri.ptr, d_v.ptr, float(alpha), d_x.ptr, float(beta), d_y.ptr))
     raise_for(lib().kvx_dev_sync())
-    yb[offsety:offsety + ly] = d_y.download(np.float64, ly)
+    ys[:] = d_y.download(np.float64, ly)

@@ -56,11 +56,25 @@ def _check_options():
 class _F:
     """Opaque factor (the reference returns a PyCapsule named 'CHOLMOD SYM D FACTOR L'/'U')."""
 
-    def __init__(self, fac, uplo, pattern):
+    def __init__(self, fac, uplo, pattern, keep, tri):
         self.fac = fac
         self.uplo = uplo
-        self.pattern = pattern          # (colptr, rowind) analysed
+        self.pattern = pattern          # (colptr, rowind) of the matrix symbolic() was given
+        self.keep = keep                # mask of its entries inside the `uplo` triangle (None: all of them)
+        self.tri = tri                  # (colptr, rowind) of that triangle: what was analysed (cholmod.c:132-181 `pack`)
         self.name = "CHOLMOD SYM D FACTOR " + uplo
+
+
+def _triangle(n, cp, ri, uplo):
+    """The `uplo` triangle of a CCS pattern as the reference's pack() reads it (cholmod.c:137-157): entries in the
+    other triangle are ignored.  Returns (keep mask or None, colptr, rowind) of the triangle."""
+    col = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp))
+    keep = ri >= col if uplo == "L" else ri <= col
+    if keep.all():
+        return None, cp, ri
+    tcp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col[keep], minlength=n), out=tcp[1:])
+    return keep, tcp, ri[keep]
 
 
 def _sp(A, what="A"):
@@ -98,13 +112,14 @@ def symbolic(A, p=None, uplo="L"):
     q = _perm(p, n)
     if uplo not in ("L", "U"):
         raise ValueError("possible values of uplo are: 'L', 'U'")
+    keep, tcp, tri = _triangle(n, cp, ri, uplo)
     try:
-        fac = Factor(n, cp, ri, uplo, q, {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts})
+        fac = Factor(n, tcp, tri, uplo, q, {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts})
     except ValueError as e:
         if "permutation" in str(e):
             raise ValueError("p is not a valid permutation")
         raise
-    return _F(fac, uplo, (cp.copy(), ri.copy()))
+    return _F(fac, uplo, (cp.copy(), ri.copy()), keep, (tcp.copy(), tri.copy()))
 
 
 def numeric(A, F):
@@ -114,9 +129,19 @@ def numeric(A, F):
         raise TypeError("A is not a sparse matrix")
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
-    if n != F.fac.n or cp.size != F.pattern[0].size or ri.size != F.pattern[1].size:
-        raise ValueError("factorization failed")       # pattern differs from the analysed one
-    F.fac.factorize(v)                                   # ArithmeticError(minor) if not positive definite
+    if n != F.fac.n:
+        raise ValueError("factorization failed")
+    # only the `uplo` triangle counts (cholmod.c:137-157): same full pattern as analysed -> reuse its mask; otherwise the
+    # triangle of this A must have the analysed triangle's pattern exactly (same nnz with other positions is an error,
+    # a matrix that differs only in the ignored triangle is accepted)
+    if ri.size == F.pattern[1].size and np.array_equal(cp, F.pattern[0]) and np.array_equal(ri, F.pattern[1]):
+        vt = v if F.keep is None else v[F.keep]
+    else:
+        keep, tcp, tri = _triangle(n, cp, ri, F.uplo)
+        if tri.size != F.tri[1].size or not np.array_equal(tcp, F.tri[0]) or not np.array_equal(tri, F.tri[1]):
+            raise ValueError("factorization failed: A does not have the sparsity pattern of the symbolic factorization")
+        vt = v if keep is None else v[keep]
+    F.fac.factorize(vt)                                  # ArithmeticError(minor) if not positive definite
 
 
 def _solve_args(F, B, sys, nrhs, ldB, offsetB):

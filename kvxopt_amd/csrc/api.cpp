@@ -1,11 +1,7 @@
 // C-ABI of libkvxhip.so (include/kvxhip.h): host orchestration of the HIP path.
 // There is NO CPU fallback: every numeric entry point needs a HIP device and returns
 // KVX_EDEVICE otherwise.
-#include "../../include/kvxhip.h"
-#include "abi_guard.hpp"
-#include "devpool.hpp"
-#include "device.hpp"
-#include "symbolic.hpp"
+#include "chol_internal.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -20,114 +16,10 @@
 using namespace kvx;
 
 static thread_local std::string g_err;
-static void set_err(const std::string &s) { g_err = s; }
-namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // for the other translation units (lu_api.cpp)
+namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // (also used by lu_api.cpp, dist_api.cpp)
 
-#define HIPCHK(call)                                                                     \
-    do {                                                                                 \
-        hipError_t e_ = (call);                                                          \
-        if (e_ != hipSuccess) {                                                          \
-            set_err(std::string(#call) + ": " + hipGetErrorString(e_));                 \
-            return KVX_EDEVICE;                                                          \
-        }                                                                                \
-    } while (0)
 
-struct LevelPlan {
-    // fronts of the level grouped by kernel class (symbolic.hpp front_class), big first
-    int64_t off[KVX_NCLS];   // offset into d_lists of class c
-    int cnt[KVX_NCLS];
-    int maxm[KVX_NCLS];
-    int maxk[KVX_NCLS];
-    int big_maxk = 0;
-    int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
-    // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
-    int64_t soff[3];
-    int scnt[3];
-    int smaxm[3];
-};
-
-struct kvx_chol {
-    Symbolic S;
-    kvx_chol_opts opts;
-    bool dev_ready = false;
-    bool numeric = false;
-    bool pending = false;     // a factorisation was enqueued and its status not yet read
-    bool is_ll = true;        // false: the factor is presented as P A P' = L D L' (options['supernodal'] = 0, or 1 on a sparse factor)
-    double *d_diag = nullptr; // diag(Lc) for the LDL' view, extracted after every factorisation
-    bool diag_valid = false;
-    int64_t minor = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
-    hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool have_ftime = false, have_stime = false;
-    double ms_factor = 0, ms_solve = 0;
-
-    int32_t *d_k = nullptr, *d_m = nullptr, *d_first = nullptr, *d_rowidx = nullptr, *d_rel = nullptr,
-            *d_children = nullptr, *d_perm = nullptr, *d_lists = nullptr;
-    int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
-            *d_amap = nullptr;
-    double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
-    double *d_X = nullptr, *d_X0 = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;   // d_X0: untouched copy of the rhs for the forward sweep
-    double *d_Linv = nullptr;
-    int64_t *d_linv_off = nullptr;
-    FrontDesc *d_fd = nullptr;
-    ChildDesc *d_cd = nullptr;
-    int32_t *d_tiles = nullptr;
-    int64_t x_cap = 0;        // right-hand sides the solve workspace holds
-    int *d_status = nullptr;
-    int *h_status = nullptr;  // pinned
-    DevSym ds{};
-    // subtree-sharded mode (kvx_chol_dist_*): levels >= dist_cut hold only this rank's subtrees, levels < dist_cut
-    // (the top of the tree) are replicated on every rank
-    int dist_rank = 0, dist_nranks = 1, dist_cut = 0;
-    int64_t dist_ulen = 0, dist_wlen = 0;      // doubles of the update-matrix / update-vector region of level dist_cut
-    uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
-    std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
-    std::vector<int64_t> lptr_host;
-    int outer_block = 1024;    // columns per outer block of the two-level update (KVX_OUTER_BLOCK; a multiple of 64): config 5 runs at 33.3 / 37.5 / 38.6 / 37.4 TF/s with 256 / 512 / 1024 / 2048
-    int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
-    // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
-    SubDesc *d_subs = nullptr;
-    int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
-    int nsub = 0, nsub32 = 0;                  // subtrees; the first nsub32 hold only fronts of order <= 32
-    bool use_subtrees = true;
-    std::vector<SubDesc> subs_host;
-    std::vector<int32_t> cd_woff_host;
-    std::vector<uint8_t> in_sub;
-    std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
-    std::vector<int> sw_cnt, sw_kmax;
-    bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)
-    int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
-    std::vector<LevelPlan> plan;
-    // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
-    // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
-    bool use_graph = true;
-    int factor_calls = 0;
-    hipGraphExec_t g_factor = nullptr;
-    struct SolveGraph { int kind; int nrhs; int calls; hipGraphExec_t exec; };
-    std::vector<SolveGraph> g_solve;
-    // optional per-kernel-family timing (bench.py roofline leg): HIP events around every launch
-    // of ONE selected family on the factor's stream
-    int prof_family = -1;
-    std::vector<hipEvent_t> prof_ev;
-    size_t prof_used = 0;
-    double prof_ms = 0;
-    int64_t prof_launches = 0;
-};
-
-namespace {
-
-template <class T>
-int upload(T **dst, const std::vector<T> &src)
-{
-    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(pool_malloc((void **)dst, bytes));
-    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-    return KVX_OK;
-}
+namespace kvx {
 
 struct ProfScope {
     kvx_chol *F;
@@ -160,17 +52,16 @@ void prof_collect(kvx_chol *F)
 }
 
 
-// per-level launch plan from F->lists_host / F->lptr_host (the level lists already uploaded to d_lists)
-void build_plan(kvx_chol *F)
+// per-level launch plan of the level lists (lists / lptr: fronts grouped by level, each level sorted by kernel class)
+void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan)
 {
-    Symbolic &S = F->S;
-    F->plan.assign((size_t)S.nlevels, LevelPlan());
+    plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
-        LevelPlan &P = F->plan[l];
+        LevelPlan &P = plan[l];
         for (int c = 0; c < KVX_NCLS; c++) { P.off[c] = 0; P.cnt[c] = 0; P.maxm[c] = 0; P.maxk[c] = 0; }
         for (int g = 0; g < 3; g++) { P.soff[g] = 0; P.scnt[g] = 0; P.smaxm[g] = 0; }
-        for (int64_t q = F->lptr_host[l]; q < F->lptr_host[l + 1]; q++) {
-            int s = F->lists_host[q];
+        for (int64_t q = lptr[l]; q < lptr[l + 1]; q++) {
+            int s = lists[q];
             int m = S.sn_m[s], k = S.sn_k[s];
             int c = front_class(m, k);
             if (P.cnt[c] == 0) P.off[c] = q;
@@ -187,6 +78,17 @@ void build_plan(kvx_chol *F)
             P.smaxm[g] = std::max(P.smaxm[g], m);
         }
     }
+}
+
+// from F->lists_host / F->lptr_host (the level lists already uploaded to d_lists)
+void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host, F->plan); }
+
+void destroy_graphs(kvx_chol *F)
+{
+    if (F->g_factor) { (void)hipGraphExecDestroy(F->g_factor); F->g_factor = nullptr; }
+    for (auto &g : F->g_solve)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    F->g_solve.clear();
 }
 
 // Leaf subtrees for the solves: maximal subtrees made of wave-class fronts only, small enough for one wavefront
@@ -353,7 +255,7 @@ int ensure_device(kvx_chol *F)
     HIPCHK(pool_malloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
     HIPCHK(pool_malloc((void **)&F->d_status, sizeof(int)));
     HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
-    std::vector<int64_t> loff_host;
+    std::vector<int64_t> &loff_host = F->linv_off_host;
     {
         // inverted diagonal blocks of the big fronts: ceil(k/NB) blocks of NB x NB each
         std::vector<int64_t> &loff = loff_host;
@@ -454,7 +356,7 @@ int wait_for_caller(kvx_chol *F)
 
 // enqueue the numeric factorisation; d_Ax already holds the values
 // levels lfrom, lfrom - 1, ..., lto; prologue = zero L, reset the status word, scatter A; epilogue = fetch the status
-int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue = true, bool epilogue = true)
+int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epilogue)
 {
     Symbolic &S = F->S;
     hipStream_t st = F->stream;
@@ -464,8 +366,9 @@ int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue 
         { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
     }
     if (lfrom < 0) lfrom = S.nlevels - 1;
+    const int32_t *lbase = F->fplan_on ? F->d_flists : F->d_lists;
     for (int l = lfrom; l >= lto; l--) {
-        const LevelPlan &P = F->plan[l];
+        const LevelPlan &P = F->fplan_on ? F->fplan[l] : F->plan[l];
         double *Uout = F->d_U[l & 1];
         const double *Uch = F->d_U[(l + 1) & 1];
         // The fronts of one level are independent.  The big-front chain keeps the main stream; the small-
@@ -512,13 +415,13 @@ int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue 
             hipStream_t sl = it.stream == 0 ? st : F->side[it.stream - 1];
             ProfScope ps(F, FAM_SMALL, sl);
             if (it.c < KVX_CLS_WAVE0)
-                launch_front_small(sl, it.c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[it.c] <= 32 ? 32 : 64, F->ds, F->d_lists + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
+                launch_front_small(sl, it.c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[it.c] <= 32 ? 32 : 64, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
             else    // the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
-                launch_front_wave(sl, wave_class_mcap(it.c), P.cnt[it.c] > 0 ? 32 : 16, F->ds, F->d_lists + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
+                launch_front_wave(sl, wave_class_mcap(it.c), P.cnt[it.c] > 0 ? 32 : 16, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
         if (have_big) {
             const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
-            const int32_t *list = F->d_lists + P.off[KVX_CLS_BIG];
+            const int32_t *list = lbase + P.off[KVX_CLS_BIG];
             { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             if (bigm >= F->two_level_m) {
@@ -570,6 +473,7 @@ hipGraphExec_t capture_graph(kvx_chol *F, Body body)
 
 int enqueue_factor(kvx_chol *F)
 {
+    if (F->dist_nranks > 1) { set_err("sharded factor: use kvx_chol_dist_factorize"); return KVX_EINVAL; }
     hipStream_t st = F->stream;
     HIPCHK(hipEventRecord(F->ev[0], st));
     const bool graph_ok = F->use_graph && F->prof_family < 0;
@@ -631,7 +535,7 @@ struct LevelStreams {
     }
 };
 
-void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0)
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int lto)
 {
     Symbolic &S = F->S;
     const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
@@ -674,7 +578,7 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, 
     }
 }
 
-void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, int lto = -1)
+void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int lto)
 {
     Symbolic &S = F->S;
     if (lto < 0) lto = S.nlevels - 1;
@@ -803,7 +707,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     return KVX_OK;
 }
 
-}  // namespace
+}  // namespace kvx
 
 extern "C" {
 
@@ -1155,164 +1059,6 @@ int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches)
     return KVX_OK;
 }
 
-// ---- subtree-sharded mode ------------------------------------------------------------------------
-static int kvx_chol_dist_owner_impl(kvx_chol *F, int nranks, int32_t *owner, int *cut)
-{
-    if (!F || nranks < 1 || !owner || !cut) return KVX_EINVAL;
-    std::vector<int32_t> ow;
-    int c = 0;
-    dist_partition(F->S, nranks, ow, c);
-    std::copy(ow.begin(), ow.end(), owner);
-    *cut = c;
-    return KVX_OK;
-}
-
-int kvx_chol_dist_owner(kvx_chol *F, int nranks, int32_t *owner, int *cut)
-{
-    return guarded([&] { return kvx_chol_dist_owner_impl(F, nranks, owner, cut); });
-}
-
-static int kvx_chol_dist_setup_impl(kvx_chol *F, int rank, int nranks, int64_t info[4])
-{
-    if (!F || nranks < 1 || rank < 0 || rank >= nranks || !info) return KVX_EINVAL;
-    int rc = ensure_device(F);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(F->stream));
-    Symbolic &S = F->S;
-    std::vector<int32_t> owner;
-    int cut = 0;
-    dist_partition(S, nranks, owner, cut);
-    // level lists: the top unfiltered, the levels from the cut down hold this rank's fronts only
-    F->lists_host.clear();
-    F->lptr_host.assign((size_t)S.nlevels + 1, 0);
-    for (int l = 0; l < S.nlevels; l++) {
-        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
-            const int32_t s = S.levellist[q];
-            if (nranks == 1 || l < cut || owner[s] == rank) F->lists_host.push_back(s);
-        }
-        F->lptr_host[l + 1] = (int64_t)F->lists_host.size();
-    }
-    if (F->d_lists) { HIPCHK(pool_free(F->d_lists)); F->d_lists = nullptr; }
-    if ((rc = upload(&F->d_lists, F->lists_host))) return rc;
-    build_plan(F);
-    F->dist_nranks = nranks;                         // (sharded mode keeps the subtrees in the level lists)
-    if ((rc = build_subtrees(F))) return rc;
-    if (F->g_factor) { (void)hipGraphExecDestroy(F->g_factor); F->g_factor = nullptr; }
-    for (auto &g : F->g_solve)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    F->g_solve.clear();
-    // regions of the parity buffers used by level `cut` (all of its fronts, owned or not)
-    int64_t ulen = 0, wlen = 0;
-    if (nranks > 1)
-        for (int64_t q = S.levelptr[cut]; q < S.levelptr[cut + 1]; q++) {
-            const int32_t s = S.levellist[q];
-            const int64_t u = S.sn_m[s] - S.sn_k[s];
-            ulen = std::max(ulen, S.ux[s] + u * u);
-            wlen = std::max(wlen, S.wx[s] + u);
-        }
-    // which entries of x this rank reports: its own subtrees' pivots; rank 0 also the top's
-    std::vector<uint8_t> keep((size_t)std::max<int64_t>(S.n, 1), 0);
-    for (int64_t s = 0; s < S.nsuper; s++) {
-        const bool mine = nranks == 1 || (S.depth[s] < cut ? rank == 0 : owner[s] == rank);
-        if (mine)
-            for (int64_t j = S.super[s]; j < S.super[s + 1]; j++) keep[j] = 1;
-    }
-    if (F->d_keep) { HIPCHK(pool_free(F->d_keep)); F->d_keep = nullptr; }
-    if ((rc = upload(&F->d_keep, keep))) return rc;
-    F->dist_rank = rank; F->dist_nranks = nranks; F->dist_cut = nranks == 1 ? 0 : cut;
-    F->dist_ulen = ulen; F->dist_wlen = wlen;
-    info[0] = F->dist_cut; info[1] = ulen; info[2] = wlen; info[3] = S.n;
-    return KVX_OK;
-}
-
-int kvx_chol_dist_setup(kvx_chol *F, int rank, int nranks, int64_t info[4])
-{
-    return guarded([&] { return kvx_chol_dist_setup_impl(F, rank, nranks, info); });
-}
-
-static int kvx_chol_dist_factor_phase_impl(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
-{
-    if (!F || !F->dev_ready || phase < 0 || phase > 1) return KVX_EINVAL;
-    Symbolic &S = F->S;
-    hipStream_t st = F->stream;
-    const int cut = F->dist_cut;
-    double *Ucut = F->d_U[cut & 1];
-    int rc;
-    if (phase == 0) {
-        if ((rc = wait_for_caller(F))) return rc;
-        if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipEventRecord(F->ev[0], st));
-        // phase 0 covers the levels nlevels-1 .. cut; the update matrices of level `cut` that other ranks own stay zero
-        HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
-        HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));
-        launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx);
-        if (cut == 0) return KVX_OK;                 // single rank: everything happens in phase 1
-        // deeper levels of the same parity run first and overwrite the region: zero it when level cut+1 is done
-        if ((rc = enqueue_factor_body(F, S.nlevels - 1, cut + 1, false, false))) return rc;
-        if (F->dist_ulen > 0) HIPCHK(hipMemsetAsync(Ucut, 0, F->dist_ulen * sizeof(double), st));
-        if ((rc = enqueue_factor_body(F, cut, cut, false, false))) return rc;
-        if (F->dist_ulen > 0) HIPCHK(hipMemcpyAsync(xchg, Ucut, F->dist_ulen * sizeof(double), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        return KVX_OK;
-    }
-    if ((rc = wait_for_caller(F))) return rc;
-    if (cut > 0 && F->dist_ulen > 0) HIPCHK(hipMemcpyAsync(Ucut, xchg, F->dist_ulen * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if ((rc = enqueue_factor_body(F, cut == 0 ? S.nlevels - 1 : cut - 1, 0, false, true))) return rc;
-    HIPCHK(hipEventRecord(F->ev[1], st));
-    F->pending = true;
-    F->have_ftime = false;
-    return finish_factor(F, minor);
-}
-
-int kvx_chol_dist_factor_phase(kvx_chol *F, int phase, const double *values_dev, double *xchg, int64_t *minor)
-{
-    return guarded([&] { return kvx_chol_dist_factor_phase_impl(F, phase, values_dev, xchg, minor); });
-}
-
-static int kvx_chol_dist_solve_phase_impl(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
-{
-    if (!F || !F->dev_ready || phase < 0 || phase > 2 || nrhs < 1 || nrhs > 65535) return KVX_EINVAL;
-    if (!F->numeric) { set_err("called with symbolic factor"); return KVX_ESYMBOLIC; }
-    if (F->minor < F->S.n) { set_err("singular matrix"); return KVX_ESINGULAR; }
-    Symbolic &S = F->S;
-    hipStream_t st = F->stream;
-    const int64_t n = S.n;
-    const int nr = (int)nrhs, cut = F->dist_cut;
-    const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
-    int rc;
-    if ((rc = ensure_solve_ws(F, nr))) return rc;
-    if ((rc = wait_for_caller(F))) return rc;
-    double *Wcut = F->d_W[cut & 1];
-    const size_t wbytes = (size_t)F->dist_wlen * sizeof(double);
-    if (phase == 0) {
-        launch_perm_gather(st, F->d_perm, n, nr, B, ldB, F->d_X, n);
-        HIPCHK(hipMemcpyAsync(F->d_X0, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
-        if (cut > 0) {
-            enqueue_fwd(F, F->d_X, n, nr, S.nlevels - 1, cut + 1);
-            if (wbytes) HIPCHK(hipMemset2DAsync(Wcut, wstride * sizeof(double), 0, wbytes, nr, st));
-            enqueue_fwd(F, F->d_X, n, nr, cut, cut);
-            if (wbytes) HIPCHK(hipMemcpy2DAsync(xchg, wbytes, Wcut, wstride * sizeof(double), wbytes, nr, hipMemcpyDeviceToDevice, st));
-        }
-    } else if (phase == 1) {
-        if (cut > 0 && wbytes) HIPCHK(hipMemcpy2DAsync(Wcut, wstride * sizeof(double), xchg, wbytes, wbytes, nr, hipMemcpyDeviceToDevice, st));
-        enqueue_fwd(F, F->d_X, n, nr, cut == 0 ? S.nlevels - 1 : cut - 1, 0);
-        enqueue_bwd(F, F->d_X, n, nr, 0, S.nlevels - 1);           // levels >= cut hold only the owned fronts
-        if (F->dist_nranks > 1) launch_mask_rows(st, F->d_keep, n, nr, F->d_X, n);
-        HIPCHK(hipMemcpyAsync(xchg, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
-    } else {
-        HIPCHK(hipMemcpyAsync(F->d_X, xchg, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, st));
-        launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, B, ldB);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
-    return KVX_OK;
-}
-
-int kvx_chol_dist_solve_phase(kvx_chol *F, int phase, double *B, int64_t nrhs, int64_t ldB, double *xchg)
-{
-    return guarded([&] { return kvx_chol_dist_solve_phase_impl(F, phase, B, nrhs, ldB, xchg); });
-}
-
 void kvx_chol_free(kvx_chol *F)
 {
     if (!F) return;
@@ -1320,8 +1066,8 @@ void kvx_chol_free(kvx_chol *F)
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
     auto lap = [&](const char *what) { if (tim) { auto t1 = now(); fprintf(stderr, "  free %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
-    if (F->dev_ready) {
-        (void)hipStreamSynchronize(F->stream);
+    {                                              // (also after a device set-up that failed half way: every member starts out null)
+        if (F->stream) (void)hipStreamSynchronize(F->stream);
         lap("sync");
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
                         F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
@@ -1344,6 +1090,8 @@ void kvx_chol_free(kvx_chol *F)
             if (F->ev_join[i]) pool_event_put(F->ev_join[i], false);
         }
         if (F->d_keep) (void)pool_free(F->d_keep);
+        if (F->d_flists) (void)pool_free(F->d_flists);
+        dist_release(F);
         for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);

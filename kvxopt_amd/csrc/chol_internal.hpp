@@ -1,0 +1,142 @@
+// Internal (library-private) view of the Cholesky factor object shared by api.cpp and dist_api.cpp.
+#pragma once
+#include "../../include/kvxhip.h"
+#include "abi_guard.hpp"
+#include "devpool.hpp"
+#include "device.hpp"
+#include "symbolic.hpp"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace kvx { void set_last_error(const std::string &s); struct DistState; }
+#define set_err(s) ::kvx::set_last_error(s)
+using namespace kvx;
+
+#define HIPCHK(call)                                                                     \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            set_err(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return KVX_EDEVICE;                                                          \
+        }                                                                                \
+    } while (0)
+
+struct LevelPlan {
+    // fronts of the level grouped by kernel class (symbolic.hpp front_class), big first
+    int64_t off[KVX_NCLS];   // offset into d_lists of class c
+    int cnt[KVX_NCLS];
+    int maxm[KVX_NCLS];
+    int maxk[KVX_NCLS];
+    int big_maxk = 0;
+    int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
+    // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
+    int64_t soff[3];
+    int scnt[3];
+    int smaxm[3];
+};
+
+struct kvx_chol {
+    Symbolic S;
+    kvx_chol_opts opts;
+    bool dev_ready = false;
+    bool numeric = false;
+    bool pending = false;     // a factorisation was enqueued and its status not yet read
+    bool is_ll = true;        // false: the factor is presented as P A P' = L D L' (options['supernodal'] = 0, or 1 on a sparse factor)
+    double *d_diag = nullptr; // diag(Lc) for the LDL' view, extracted after every factorisation
+    bool diag_valid = false;
+    int64_t minor = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
+    hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool have_ftime = false, have_stime = false;
+    double ms_factor = 0, ms_solve = 0;
+
+    int32_t *d_k = nullptr, *d_m = nullptr, *d_first = nullptr, *d_rowidx = nullptr, *d_rel = nullptr,
+            *d_children = nullptr, *d_perm = nullptr, *d_lists = nullptr;
+    int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
+            *d_amap = nullptr;
+    double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
+    double *d_X = nullptr, *d_X0 = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;   // d_X0: untouched copy of the rhs for the forward sweep
+    double *d_Linv = nullptr;
+    int64_t *d_linv_off = nullptr;
+    FrontDesc *d_fd = nullptr;
+    ChildDesc *d_cd = nullptr;
+    int32_t *d_tiles = nullptr;
+    int64_t x_cap = 0;        // right-hand sides the solve workspace holds
+    int *d_status = nullptr;
+    int *h_status = nullptr;  // pinned
+    DevSym ds{};
+    // sharded mode (kvx_chol_dist_*, dist_api.cpp): the level lists hold only the fronts this rank takes part in; the
+    // factorisation additionally leaves out the block-cyclic fronts (factored by dist_api.cpp's panel loop): fplan / d_flists
+    int dist_rank = 0, dist_nranks = 1;
+    kvx::DistState *dist = nullptr;
+    bool fplan_on = false;
+    std::vector<LevelPlan> fplan;
+    int32_t *d_flists = nullptr;
+    std::vector<int64_t> linv_off_host;        // per front: offset of its inverted diagonal blocks in d_Linv (-1: not a big front)
+    uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
+    std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
+    std::vector<int64_t> lptr_host;
+    int outer_block = 1024;    // columns per outer block of the two-level update (KVX_OUTER_BLOCK; a multiple of 64): config 5 runs at 33.3 / 37.5 / 38.6 / 37.4 TF/s with 256 / 512 / 1024 / 2048
+    int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
+    // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
+    SubDesc *d_subs = nullptr;
+    int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
+    int nsub = 0, nsub32 = 0;                  // subtrees; the first nsub32 hold only fronts of order <= 32
+    bool use_subtrees = true;
+    std::vector<SubDesc> subs_host;
+    std::vector<int32_t> cd_woff_host;
+    std::vector<uint8_t> in_sub;
+    std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
+    std::vector<int> sw_cnt, sw_kmax;
+    bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)
+    int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
+    std::vector<LevelPlan> plan;
+    // hipGraph replay of the (static) launch sequences: captured on the second call, replayed after.
+    // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
+    bool use_graph = true;
+    int factor_calls = 0;
+    hipGraphExec_t g_factor = nullptr;
+    struct SolveGraph { int kind; int nrhs; int calls; hipGraphExec_t exec; };
+    std::vector<SolveGraph> g_solve;
+    // optional per-kernel-family timing (bench.py roofline leg): HIP events around every launch
+    // of ONE selected family on the factor's stream
+    int prof_family = -1;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_ms = 0;
+    int64_t prof_launches = 0;
+};
+
+namespace kvx {
+
+template <class T>
+int upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(pool_malloc((void **)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KVX_OK;
+}
+
+// api.cpp
+void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan);
+void build_plan(kvx_chol *F);
+int build_subtrees(kvx_chol *F);
+int ensure_device(kvx_chol *F);
+int ensure_solve_ws(kvx_chol *F, int64_t nrhs);
+int wait_for_caller(kvx_chol *F);
+int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue = true, bool epilogue = true);
+int finish_factor(kvx_chol *F, int64_t *minor);
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0);
+void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, int lto = -1);
+void destroy_graphs(kvx_chol *F);
+// dist_api.cpp
+void dist_release(kvx_chol *F);
+
+}  // namespace kvx

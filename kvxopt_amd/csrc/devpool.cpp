@@ -78,7 +78,14 @@ hipError_t pool_free(void *p)
     g_live.erase(it);
     if (bytes > MAX_BLOCK || cache_cap() == 0 || g_cached + bytes > cache_cap()) { lk.unlock(); return hipFree(p); }
     lk.unlock();
-    hipError_t e = hipDeviceSynchronize();          // what hipFree guarantees: nothing in flight still touches the block
+    hipError_t e;
+    {                                               // what hipFree guarantees: nothing in flight on the BLOCK's device still touches it
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != key.dev) (void)hipSetDevice(key.dev);
+        e = hipDeviceSynchronize();
+        if (cur != key.dev) (void)hipSetDevice(cur);
+    }
     lk.lock();
     g_free.emplace(key, p);
     g_cached += bytes;

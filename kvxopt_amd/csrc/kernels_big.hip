@@ -426,9 +426,20 @@ union SyrkLds {
 // update of the two-level blocking, which is what makes this kernel pay: four times the flops per pass over C).
 // (launch bound: two waves per SIMD -- the 128 accumulator registers live in AGPRs, the rest must fit 128 VGPRs;
 // at one wave per SIMD nothing hides the staging loads and the kernel ran at 21 TF/s)
+// DIST (sharded mode, dist_api.cpp): the columns of the front are dealt out in blocks of own.ob columns, round-robin over
+// own.g ranks -- the pivot columns from column 0, the update columns from column k on (so that the blocks of the update
+// matrix do not depend on k mod ob); this rank (own.r) updates only the columns it owns and the next diagonal block is
+// factored by a launch of its own (its owner is whoever owns the block, not this kernel's (0, 0) tile).
+struct ColOwner { int ob, g, r; };
+__device__ __forceinline__ bool col_owned(const ColOwner &o, int c, int k, int nkb)
+{
+    const int blk = c < k ? c / o.ob : nkb + (c - k) / o.ob;
+    return blk % o.g == o.r;
+}
+template <bool DIST>
 __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
                                                           double *__restrict__ Lx, double *__restrict__ Uo,
-                                                          double *__restrict__ Linv, int *status)
+                                                          double *__restrict__ Linv, int *status, ColOwner own)
 {
     __shared__ SyrkLds lds;
     // XCD-aware tile order: workgroup ids go round-robin over the 8 XCDs, each with its own 4 MB L2.  The lower
@@ -455,6 +466,16 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
     const int t0 = kb + nbk;
     const int r0 = t0 + SY_T * ti, c0 = t0 + SY_T * tj;
     if (r0 >= m) return;
+    const int nkb = DIST ? (k + own.ob - 1) / own.ob : 0;
+    if (DIST) {                                                    // workgroup-uniform: a tile without a column of this rank
+        bool any = false;
+        for (int c = c0; c < min(c0 + SY_T, m) && !any; ) {
+            any = col_owned(own, c, k, nkb);
+            const int step = c < k ? min(own.ob - c % own.ob, k - c) : own.ob - (c - k) % own.ob;   // first column of the next block
+            c += step;
+        }
+        if (!any) return;
+    }
     double *P = Lx + fd.px;
     double *U = Uo + fd.ux;
     const int tid = threadIdx.x;
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
         // iteration writes it before its own barrier, so one barrier per chunk suffices
     }
     // epilogue: lane holds C[row = .. + 16 s2 + lr][col = .. + 16 t + lk + 4 q]; branch-free RMW in batches of 16
-    const bool fuse = ti == 0 && tj == 0 && t0 < k;               // workgroup-uniform
+    const bool fuse = !DIST && ti == 0 && tj == 0 && t0 < k;      // workgroup-uniform
     const int nb2 = min(NB, k - t0);
     if (fuse) __syncthreads();                                     // staging buffers are about to become the potrf image
     if (active) {
@@ -536,7 +557,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int c = c0 + 64 * wc + 16 * t + lk + 4 * q;
-                    ok[t][q] = rin && c <= rr;
+                    ok[t][q] = rin && c <= rr && (!DIST || col_owned(own, c, k, nkb));
                     const int cs = min(c, rs);
                     ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
                     old[t][q] = *ptr[t][q];
@@ -584,7 +605,7 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     const char *e = getenv("KVX_SYRK128_TILES");
     const int64_t big_limit = e ? atoll(e) : INT64_MAX;
     if (T * (T + 1) / 2 * count >= big_limit) {
-        hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status);
+        hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0});
     } else {                                          // latency regime: more, smaller workgroups
         hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
@@ -612,7 +633,17 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (count <= 0) return;
     int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trailing128, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status);
+    hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0});
+}
+
+// sharded mode: the rank-ob_len update of the columns this rank owns (block-cyclic, see ColOwner); no fused factorisation
+void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,
+                            int own_ob, int own_g, int own_r, double *Lx, double *Uout)
+{
+    int rows = max_m - ob - 1;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_syrk_trailing128<true>, syrk128_grid(rows, 1), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout,
+                       (double *)nullptr, (int *)nullptr, ColOwner{own_ob, own_g, own_r});
 }
 
 // ------------------------------------------------------------------------------------------

@@ -170,6 +170,16 @@ int lds_class(int m)
     return KVX_LU_LDS_M;
 }
 
+// Device-pointer entry points: the caller's producers (torch's default stream, the kvx_* kernels of the KKT layer) run on
+// the legacy null stream, N->st is non-blocking: order it behind them explicitly (st2 / st3 fork from st).  Same contract
+// as the Cholesky path (api.cpp wait_for_caller); documented in include/kvxhip.h.
+int lu_wait_for_caller(kvx_lu_num *N)
+{
+    HIPCHK(hipEventRecord(N->ev0, nullptr));
+    HIPCHK(hipStreamWaitEvent(N->st, N->ev0, 0));
+    return KVX_OK;
+}
+
 // One numeric pass over the current plan.  fail_host receives the per-front flags.
 int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int32_t> &fail_host)
 {
@@ -464,7 +474,7 @@ static int kvx_lu_factor_dev_impl(kvx_lu_sym *S, int64_t nnz, const double *valu
     int rc = new_numeric(S, nnz, out);
     if (rc) return rc;
     kvx_lu_num *N = *out;
-    if ((rc = ensure_device(N)) || (rc = factor_loop(N, values_dev, 0))) { kvx_lu_free_numeric(N); *out = nullptr; return rc; }
+    if ((rc = ensure_device(N)) || (rc = lu_wait_for_caller(N)) || (rc = factor_loop(N, values_dev, 0))) { kvx_lu_free_numeric(N); *out = nullptr; return rc; }
     return KVX_OK;
 }
 
@@ -493,6 +503,7 @@ int kvx_lu_factor(kvx_lu_sym *S, int64_t nnz, const double *values, kvx_lu_num *
 static int kvx_lu_refactor_dev_impl(kvx_lu_num *N, int64_t nnz, const double *values_dev)
 {
     if (!N || nnz != N->nnz) return KVX_EINVAL;
+    if (int rc = lu_wait_for_caller(N)) return rc;
     if (!N->factored) return factor_loop(N, values_dev, 0);
     return factor_loop(N, values_dev, 1);
 }
@@ -521,6 +532,7 @@ static int kvx_lu_solve_dev_impl(kvx_lu_num *N, int trans, double *B_dev, int64_
     if (nrhs == 0) return KVX_OK;
     int rc = ensure_rhs(N, nrhs);
     if (rc) return rc;
+    if ((rc = lu_wait_for_caller(N))) return rc;
     if ((rc = solve_on_device(N, trans, B_dev, nrhs, ldB))) return rc;
     HIPCHK(hipStreamSynchronize(N->st));
     return KVX_OK;

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <exception>
 #include <thread>
 
 namespace kvx {
@@ -297,38 +298,52 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
         std::condition_variable cv;
         std::vector<NDTask> pool{NDTask{0, n, 0}};
         int busy = 0;                               // tasks taken and not finished (guarded by mu)
+        std::exception_ptr failure;                 // first exception of any worker (guarded by mu); rethrown on the caller
+        bool stop = false;
         auto worker = [&]() {
-            NDWorker wk;
-            std::vector<NDTask> out;
-            for (;;) {
-                NDTask t;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return !pool.empty() || busy == 0; });
-                    if (pool.empty()) return;       // nothing queued and nobody who could queue more
-                    t = pool.back();
-                    pool.pop_back();
-                    busy++;
+            try {
+                NDWorker wk;
+                std::vector<NDTask> out;
+                for (;;) {
+                    NDTask t;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || !pool.empty() || busy == 0; });
+                        if (stop || pool.empty()) return;   // failed elsewhere / nothing queued and nobody who could queue more
+                        t = pool.back();
+                        pool.pop_back();
+                        busy++;
+                    }
+                    try {
+                        out.clear();
+                        if (t.hi - t.lo < cutoff) nd_run_local(st, wk, t, leaf);
+                        else nd_step(st, wk, t, leaf, out);
+                        std::lock_guard<std::mutex> lk(mu);
+                        for (const NDTask &c : out) pool.push_back(c);
+                        busy--;
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (!failure) failure = std::current_exception();
+                        stop = true;
+                        busy--;
+                    }
+                    cv.notify_all();
                 }
-                if (t.hi - t.lo < cutoff) {
-                    nd_run_local(st, wk, t, leaf);
-                    out.clear();
-                } else {
-                    out.clear();
-                    nd_step(st, wk, t, leaf, out);
-                }
-                {
-                    std::lock_guard<std::mutex> lk(mu);
-                    for (const NDTask &c : out) pool.push_back(c);
-                    busy--;
-                }
+            } catch (...) {                         // allocation of the worker's own state
+                std::lock_guard<std::mutex> lk(mu);
+                if (!failure) failure = std::current_exception();
+                stop = true;
                 cv.notify_all();
             }
         };
         std::vector<std::thread> th;
-        for (int i = 1; i < nthreads; i++) th.emplace_back(worker);
+        try {
+            for (int i = 1; i < nthreads; i++) th.emplace_back(worker);
+        } catch (...) {                             // could not start every thread: the ones running finish the work
+        }
         worker();
         for (auto &x : th) x.join();
+        if (failure) std::rethrow_exception(failure);   // -> KVX_ENOMEM / KVX_EINVAL at the C ABI (abi_guard.hpp, kvx_chol_analyze)
     }
     for (int64_t i = 0; i < n; i++) perm[(size_t)i] = st.verts[(size_t)i];
 }

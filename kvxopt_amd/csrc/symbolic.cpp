@@ -472,48 +472,110 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         }
 }
 
-void dist_partition(const Symbolic &S, int nranks, std::vector<int32_t> &owner, int &cut)
+// flops of eliminating the k pivots of a front of order m: sum_{j < k} (m - j)^2
+static double front_flops(double m, double k)
+{
+    auto S2 = [](double x) { return x * (x + 1.0) * (2.0 * x + 1.0) / 6.0; };
+    return S2(m) - S2(m - k);
+}
+
+void dist_map(const Symbolic &S, int nranks, int ob, int min_m, DistMap &M)
 {
     const int64_t ns = S.nsuper;
-    owner.assign((size_t)ns, -1);
-    cut = 0;
-    if (nranks <= 1 || S.nlevels <= 1) { cut = 0; std::fill(owner.begin(), owner.end(), 0); return; }
-    // subtree work: children precede parents in the postordered supernode numbering
+    M.nranks = std::max(nranks, 1);
+    M.ob = std::max(64, ob / 64 * 64);
+    M.min_m = min_m;
+    M.glo.assign((size_t)ns, 0);
+    M.ghi.assign((size_t)ns, 1);
+    M.mode.assign((size_t)ns, 0);
+    M.rank_flops.assign((size_t)M.nranks, 0.0);
+    M.rank_panel_flops.assign((size_t)M.nranks, 0.0);
+    M.total_flops = 0.0;
+    M.replicated_flops = 0.0;
+    const int P = M.nranks;
+    // subtree work (children precede parents in the postordered numbering)
     std::vector<double> wsub((size_t)ns, 0.0);
     for (int64_t s = 0; s < ns; s++) {
-        const double m = S.sn_m[s], k = S.sn_k[s];
-        wsub[s] += k * m * m + 1.0;
+        wsub[s] += front_flops(S.sn_m[s], S.sn_k[s]) + 1.0;
         if (S.sparent[s] >= 0) wsub[S.sparent[s]] += wsub[s];
     }
-    // the cut depth minimises (replicated work above the cut) + (largest per-rank sum of subtree work below it),
-    // subtrees assigned longest-first to the least loaded rank
-    auto lpt = [&](int d, std::vector<int32_t> *assign) {
-        std::vector<int32_t> roots;
-        for (int64_t q = S.levelptr[d]; q < S.levelptr[d + 1]; q++) roots.push_back(S.levellist[q]);
-        std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
-        std::vector<double> load((size_t)nranks, 0.0);
-        for (int32_t r : roots) {
-            int best = 0;
-            for (int t = 1; t < nranks; t++)
-                if (load[t] < load[best]) best = t;
-            if (assign) (*assign)[r] = best;
-            load[best] += wsub[r];
+    // Proportional mapping, top down: a front worked on by the ranks [lo, hi) hands each child a contiguous window of them
+    // whose width follows the child's share of the work below the front; a child whose share is below 1.5 ranks goes to ONE
+    // rank (the least loaded), and from there down its whole subtree belongs to that rank.
+    auto assign_children = [&](std::vector<int32_t> &ch, int lo, int hi) {
+        const int g = hi - lo;
+        if (g <= 1) {
+            for (int32_t c : ch) { M.glo[c] = lo; M.ghi[c] = lo + 1; }
+            return;
         }
-        return *std::max_element(load.begin(), load.end());
+        std::stable_sort(ch.begin(), ch.end(), [&](int32_t a, int32_t b) { return wsub[a] != wsub[b] ? wsub[a] > wsub[b] : a < b; });
+        double W = 0.0;
+        for (int32_t c : ch) W += wsub[c];
+        std::vector<double> load((size_t)g, 0.0);
+        for (int32_t c : ch) {
+            const double want = W > 0.0 ? wsub[c] / W * g : 0.0;
+            int gi = (int)(want + 0.5);
+            if (gi >= 2) {
+                gi = std::min(gi, g);
+                int best = 0;
+                double bsum = 0.0, bmax = 0.0;
+                for (int a = 0; a + gi <= g; a++) {
+                    double sm = 0.0, mx = 0.0;
+                    for (int r = a; r < a + gi; r++) { sm += load[r]; mx = std::max(mx, load[r]); }
+                    if (a == 0 || sm < bsum || (sm == bsum && mx < bmax)) { best = a; bsum = sm; bmax = mx; }
+                }
+                for (int r = best; r < best + gi; r++) load[r] += wsub[c] / gi;
+                M.glo[c] = lo + best; M.ghi[c] = lo + best + gi;
+            } else {
+                int best = 0;
+                for (int r = 1; r < g; r++)
+                    if (load[r] < load[best]) best = r;
+                load[best] += wsub[c];
+                M.glo[c] = lo + best; M.ghi[c] = lo + best + 1;
+            }
+        }
     };
-    double top = 0.0, best_cost = 0.0;
-    cut = 1;
-    for (int d = 1; d < S.nlevels; d++) {
-        for (int64_t q = S.levelptr[d - 1]; q < S.levelptr[d]; q++) {
-            const int32_t s = S.levellist[q];
-            top += (double)S.sn_k[s] * S.sn_m[s] * S.sn_m[s] + 1.0;
-        }
-        const double cost = top + lpt(d, nullptr);
-        if (d == 1 || cost < best_cost) { best_cost = cost; cut = d; }
+    std::vector<int32_t> ch;
+    for (int64_t s = 0; s < ns; s++)
+        if (S.sparent[s] < 0) ch.push_back((int32_t)s);
+    assign_children(ch, 0, P);                                  // the roots of the forest share all ranks
+    for (int64_t s = ns - 1; s >= 0; s--) {
+        ch.assign(S.children.begin() + S.childptr[s], S.children.begin() + S.childptr[s + 1]);
+        if (!ch.empty()) assign_children(ch, M.glo[s], M.ghi[s]);
     }
-    lpt(cut, &owner);
-    for (int64_t s = ns - 1; s >= 0; s--)           // parents first
-        if (S.depth[s] > cut) owner[s] = owner[S.sparent[s]];
+    // block-cyclic fronts + the flops every rank executes
+    for (int64_t s = 0; s < ns; s++) {
+        const int g = M.ghi[s] - M.glo[s];
+        const double m = S.sn_m[s], k = S.sn_k[s];
+        const double f = front_flops(m, k);
+        M.total_flops += f;
+        const bool big = front_class(S.sn_m[s], S.sn_k[s]) == KVX_CLS_BIG;
+        if (g > 1 && big && S.sn_m[s] >= min_m && S.sn_k[s] >= std::min(M.ob, 256)) M.mode[s] = 1;
+        if (g == 1) { M.rank_flops[M.glo[s]] += f; continue; }
+        if (!M.mode[s]) {
+            for (int r = M.glo[s]; r < M.ghi[s]; r++) M.rank_flops[r] += f;
+            M.replicated_flops += f;
+            continue;
+        }
+        const int64_t mm = S.sn_m[s], kk = S.sn_k[s], OB = M.ob;
+        const int64_t nkb = (kk + OB - 1) / OB;
+        for (int64_t b = 0; b < nkb; b++) {
+            const int64_t o = b * OB, nb = std::min<int64_t>(OB, kk - o), t = mm - o - nb;
+            const double tot = front_flops((double)(mm - o), (double)nb);
+            const double upd = (double)nb * t * (t + 1);
+            const int owner = M.glo[s] + (int)(b % g);
+            M.rank_flops[owner] += tot - upd;
+            M.rank_panel_flops[owner] += tot - upd;
+            // the rank-nb update of the columns right of the block, by column block
+            for (int64_t c0 = o + nb; c0 < mm; ) {
+                const int64_t blk = c0 < kk ? c0 / OB : nkb + (c0 - kk) / OB;
+                const int64_t c1 = std::min<int64_t>(mm, c0 < kk ? std::min<int64_t>((blk + 1) * OB, kk) : kk + (blk - nkb + 1) * OB);
+                const double ent = 0.5 * (double)(c1 - c0) * (double)((mm - c0) + (mm - c1 + 1));   // lower-trapezoid entries
+                M.rank_flops[M.glo[s] + (int)(blk % g)] += 2.0 * nb * ent;
+                c0 = c1;
+            }
+        }
+    }
 }
 
 }  // namespace kvx

@@ -84,10 +84,20 @@ void analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
               int leaf, std::vector<int64_t> &perm);
 
-// Shard the elimination tree over nranks: the fronts at depth < cut are the replicated top of
-// the tree; each front at depth == cut roots a subtree owned by one rank (longest-processing-time assignment
-// on the subtree flop counts).  owner[s] = rank for depth >= cut, -1 for the top.  cut minimises the estimate
-// (work of the replicated top) + (largest per-rank subtree work).  Host-only, deterministic.
-void dist_partition(const Symbolic &S, int nranks, std::vector<int32_t> &owner, int &cut);
+// Sharding of ONE factorisation over nranks processes, host-only and deterministic: every rank computes the same map.
+// Proportional mapping of the elimination tree: front s is worked on by the contiguous rank range [glo[s], ghi[s]).  A range of
+// one rank owns the front (and then its whole subtree).  A front shared by several ranks is either replicated on them
+// (mode 0: small fronts of the top of the tree -- every rank of the range factors it, no communication inside the front) or
+// block-cyclic (mode 1: order >= min_m): its columns are dealt out in blocks of `ob` columns round-robin over the range, the
+// owner of a pivot block factors the panel and broadcasts it, every rank applies the rank-ob update to its own blocks.
+struct DistMap {
+    int nranks = 1, ob = 512, min_m = 6144;
+    std::vector<int32_t> glo, ghi;
+    std::vector<uint8_t> mode;
+    std::vector<double> rank_flops;        // factorisation flops executed by each rank (replicated fronts count on every rank)
+    std::vector<double> rank_panel_flops;  // of which: panel factorisations of block-cyclic fronts (serial within the front's range)
+    double total_flops = 0, replicated_flops = 0;   // sum_j c_j^2 ; flops of the replicated (mode 0, range > 1) fronts, counted once
+};
+void dist_map(const Symbolic &S, int nranks, int ob, int min_m, DistMap &M);
 
 }  // namespace kvx

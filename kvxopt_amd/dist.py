@@ -3,12 +3,14 @@
 Two ways the factor/solve path shards (multi-GPU):
   * independent systems -- `shard()`: every rank factors its own systems, no data-path collective
     (bench.py --gpus N, weak scaling);
-  * ONE system over the ranks -- `DistFactor`: the elimination tree is cut below its top separators, every
-    rank factors and solves the subtrees it owns, the top of the tree is replicated; the real exchange steps
-    are all-reduce sums of (a) the update matrices of the subtree roots, once per factorisation, (b) their
-    update vectors and (c) the owned pieces of x, per solve.  The library does the packing
-    (`kvx_chol_dist_*`, include/kvxhip.h), torch.distributed the collectives (RCCL on a node; gloo in
-    tests/test_dist_gpu.py, where the ranks share the one GPU of the box).
+  * ONE system over the ranks -- `DistFactor`: proportional mapping of the elimination tree gives every front a
+    contiguous range of ranks.  Subtrees mapped to one rank are factored and solved by it alone; the big fronts of
+    the top separators are block-cyclic over their range (the owner of a pivot block factors the panel and
+    broadcasts it, every rank updates the column blocks it owns); small shared fronts are replicated on their range.
+    Exchange steps: broadcasts of child update matrices / panels / update vectors inside a front's range, one
+    all-reduce of x per solve, one MIN per factorisation.  The library decides what travels and packs it
+    (`kvx_chol_dist_*`, include/kvxhip.h); the collectives themselves run here through torch.distributed
+    (backend "nccl" = RCCL over xGMI on a node; gloo in tests/test_dist_gpu.py, where the ranks share one GPU).
 """
 import os
 
@@ -57,32 +59,40 @@ def sum_over_ranks(value, dist, device="cpu"):
     return float(t.item())
 
 
-def partition(factor, nranks):
-    """Host-only: (owner per front, cut depth) of the subtree sharding of `factor` (kvxopt_amd.chol.Factor)."""
+def partition(factor, nranks, ob=0, min_m=0):
+    """Host-only: the map of `factor` (kvxopt_amd.chol.Factor) over `nranks` ranks -- dict with, per front, the rank range
+    [glo, ghi) and mode (1 = block-cyclic), per rank the factorisation flops it executes (`rank_flops`) and the panel part
+    of them (`panel_flops`), and the totals (`flops` = sum_j c_j^2, `replicated` = flops of the small replicated fronts)."""
     import ctypes
 
     import numpy as np
 
-    from ._lib import lib, raise_for
-    ns = factor.info()["nsuper"]
-    owner = np.zeros(max(int(ns), 1), dtype=np.int32)
-    cut = ctypes.c_int(0)
-    raise_for(lib().kvx_chol_dist_owner(factor._h, int(nranks), owner.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
-                                        ctypes.byref(cut)), "partition failed")
-    return owner[:ns], cut.value
+    from ._lib import f64p, lib, raise_for
+    ns = max(int(factor.info()["nsuper"]), 1)
+    glo = np.zeros(ns, dtype=np.int32); ghi = np.zeros(ns, dtype=np.int32); mode = np.zeros(ns, dtype=np.uint8)
+    rf = np.zeros(nranks); pf = np.zeros(nranks); tot = np.zeros(2)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    raise_for(lib().kvx_chol_dist_map(factor._h, int(nranks), int(ob), int(min_m), glo.ctypes.data_as(i32p), ghi.ctypes.data_as(i32p),
+                                      mode.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rf.ctypes.data_as(f64p),
+                                      pf.ctypes.data_as(f64p), tot.ctypes.data_as(f64p)), "partition failed")
+    ns = int(factor.info()["nsuper"])
+    return {"glo": glo[:ns], "ghi": ghi[:ns], "mode": mode[:ns], "rank_flops": rf, "panel_flops": pf,
+            "flops": float(tot[0]), "replicated": float(tot[1])}
 
 
 class DistFactor:
     """One SPD system factored and solved by all ranks of `group` (one GPU each); see the module docstring.
-    Every rank passes the same matrix; values / right-hand sides are torch tensors on the rank's device."""
+    Every rank passes the same matrix; values / right-hand sides are torch tensors on the rank's device.
+    ob / min_m: column-block width and smallest order of the block-cyclic fronts (0 = library defaults 512 / 6144)."""
 
-    def __init__(self, n, colptr, rowind, uplo="L", perm=None, opts=None, group=None, device=None):
+    def __init__(self, n, colptr, rowind, uplo="L", perm=None, opts=None, group=None, device=None, ob=0, min_m=0, xchg_doubles=0):
         import ctypes
 
         import numpy as np
         import torch
         import torch.distributed as dist
 
+        from . import _lib
         from ._lib import lib, raise_for
         from .chol import Factor
         self._dist = dist if dist.is_available() and dist.is_initialized() else None
@@ -92,64 +102,93 @@ class DistFactor:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.F = Factor(n, colptr, rowind, uplo, perm, opts)
         self.n = int(n)
-        info = np.zeros(4, dtype=np.int64)
+        info = np.zeros(8, dtype=np.int64)
         with torch.cuda.device(self.device):
-            raise_for(lib().kvx_chol_dist_setup(self.F._h, self.rank, self.world, info.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))),
-                      "sharded setup failed")
-        self.cut, self.ulen, self.wlen = int(info[0]), int(info[1]), int(info[2])
-        self._xchg = torch.zeros(max(self.ulen, self.n, 1), dtype=torch.float64, device=self.device)
+            raise_for(lib().kvx_chol_dist_setup(self.F._h, self.rank, self.world, int(ob), int(min_m),
+                                                info.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))), "sharded setup failed")
+        self.nshared, self.ncyclic, self.ob, self.min_m = int(info[3]), int(info[4]), int(info[6]), int(info[7])
+        # one communicator per distinct rank range of the map (the same list, in the same order, on every rank)
+        ng = int(info[5])
+        lohi = np.zeros(max(2 * ng, 2), dtype=np.int32)
+        if ng:
+            raise_for(lib().kvx_chol_dist_groups(self.F._h, lohi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        self._ranks = list(range(self.world)) if (self._dist is None or group is None) else self._dist.get_process_group_ranks(group)
+        self._groups = {}
+        for i in range(ng):
+            lo, hi = int(lohi[2 * i]), int(lohi[2 * i + 1])
+            if (lo, hi) == (0, self.world):
+                self._groups[(lo, hi)] = group
+            elif self._dist is not None:
+                self._groups[(lo, hi)] = self._dist.new_group([self._ranks[r] for r in range(lo, hi)])
+        self._groups.setdefault((0, self.world), group)
+        cnt = max(int(info[1]), int(xchg_doubles) if xchg_doubles else int(info[2]))
+        self._xchg = torch.zeros(cnt, dtype=torch.float64, device=self.device)
+        raise_for(lib().kvx_chol_dist_set_xchg(self.F._h, self._xchg.data_ptr(), cnt))
+        self._base = self._xchg.data_ptr()
+        self._host_staged = self._dist is not None and self._dist.get_backend(group) != "nccl"
+        self.collectives = 0
+        self.bytes_moved = 0
+        self._err = None
+        self._cb = _lib.DIST_COMM_FN(self._comm)               # keep the callback object alive as long as the factor
 
-    def _allreduce(self, count, op=None):
-        if self._dist is not None and self.world > 1 and count > 0:
-            self._dist.all_reduce(self._xchg[:count], op=op or self._dist.ReduceOp.SUM, group=self.group)
+    def _comm(self, ctx, op_p):
+        """One collective on a slice of the exchange buffer, in the current (null) stream's order."""
+        try:
+            import torch
+            op = op_p.contents
+            if self._dist is None or self.world == 1:
+                return 0
+            off = (int(op.buf_dev) - self._base) // 8
+            t = self._xchg[off:off + int(op.count)]
+            g = self._groups[(int(op.lo), int(op.hi))]
+            if self._host_staged:                                   # gloo stages through the host: settle the producers first
+                torch.cuda.current_stream().synchronize()
+            if op.kind == 1:
+                self._dist.broadcast(t, src=self._ranks[int(op.root)], group=g)
+            elif op.kind == 2:
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=g)
+            elif op.kind == 3:
+                self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=g)
+            else:
+                raise ValueError("unknown collective kind %d" % op.kind)
+            if self._host_staged:
+                torch.cuda.current_stream().synchronize()
+            self.collectives += 1
+            self.bytes_moved += 8 * int(op.count)
+            return 0
+        except BaseException as e:                                  # never let an exception cross the C frames
+            self._err = e
+            return 1
 
-    def _buf(self, count):
-        import torch
-        if self._xchg.numel() < count:
-            self._xchg = torch.zeros(count, dtype=torch.float64, device=self.device)
-        return self._xchg
+    def _check(self, rc, what):
+        from ._lib import raise_for
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+        raise_for(rc, what)
 
     def factorize(self, values_dev):
-        """values_dev: float64 tensor (nnz of the analysed triangle) on this rank's device, identical on all ranks."""
+        """values_dev: float64 tensor (nnz of the analysed triangle) on this rank's device, identical on all ranks.
+        Raises ArithmeticError(failing column) on every rank when the matrix is not positive definite."""
         import ctypes
 
         import torch
 
-        from ._lib import KVX_ENOTPOSDEF, lib, raise_for
-        L = lib()
+        from ._lib import KVX_ENOTPOSDEF, lib
         minor = ctypes.c_int64(self.n)
         with torch.cuda.device(self.device):
-            torch.cuda.current_stream().synchronize()
-            raise_for(L.kvx_chol_dist_factor_phase(self.F._h, 0, values_dev.data_ptr(), self._xchg.data_ptr(), None), "factorization failed")
-            self._allreduce(self.ulen)
-            torch.cuda.current_stream().synchronize()
-            rc = L.kvx_chol_dist_factor_phase(self.F._h, 1, values_dev.data_ptr(), self._xchg.data_ptr(), ctypes.byref(minor))
-        m = int(minor.value)
-        if self._dist is not None and self.world > 1:          # a failing column may sit in another rank's subtree
-            t = torch.tensor([m], dtype=torch.int64, device=self.device)
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN, group=self.group)
-            m = int(t.item())
-        if m < self.n:
-            raise ArithmeticError(m)
-        if rc != KVX_ENOTPOSDEF:
-            raise_for(rc, "factorization failed")
+            rc = lib().kvx_chol_dist_factorize(self.F._h, values_dev.data_ptr(), self._cb, None, ctypes.byref(minor))
+        if rc == KVX_ENOTPOSDEF and self._err is None:
+            raise ArithmeticError(int(minor.value))
+        self._check(rc, "factorization failed")
 
     def solve(self, B_dev, nrhs=1, ldB=None):
         """Solve A X = B in place; B_dev: float64 tensor (column-major n x nrhs, ld = ldB) on this rank's device,
         identical on all ranks; every rank ends with the full solution."""
         import torch
 
-        from ._lib import lib, raise_for
-        L = lib()
+        from ._lib import lib
         ldB = self.n if ldB is None else int(ldB)
-        need = max(self.wlen, self.n) * int(nrhs)
-        buf = self._buf(need)
         with torch.cuda.device(self.device):
-            torch.cuda.current_stream().synchronize()
-            raise_for(L.kvx_chol_dist_solve_phase(self.F._h, 0, B_dev.data_ptr(), int(nrhs), ldB, buf.data_ptr()), "solve failed")
-            self._allreduce(self.wlen * int(nrhs))
-            torch.cuda.current_stream().synchronize()
-            raise_for(L.kvx_chol_dist_solve_phase(self.F._h, 1, B_dev.data_ptr(), int(nrhs), ldB, buf.data_ptr()), "solve failed")
-            self._allreduce(self.n * int(nrhs))
-            torch.cuda.current_stream().synchronize()
-            raise_for(L.kvx_chol_dist_solve_phase(self.F._h, 2, B_dev.data_ptr(), int(nrhs), ldB, buf.data_ptr()), "solve failed")
+            rc = lib().kvx_chol_dist_solve(self.F._h, B_dev.data_ptr(), int(nrhs), ldB, self._cb, None)
+        self._check(rc, "solve failed")

@@ -27,10 +27,6 @@ def _buf(x):
     return base._dense_buffer(x)
 
 
-def _run1(fn, x, *dev_args_builder):
-    raise NotImplementedError
-
-
 def _up(a):
     return DeviceBuffer.from_array(np.ascontiguousarray(a, dtype=np.float64))
 

@@ -30,14 +30,16 @@ def laplacian_2d(g, h=None):
     return (n,) + _tril_ccs_from_coo(n, np.concatenate(rows), np.concatenate(cols), np.concatenate(vals))
 
 
-def laplacian_3d(g):
-    """7-point Laplacian on a g^3 grid, lower triangle (config 5 uses g = 200)."""
-    n = g * g * g
+def laplacian_3d(g, h=None, d=None):
+    """7-point Laplacian on a g x h x d grid (a g^3 cube by default), lower triangle (config 5 uses g = 200)."""
+    h = g if h is None else h
+    d = g if d is None else d
+    n = g * h * d
     idx = np.arange(n, dtype=np.int64)
     x = idx % g
-    y = (idx // g) % g
-    m1, m2, m3 = x + 1 < g, y + 1 < g, idx + g * g < n
-    rows = np.concatenate([idx, idx[m1] + 1, idx[m2] + g, idx[m3] + g * g])
+    y = (idx // g) % h
+    m1, m2, m3 = x + 1 < g, y + 1 < h, idx + g * h < n
+    rows = np.concatenate([idx, idx[m1] + 1, idx[m2] + g, idx[m3] + g * h])
     cols = np.concatenate([idx, idx[m1], idx[m2], idx[m3]])
     vals = np.concatenate([np.full(n, 6.0), np.full(m1.sum() + m2.sum() + m3.sum(), -1.0)])
     return (n,) + _tril_ccs_from_coo(n, rows, cols, vals)

@@ -512,6 +512,35 @@ def g12_nonlinear_block():
     np.savez_compressed(os.path.join(HERE, "g12_nonlinear_block.npz"), **out)
 
 
+def g13_gemv_subblocks():
+    """base.gemv (base.c:744-851 -> sparse.c:1073-1104) with the sub-block arguments m, n, offsetA and strides, sparse A."""
+    from kvxopt import base, matrix, spmatrix
+    rng = np.random.default_rng(1300)
+    A, (cp, ri, v) = None, (None, None, None)
+    M, N = 9, 7
+    D = rng.standard_normal((M, N)) * (rng.uniform(size=(M, N)) < 0.45)
+    I, J = np.nonzero(D)
+    A = spmatrix(D[I, J].tolist(), I.tolist(), J.tolist(), (M, N))
+    cp, ri, v = ccs(A)
+    out = {"M": np.array(M), "N": np.array(N), "cp": cp, "ri": ri, "v": v}
+    cases = []
+    for ci, (trans, m, n, oi, oj, incx, incy, ox, oy, alpha, beta) in enumerate([
+            ("N", 4, 3, 2, 1, 1, 1, 0, 0, 1.0, 0.0), ("T", 4, 3, 2, 1, 1, 1, 0, 0, -2.0, 0.5),
+            ("N", 9, 7, 0, 0, 2, 1, 1, 3, 0.5, -1.0), ("T", 5, 5, 4, 2, 1, 2, 2, 0, 1.5, 1.0),
+            ("N", 3, 2, 6, 5, -1, 1, 0, 1, 1.0, 2.0), ("T", 6, 4, 1, 3, 1, -2, 0, 0, -1.0, 0.25),
+            ("N", 0, 3, 0, 0, 1, 1, 0, 0, 1.0, 0.0), ("N", 4, 0, 1, 1, 1, 1, 0, 0, 1.0, 0.5)]):
+        lx, ly = (n, m) if trans == "N" else (m, n)
+        x = rng.standard_normal(ox + max(lx - 1, 0) * abs(incx) + 3)
+        y = rng.standard_normal(oy + max(ly - 1, 0) * abs(incy) + 3)
+        ym = matrix(y.copy())
+        base.gemv(A, matrix(x), ym, trans=trans, alpha=alpha, beta=beta, m=m, n=n, incx=incx, incy=incy,
+                  offsetA=oi + oj * M, offsetx=ox, offsety=oy)
+        out["c%d_x" % ci] = x; out["c%d_y" % ci] = y; out["c%d_out" % ci] = tolist(ym)
+        cases.append([trans, m, n, oi + oj * M, incx, incy, ox, oy, alpha, beta])
+    out["cases"] = np.array(json.dumps(cases))
+    np.savez(os.path.join(HERE, "g13_gemv_subblocks.npz"), **out)
+
+
 if __name__ == "__main__":
     stage()
     import kvxopt
@@ -532,4 +561,5 @@ if __name__ == "__main__":
     g10_conelp_starts()
     g11_coneqp_initvals()
     g12_nonlinear_block()
+    g13_gemv_subblocks()
     print("goldens written to", HERE)

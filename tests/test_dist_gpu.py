@@ -1,6 +1,8 @@
-"""Subtree-sharded factor + solve (kvxopt_amd.dist.DistFactor, kvx_chol_dist_*): 2 and 3 ranks over gloo, all on
-the one GPU of the box (the collectives are backend-agnostic; a real node uses backend "nccl" = RCCL, one GPU per
-rank).  Every rank must end with the solution of the single-process path."""
+"""Sharded factor + solve (kvxopt_amd.dist.DistFactor, kvx_chol_dist_*): 2, 3 and 4 ranks over gloo, all on the one GPU
+of the box (the library is collective-agnostic; a real node uses backend "nccl" = RCCL, one GPU per rank).  Every rank
+must end with the solution of the single-process path and of the CPU oracle, on 2-D grids, 3-D grids (config 5's
+structure) and a random SPD pattern -- with thresholds small enough that the top fronts of these small systems take the
+block-cyclic path (panel broadcasts, owned-column updates, gathered update matrices), not only the replicated one."""
 import os
 import socket
 
@@ -17,14 +19,15 @@ def _free_port():
 def _systems():
     import scipy.sparse as sp
     from kvxopt_amd import workloads
-    out = [workloads.laplacian_2d(120), workloads.laplacian_2d(33, 71)]
+    out = [("lap2d120", workloads.laplacian_2d(120)), ("lap2d33x71", workloads.laplacian_2d(33, 71)),
+           ("lap3d24", workloads.laplacian_3d(24)), ("lap3d13x20x31", workloads.laplacian_3d(13, 20, 31))]
     M = sp.random(1500, 1500, 0.004, random_state=3, format="csc")
     S = sp.tril((M @ M.T + sp.eye(1500) * 4.0).tocsc()).tocsc(); S.sort_indices()
-    out.append((1500, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data))
+    out.append(("random1500", (1500, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data)))
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, big):
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0",
                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     import torch
@@ -32,14 +35,19 @@ def _worker(rank, world, port, q):
     from kvxopt_amd import workloads
     from kvxopt_amd.chol import Factor
     from kvxopt_amd.dist import DistFactor
+    from oracle.kvx_oracle import OracleChol
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     res = []
-    for (n, cp, ri, vx) in _systems():
+    systems = _systems() if not big else [("lap3d40", workloads.laplacian_3d(40))]
+    for name, (n, cp, ri, vx) in systems:
         nrhs = 2
         B = np.asfortranarray(np.random.default_rng(7).standard_normal((n, nrhs)))
-        DF = DistFactor(n, cp, ri)
+        # small blocks / low threshold: the top fronts of these small systems are block-cyclic; a small exchange buffer
+        # makes the messages split (bcast_regions' chunking) on the 2-D grid
+        kw = dict(ob=64, min_m=96) if not big else dict(ob=256, min_m=1024)
+        DF = DistFactor(n, cp, ri, xchg_doubles=(6000 if name == "lap2d120" else 0), **kw)
         v_d = torch.from_numpy(vx).to(dev)
         for _ in range(2):                                   # a second numeric factorisation on the same handle
             DF.factorize(v_d)
@@ -49,8 +57,14 @@ def _worker(rank, world, port, q):
         F1 = Factor(n, cp, ri)                               # single-process path, same device
         F1.factorize(vx)
         X1 = B.copy(order="F"); F1.solve(X1)
+        O = OracleChol(n, cp, ri, "L", F1.perm())            # CPU oracle, same permutation
+        O.factorize(vx)
+        Xo = B.copy(order="F"); O.solve(Xo)
         R = workloads.sym_matvec(n, cp, ri, vx, X) - B
-        res.append((DF.cut, float(np.abs(X - X1).max() / np.abs(X1).max()), float(np.linalg.norm(R) / np.linalg.norm(B))))
+        res.append((name, DF.nshared, DF.ncyclic, DF.collectives, float(np.abs(X - X1).max() / np.abs(X1).max()),
+                    float(np.abs(X - Xo).max() / np.abs(Xo).max()), float(np.linalg.norm(R) / np.linalg.norm(B))))
+        if big:
+            continue
         # a non-positive pivot inside ONE rank's subtree is reported by every rank, with the single-process column
         bad = vx.copy(); bad[cp[int(F1.perm()[3])]] = -1.0
         try:
@@ -62,30 +76,65 @@ def _worker(rank, world, port, q):
         except ArithmeticError as e:
             got = e.args[0]
         res.append(("minor", ref, got))
+        # ... and one inside a block-cyclic top front (last column of the matrix = last pivot of the root front)
+        bad = vx.copy(); bad[cp[int(F1.perm()[n - 1])]] = -1.0
+        try:
+            F1.factorize(bad); ref = None
+        except ArithmeticError as e:
+            ref = e.args[0]
+        try:
+            DF.factorize(torch.from_numpy(bad).to(dev)); got = None
+        except ArithmeticError as e:
+            got = e.args[0]
+        res.append(("minor", ref, got))
         DF.factorize(v_d)
+        b_d = torch.from_numpy(B.reshape(-1, order="F").copy()).to(dev)
+        DF.solve(b_d, nrhs)                                  # usable again after a failed factorisation
+        X2 = b_d.cpu().numpy().reshape(n, nrhs, order="F")
+        res.append(("again", float(np.abs(X2 - X).max())))
     dist.barrier()
     q.put((rank, res))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_factor_solve_matches_single_process(world):
+def _run(world, big=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, big)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=600) for _ in procs)
+    out = sorted(q.get(timeout=900) for _ in procs)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_factor_solve_matches_single_process(world):
+    out = _run(world)
+    cyclic_seen = 0
     for rank, res in out:
         for item in res:
             if item[0] == "minor":
                 assert item[1] is not None and item[1] == item[2], (rank, item)
+            elif item[0] == "again":
+                assert item[1] == 0.0, (rank, item)                        # bitwise repeatable on the same handle
             else:
-                cut, dx, rr = item
-                assert cut >= 1, (rank, item)
-                assert dx < 1e-11 and rr < 1e-11, (rank, item)        # same L up to summation order of the root updates
+                name, nshared, ncyclic, ncoll, dx, dxo, rr = item
+                assert nshared >= 1 and ncoll >= 2, (rank, item)
+                cyclic_seen += ncyclic
+                # same L up to the summation order of the blocked updates; north_star bar 1e-10, observed ~1e-14
+                assert dx < 1e-11 and dxo < 1e-11 and rr < 1e-11, (rank, item)
+    assert cyclic_seen >= world                                            # the block-cyclic path really ran
+
+
+def test_sharded_3d_grid_40_four_ranks():
+    """Config 5's workload shape at 1/125 of its size: 7-point Laplacian 40^3 (n = 64 000) over 4 ranks with 256-column
+    blocks; equal to the single-process path and the oracle to 1e-11."""
+    out = _run(4, big=True)
+    for rank, res in out:
+        name, nshared, ncyclic, ncoll, dx, dxo, rr = res[0]
+        assert ncyclic >= 1 and dx < 1e-11 and dxo < 1e-11 and rr < 1e-11, (rank, res[0])

@@ -4,6 +4,7 @@ generated from the REFERENCE (tests/golden/make_goldens.py) and against the CPU 
 
 Floating-point tolerance: elementwise kernels are compared to 1e-14 relative (identical formulas,
 one rounding each); assembled sums / solves to 1e-10 relative (BASELINE.json north_star bar)."""
+import array
 import json
 import os
 
@@ -590,3 +591,111 @@ def test_base_gemv_sparse_and_dense_with_offsets():
             ref = y.copy(); ref[2:] = -1.5 * (op @ x[3:]) + 0.5 * y[2:]
             assert rel(yx._a, ref) < 1e-14
 
+
+
+def test_base_gemv_subblocks_match_reference(golden_dir):
+    """G13: base.gemv with m, n, offsetA, incx, incy (sparse.c:1073-1104: the m x n block of A at
+    (offsetA % nrows, offsetA // nrows)), expected vectors from the reference's own base.gemv."""
+    g = np.load(os.path.join(golden_dir, "g13_gemv_subblocks.npz"))
+    A = spmatrix.from_ccs(int(g["M"]), int(g["N"]), g["cp"], g["ri"], g["v"])
+    for ci, (trans, m, n, oA, incx, incy, ox, oy, alpha, beta) in enumerate(json.loads(str(g["cases"]))):
+        y = matrix(g["c%d_y" % ci].copy())
+        base.gemv(A, matrix(g["c%d_x" % ci]), y, trans=trans, alpha=alpha, beta=beta, m=m, n=n, incx=incx, incy=incy,
+                  offsetA=oA, offsetx=ox, offsety=oy)
+        assert np.allclose(y._a, g["c%d_out" % ci], rtol=1e-14, atol=1e-15), ci
+    y = matrix(np.array([np.nan, 1.0, np.nan]))
+    base.gemv(A, matrix(np.ones(2)), y, m=3, n=2, beta=0.0)       # beta = 0 overwrites y, whatever it held
+    assert np.all(np.isfinite(y._a))
+    with pytest.raises(TypeError):
+        base.gemv(A, matrix(np.ones(7)), matrix(np.ones(9)), m=9, n=7, offsetA=1)
+
+
+class _ForeignDense(array.array):
+    """Stand-in for the reference's own `matrix`: nothing but .size, .typecode and the buffer protocol
+    (dense.c:1350-1385 exports a column-major 'd' buffer)."""
+
+    def __new__(cls, a):
+        a = np.asarray(a, dtype=np.float64)
+        self = super().__new__(cls, "d", a.reshape(-1, order="F").tolist())
+        self.size = a.shape if a.ndim == 2 else (a.size, 1)
+        return self
+
+
+class _ForeignSparse:
+    """Stand-in for the reference's own `spmatrix`: .size, .typecode and .CCS only (sparse.c: CCS getter returns three
+    kvxopt matrices; plain sequences here)."""
+
+    def __init__(self, n, cp, ri, v):
+        self.size = (n, n)
+        self.typecode = "d"
+        self.CCS = (list(map(int, cp)), list(map(int, ri)), list(map(float, v)))
+
+
+def test_cholmod_accepts_foreign_matrix_objects():
+    """The drop-in claim of SURVEY 8(b): kvxopt_amd.cholmod driven with objects that are NOT this package's types -- only
+    the attributes the reference's own matrix / spmatrix expose (.CCS, .size, .typecode, buffer protocol)."""
+    n, cp, ri, v = workloads.laplacian_2d(13, 9)
+    A = _ForeignSparse(n, cp, ri, v)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((n, 2))
+    F = cholmod.symbolic(A)
+    cholmod.numeric(A, F)
+    Xf = _ForeignDense(B)
+    cholmod.solve(F, Xf)                            # overwritten in place through the buffer protocol (cholmod.c:482-491)
+    X = np.array(Xf).reshape(n, 2, order="F")
+    R = workloads.sym_matvec(n, cp, ri, v, X) - B
+    assert np.linalg.norm(R) / np.linalg.norm(B) < 1e-12
+    X2 = _ForeignDense(B)
+    cholmod.linsolve(A, X2)
+    assert rel(np.array(X2).reshape(n, 2, order="F"), X) < 1e-13
+    d = cholmod.diag(F)
+    assert np.all(np.asarray(d._a) > 0)
+    # misc.kkt_chol2 with a foreign sparse G: factor + solve equals a dense KKT solve
+    ml, nn = 12, 5
+    Gd = rng.standard_normal((ml, nn)) * (rng.random((ml, nn)) < 0.6) + np.vstack([np.eye(nn), np.zeros((ml - nn, nn))])
+    I, J = np.nonzero(Gd)
+    Gs = spmatrix(Gd[I, J], I, J, (ml, nn))
+
+    class FG:
+        size, typecode, CCS = Gs.size, "d", (Gs.colptr.tolist(), Gs.rowind.tolist(), Gs.values.tolist())
+    dims = {"l": ml, "q": [], "s": []}
+    factor = misc.kkt_chol2(FG(), dims, spmatrix([], [], [], (0, nn)))
+    dd = rng.uniform(0.5, 2.0, ml)
+    f = factor(W_of(dd, 1.0 / dd))
+    bx, bz = rng.standard_normal(nn), rng.standard_normal(ml)
+    x, z = matrix(bx.copy()), matrix(bz.copy())
+    f(x, matrix(np.zeros((0, 1))), z)
+    K = np.block([[np.zeros((nn, nn)), Gd.T], [Gd, -np.diag(dd * dd)]])
+    sol = np.linalg.solve(K, np.concatenate([bx, bz]))
+    assert rel(x._a, sol[:nn]) < 1e-10 and rel(z._a, dd * sol[nn:]) < 1e-10
+
+
+def test_numeric_checks_the_analysed_triangle_only():
+    """cholmod.c:137-157 (`pack` reads only the `uplo` triangle): a matrix with the same number of entries in OTHER positions
+    is refused; one that differs only in the ignored triangle factors fine."""
+    n, cp, ri, v = workloads.laplacian_2d(6, 5)
+    A = spmatrix.from_ccs(n, n, cp, ri, v)
+    F = cholmod.symbolic(A)
+    cholmod.numeric(A, F)
+    ri2 = ri.copy()
+    j = 3                                           # move one sub-diagonal entry of column 3 to another row
+    p = cp[j] + 1
+    ri2[p] = ri[p] + 1 if (p + 1 == cp[j + 1] or ri[p] + 1 < ri[p + 1]) else ri[p]
+    assert not np.array_equal(ri2, ri)
+    with pytest.raises(ValueError):
+        cholmod.numeric(spmatrix.from_ccs(n, n, cp, ri2, v), F)
+    # full symmetric storage with junk in the upper triangle: only the lower one is read
+    Ad = A.todense()
+    full = Ad + np.tril(Ad, -1).T * 7.0
+    I, J = np.nonzero(full)
+    Afull = spmatrix(full[I, J], I, J, (n, n))
+    cholmod.numeric(Afull, F)
+    b = np.random.default_rng(1).standard_normal(n)
+    x = matrix(b.copy())
+    cholmod.solve(F, x)
+    S = Ad + np.tril(Ad, -1).T
+    assert rel(S @ x._a, b) < 1e-12
+    F2 = cholmod.symbolic(Afull)                    # analysed from the full matrix, refactored from the triangle
+    cholmod.numeric(A, F2)
+    x2 = matrix(b.copy()); cholmod.solve(F2, x2)
+    assert rel(x2._a, x._a) < 1e-13
