@@ -12,7 +12,12 @@ metric = (sum_j c_j^2 + 4 nnz(L) nrhs) / time  [GF/s], c_j from the library's ow
 analysis for the permutation it uses.
 
 One JSON line on stdout (rank 0).  N > 1 ranks: every rank factors its own system (the
-systems are independent; no data-path collective) -> "scaling": "weak".
+systems are independent; no data-path collective) -> "scaling": "weak".  `--dist subtree`
+shards ONE system over the ranks instead (kvxopt_amd/dist.py) -> "scaling": "strong";
+`--workload lap3d --grid 200` is BASELINE configs[4].  The line carries `roofline` (dominant
+kernel family, timed live with HIP events on the stream it runs on) and `cpu_baseline` (host
+supernodal restatement on all cores, SciPy SuperLU and the simplicial oracle beside it) in
+both modes, and `ipm` (IPM iterations/s with its own roofline and CPU baseline).
 """
 import argparse
 import ctypes
@@ -35,7 +40,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", type=int, default=1000, help="grid side of the 5-pt Laplacian (config 2: 1000)")
+    ap.add_argument("--grid", type=int, default=0, help="grid side (default: 1000 for the 5-pt Laplacian of config 2, 100 for --workload lap3d)")
+    ap.add_argument("--workload", default="lap2d", choices=["lap2d", "lap3d"],
+                    help="lap2d = BASELINE configs[1] (5-pt Laplacian, the headline); lap3d = 7-pt Laplacian on a cube (configs[4] is --grid 200)")
+    ap.add_argument("--dist-ob", type=int, default=0, help="--dist subtree: column-block width of the block-cyclic fronts (0 = library default)")
+    ap.add_argument("--dist-min-m", type=int, default=0, help="--dist subtree: smallest order of a block-cyclic front (0 = library default)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the host supernodal baseline (0 = all cores)")
+    ap.add_argument("--no-splu", action="store_true", help="skip the SciPy SuperLU line of the CPU baseline (it takes ~10 s on config 2)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
@@ -44,8 +55,8 @@ def parse():
     ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop and the CPU baseline (experiments)")
     ap.add_argument("--dist", default="replicas", choices=["replicas", "subtree"],
                     help="N > 1 ranks: 'replicas' = every rank factors its own system (weak scaling, no data-path collective; default); "
-                         "'subtree' = ONE system sharded by elimination-tree subtrees over the ranks (kvxopt_amd.dist.DistFactor: "
-                         "all-reduce of the subtree-root update matrices per factorisation, of update vectors and x per solve; strong scaling)")
+                         "'subtree' = ONE system sharded over the ranks (kvxopt_amd.dist.DistFactor: subtrees by proportional mapping, "
+                         "block-cyclic top fronts with panel broadcasts; strong scaling)")
     return ap.parse_args()
 
 
@@ -80,6 +91,170 @@ def front_stats(F):
             "n_small": int(small.sum()), "n_big": int((~small).sum())}
 
 
+def host_threads(args):
+    """Threads of the host baselines: the cores this process may run on (affinity mask), at most 32 -- the OpenBLAS inside scipy is
+    built for 64 threads and its buffer table overflows when more OpenMP threads than that call it at once."""
+    if args.cpu_threads:
+        return max(1, min(int(args.cpu_threads), 32))
+    try:
+        c = len(os.sched_getaffinity(0))
+    except Exception:
+        c = os.cpu_count() or 1
+    return max(1, min(c, 16))                     # 16 = the CPU share that goes with one GPU of this node
+
+
+def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu):
+    """The reference's CPU path is SuiteSparse CHOLMOD (third-party, absent from this image: probed below).  Timed instead, on
+    the same matrix, permutation and flop count: (1) the host supernodal multifrontal restatement on all cores (OpenMP
+    subtrees + OpenBLAS BLAS-3 in the fronts, oracle/kvx_supernodal.c) -- the strongest CPU number and the headline baseline;
+    (2) SciPy SuperLU on P A P' with the natural column order, 1 thread (the calibration of BASELINE.md section 2);
+    (3) the simplicial up-looking oracle, 1 core (the parity checker)."""
+    import ctypes.util
+    B = np.asfortranarray(b_host.reshape(n, nrhs, order="F").copy())
+    cores = host_threads(args)
+    out = {"cholmod_found": bool(ctypes.util.find_library("cholmod")), "os_cpu_count": os.cpu_count(), "affinity_cores": (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None),
+           "env_threads": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS") if os.environ.get(k)}}
+    others = {}
+    try:
+        from oracle.kvx_oracle import OracleSupernodal
+        S = OracleSupernodal.from_factor(n, colptr, rowind, F, threads=cores)
+        best = None
+        for _ in range(3):                              # first pass pays page faults and thread start-up: best of three
+            xb = B.copy(order="F")
+            t0 = time.perf_counter(); S.factorize(values); t1 = time.perf_counter(); S.solve(xb); t2 = time.perf_counter()
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+        diff = float(np.abs(xb.reshape(-1, order="F") - x_gpu).max() / np.abs(xb).max())
+        out.update({"value": work / best[0] / 1e9, "unit": "GF/s", "cores": cores, "kind": "port",
+                    "library": "host supernodal multifrontal restatement (oracle/kvx_supernodal.c): OpenMP over elimination-tree subtrees, "
+                               "OpenBLAS dpotrf/dtrsm/dsyrk inside the fronts (the OpenBLAS that ships in scipy)",
+                    "sample": "same system, permutation and supernodes as the GPU run: numeric factorisation %.3f s + solve %.3f s, best of 3"
+                              % (best[1], best[2]),
+                    "max_rel_diff_vs_gpu": diff})
+        del S
+    except Exception as e:
+        out["supernodal_error"] = repr(e)
+    if not args.no_splu and n <= 1200000:
+        try:
+            import scipy.sparse as sp
+            from scipy.sparse.linalg import splu
+            perm = F.perm()
+            A = sp.csc_matrix((values, rowind, colptr), shape=(n, n))
+            A = (A + sp.tril(A, -1).T).tocsc()
+            Ap = A[perm][:, perm].tocsc()
+            t0 = time.perf_counter()
+            lu = splu(Ap, permc_spec="NATURAL", diag_pivot_thresh=0.0, options={"SymmetricMode": True})
+            t1 = time.perf_counter()
+            xs = lu.solve(B[perm])
+            t2 = time.perf_counter()
+            xs_full = np.empty_like(xs); xs_full[perm] = xs
+            others["scipy_splu"] = {"value": work / (t2 - t0) / 1e9, "unit": "GF/s", "cores": 1, "kind": "port",
+                                    "library": "scipy.sparse.linalg.splu (SuperLU), permc_spec=NATURAL on P A P', diag_pivot_thresh=0, SymmetricMode",
+                                    "factor_s": t1 - t0, "solve_s": t2 - t1, "nnz_L": int(lu.L.nnz),
+                                    "max_rel_diff_vs_gpu": float(np.abs(xs_full.reshape(-1, order="F") - x_gpu).max() / np.abs(xs_full).max())}
+            del lu, Ap, A
+        except Exception as e:
+            others["scipy_splu"] = {"error": repr(e)}
+    try:
+        from oracle.kvx_oracle import OracleChol
+        O = OracleChol(n, colptr, rowind, "L", F.perm())
+        t0 = time.perf_counter()
+        O.factorize(values)
+        xb = B.copy(order="F")
+        O.solve(xb)
+        tc = time.perf_counter() - t0
+        others["simplicial_oracle"] = {"value": work / tc / 1e9, "unit": "GF/s", "cores": 1, "kind": "port",
+                                       "library": "oracle/kvx_oracle.c (up-looking simplicial, the parity checker)", "seconds": tc,
+                                       "max_rel_diff_vs_gpu": float(np.abs(xb.reshape(-1, order="F") - x_gpu).max() / np.abs(xb).max())}
+    except Exception as e:
+        others["simplicial_oracle"] = {"error": repr(e)}
+    out["others"] = others
+    if "value" not in out:                               # the supernodal library could not be built: fall back to the best other line
+        ok = [v for v in others.values() if "value" in v]
+        if ok:
+            bestv = max(ok, key=lambda v: v["value"])
+            out.update({k: bestv[k] for k in ("value", "unit", "cores", "kind", "library")})
+            out["sample"] = "same system and permutation, 1 numeric factorisation + 1 solve"
+    return out
+
+
+def ipm_leg(args, torch):
+    """IPM iterations/s of the device-resident conelp on BASELINE configs[3] (inequality form), with the roofline of the
+    normal-equations assembly kernel (k_atda, HBM-bound: 12 nnz(G) + 8 ml + 8 nnz(S) bytes per launch) timed
+    live with events on the stream it runs on (the null stream), and a CPU run of the same loop beside it."""
+    from kvxopt_amd import _lib
+    from kvxopt_amd import lp as kvx_lp
+    from kvxopt_amd import workloads
+    from kvxopt_amd.base import spmatrix
+    Pl = workloads.lp_grid(250, 200)
+    ml, nl = Pl["ml"], Pl["n"]
+    Gl = spmatrix.from_ccs(ml, nl, Pl["Gp"], Pl["Gi"], Pl["Gx"])
+    kvx_lp.conelp(Pl["c"], Gl, Pl["h"], options={"maxiters": 2})
+    tl0 = time.perf_counter()
+    sl = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])
+    tl = time.perf_counter() - tl0
+    ipm = {"metric": "IPM iterations/s", "value": sl["iterations"] / sl["loop seconds"], "unit": "iterations/s",
+           "workload": "conelp, grid LP 250x200: ml=200000 inequalities, n=50000 (BASELINE configs[3], inequality form)",
+           "iterations": sl["iterations"], "status": sl["status"], "loop_s": sl["loop seconds"], "whole_call_s": tl,
+           "value_whole_call": sl["iterations"] / tl}
+    # roofline of the assembly kernel: S = G' diag(w) G on the fixed pattern, launched back to back on the null stream
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    _lib.raise_for(L.kvx_atda_plan(ml, nl, _lib.pi(Pl["Gp"]), _lib.pi(Pl["Gi"]), None, None, ctypes.byref(h)))
+    snz = ctypes.c_int64()
+    _lib.raise_for(L.kvx_atda_pattern(h, ctypes.byref(snz), None, None))
+    gx = torch.from_numpy(Pl["Gx"]).cuda(); w = torch.rand(ml, dtype=torch.float64, device="cuda") + 0.5
+    sx = torch.zeros(max(snz.value, 1), dtype=torch.float64, device="cuda")
+    reps = 50
+    for _ in range(5):
+        _lib.raise_for(L.kvx_atda_assemble_dev(h, gx.data_ptr(), w.data_ptr(), None, sx.data_ptr()))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        _lib.raise_for(L.kvx_atda_assemble_dev(h, gx.data_ptr(), w.data_ptr(), None, sx.data_ptr()))
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = 12.0 * len(Pl["Gx"]) + 8.0 * ml + 8.0 * snz.value
+    ipm["roofline"] = {"kernel": "k_atda (S = G' diag(w) G on the fixed pattern)", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
+                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": reps,
+                       "note": "back-to-back launches: time per launch includes the launch gap; the loop itself is bound by the factor/solve latency chains"}
+    L.kvx_atda_free(h)
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_ipm_pmc.json")))
+        ipm["roofline"]["traffic"] = pm.get("k_atda_bytes_per_launch")
+    except Exception:
+        pass
+    # CPU run of the same loop (oracle/lp_oracle.py: coneprog.py:859-1436 restated over the host supernodal Cholesky)
+    if not args.no_cpu_baseline:
+        try:
+            import scipy.sparse as sp
+            from kvxopt_amd.chol import Factor
+            from oracle import lp_oracle
+            G = sp.csc_matrix((Pl["Gx"], Pl["Gi"], Pl["Gp"]), shape=(ml, nl))
+            Sp_ = sp.tril((abs(G.T) @ abs(G)).tocsc()).tocsc(); Sp_.sort_indices()
+            Sp, Si = Sp_.indptr.astype(np.int64), Sp_.indices.astype(np.int64)
+            Fs = Factor(nl, Sp, Si)
+            sup, nrows, parent, level = Fs.supernodes()
+            rp, ri = Fs.front_rows()
+            cores = host_threads(args)
+            sc = lp_oracle.conelp_l(Pl["c"], ml, nl, Pl["Gp"], Pl["Gi"], Pl["Gx"], Pl["h"], structure=(Fs.perm(), sup, rp, ri, parent, Sp, Si),
+                                    threads=cores)
+            ipm["cpu_baseline"] = {"value": sc["iterations"] / sc["loop seconds"], "unit": "iterations/s", "cores": cores, "kind": "port",
+                                   "library": "oracle/lp_oracle.py (coneprog.py:859-1436 restated, numpy) over the host supernodal Cholesky "
+                                              "(oracle/kvx_supernodal.c) and the 1-thread C assembly of S (oracle/kvx_oracle.c)",
+                                   "sample": "the whole run: %d iterations in %.2f s (assembly %.2f s, factor %.2f s, solves %.2f s)"
+                                             % (sc["iterations"], sc["loop seconds"], sc["assemble_s"], sc["factor_s"], sc["solve_s"]),
+                                   "iterations": sc["iterations"], "status": sc["status"],
+                                   "max_abs_diff_x_vs_gpu": float(np.abs(np.asarray(sc["x"]) - np.asarray(sl["x"]).reshape(-1)).max())}
+            ipm["vs_cpu_baseline"] = ipm["value"] / ipm["cpu_baseline"]["value"]
+        except Exception as e:
+            ipm["cpu_baseline"] = {"error": repr(e)}
+    return ipm
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -105,10 +280,22 @@ def main():
     from kvxopt_amd import workloads
     from kvxopt_amd.chol import Factor
 
-    g = args.grid
-    n, colptr, rowind, values = workloads.laplacian_2d(g)
+    g = args.grid or (1000 if args.workload == "lap2d" else 100)
+    if args.workload == "lap2d":
+        n, colptr, rowind, values = workloads.laplacian_2d(g)
+        wname = "5-pt Laplacian %dx%d" % (g, g)
+    else:
+        n, colptr, rowind, values = workloads.laplacian_3d(g)
+        wname = "7-pt Laplacian %dx%dx%d" % (g, g, g)
+    chol_opts = json.loads(args.chol_opts) if args.chol_opts else None
+    DF = None
     t0 = time.time()
-    F = Factor(n, colptr, rowind, "L", None, json.loads(args.chol_opts) if args.chol_opts else None)
+    if args.dist == "subtree":
+        from kvxopt_amd.dist import DistFactor
+        DF = DistFactor(n, colptr, rowind, "L", None, chol_opts, device=torch.device("cuda", local_rank), ob=args.dist_ob, min_m=args.dist_min_m)
+        F = DF.F
+    else:
+        F = Factor(n, colptr, rowind, "L", None, chol_opts)
     t_analyze = time.time() - t0
     info = F.info()
     nrhs = args.nrhs
@@ -121,11 +308,6 @@ def main():
     b_d = torch.from_numpy(np.ascontiguousarray(b_host)).to(dev)
     x_d = torch.empty_like(b_d)
     torch.cuda.synchronize()
-
-    DF = None
-    if args.dist == "subtree" and world > 1:
-        from kvxopt_amd.dist import DistFactor
-        DF = DistFactor(n, colptr, rowind, "L", None, json.loads(args.chol_opts) if args.chol_opts else None, device=dev)
 
     def step():
         if DF is not None:                                   # one system over all ranks
@@ -157,6 +339,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_factor, ms_solve = F.timing()
+    steps_run = args.warmup + args.steps
+    if DF is not None:
+        steps_run_marker = (DF.collectives, DF.bytes_moved)   # (counted up to here: warm-up + timed steps)
 
     # residual of the last solve (parity bar: <= 1e-10 relative)
     x = x_d.cpu().numpy()
@@ -175,18 +360,6 @@ def main():
         samples.sort(key=lambda t: t[0])
         fam_times[fam] = (samples[1][0], samples[1][1])
     F.prof_select(None)
-    if DF is not None:
-        if rank == 0:
-            print(json.dumps({"metric": "sparse Cholesky factor+solve GF/s", "value": work * args.steps / dt / 1e9, "unit": "GF/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                              "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "5-pt Laplacian %dx%d, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (g, g, n, nrhs),
-                                         "parallelism": "subtree-sharded x%d (cut depth %d, %.1f MB all-reduced per factorisation)"
-                                                        % (world, DF.cut, DF.ulen * 8 / 1e6)},
-                              "rel_residual": relres, "roofline": None, "cpu_baseline": None}))
-        if dist is not None:
-            dist.destroy_process_group()
-        return
     if args.quick:
         if rank == 0:
             print(json.dumps({"value": work * args.steps * world / dt / 1e9, "ms_per_step": dt / args.steps * 1e3, "ms_factor": ms_factor,
@@ -195,6 +368,12 @@ def main():
         return
     dom = max(fam_times, key=lambda f: fam_times[f][0]) if args.roofline_family == "auto" else args.roofline_family
     dom_ms, dom_launches = fam_times[dom]
+    if DF is not None and world > 1:
+        # rank 0 times its own launches: scale the family's work by the share of the flops rank 0 executes (host-side map)
+        from kvxopt_amd.dist import partition
+        mp = partition(F, world, DF.ob, DF.min_m)
+        share0 = float(mp["rank_flops"][0] / mp["flops"])
+        st = {k: (v * share0 if isinstance(v, float) else v) for k, v in st.items()}
     if dom == "syrk_trailing":
         achieved = st["flops_syrk"] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -215,7 +394,7 @@ def main():
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null when no profile matches.
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write_per_kernel.json")))
-        if g == 1000 and nrhs == 1 and dom in pmc.get("family_bytes_per_step", {}):
+        if args.workload == "lap2d" and g == 1000 and nrhs == 1 and DF is None and dom in pmc.get("family_bytes_per_step", {}):
             roofline["traffic"] = pmc["family_bytes_per_step"][dom] / max(dom_launches, 1)
             roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/r01b_pmc_fetch_write_per_kernel.json)"
             roofline["algorithmic_bytes_per_launch"] = (alg_bytes / max(dom_launches, 1)) if roofline["bound"] == "hbm" else None
@@ -225,52 +404,37 @@ def main():
     roofline["launches_per_step"] = dom_launches
     roofline["family_ms_per_step"] = {f: round(v[0], 4) for f, v in fam_times.items()}
 
-    # --- CPU baseline: the oracle (plain-C restatement, 1 thread) on the same workload -----------
+    # --- CPU baselines on the same system and permutation (rank 0, host cores of this box) -------
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle.kvx_oracle import OracleChol
-        perm = F.perm()
-        O = OracleChol(n, colptr, rowind, "L", perm)
-        tc0 = time.perf_counter()
-        O.factorize(values)
-        xb = np.asfortranarray(b_host.reshape(n, nrhs, order="F").copy())
-        O.solve(xb)
-        tc = time.perf_counter() - tc0
-        ref_diff = float(np.abs(xb.reshape(-1, order="F") - x).max() / np.abs(xb).max())
-        cpu = {"value": work / tc / 1e9, "unit": "GF/s", "cores": 1, "kind": "port",
-               "sample": "same system and permutation, 1 numeric factorisation + 1 solve (%.1f s)" % tc,
-               "max_rel_diff_vs_gpu": ref_diff}
+        cpu = cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x)
 
     # --- the other half of BASELINE.json's metric: IPM iterations/s of the device-resident conelp on configs[3]
     # (inequality form), rank 0 only, a few hundred ms; never part of `value`
     ipm = None
     if rank == 0 and not args.no_ipm:
         try:
-            from kvxopt_amd import lp as kvx_lp
-            from kvxopt_amd.base import spmatrix
-            Pl = workloads.lp_grid(250, 200)
-            Gl = spmatrix.from_ccs(Pl["ml"], Pl["n"], Pl["Gp"], Pl["Gi"], Pl["Gx"])
-            kvx_lp.conelp(Pl["c"], Gl, Pl["h"], options={"maxiters": 2})
-            tl0 = time.perf_counter()
-            sl = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])
-            tl = time.perf_counter() - tl0
-            ipm = {"metric": "IPM iterations/s", "value": sl["iterations"] / sl["loop seconds"], "unit": "iterations/s",
-                   "workload": "conelp, grid LP 250x200: ml=200000 inequalities, n=50000 (BASELINE configs[3], inequality form)",
-                   "iterations": sl["iterations"], "status": sl["status"], "loop_s": sl["loop seconds"], "whole_call_s": tl,
-                   "value_whole_call": sl["iterations"] / tl}
+            ipm = ipm_leg(args, torch)
         except Exception as e:                      # the headline line must not depend on this leg
             ipm = {"error": repr(e)}
 
     if rank == 0:
-        total = work * args.steps * world
+        total = work * args.steps * (1 if DF is not None else world)
         out = {
             "metric": "sparse Cholesky factor+solve GF/s", "value": total / dt / 1e9, "unit": "GF/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "5-pt Laplacian %dx%d, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (g, g, n, nrhs),
+            "higher_is_better": True, "scaling": "strong" if DF is not None else "weak",
+            "vs_baseline": None,                    # BASELINE.md holds no published number for this metric
+            "vs_cpu_baseline": (total / dt / 1e9 / cpu["value"]) if (cpu and cpu.get("value")) else None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (wname, n, nrhs),
                        "nnz_lower": int(len(values)), "lnz": int(info["lnz"]), "flops_sum_cj2": info["flops"],
                        "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]), "max_front": int(info["max_front"]),
-                       "analyze_s": round(t_analyze, 3), "parallelism": "replicas x%d" % world},
+                       "analyze_s": round(t_analyze, 3),
+                       "parallelism": ("replicas x%d" % world) if DF is None else
+                                      ("one system sharded x%d: proportional mapping, %d shared fronts on rank 0 (%d block-cyclic, %d-column blocks), "
+                                       "%d collectives / %.1f MB per step on rank 0" % (world, DF.nshared, DF.ncyclic, DF.ob,
+                                                                                        steps_run_marker[0] // max(steps_run, 1), steps_run_marker[1] / max(steps_run, 1) / 1e6))},
             "ms_factor": ms_factor, "ms_solve": ms_solve, "rel_residual": relres,
             "roofline": roofline, "cpu_baseline": cpu, "ipm": ipm,
         }

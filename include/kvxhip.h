@@ -121,6 +121,9 @@ int kvx_chol_get_perm(kvx_chol *F, int64_t *perm);     /* final permutation (ord
 /* Supernode layout for tests: super[nsuper+1] column starts, nrows[nsuper] front orders,
  * parent[nsuper], level[nsuper]. Any pointer may be NULL. */
 int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level);
+/* Row structure of the fronts (CHOLMOD's L->s / L->pi of a supernodal factor, cholmod.c:927-943): rowptr (nsuper + 1) and the
+ * sorted permuted row indices of every front, pivot rows first.  rowidx may be NULL (sizes only: rowptr[nsuper] entries). */
+int kvx_chol_get_front_rows(kvx_chol *F, int64_t *rowptr, int64_t *rowidx);
 /* Dominant-kernel timing of the last factorize/solve, measured with HIP events on the
  * factor's own stream (bench.py roofline leg). ms_factor / ms_solve may be NULL. */
 int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);

@@ -61,6 +61,7 @@ _SIGS = {
     "kvx_chol_get_info": (ctypes.c_int, [vp, ctypes.POINTER(CholInfo)]),
     "kvx_chol_get_perm": (ctypes.c_int, [vp, i64p]),
     "kvx_chol_get_supernodes": (ctypes.c_int, [vp, i64p, i64p, i64p, i64p]),
+    "kvx_chol_get_front_rows": (ctypes.c_int, [vp, i64p, i64p]),
     "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
     "kvx_chol_prof_select": (ctypes.c_int, [vp, ctypes.c_int]),
     "kvx_chol_prof_read": (ctypes.c_int, [vp, f64p, i64p]),

@@ -73,6 +73,15 @@ class Factor:
         raise_for(lib().kvx_chol_get_supernodes(self._h, pi(sup), pi(nrows), pi(parent), pi(level)))
         return sup, nrows, parent, level
 
+    def front_rows(self):
+        """(rowptr, rowidx): sorted permuted row indices of every front, pivot rows first."""
+        ns = self.info()["nsuper"]
+        rp = np.zeros(ns + 1, dtype=np.int64)
+        raise_for(lib().kvx_chol_get_front_rows(self._h, pi(rp), None))
+        ri = np.zeros(max(int(rp[-1]), 1), dtype=np.int64)
+        raise_for(lib().kvx_chol_get_front_rows(self._h, pi(rp), pi(ri)))
+        return rp, ri[:int(rp[-1])]
+
     def timing(self):
         a, b = ctypes.c_double(), ctypes.c_double()
         raise_for(lib().kvx_chol_last_timing(self._h, ctypes.byref(a), ctypes.byref(b)))

@@ -21,37 +21,6 @@ namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // 
 
 namespace kvx {
 
-struct ProfScope {
-    kvx_chol *F;
-    bool on;
-    hipStream_t st;
-    ProfScope(kvx_chol *F_, int fam, hipStream_t st_ = nullptr) : F(F_), on(F_->prof_family == fam), st(st_ ? st_ : F_->stream)
-    {
-        if (!on) return;
-        if (F->prof_used + 2 > F->prof_ev.size()) {
-            size_t old = F->prof_ev.size();
-            F->prof_ev.resize(old + 256, nullptr);
-            for (size_t i = old; i < F->prof_ev.size(); i++) (void)pool_event_get(&F->prof_ev[i], true);
-        }
-        (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
-    }
-    ~ProfScope()
-    {
-        if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
-    }
-};
-enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7 };
-
-void prof_collect(kvx_chol *F)
-{
-    for (size_t i = 0; i + 1 < F->prof_used; i += 2) {
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, F->prof_ev[i], F->prof_ev[i + 1]) == hipSuccess) { F->prof_ms += ms; F->prof_launches++; }
-    }
-    F->prof_used = 0;
-}
-
-
 // per-level launch plan of the level lists (lists / lptr: fronts grouped by level, each level sorted by kernel class)
 void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan)
 {
@@ -1028,6 +997,15 @@ static int kvx_chol_get_supernodes_impl(kvx_chol *F, int64_t *super, int64_t *nr
 int kvx_chol_get_supernodes(kvx_chol *F, int64_t *super, int64_t *nrows, int64_t *parent, int64_t *level)
 {
     return guarded([&] { return kvx_chol_get_supernodes_impl(F, super, nrows, parent, level); });
+}
+
+int kvx_chol_get_front_rows(kvx_chol *F, int64_t *rowptr, int64_t *rowidx)
+{
+    if (!F || !rowptr) return KVX_EINVAL;
+    const Symbolic &S = F->S;
+    std::copy(S.rowptr.begin(), S.rowptr.end(), rowptr);
+    if (rowidx) std::copy(S.rowidx.begin(), S.rowidx.end(), rowidx);
+    return KVX_OK;
 }
 
 int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)

@@ -124,6 +124,38 @@ int upload(T **dst, const std::vector<T> &src)
     return KVX_OK;
 }
 
+// optional per-kernel-family timing: HIP events around every launch of the selected family, on the stream it is launched on
+struct ProfScope {
+    kvx_chol *F;
+    bool on;
+    hipStream_t st;
+    ProfScope(kvx_chol *F_, int fam, hipStream_t st_ = nullptr) : F(F_), on(F_->prof_family == fam), st(st_ ? st_ : F_->stream)
+    {
+        if (!on) return;
+        if (F->prof_used + 2 > F->prof_ev.size()) {
+            size_t old = F->prof_ev.size();
+            F->prof_ev.resize(old + 256, nullptr);
+            for (size_t i = old; i < F->prof_ev.size(); i++) (void)pool_event_get(&F->prof_ev[i], true);
+        }
+        (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
+    }
+    ~ProfScope()
+    {
+        if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
+    }
+};
+enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7 };
+
+inline void prof_collect(kvx_chol *F)
+{
+    for (size_t i = 0; i + 1 < F->prof_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, F->prof_ev[i], F->prof_ev[i + 1]) == hipSuccess) { F->prof_ms += ms; F->prof_launches++; }
+    }
+    F->prof_used = 0;
+}
+
+
 // api.cpp
 void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan);
 void build_plan(kvx_chol *F);

@@ -164,17 +164,17 @@ int factor_cyclic_front(Comm &C, int32_t s, int l)
     const double *Uch = F->d_U[(l + 1) & 1];
     double *P = F->d_Lx + S.px[s];
     double *Y = F->d_Linv + F->linv_off_host[s];
-    launch_assemble_big(st, F->ds, list, 1, m, F->d_Lx, Uch, Uout);
+    { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, 1, m, F->d_Lx, Uch, Uout); }
     std::vector<Region> regs;
     int b = 0;
     for (int o = 0; o < k; o += OB, b++) {
         const int nb = std::min(OB, k - o), owner = lo + b % g;
         if (D.rank == owner) {
-            launch_potrf_blk(st, F->ds, list, 1, o, F->d_Lx, F->d_Linv, F->d_status);
+            { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, 1, o, F->d_Lx, F->d_Linv, F->d_status); }
             for (int jb = o; jb < o + nb; jb += KVX_NB) {
                 // (the update of panel jb also factors the diagonal block of panel jb + 64 while it is inside this block)
-                launch_trsm_blk(st, F->ds, list, 1, m, jb, F->d_Lx, F->d_Linv);
-                launch_syrk_inner(st, F->ds, list, 1, m, jb, o + nb, F->d_Lx, Uout, F->d_Linv, F->d_status);
+                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, 1, m, jb, F->d_Lx, F->d_Linv); }
+                { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, 1, m, jb, o + nb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
             }
         }
         regs.clear();
@@ -182,7 +182,7 @@ int factor_cyclic_front(Comm &C, int32_t s, int l)
         regs.push_back(Region{Y + (int64_t)(o / KVX_NB) * KVX_NB * KVX_NB, KVX_NB * KVX_NB, KVX_NB * KVX_NB, (nb + KVX_NB - 1) / KVX_NB});
         int rc = bcast_regions(C, owner, lo, hi, regs);
         if (rc) return rc;
-        if (o + nb < m) launch_syrk_outer_dist(st, F->ds, list, m, o, nb, OB, g, r, F->d_Lx, Uout);
+        if (o + nb < m) { ProfScope ps(F, FAM_SYRK); launch_syrk_outer_dist(st, F->ds, list, m, o, nb, OB, g, r, F->d_Lx, Uout); }
     }
     HIPCHK(hipGetLastError());
     return KVX_OK;
@@ -248,6 +248,7 @@ int dist_factorize_impl(kvx_chol *F, const double *values_dev, kvx_dist_comm_fn 
     }
     float ms = 0;
     if (hipEventElapsedTime(&ms, F->ev[0], F->ev[1]) == hipSuccess) { F->ms_factor = ms; F->have_ftime = true; }
+    prof_collect(F);
     F->pending = false;
     F->numeric = true;
     F->minor = (int64_t)mn;
@@ -303,6 +304,7 @@ int dist_solve_impl(kvx_chol *F, double *B, int64_t nrhs, int64_t ldB, kvx_dist_
     HIPCHK(hipEventRecord(F->ev[3], st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    prof_collect(F);
     float ms = 0;
     if (hipEventElapsedTime(&ms, F->ev[2], F->ev[3]) == hipSuccess) { F->ms_solve = ms; F->have_stime = true; }
     return KVX_OK;

@@ -279,3 +279,78 @@ class OracleKLU:
         if getattr(self, "_h", None):
             lib().kvxo_klu_free(self._h)
             self._h = None
+
+
+# ---- host supernodal multifrontal Cholesky on all cores (oracle/kvx_supernodal.c): the CPU baseline beside the GPU numbers
+_SLIB = None
+
+
+def supernodal_lib():
+    """libkvxsupernodal.so (OpenMP + the OpenBLAS inside scipy); built on demand.  Raises OSError when it cannot be built."""
+    global _SLIB
+    if _SLIB is None:
+        so = os.path.join(_HERE, "libkvxsupernodal.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libkvxsupernodal.so"])
+        L = ctypes.CDLL(so)
+        L.kvxs_analyze.restype = ctypes.c_void_p
+        L.kvxs_analyze.argtypes = [ctypes.c_int64, _i64p, _i64p, _i64p, ctypes.c_int64, _i64p, _i64p, _i64p, _i64p]
+        L.kvxs_free.argtypes = [ctypes.c_void_p]
+        L.kvxs_set_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.kvxs_factorize.argtypes = [ctypes.c_void_p, _f64p]
+        L.kvxs_factorize.restype = ctypes.c_int
+        L.kvxs_solve.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int64, ctypes.c_int64]
+        L.kvxs_solve.restype = ctypes.c_int
+        L.kvxs_minor.argtypes = [ctypes.c_void_p]
+        L.kvxs_minor.restype = ctypes.c_int64
+        _SLIB = L
+    return _SLIB
+
+
+class OracleSupernodal:
+    """Supernodal multifrontal P A P' = L L' on the host cores, on the supernodes and permutation of a kvxopt_amd.chol.Factor
+    (`structure` = (perm, super, front rowptr, front rowidx, parent), all host-side analysis results): the role CHOLMOD's
+    supernodal factorisation plays for the reference (cholmod.c:362-364, 483).  A must be the lower-triangular CCS."""
+
+    def __init__(self, n, colptr, rowind, structure, threads=None):
+        perm, sup, rp, ri, parent = [np.ascontiguousarray(a, dtype=np.int64) for a in structure]
+        self.n = int(n)
+        self.cp = np.ascontiguousarray(colptr, dtype=np.int64)
+        self.ri = np.ascontiguousarray(rowind, dtype=np.int64)
+        col = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.cp))
+        if np.any(self.ri < col):
+            raise ValueError("OracleSupernodal expects the lower triangle")
+        L = supernodal_lib()
+        self._h = L.kvxs_analyze(self.n, _ptr_i(self.cp), _ptr_i(self.ri), _ptr_i(perm), len(sup) - 1, _ptr_i(sup), _ptr_i(rp),
+                                 _ptr_i(ri), _ptr_i(parent))
+        if not self._h:
+            raise MemoryError
+        self.threads = max(1, min(int(threads or len(os.sched_getaffinity(0)) or 1), 32))
+        L.kvxs_set_threads(self._h, self.threads)
+
+    @classmethod
+    def from_factor(cls, n, colptr, rowind, F, threads=None):
+        sup, nrows, parent, level = F.supernodes()
+        rp, ri = F.front_rows()
+        return cls(n, colptr, rowind, (F.perm(), sup, rp, ri, parent), threads)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            supernodal_lib().kvxs_free(self._h)
+            self._h = None
+
+    def factorize(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        rc = supernodal_lib().kvxs_factorize(self._h, _ptr_d(v))
+        if rc == 1:
+            raise ArithmeticError(int(supernodal_lib().kvxs_minor(self._h)))
+        if rc:
+            raise MemoryError
+
+    def solve(self, B):
+        """B: column-major (n x nrhs) float64, overwritten with the solution of A X = B."""
+        B2 = B.reshape(self.n, -1, order="F") if B.ndim == 1 else B
+        assert B2.flags.f_contiguous and B2.dtype == np.float64
+        rc = supernodal_lib().kvxs_solve(self._h, _ptr_d(B2), B2.shape[1], max(self.n, 1))
+        if rc:
+            raise ArithmeticError("singular matrix")

@@ -15,6 +15,9 @@ def pytest_configure(config):
     so = os.path.join(ROOT, "oracle", "libkvxoracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libkvxoracle.so"])
+    so2 = os.path.join(ROOT, "oracle", "libkvxsupernodal.so")
+    if not os.path.exists(so2):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libkvxsupernodal.so"])
     lib = os.path.join(ROOT, "kvxopt_amd", "libkvxhip.so")
     if not os.path.exists(lib):
         subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "kvxopt_amd", "csrc")])

@@ -136,3 +136,67 @@ def test_atda_and_spmv_against_dense():
     assert np.allclose(y2, 2 * (G @ x) - 0.5 * y)
     x2 = x.copy(); spmv("T", 40, 12, G.indptr, G.indices, G.data, y, x2, -1.0, 1.0)
     assert np.allclose(x2, x - G.T @ y)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_host_supernodal_baseline_matches_the_simplicial_oracle(threads):
+    """oracle/kvx_supernodal.c (the all-cores CPU baseline of bench.py): same solutions as the pinned simplicial oracle on
+    the GPU library's own supernodes and permutation, for any thread count; a non-positive pivot is reported with the
+    oracle's column."""
+    from kvxopt_amd import workloads
+    from kvxopt_amd.chol import Factor
+    from oracle.kvx_oracle import OracleChol, OracleSupernodal
+    for (n, cp, ri, v) in (workloads.laplacian_2d(70, 41), workloads.laplacian_3d(12)):
+        F = Factor(n, cp, ri)                                    # host-side analysis only
+        O = OracleChol(n, cp, ri, "L", F.perm()); O.factorize(v)
+        S = OracleSupernodal.from_factor(n, cp, ri, F, threads=threads); S.factorize(v)
+        B = np.random.default_rng(3).standard_normal((n, 3))
+        x1 = np.asfortranarray(B.copy()); O.solve(x1)
+        x2 = np.asfortranarray(B.copy()); S.solve(x2)
+        assert np.abs(x1 - x2).max() / np.abs(x1).max() < 1e-12
+        bad = v.copy(); bad[cp[int(F.perm()[n // 2])]] = -3.0
+        with pytest.raises(ArithmeticError) as eo:
+            O.factorize(bad)
+        with pytest.raises(ArithmeticError) as es:
+            S.factorize(bad)
+        assert es.value.args[0] == eo.value.args[0]
+        S.factorize(v)
+        x3 = np.asfortranarray(B.copy()); S.solve(x3)
+        assert np.abs(x3 - x1).max() / np.abs(x1).max() < 1e-12
+
+
+def test_cpu_conelp_restatement_reproduces_the_reference_traces(golden_dir):
+    """oracle/lp_oracle.py (the CPU baseline of the IPM metric) against golden G4 from the reference's conelp: same iteration
+    counts, same solutions, same certificates -- over the simplicial oracle and over the host supernodal Cholesky."""
+    import json
+    import scipy.sparse as sp
+    from kvxopt_amd import workloads
+    from kvxopt_amd.chol import Factor
+    from oracle import lp_oracle
+    g = np.load(os.path.join(golden_dir, "g4_conelp.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g4_conelp.json")))["cases"]
+    for name, gx, gy in (("grid6x5", 6, 5), ("grid25x20", 25, 20)):
+        P = workloads.lp_grid(gx, gy)
+        G = sp.csc_matrix((P["Gx"], P["Gi"], P["Gp"]), shape=(P["ml"], P["n"]))
+        Spat = sp.tril((abs(G.T) @ abs(G)).tocsc()).tocsc(); Spat.sort_indices()
+        Sp, Si = Spat.indptr.astype(np.int64), Spat.indices.astype(np.int64)
+        Fs = Factor(P["n"], Sp, Si)
+        sup, nrows, parent, level = Fs.supernodes()
+        rp, ri = Fs.front_rows()
+        for structure in (None, (Fs.perm(), sup, rp, ri, parent, Sp, Si)):
+            sol = lp_oracle.conelp_l(P["c"], P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"], P["h"], structure=structure, threads=2)
+            assert sol["status"] == meta[name]["status"] == "optimal" and sol["iterations"] == meta[name]["iterations"]
+            assert np.abs(sol["x"] - g[name + "_x"]).max() < 1e-9 and np.abs(sol["z"] - g[name + "_z"]).max() < 1e-9
+            assert abs(sol["primal objective"] - meta[name]["primal objective"]) < 1e-9 * max(1.0, abs(meta[name]["primal objective"]))
+
+    def ccs(V, I, J, shape):
+        A = sp.csc_matrix((V, (I, J)), shape=shape); A.sort_indices()
+        return A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data
+    Gp, Gi, Gx = ccs([-1.0, 1.0], [0, 1], [0, 0], (2, 1))
+    sol = lp_oracle.conelp_l(np.array([1.0]), 2, 1, Gp, Gi, Gx, np.array([-1.0, 0.0]))
+    assert sol["status"] == "primal infeasible" and sol["iterations"] == meta["primal_infeasible"]["iterations"]
+    assert np.allclose(sol["z"], meta["primal_infeasible"]["z"], atol=1e-9)
+    Gp, Gi, Gx = ccs([-1.0, -1.0], [0, 1], [0, 1], (2, 2))
+    sol = lp_oracle.conelp_l(np.array([-1.0, 0.5]), 2, 2, Gp, Gi, Gx, np.array([0.0, 0.0]))
+    assert sol["status"] == "dual infeasible" and sol["iterations"] == meta["dual_infeasible"]["iterations"]
+    assert np.allclose(sol["x"], meta["dual_infeasible"]["x"], rtol=1e-9)
