@@ -73,7 +73,7 @@ def chol_case(name, n, colptr, rowind, values, nrhs, steps, warmup):
             "rel_residual": float(np.linalg.norm(r) / np.linalg.norm(B))}
 
 
-def lp_case(gx, gy):
+def lp_case(gx, gy, repeat=1, kkt_timing=True):
     from kvxopt_amd import lp, workloads
     from kvxopt_amd.base import spmatrix
     P = workloads.lp_grid(gx, gy)
@@ -81,9 +81,13 @@ def lp_case(gx, gy):
     cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
     G = spmatrix(P["Gx"], P["Gi"], cols, (ml, n))
     lp.conelp(P["c"], G, P["h"], options={"maxiters": 2})            # warm-up: HIP module load, first-touch allocations
-    t0 = time.perf_counter()
-    sol = lp.conelp(P["c"], G, P["h"])
-    dt = time.perf_counter() - t0
+    for _ in range(max(1, repeat)):                                 # (--repeat: several whole runs under a profiler)
+        t0 = time.perf_counter()
+        sol = lp.conelp(P["c"], G, P["h"])
+        dt = time.perf_counter() - t0
+    if not kkt_timing:
+        return {"case": "lp4b", "metric": "IPM iterations/s", "value": sol["iterations"] / dt, "unit": "iterations/s",
+                "iterations": sol["iterations"], "status": sol["status"], "wall_s": dt, "loop_s": sol["loop seconds"], "runs": repeat}
     # per-iteration KKT costs on the same pattern
     kkt = lp.KKTChol2Dev(ml, n, P["Gp"], P["Gi"], P["Gx"])
     di = lp.DVec(ml, np.random.default_rng(4).uniform(0.2, 5.0, ml))
@@ -221,6 +225,7 @@ def main():
     ap.add_argument("--grid", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeat", type=int, default=0, help="lp4b: this many whole conelp runs and nothing else (profiling runs)")
     args = ap.parse_args()
     import torch
     if not torch.cuda.is_available():
@@ -238,7 +243,7 @@ def main():
         elif case == "lp4a":
             out = lp_std_case(250, 200)
         elif case == "lp4b":
-            out = lp_case(250, 200)
+            out = lp_case(250, 200, args.repeat, kkt_timing=args.repeat == 0)
         elif case == "lp4c":
             out = lp_eq_case(250, 200, 200)
         elif case == "lu2d":
