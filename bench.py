@@ -87,7 +87,10 @@ def front_stats(F):
             jb += 64
     lsize = float(np.sum(m * k))
     sum_m = float(np.sum(m))
-    return {"bytes_small": bytes_small, "flops_syrk": flops_syrk, "lsize": lsize, "sum_m": sum_m,
+    mid = ~small & (m <= int(os.environ.get("KVX_MID_M", "0")))   # big-class fronts factored by one workgroup each (opt-in experiment)
+    S2 = lambda v: v * (v + 1.0) * (2.0 * v + 1.0) / 6.0
+    flops_mid = float(np.sum((S2(m.astype(float)) - S2((m - k).astype(float)))[mid]))
+    return {"bytes_small": bytes_small, "flops_syrk": flops_syrk, "flops_mid": flops_mid, "lsize": lsize, "sum_m": sum_m,
             "n_small": int(small.sum()), "n_big": int((~small).sum())}
 
 
@@ -374,8 +377,8 @@ def main():
         mp = partition(F, world, DF.ob, DF.min_m)
         share0 = float(mp["rank_flops"][0] / mp["flops"])
         st = {k: (v * share0 if isinstance(v, float) else v) for k, v in st.items()}
-    if dom == "syrk_trailing":
-        achieved = st["flops_syrk"] / (dom_ms * 1e-3) / 1e12
+    if dom in ("syrk_trailing", "front_mid"):
+        achieved = st["flops_syrk" if dom == "syrk_trailing" else "flops_mid"] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None}
     else:

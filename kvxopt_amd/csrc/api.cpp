@@ -22,7 +22,7 @@ namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // 
 namespace kvx {
 
 // per-level launch plan of the level lists (lists / lptr: fronts grouped by level, each level sorted by kernel class)
-void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan)
+void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan, int mid_m)
 {
     plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
@@ -39,6 +39,8 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
             P.maxk[c] = std::max(P.maxk[c], k);
             if (c == KVX_CLS_BIG) {
                 P.big_maxk = std::max(P.big_maxk, k);
+                if (m <= mid_m) P.nmid++;                  // (the class is sorted by decreasing order: these are its tail)
+                else P.chain_maxk = std::max(P.chain_maxk, k);
                 P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
             }
             int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
@@ -50,7 +52,7 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
 }
 
 // from F->lists_host / F->lptr_host (the level lists already uploaded to d_lists)
-void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host, F->plan); }
+void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host, F->plan, F->mid_m); }
 
 void destroy_graphs(kvx_chol *F)
 {
@@ -190,13 +192,15 @@ int ensure_device(kvx_chol *F)
     }
     Symbolic &S = F->S;
     analyze_subtrees(F);
-    HIPCHK(pool_stream_get(&F->stream));
+    { const char *e = getenv("KVX_CHAIN_PRIO"); F->prio_stream = !(e && e[0] == '0'); }
+    HIPCHK(pool_stream_get(&F->stream, F->prio_stream));
     for (int i = 0; i < 4; i++) HIPCHK(pool_event_get(&F->ev[i], true));
     for (int i = 0; i < 4; i++) {
         HIPCHK(pool_stream_get(&F->side[i]));
         HIPCHK(pool_event_get(&F->ev_join[i], false));
     }
     HIPCHK(pool_event_get(&F->ev_fork, false));
+    HIPCHK(pool_event_get(&F->ev_fork2, false));
     HIPCHK(pool_event_get(&F->ev_in, false));
     HIPCHK(pool_event_get(&F->ev_out, false));
     int rc;
@@ -279,6 +283,7 @@ int ensure_device(kvx_chol *F)
     }
     F->lists_host = S.levellist;
     F->lptr_host = S.levelptr;
+    { const char *e = getenv("KVX_MID_M"); if (e) F->mid_m = std::max(0, std::min(atoi(e), 512)); }
     build_plan(F);
     { const char *e = getenv("KVX_NO_SUBTREES"); F->use_subtrees = !(e && e[0] == '1'); }
     if ((rc = build_subtrees(F))) return rc;
@@ -374,7 +379,7 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             items[i].stream = best;
             if (best > 0) side_used[best - 1] = true;
         }
-        if (side_used[0] || side_used[1]) {
+        if (side_used[0] || side_used[1]) {        // (side_used[2], the mid-front launch, forks with an event of its own below)
             HIPCHK(hipEventRecord(F->ev_fork, st));
             for (int i = 0; i < 2; i++)
                 if (side_used[i]) HIPCHK(hipStreamWaitEvent(F->side[i], F->ev_fork, 0));
@@ -388,10 +393,27 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             else    // the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
                 launch_front_wave(sl, wave_class_mcap(it.c), P.cnt[it.c] > 0 ? 32 : 16, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
-        if (have_big) {
-            const int nbig = P.cnt[KVX_CLS_BIG], bigm = P.maxm[KVX_CLS_BIG];
+        // big class: its tail of fronts of order <= mid_m goes to ONE launch of the one-workgroup-per-front kernel (its own
+        // stream beside the chain); the larger ones run the batched multi-workgroup panel chain on the main stream
+        const int nchain = P.cnt[KVX_CLS_BIG] - P.nmid;
+        if (have_big) {                                     // extend-add of every big front of the level, one launch
+            ProfScope ps(F, FAM_ASSEMBLE);
+            launch_assemble_big(st, F->ds, lbase + P.off[KVX_CLS_BIG], P.cnt[KVX_CLS_BIG], P.maxm[KVX_CLS_BIG], F->d_Lx, Uch, Uout);
+        }
+        if (P.nmid > 0) {
+            hipStream_t sm = st;
+            if (nchain > 0) {
+                HIPCHK(hipEventRecord(F->ev_fork2, st));
+                HIPCHK(hipStreamWaitEvent(F->side[2], F->ev_fork2, 0));
+                sm = F->side[2];
+                side_used[2] = true;
+            }
+            ProfScope ps(F, FAM_MID, sm);
+            launch_front_mid(sm, F->ds, lbase + P.off[KVX_CLS_BIG] + nchain, P.nmid, F->d_Lx, Uch, Uout, F->d_Linv, F->d_status);
+        }
+        if (nchain > 0) {
+            const int nbig = nchain, bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = lbase + P.off[KVX_CLS_BIG];
-            { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, nbig, bigm, F->d_Lx, Uch, Uout); }
             { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             if (bigm >= F->two_level_m) {
                 // outer blocks of `outer_block` (1024) columns, one rank-1024 update of the trailing matrix per block (128-tile kernel: 34 TF/s
@@ -401,15 +423,15 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 // block, so it is used for very large fronts only; look-ahead (outer update of block b beside the panel
                 // chain of block b + 1) is the missing piece
                 const int OB = F->outer_block;
-                for (int ob = 0; ob < P.big_maxk; ob += OB) {
-                    for (int jb = ob; jb < std::min(ob + OB, P.big_maxk); jb += KVX_NB) {
+                for (int ob = 0; ob < P.chain_maxk; ob += OB) {
+                    for (int jb = ob; jb < std::min(ob + OB, P.chain_maxk); jb += KVX_NB) {
                         { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
                         { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, ob + OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
                     }
                     { ProfScope ps(F, FAM_SYRK); launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
                 }
             } else {
-                for (int jb = 0; jb < P.big_maxk; jb += KVX_NB) {
+                for (int jb = 0; jb < P.chain_maxk; jb += KVX_NB) {
                     // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
                     { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
                     { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
@@ -1019,7 +1041,7 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)
 
 int kvx_chol_prof_select(kvx_chol *F, int family)
 {
-    if (!F || family < -1 || family > 7) return KVX_EINVAL;
+    if (!F || family < -1 || family > 8) return KVX_EINVAL;
     if (F->pending) finish_factor(F, nullptr);
     F->prof_family = family;
     F->prof_ms = 0;
@@ -1073,9 +1095,10 @@ void kvx_chol_free(kvx_chol *F)
         for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
+        if (F->ev_fork2) pool_event_put(F->ev_fork2, false);
         if (F->ev_in) pool_event_put(F->ev_in, false);
         if (F->ev_out) pool_event_put(F->ev_out, false);
-        if (F->stream) pool_stream_put(F->stream);
+        if (F->stream) pool_stream_put(F->stream, F->prio_stream);
         lap("streams");
     }
     delete F;

@@ -168,6 +168,9 @@ void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, con
                        double *Lx, const double *Uchild, double *Uout, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
+// one workgroup per front, one launch: extend-add + the whole panel loop (big-class fronts of order <= KVX_MID_M)
+void launch_front_mid(hipStream_t st, const DevSym &ds, const int32_t *list, int count, double *Lx, const double *Uchild,
+                      double *Uout, double *Linv, int *status);
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
                       double *Lx, double *Linv, int *status);
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,

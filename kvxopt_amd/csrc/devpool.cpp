@@ -18,6 +18,7 @@ size_t g_cached = 0;
 constexpr size_t MAX_BLOCK = (size_t)1 << 30;
 
 std::multimap<int, hipStream_t> g_streams;      // by device
+std::multimap<int, hipStream_t> g_streams_hi;   // ... of the highest priority
 std::multimap<int, hipEvent_t> g_events[2];      // [timing] by device
 
 size_t cache_cap()
@@ -92,27 +93,36 @@ hipError_t pool_free(void *p)
     return e;
 }
 
-hipError_t pool_stream_get(hipStream_t *s)
+// high = true: a stream of the highest priority the device offers (the pivot chain of a factorisation: its kernels are
+// dispatched ahead of the side streams' when both have workgroups waiting for a CU); kept in a pool of its own
+hipError_t pool_stream_get(hipStream_t *s, bool high)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_streams.find(dev);
-        if (it != g_streams.end()) { *s = it->second; g_streams.erase(it); return hipSuccess; }
+        auto &pool = high ? g_streams_hi : g_streams;
+        auto it = pool.find(dev);
+        if (it != pool.end()) { *s = it->second; pool.erase(it); return hipSuccess; }
+    }
+    if (high) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
     }
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
-void pool_stream_put(hipStream_t s)
+void pool_stream_put(hipStream_t s, bool high)
 {
     if (!s) return;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipStreamDestroy(s); return; }
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_streams.size() >= 64) { (void)hipStreamDestroy(s); return; }
-    g_streams.emplace(dev, s);
+    auto &pool = high ? g_streams_hi : g_streams;
+    if (pool.size() >= 64) { (void)hipStreamDestroy(s); return; }
+    pool.emplace(dev, s);
 }
 
 hipError_t pool_event_get(hipEvent_t *ev, bool timing)
@@ -147,6 +157,8 @@ void pool_release_all()
     release_all_locked();
     for (auto &kv : g_streams) (void)hipStreamDestroy(kv.second);
     g_streams.clear();
+    for (auto &kv : g_streams_hi) (void)hipStreamDestroy(kv.second);
+    g_streams_hi.clear();
     for (auto &m : g_events) { for (auto &kv : m) (void)hipEventDestroy(kv.second); m.clear(); }
 }
 }  // namespace kvx

@@ -13,8 +13,8 @@ hipError_t pool_malloc(void **p, size_t bytes);
 hipError_t pool_free(void *p);
 // Streams (non-blocking) and events are recycled too: creating and destroying the nine streams and dozen events of a factor cost
 // ~5 ms + ~13 ms per factor lifetime.  A stream / event must be idle when it is put back (kvx_*_free synchronise first).
-hipError_t pool_stream_get(hipStream_t *s);
-void pool_stream_put(hipStream_t s);
+hipError_t pool_stream_get(hipStream_t *s, bool high = false);
+void pool_stream_put(hipStream_t s, bool high = false);
 hipError_t pool_event_get(hipEvent_t *e, bool timing);
 void pool_event_put(hipEvent_t e, bool timing);
 void pool_release_all();          // really free everything cached (tests, out-of-memory retry)

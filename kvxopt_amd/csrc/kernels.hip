@@ -41,98 +41,6 @@ void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int
 }
 
 // ------------------------------------------------------------------------------------------
-// Big fronts: extend-add in HBM.  Workgroup (x, front) owns target columns [16x, 16x+16) of the
-// parent front: it first zeroes their part of the update matrix (no separate memset on the level's
-// critical path), then pulls the matching columns of every child, children in sequence (parent-pull:
-// no atomics, bitwise reproducible).  The child columns that land in the tile come from a host-built
-// table (ChildDesc::tile).  The kernel is a chain of indirect accesses, i.e. latency-bound, so each
-// wave works on its (up to) four child columns at once -- 16 independent row updates per lane in
-// flight -- and the next child's descriptor is fetched while the current child is added.
-__global__ __launch_bounds__(256) void k_assemble_big(DevSym ds, const int32_t *__restrict__ list,
-                                                      double *__restrict__ Lx, const double *__restrict__ Uc,
-                                                      double *__restrict__ Uo)
-{
-    const FrontDesc fd = ds.fd[list[blockIdx.y]];
-    const int k = fd.k, m = fd.m, u = m - k;
-    const int c0 = blockIdx.x * KVX_ASM_TC;
-    if (c0 >= m) return;
-    double *P = Lx + fd.px;
-    double *U = Uo + fd.ux;
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    ChildDesc cd{};
-    if (fd.nchild > 0) cd = ds.cd[fd.childptr];
-    for (int c = max(c0, k); c < min(c0 + KVX_ASM_TC, m); c++) {
-        double *col = U + (int64_t)(c - k) * u - k;
-        for (int i = c + (int)threadIdx.x; i < m; i += 256) col[i] = 0.0;
-    }
-    __syncthreads();
-    for (int c = 0; c < fd.nchild; c++) {
-        ChildDesc nx = cd;
-        if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
-        const int uc = cd.uc;
-        if (uc > 0) {
-            const int32_t *rl = ds.rel + cd.rel;
-            const int jlo = ds.tiles[cd.tile + blockIdx.x], jhi = ds.tiles[cd.tile + blockIdx.x + 1];
-            const double *Uch = Uc + cd.ux;
-            if (jlo < jhi) {                           // workgroup-uniform
-                int jc[4];
-                bool okc[4];
-                const double *src[4];
-                double *dst[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    jc[t] = jlo + wv + 4 * t;
-                    okc[t] = jc[t] < jhi;
-                    if (!okc[t]) jc[t] = jlo;
-                }
-                int tcs[4];
-#pragma unroll
-                for (int t = 0; t < 4; t++) tcs[t] = rl[jc[t]];
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    src[t] = Uch + (int64_t)jc[t] * uc;
-                    dst[t] = (tcs[t] < k) ? P + (int64_t)tcs[t] * m : U + (int64_t)(tcs[t] - k) * u - k;
-                }
-                for (int base = ln; base < uc - jlo; base += 256) {
-                    int r[4][4];
-                    double v[4][4], old[4][4];
-                    bool ok[4][4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int i = jc[t] + base + 64 * q;
-                            ok[t][q] = okc[t] && i < uc;
-                            const int ii = ok[t][q] ? i : jc[t];       // row j of column j is always in range
-                            r[t][q] = rl[ii];
-                            v[t][q] = src[t][ii];
-                        }
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) old[t][q] = dst[t][r[t][q]];
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (ok[t][q]) dst[t][r[t][q]] = old[t][q] + v[t][q];
-                }
-            }
-        }
-        __syncthreads();
-        cd = nx;
-    }
-}
-
-void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
-                         double *Lx, const double *Uchild, double *Uout)
-{
-    if (count <= 0) return;
-    dim3 grid((unsigned)((max_m + KVX_ASM_TC - 1) / KVX_ASM_TC), (unsigned)count);
-    hipLaunchKernelGGL(k_assemble_big, grid, dim3(256), 0, st, ds, list, Lx, Uchild, Uout);
-}
-
-// ------------------------------------------------------------------------------------------
 // Triangular solves, one workgroup per front and right-hand side.
 constexpr int SOLVE_B = 64, SOLVE_LD = 65;
 

@@ -29,6 +29,106 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = KVX_NB;
 
 // ------------------------------------------------------------------------------------------
+// Big fronts: extend-add in HBM.  Workgroup (x, front) owns target columns [16x, 16x+16) of the
+// parent front: it first zeroes their part of the update matrix (no separate memset on the level's
+// critical path), then pulls the matching columns of every child, children in sequence (parent-pull:
+// no atomics, bitwise reproducible).  The child columns that land in the tile come from a host-built
+// table (ChildDesc::tile).  The kernel is a chain of indirect accesses, i.e. latency-bound, so each
+// wave works on its (up to) four child columns at once -- 16 independent row updates per lane in
+// flight -- and the next child's descriptor is fetched while the current child is added.
+// (device function: the multi-workgroup kernel calls it once per workgroup, the one-workgroup-per-front kernel k_front_mid
+// loops over the column tiles; 256 threads, contains barriers: every thread of the workgroup must call it)
+__device__ __forceinline__ void assemble_cols(const DevSym &ds, const FrontDesc &fd, const int ct, double *__restrict__ Lx,
+                                              const double *__restrict__ Uc, double *__restrict__ Uo)
+{
+    const int k = fd.k, m = fd.m, u = m - k;
+    const int c0 = ct * KVX_ASM_TC;
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    ChildDesc cd{};
+    if (fd.nchild > 0) cd = ds.cd[fd.childptr];
+    for (int c = max(c0, k); c < min(c0 + KVX_ASM_TC, m); c++) {
+        double *col = U + (int64_t)(c - k) * u - k;
+        for (int i = c + (int)threadIdx.x; i < m; i += 256) col[i] = 0.0;
+    }
+    __syncthreads();
+    for (int c = 0; c < fd.nchild; c++) {
+        ChildDesc nx = cd;
+        if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
+        const int uc = cd.uc;
+        if (uc > 0) {
+            const int32_t *rl = ds.rel + cd.rel;
+            const int jlo = ds.tiles[cd.tile + ct], jhi = ds.tiles[cd.tile + ct + 1];
+            const double *Uch = Uc + cd.ux;
+            if (jlo < jhi) {                           // workgroup-uniform
+                int jc[4];
+                bool okc[4];
+                const double *src[4];
+                double *dst[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    jc[t] = jlo + wv + 4 * t;
+                    okc[t] = jc[t] < jhi;
+                    if (!okc[t]) jc[t] = jlo;
+                }
+                int tcs[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) tcs[t] = rl[jc[t]];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    src[t] = Uch + (int64_t)jc[t] * uc;
+                    dst[t] = (tcs[t] < k) ? P + (int64_t)tcs[t] * m : U + (int64_t)(tcs[t] - k) * u - k;
+                }
+                for (int base = ln; base < uc - jlo; base += 256) {
+                    int r[4][4];
+                    double v[4][4], old[4][4];
+                    bool ok[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int i = jc[t] + base + 64 * q;
+                            ok[t][q] = okc[t] && i < uc;
+                            const int ii = ok[t][q] ? i : jc[t];       // row j of column j is always in range
+                            r[t][q] = rl[ii];
+                            v[t][q] = src[t][ii];
+                        }
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) old[t][q] = dst[t][r[t][q]];
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (ok[t][q]) dst[t][r[t][q]] = old[t][q] + v[t][q];
+                }
+            }
+        }
+        __syncthreads();
+        cd = nx;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_assemble_big(DevSym ds, const int32_t *__restrict__ list,
+                                                      double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                      double *__restrict__ Uo)
+{
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    if ((int)blockIdx.x * KVX_ASM_TC >= fd.m) return;
+    assemble_cols(ds, fd, (int)blockIdx.x, Lx, Uc, Uo);
+}
+
+void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                         double *Lx, const double *Uchild, double *Uout)
+{
+    if (count <= 0) return;
+    dim3 grid((unsigned)((max_m + KVX_ASM_TC - 1) / KVX_ASM_TC), (unsigned)count);
+    hipLaunchKernelGGL(k_assemble_big, grid, dim3(256), 0, st, ds, list, Lx, Uchild, Uout);
+}
+
+// ------------------------------------------------------------------------------------------
 // 64x64 diagonal block: Cholesky factor AND its inverse, one 256-thread workgroup, entirely in LDS.
 // Right-looking over four 16-column blocks; per block step s:
 //   A  wave 0 factors the 16x16 diagonal block and inverts it in the SAME instruction stream: lanes
@@ -206,13 +306,11 @@ __device__ __forceinline__ void potrf_store(const PotrfLds &lds, int nbk, int ti
     }
 }
 
-__global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                   double *__restrict__ Lx, double *__restrict__ Linv, int *status)
+// load the diagonal block jb of the panel into lds.S (identity padding), factor + invert it, store both (256 threads, barriers)
+__device__ __forceinline__ void potrf_block(const DevSym &ds, const FrontDesc &fd, int jb, double *__restrict__ Lx,
+                                            double *__restrict__ Linv, int *status, PotrfLds &lds)
 {
-    __shared__ PotrfLds lds;
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m;
-    if (jb >= k) return;
     const int nbk = min(NB, k - jb);
     const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
     double *P = Lx + fd.px;
@@ -234,6 +332,15 @@ __global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__r
     potrf_store(lds, nbk, tid, P, m, jb, Linv + fd.linv + (int64_t)(jb / NB) * NB * NB);
 }
 
+__global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                   double *__restrict__ Lx, double *__restrict__ Linv, int *status)
+{
+    __shared__ PotrfLds lds;
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    if (jb >= fd.k) return;
+    potrf_block(ds, fd, jb, Lx, Linv, status, lds);
+}
+
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
                       double *Lx, double *Linv, int *status)
 {
@@ -246,14 +353,11 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
 // trailing update (D[i][j]: i <-> panel column, j <-> row) so that stores run along rows.  All
 // operand loads of the 16 k-steps are branch-free; Linv is lower triangular, so k-groups above a
 // column tile are skipped.
-__global__ __launch_bounds__(256) void k_trsm_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
-                                                  double *__restrict__ Lx, const double *__restrict__ Linv)
+__device__ __forceinline__ void trsm_rows(const FrontDesc &fd, int jb, int rb, double *__restrict__ Lx, const double *__restrict__ Linv)
 {
-    const FrontDesc fd = ds.fd[list[blockIdx.y]];
     const int k = fd.k, m = fd.m;
-    if (jb >= k) return;
     const int nbk = min(NB, k - jb);
-    const int r0 = jb + nbk + blockIdx.x * 64;
+    const int r0 = jb + nbk + rb * 64;
     if (r0 >= m) return;
     double *P = Lx + fd.px;
     const double *Y = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
@@ -294,6 +398,14 @@ __global__ __launch_bounds__(256) void k_trsm_blk(DevSym ds, const int32_t *__re
                 if (c < nbk) P[rr + (int64_t)(jb + c) * m] = acc[t][qq];
             }
     }
+}
+
+__global__ __launch_bounds__(256) void k_trsm_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
+                                                  double *__restrict__ Lx, const double *__restrict__ Linv)
+{
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    if (jb >= fd.k) return;
+    trsm_rows(fd, jb, (int)blockIdx.x, Lx, Linv);
 }
 
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
@@ -400,6 +512,104 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
         potrf_lds(lds, nb2, threadIdx.x, status, fd.first + t0, make_piv_rule(ds));
         potrf_store(lds, nb2, threadIdx.x, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mid-size fronts (big class, order <= KVX_MID_M): the whole front in ONE workgroup and ONE launch per level -- extend-add,
+// then per 64-column panel: diagonal block (potrf_lds), panel solve, trailing update, tile after tile.  On config 2 three
+// quarters of the "big" fronts of the middle levels have 129..256 rows; going through the batched multi-workgroup chain they
+// cost those levels an extend-add + 3 launches per 64 columns whose grids are sized for the largest front of the level.
+// Here a front costs its own time only, the fronts of a level run side by side on the CUs (50 KB of LDS: three per CU), and
+// the chain of the few larger fronts runs beside them on the main stream.  Same arithmetic, same order of operations per
+// entry as the multi-workgroup kernels (bitwise identical factors).
+__device__ __forceinline__ void syrk_tile(const FrontDesc &fd, int jb, int ti, int tj, double *__restrict__ P, double *__restrict__ U)
+{
+    const int k = fd.k, m = fd.m, u = m - k;
+    const int nbk = min(NB, k - jb);
+    const int t0 = jb + nbk;
+    const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+    d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int rr = r0 + 16 * w + lr;
+    const bool rin = rr < m;
+    bool cin[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) cin[t] = (c0 + 16 * t + lr) < m;
+#pragma unroll
+    for (int kg = 0; kg < NB; kg += 16) {
+        if (kg < nbk) {                             // wave-uniform
+            double bq[4], aq[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int kc = kg + 4 * q + lk;
+                const bool kin = kc < nbk;
+                const int64_t coff = (int64_t)(jb + kc) * m;
+                bq[q] = kvx_ld0(P, rr + coff, kin && rin);
+#pragma unroll
+                for (int t = 0; t < 4; t++) aq[q][t] = kvx_ld0(P, (c0 + 16 * t + lr) + coff, kin && cin[t]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
+        }
+    }
+    const int rs = min(rr, m - 1);
+    double *ptr[4][4];
+    double old[4][4];
+    bool ok[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = c0 + 16 * t + lk + 4 * q;
+            ok[t][q] = rin && c <= rr;
+            const int cs = min(c, rs);
+            ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
+            old[t][q] = *ptr[t][q];
+        }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
+}
+
+__global__ __launch_bounds__(256) void k_front_mid(DevSym ds, const int32_t *__restrict__ list, double *__restrict__ Lx,
+                                                   const double *__restrict__ Uc, double *__restrict__ Uo,
+                                                   double *__restrict__ Linv, int *status)
+{
+    __shared__ PotrfLds lds;
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    const int k = fd.k, m = fd.m;
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
+    // (the extend-add stays with the multi-workgroup kernel, all big fronts of the level in one launch: done by ONE
+    // workgroup it is a chain of dependent index loads per 16-column tile, 130 us for a front of order 256)
+    (void)Uc;
+    // right-looking over the 64-column panels
+    for (int jb = 0; jb < k; jb += NB) {
+        potrf_block(ds, fd, jb, Lx, Linv, status, lds);
+        __syncthreads();
+        const int nbk = min(NB, k - jb);
+        const int rows = m - jb - nbk;
+        if (rows <= 0) break;
+        const int T = (rows + KVX_TILE - 1) / KVX_TILE;
+        for (int rb = 0; rb < T; rb++) trsm_rows(fd, jb, rb, Lx, Linv);
+        __syncthreads();
+        for (int ti = 0; ti < T; ti++)
+            for (int tj = 0; tj <= ti; tj++) syrk_tile(fd, jb, ti, tj, P, U);
+        __syncthreads();
+    }
+}
+
+void launch_front_mid(hipStream_t st, const DevSym &ds, const int32_t *list, int count, double *Lx, const double *Uchild,
+                      double *Uout, double *Linv, int *status)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_front_mid, dim3((unsigned)count), dim3(256), 0, st, ds, list, Lx, Uchild, Uout, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -302,6 +302,38 @@ def test_full_size_properties():
     assert np.array_equal(x, x2)
 
 
+def test_config5_workload_properties_on_one_gpu():
+    """BASELINE.json configs[4]'s workload -- the 7-point Laplacian on a cube -- through the HIP path at 100^3 (n = 1e6, an eighth
+    of config 5's unknowns; top front of order ~14 000: the two-level blocked MFMA update path), by properties that need no
+    oracle run: residual <= 1e-10, linearity, permutation round trip, bitwise reproducible refactor and solve, positive diagonal
+    with the known log-determinant sign structure, and the failing column of a matrix made indefinite in its LAST column."""
+    n, cp, ri, vx = workloads.laplacian_3d(100)
+    F = Factor(n, cp, ri)
+    assert F.info()["max_front"] >= 6144                       # (the threshold of the two-level update: this test must cross it)
+    F.factorize(vx)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n)
+    x = b.copy(); F.solve(x)
+    assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - b) / np.linalg.norm(b) < 1e-10
+    c = rng.standard_normal(n)
+    X = np.asfortranarray(np.stack([c, 2.0 * b - 3.0 * c], axis=1))
+    F.solve(X)
+    assert rel(2.0 * x - 3.0 * X[:, 0], X[:, 1]) < 1e-9
+    y = b.copy(); F.solve(y, sys=7); F.solve(y, sys=8)
+    assert np.array_equal(y, b)
+    d1 = F.diag()
+    assert np.all(d1 > 0) and np.all(d1 <= np.sqrt(6.0) + 1e-12)   # l_jj^2 <= a_jj = 6
+    F.factorize(vx)
+    assert np.array_equal(d1, F.diag())
+    x2 = b.copy(); F.solve(x2)
+    assert np.array_equal(x, x2)
+    bad = vx.copy(); p = F.perm()
+    bad[cp[int(p[n - 1])]] = -1.0                                  # the last pivot of the root front
+    with pytest.raises(ArithmeticError) as e:
+        F.factorize(bad)
+    assert e.value.args[0] == n - 1
+
+
 def test_dbound_replaces_small_pivots():
     """cholmod.options['dbound'] (cholmod.c:116-117; CHOLMOD: diagonal entries of L below dbound are replaced by dbound),
     in every kernel class (wave, LDS, blocked), and the drop-the-row form used by the interior-point driver."""
