@@ -1,9 +1,14 @@
 // Symbolic analysis (host): see symbolic.hpp.  Reference role: cholmod_l_analyze_p as
 // called from src/C/cholmod.c:274 after pack() (:132-181).
 #include "symbolic.hpp"
+#include "par.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 
@@ -21,27 +26,38 @@ struct LowerPattern {
 void build_lower(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo,
                  const std::vector<int64_t> &iperm, LowerPattern &Lo)
 {
+    // threads scan disjoint ranges of the caller's columns and claim slots of the destination columns with atomic counters;
+    // the order inside a column depends on the race, the sort at the end makes the result canonical
+    const int T = analyze_threads();
     Lo.ptr.assign((size_t)n + 1, 0);
-    for (int64_t j = 0; j < n; j++)
-        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-            int64_t i = Ai[p];
-            if (i == j) continue;
-            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
-            int64_t a = iperm[i], b = iperm[j];
-            Lo.ptr[(size_t)std::min(a, b) + 1]++;
-        }
+    int64_t *cnt = Lo.ptr.data() + 1;
+    parallel_for(n, T, 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; j++)
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                int64_t i = Ai[p];
+                if (i == j) continue;
+                if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                int64_t a = iperm[i], b = iperm[j];
+                __atomic_fetch_add(&cnt[std::min(a, b)], (int64_t)1, __ATOMIC_RELAXED);
+            }
+    });
     for (int64_t j = 0; j < n; j++) Lo.ptr[j + 1] += Lo.ptr[j];
     Lo.idx.resize((size_t)Lo.ptr[n]);
     std::vector<int64_t> cur(Lo.ptr.begin(), Lo.ptr.end() - 1);
-    for (int64_t j = 0; j < n; j++)
-        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-            int64_t i = Ai[p];
-            if (i == j) continue;
-            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
-            int64_t a = iperm[i], b = iperm[j];
-            Lo.idx[(size_t)cur[std::min(a, b)]++] = (int32_t)std::max(a, b);
-        }
-    for (int64_t j = 0; j < n; j++) std::sort(Lo.idx.begin() + Lo.ptr[j], Lo.idx.begin() + Lo.ptr[j + 1]);
+    parallel_for(n, T, 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; j++)
+            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                int64_t i = Ai[p];
+                if (i == j) continue;
+                if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                int64_t a = iperm[i], b = iperm[j];
+                const int64_t slot = __atomic_fetch_add(&cur[(size_t)std::min(a, b)], (int64_t)1, __ATOMIC_RELAXED);
+                Lo.idx[(size_t)slot] = (int32_t)std::max(a, b);
+            }
+    });
+    parallel_for(n, T, 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t j = lo; j < hi; j++) std::sort(Lo.idx.begin() + Lo.ptr[j], Lo.idx.begin() + Lo.ptr[j + 1]);
+    });
 }
 
 // Elimination tree from the strictly-lower pattern by column.  Liu's algorithm needs,
@@ -79,17 +95,30 @@ void postorder(int64_t n, const std::vector<int32_t> &parent, std::vector<int32_
     std::vector<int64_t> size((size_t)n, 1);
     for (int64_t j = 0; j < n; j++)
         if (parent[j] >= 0) size[parent[j]] += size[j];
-    // child lists sorted by (size, index): bucket via sort of indices
-    std::vector<int32_t> order((size_t)n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return size[a] > size[b]; });
-    // push in decreasing size so that list heads are the smallest
-    std::vector<int32_t> head((size_t)n, -1), next((size_t)n, -1), roots_head(1, -1);
-    int32_t root_list = -1;
-    for (int32_t j : order) {
-        if (parent[j] >= 0) { next[j] = head[parent[j]]; head[parent[j]] = j; }
-        else { next[j] = root_list; root_list = j; }
+    // child lists by increasing size (ties: larger index first): the children of every node are collected in index order (two counting
+    // passes) and each list is sorted on its own -- lists are short, a global sort of all n nodes by size is not needed
+    std::vector<int64_t> cptr((size_t)n + 2, 0);
+    for (int64_t j = 0; j < n; j++) cptr[(size_t)(parent[j] >= 0 ? parent[j] : n) + 1]++;
+    for (int64_t j = 0; j <= n; j++) cptr[j + 1] += cptr[j];
+    std::vector<int32_t> clist((size_t)n);
+    {
+        std::vector<int64_t> cur(cptr.begin(), cptr.end() - 1);
+        for (int64_t j = 0; j < n; j++) clist[(size_t)cur[parent[j] >= 0 ? parent[j] : n]++] = (int32_t)j;
     }
+    parallel_for(n + 1, analyze_threads(), 1 << 15, [&](int64_t lo, int64_t hi) {
+        for (int64_t v = lo; v < hi; v++)
+            if (cptr[v + 1] - cptr[v] > 1)
+                std::sort(clist.begin() + cptr[v], clist.begin() + cptr[v + 1],
+                          [&](int32_t a, int32_t b) { return size[a] != size[b] ? size[a] < size[b] : a > b; });
+    });
+    std::vector<int32_t> head((size_t)n, -1), next((size_t)n, -1);
+    int32_t root_list = -1;
+    for (int64_t v = 0; v <= n; v++)
+        for (int64_t q = cptr[v + 1] - 1; q >= cptr[v]; q--) {       // push back to front: list heads are the smallest
+            const int32_t j = clist[q];
+            if (v < n) { next[j] = head[v]; head[v] = j; }
+            else { next[j] = root_list; root_list = j; }
+        }
     post.resize((size_t)n);
     int64_t k = 0;
     std::vector<int32_t> stack;
@@ -147,12 +176,28 @@ void column_counts(int64_t n, const LowerPattern &Lo, const std::vector<int32_t>
 
 }  // namespace
 
+namespace {
+struct PhaseTimer {                                  // KVX_ANALYZE_TIMING=1: wall time of every phase of analyze() on stderr
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseTimer() : on(getenv("KVX_ANALYZE_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "  analyze %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t).count());
+        t = t1;
+    }
+};
+}  // namespace
+
 void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const int64_t *user_perm,
              const SymOpts &opts, Symbolic &S)
 {
     if (n < 0) throw std::runtime_error("negative dimension");
     if (n >= (int64_t)1 << 31) throw std::runtime_error("order exceeds 2^31-1");
     if (uplo != 'L' && uplo != 'U') throw std::runtime_error("uplo must be 'L' or 'U'");
+    PhaseTimer pt;
     S = Symbolic();
     S.n = n;
     S.nnzA = n ? Ap[n] : 0;
@@ -198,6 +243,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         for (int64_t k = 0; k < n; k++) iperm0[perm0[k]] = k;
     }
 
+    pt.lap("1 ordering");
     // ---- 2. etree + postorder, fold the postorder into the permutation ---------------------
     LowerPattern Lo;
     std::vector<int32_t> parent;
@@ -230,10 +276,15 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             for (int64_t k = 0; k < n; k++) S.perm[k] = perm0[post[k]];
             for (int64_t k = 0; k < n; k++) S.iperm[S.perm[k]] = k;
             build_lower(n, Ap, Ai, uplo, S.iperm, Lo);
-            etree_from_lower(n, Lo, parent);
+            // the elimination tree of the relabelled matrix is the relabelled tree: no second pass of Liu's algorithm
+            std::vector<int32_t> ipost((size_t)n), np((size_t)n);
+            for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
+            for (int64_t k = 0; k < n; k++) np[k] = parent[post[k]] >= 0 ? ipost[parent[post[k]]] : -1;
+            parent.swap(np);
         }
     }
 
+    pt.lap("2 etree+postorder");
     // ---- 3. column counts ---------------------------------------------------------------
     column_counts(n, Lo, parent, S.colcount);
     S.lnz = 0;
@@ -243,6 +294,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         S.flops += (double)S.colcount[j] * (double)S.colcount[j];
     }
 
+    pt.lap("3 colcounts");
     // ---- 4. supernodes: maximal zero-fill chains, then relaxed amalgamation ----------------
     std::vector<int64_t> sstart;           // first column of each supernode
     for (int64_t j = 0; j < n; j++) {
@@ -356,6 +408,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             if (S.sparent[s] >= 0) S.children[(size_t)cur[S.sparent[s]]++] = (int32_t)s;
     }
 
+    pt.lap("4 supernodes");
     // ---- 5. front row structures (supernodal symbolic factorisation) -------------------------
     S.rowptr.assign((size_t)ns + 1, 0);
     S.sn_m.resize((size_t)ns);
@@ -387,6 +440,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             S.sn_m[s] = (int32_t)(e - f + (int64_t)tail.size());
         }
     }
+    pt.lap("5 front rows");
     // ---- 6. relative indices child -> parent --------------------------------------------------
     S.rel.assign(S.rowidx.size(), -1);
     for (int64_t s = 0; s < ns; s++) {
@@ -403,6 +457,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             S.rel[a] = (int32_t)(b - S.rowptr[p]);
         }
     }
+    pt.lap("6 relative indices");
     // ---- 7. storage offsets, levels ---------------------------------------------------------------
     S.px.assign((size_t)ns + 1, 0);
     S.max_m = 0; S.max_k = 0; S.sum_m = 0;
@@ -453,23 +508,36 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         S.upd_size[l & 1] = std::max(S.upd_size[l & 1], off);
         S.wrk_size[l & 1] = std::max(S.wrk_size[l & 1], woff);
     }
+    pt.lap("7 offsets+levels");
     // ---- 8. scatter map caller entries -> panels ------------------------------------------------
     S.amap.assign((size_t)S.nnzA, -1);
-    S.nnzTri = 0;
-    for (int64_t j = 0; j < n; j++)
-        for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-            int64_t i = Ai[p];
-            if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
-            S.nnzTri++;
-            int64_t a = S.iperm[i], b = S.iperm[j];
-            int64_t r = std::max(a, b), c = std::min(a, b);
-            int32_t s = col2s[c];
-            const int32_t *rb = S.rowidx.data() + S.rowptr[s];
-            const int32_t *re = S.rowidx.data() + S.rowptr[s + 1];
-            const int32_t *it = std::lower_bound(rb, re, (int32_t)r);
-            if (it == re || *it != r) throw std::runtime_error("internal: entry outside the front structure");
-            S.amap[p] = S.px[s] + (it - rb) + (c - S.super[s]) * (int64_t)S.sn_m[s];
-        }
+    {
+        std::vector<int64_t> tri_part(64, 0);
+        int part = 0;
+        std::mutex mu;
+        parallel_for(n, analyze_threads(), 1 << 14, [&](int64_t lo, int64_t hi) {
+            int64_t tri = 0;
+            for (int64_t j = lo; j < hi; j++)
+                for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                    int64_t i = Ai[p];
+                    if ((uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                    tri++;
+                    int64_t a = S.iperm[i], b = S.iperm[j];
+                    int64_t r = std::max(a, b), c = std::min(a, b);
+                    int32_t s = col2s[c];
+                    const int32_t *rb = S.rowidx.data() + S.rowptr[s];
+                    const int32_t *re = S.rowidx.data() + S.rowptr[s + 1];
+                    const int32_t *it = std::lower_bound(rb, re, (int32_t)r);
+                    if (it == re || *it != r) throw std::runtime_error("internal: entry outside the front structure");
+                    S.amap[p] = S.px[s] + (it - rb) + (c - S.super[s]) * (int64_t)S.sn_m[s];
+                }
+            std::lock_guard<std::mutex> lk(mu);
+            tri_part[(size_t)part++ % 64] += tri;
+        });
+        S.nnzTri = 0;
+        for (int64_t v : tri_part) S.nnzTri += v;
+    }
+    pt.lap("8 scatter map");
 }
 
 // flops of eliminating the k pivots of a front of order m: sum_{j < k} (m - j)^2
