@@ -1,6 +1,8 @@
 // Host analysis of the sparse LU path: see lu_symbolic.hpp.  Reference role: klu_analyze (src/C/klu.c:141,264).
 #include "lu_symbolic.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -123,7 +125,11 @@ void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *A
         for (int64_t p = 0; p < Y.nnz; p++) rmax[Ai[p]] = std::max(rmax[Ai[p]], std::fabs(Ax[p]));
         for (int64_t i = 0; i < n; i++) rinv[i] = (rmax[i] > 0 && std::isfinite(rmax[i])) ? 1.0 / rmax[i] : 1.0;
     }
+    const bool tim = std::getenv("KVX_ANALYZE_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *w) { if (tim) { auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "  lu_analyze %-20s %8.3f ms\n", w, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; } };
     const int64_t matched = lu_matching(n, Ap, Ai, Ax, rinv.data(), Y.rowfor);
+    lap("matching");
     Y.structurally_singular = matched < n;
     // M(colof[i], j) = A(i, j)
     std::vector<int64_t> colof((size_t)n);
@@ -195,6 +201,7 @@ void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *A
             }
         }
     }
+    lap("btf");
     // pattern of tril(D + D') with the diagonal, D = the diagonal blocks of M
     std::vector<int64_t> cnt((size_t)n + 1, 0);
     for (int64_t j = 0; j < n; j++) {
@@ -221,8 +228,10 @@ void lu_analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, const double *A
         uniq.insert(uniq.end(), idx.begin() + cnt[j], e);
         ptr[j + 1] = (int64_t)uniq.size();
     }
+    lap("pattern");
     SymOpts so;
     analyze(n, ptr.data(), uniq.data(), 'L', nullptr, so, Y.S);
+    lap("cholesky analysis");
     Y.uf.resize((size_t)Y.S.nsuper);
     std::iota(Y.uf.begin(), Y.uf.end(), 0);
 }

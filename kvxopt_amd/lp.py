@@ -10,8 +10,8 @@ reference: 1 numeric refactorisation of S = G' diag(di^2) G on a fi
 3 KKT solves, 2 products with G and 2 with G', the NT-scaling update -- all HIP kernels of
 libkvxhip.so.  No CPU fallback.
 
-Equality constraints (p > 0, K = A S^{-1} A') go through the host-array compatibility layer
-(`kvxopt_amd.misc.kkt_chol2`); the device-resident driver raises for them for now.
+Equality constraints (p > 0, K = A S^{-1} A') are device-resident too: KKTDiagEqDev (diagonal S, sparse K on a fixed
+pattern) and KKTGenEqDev (general S, dense K in HBM, any p).  `kvxopt_amd.misc.kkt_chol2` is built on the same classes.
 """
 import ctypes
 import math
@@ -126,12 +126,20 @@ class SpMatDev:
         self.vx = DeviceBuffer.from_array(values) if len(values) else DeviceBuffer(8)
         cols = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(colptr))
         order = np.lexsort((cols, rowind))
+        self._order = order                               # CCS position of every entry of the transposed copy
         tp = np.zeros(self.m + 1, dtype=np.int64)
         np.add.at(tp, rowind + 1, 1)
         np.cumsum(tp, out=tp)
         self.tcp = DeviceBuffer.from_array(tp)
         self.tri = DeviceBuffer.from_array(cols[order]) if len(rowind) else DeviceBuffer(8)
         self.tvx = DeviceBuffer.from_array(values[order]) if len(values) else DeviceBuffer(8)
+
+    def set_values(self, values):
+        """New values on the same pattern (both copies)."""
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        if values.size:
+            self.vx.upload(values)
+            self.tvx.upload(np.ascontiguousarray(values[self._order]))
 
     def gemv(self, x, y, trans="N", alpha=1.0, beta=0.0):
         """y := alpha*op(A)*x + beta*y  (base.gemv -> sparse.c:1073-1104)."""
@@ -182,6 +190,11 @@ class KKTChol2Dev:
         if getattr(self, "_plan", None):
             lib().kvx_atda_free(self._plan)
             self._plan = None
+
+    def set_hessian(self, Px):
+        """New values of H on the pattern given at construction (cvxprog: H changes at every iteration)."""
+        if self.Px is not None and len(Px):
+            self.Px.set(Px)
 
     def factor(self, di, sync=True):
         """S = G' diag(di)^2 G on the fixed pattern, numeric refactorisation (misc.py:1418-1462).
@@ -346,14 +359,15 @@ class KKTGenEqDev:
     same Cholesky (dense lower pattern, analysed once).  KKT solve (misc.py:1489-1563 written with S^-1):
     u = S^-1 (bx + G' W^-1 W^-T bz), uy = K^-1 (A u - by), ux = S^-1 (bx + G'.. - A' uy), uz = W^-T (G ux - bz)."""
 
-    MAX_P = 2048
+    BLOCK_BYTES = 1 << 30        # X = S^-1 A' is formed in column blocks of about this size (n x cols doubles)
 
     def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts=None, Pp=None, Pi=None, Px=None):
-        """Pp, Pi, Px: optional lower-triangular CCS of the QP Hessian (coneqp): S = P + G' W^-1 W^-T G."""
-        if p > self.MAX_P:
-            raise NotImplementedError("device-resident conelp with a general G handles up to %d equality constraints "
-                                      "(dense K); use kvxopt_amd.misc.kkt_chol2 (host arrays) beyond" % self.MAX_P)
+        """Pp, Pi, Px: optional lower-triangular CCS of the QP Hessian (coneqp): S = P + G' W^-1 W^-T G.
+        Any p: K = A S^-1 A' is structurally dense whenever S is irreducible (every column of L^-1 P A' reaches the root of
+        the elimination tree), so it is held as a dense p x p matrix in HBM (20 GB at p = 50 000) and X = S^-1 A' is formed
+        and consumed in column blocks -- never as a whole."""
         self.ml, self.n, self.p = ml, n, p
+        self.cols = max(1, min(max(p, 1), self.BLOCK_BYTES // (8 * max(n, 1))))
         self.S = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
         self.G = self.S.G
         self.A = SpMatDev(p, n, Ap, Ai, Ax)
@@ -365,7 +379,7 @@ class KKTGenEqDev:
         np.add.at(ATp, Ai + 1, 1)
         np.cumsum(ATp, out=ATp)
         self.AT = SpMatDev(n, p, ATp, cols[order], Ax[order])
-        self.X = DVec(max(n * p, 1))
+        self.X = DVec(max(n * self.cols, 1))
         self.Kd = DVec(max(p * p, 1))
         self.Kx = DVec(max(p * (p + 1) // 2, 1))
         Kp = np.zeros(p + 1, dtype=np.int64)
@@ -393,9 +407,12 @@ class KKTGenEqDev:
     def factor(self, di, sync=True):
         n, p = self.n, self.p
         self.S.factor(di, sync=False)                                  # S = G' W^-1 W^-T G: assembly + numeric refactorisation
-        raise_for(lib().kvx_dense_from_ccs_dev(n, p, self.AT.cp.ptr, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n))   # X := A'
-        self.S.fac.solve_dev(self.X.ptr, 0, p, n, sync=False)          # X := S^-1 A'   (a failed S surfaces in check())
-        raise_for(lib().kvx_spmm_t_dev(p, p, self.AT.cp.ptr, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n, self.Kd.ptr, p))  # K := A X
+        for c0 in range(0, p, self.cols):                              # column blocks of X = S^-1 A' and of K = A X
+            nb = min(self.cols, p - c0)
+            raise_for(lib().kvx_dense_from_ccs_dev(n, nb, self.AT.cp.ptr + 8 * c0, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n))
+            self.S.fac.solve_dev(self.X.ptr, 0, nb, n, sync=False)     # (a failed S surfaces in check())
+            raise_for(lib().kvx_spmm_t_dev(p, nb, self.AT.cp.ptr, self.AT.ri.ptr, self.AT.vx.ptr, self.X.ptr, n,
+                                           self.Kd.ptr + 8 * c0 * p, p))
         raise_for(lib().kvx_pack_lower_dev(p, self.Kd.ptr, p, self.Kx.ptr))
         # scale to max diag K = 1 (one host round trip; it also surfaces a failed factorisation of S)
         raise_for(lib().kvx_vec_copy_strided_dev(p, self.Kd.ptr, p + 1, self.kdiag.ptr))
@@ -438,7 +455,7 @@ class KKTGenEqDev:
 def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, primalstart=None, dualstart=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
     (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints either G has at most one entry per
-    row (standard form: KKTDiagEqDev, any p) or p <= 2048 (general G: KKTGenEqDev, dense K).  primalstart = {'x', 's'},
+    row (standard form: KKTDiagEqDev, sparse K on a fixed pattern) or any other sparse G (KKTGenEqDev, dense K in HBM).  primalstart = {'x', 's'},
     dualstart = {'y', 'z'} (y optional) as in the reference (coneprog.py:683-737): s and z must be strictly positive.  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
     _lib.require_device()
     opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
@@ -759,8 +776,7 @@ def _lower_ccs(P, n):
 
 
 def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=None):
-    """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h, Ax = b  on the GPU (orthant cone; at most
-    KKTGenEqDev.MAX_P equality rows): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
+    """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h, Ax = b  on the GPU (orthant cone): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
     misc.kkt_chol2 with H = P.  P: spmatrix-like, its lower triangle is used.  Returns the reference's result
     dictionary (coneprog.py:2216-2221) with numpy arrays, plus "factorizations"."""
     _lib.require_device()

@@ -13,7 +13,7 @@ import ctypes
 
 import numpy as np
 
-from . import _lib, base, cholmod
+from . import _lib, base
 from ._lib import DeviceBuffer, lib, raise_for
 from .base import matrix, spmatrix
 
@@ -185,110 +185,164 @@ def max_step(x, dims, mnl=0, sigma=None):
     return r.value
 
 
-def kkt_chol2(G, dims, A, mnl=0):
-    """KKT solver factory, sparse-G branch of misc.py:1352-1567 (same state machine: first call
-    fixes the pattern of S = G' W^{-1} W^{-T} G (+H); later calls refactor numerically on the same
-    symbolic analysis; K = A S^{-1} A' is refactored with a fresh analysis every call; the singular-S
-    fallback adds A'A).  Returns factor(W, H=None, Df=None) -> solve(x, y, z).
+class _Chol2Device:
+    """Device side of one `kkt_chol2` factory: the stacked constraint matrix J = [Df; G] (plus the rows of A when S turned out
+    singular), its row weights, the assembly plan of S = J' diag(w^2) J + H and the KKT object of kvxopt_amd.lp that owns
+    the Cholesky factors.  Built at the first factor() call -- the call that fixes the sparsity patterns in the reference
+    too (misc.py:1405-1432) -- and refilled with new values afterwards."""
 
-    mnl > 0 (cvxprog, misc.py:1396-1400, 1413-1415, 1423-1424, 1452-1453, 1523, 1560-1561): Df is the mnl x n sparse
-    Jacobian of the nonlinear constraints, stacked on top of G:  S = Df' Wnl^-2 Df + G' Wl^-2 G + H; its pattern is
-    fixed by the first call like G's.  A dense Df (or dense G, H) sends the reference to its LAPACK branch, which is out
-    of scope here; a dense A (the reference's "mixed" branch, misc.py:1476-1481) is accepted."""
+    def __init__(self, G, A, mnl, Df, H, with_A_rows):
+        from . import lp
+        gm, n, gcp, gri, gv = base._as_ccs(G)
+        self.n, self.ml, self.mnl = n, gm, mnl
+        self.p = A.size[0]
+        am, an, acp, ari, av = base._as_ccs(A)
+        blocks = []                                   # (row offset, colptr, rowind, value count) of every block of J
+        if mnl:
+            dm, dn, dcp, dri, dv = base._as_ccs(Df)
+            if (dm, dn) != (mnl, n):
+                raise TypeError("Df must be an mnl x n sparse matrix")
+            blocks.append((0, dcp, dri, dv.size))
+        blocks.append((mnl, gcp, gri, gv.size))
+        if with_A_rows:
+            blocks.append((mnl + gm, acp, ari, av.size))
+        rows = np.concatenate([ri + off for off, cp, ri, cnt in blocks]) if blocks else np.zeros(0, np.int64)
+        cols = np.concatenate([np.repeat(np.arange(n, dtype=np.int64), np.diff(cp)) for off, cp, ri, cnt in blocks])
+        self._perm = np.lexsort((rows, cols))         # J's CCS order; also the gather of its value array from the blocks'
+        self.Jp = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(cols, minlength=n), out=self.Jp[1:])
+        self.Ji = np.ascontiguousarray(rows[self._perm])
+        self.mj = mnl + gm + (am if with_A_rows else 0)
+        self.with_A_rows = with_A_rows
+        self._gv, self._av = gv, av
+        Hp = Hi = Hx = None
+        self._hkeep = None
+        if H is not None:
+            hm, hn, hcp, hri, hv = base._as_ccs(H)
+            hcol = np.repeat(np.arange(hn, dtype=np.int64), np.diff(hcp))
+            self._hkeep = hri >= hcol                 # S is stored by its lower triangle: that part of H is added
+            Hp = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.bincount(hcol[self._hkeep], minlength=n), out=Hp[1:])
+            Hi, Hx = np.ascontiguousarray(hri[self._hkeep]), np.ascontiguousarray(hv[self._hkeep])
+            self._hpat = (hcp.copy(), hri.copy())
+        Jx = self._values(Df)
+        diag_s = (self.p > 0 and H is None and mnl == 0 and not with_A_rows and
+                  (self.Ji.size == 0 or np.bincount(self.Ji, minlength=max(self.mj, 1)).max() <= 1))
+        if self.p == 0:
+            self.kkt = lp.KKTChol2Dev(self.mj, n, self.Jp, self.Ji, Jx, None, Hp, Hi, Hx)
+            self.J, self.chol = self.kkt.G, self.kkt
+        elif diag_s:
+            self.kkt = lp.KKTDiagEqDev(self.mj, n, self.Jp, self.Ji, Jx, self.p, acp, ari, av)
+            self.J, self.chol = None, None
+        else:
+            self.kkt = lp.KKTGenEqDev(self.mj, n, self.Jp, self.Ji, Jx, self.p, acp, ari, av, None, Hp, Hi, Hx)
+            self.J, self.chol = self.kkt.G, self.kkt.S
+        self.Adev = lp.SpMatDev(am, an, acp, ari, av) if (with_A_rows and self.p) else None
+        self.w = lp.DVec(max(self.mj, 1))
+        self.x, self.z = lp.DVec(max(n, 1)), lp.DVec(max(self.mj, 1))
+        self.y = lp.DVec(max(self.p, 1))
+        self._first = True
+
+    def _values(self, Df):
+        parts = []
+        if self.mnl:
+            parts.append(base._as_ccs(Df)[4])
+        parts.append(self._gv)
+        if self.with_A_rows:
+            parts.append(self._av)
+        return np.ascontiguousarray(np.concatenate(parts)[self._perm]) if parts else np.zeros(0)
+
+    def refactor(self, W, H, Df):
+        """New weights (and Df / H values) on the fixed patterns; numeric refactorisation.  ArithmeticError if S (or K) is
+        not positive definite."""
+        wl = [np.asarray(_buf(W["dnli"])[0], dtype=np.float64)[:self.mnl]] if self.mnl else []
+        wl.append(np.asarray(_buf(W["di"])[0], dtype=np.float64)[:self.ml])
+        if self.with_A_rows:
+            wl.append(np.ones(self.p))
+        w = np.concatenate(wl) if self.mj else np.zeros(1)
+        if w.size != max(self.mj, 1) and self.mj:
+            raise TypeError("W['di'] does not match the number of inequality rows")
+        self.w.set(w)
+        if self.mnl and not self._first and self.J is not None:
+            self.J.set_values(self._values(Df))
+        if H is not None:
+            if self._hkeep is None:
+                raise ValueError("kkt_chol2: H appeared after the first call fixed the pattern of S without it")
+            hm, hn, hcp, hri, hv = base._as_ccs(H)
+            if hri.size != self._hpat[1].size or not np.array_equal(hcp, self._hpat[0]) or not np.array_equal(hri, self._hpat[1]):
+                raise ValueError("kkt_chol2: H must keep the sparsity pattern of the first call")
+            if not self._first and self.chol is not None:
+                self.chol.set_hessian(np.ascontiguousarray(hv[self._hkeep]))
+        self._first = False
+        self.kkt.factor(self.w, sync=True)
+
+    def solve(self, x, y, z):
+        """(x, y, z) := (ux, uy, W uz) of the KKT system, host vectors in and out; the arithmetic stays on the device."""
+        xb, yb, zb = _buf(x)[0], _buf(y)[0], _buf(z)[0]
+        n, p, m = self.n, self.p, self.mnl + self.ml
+        self.x.set(xb[:n])
+        zz = np.zeros(max(self.mj, 1))
+        zz[:m] = zb[:m]
+        self.z.set(zz)                                   # (the rows of A appended to J carry no right-hand side)
+        if p:
+            self.y.set(yb[:p])
+            if self.with_A_rows:
+                self.Adev.gemv(self.y, self.x, trans="T", alpha=1.0, beta=1.0)   # singular S: bx + A' by (misc.py:1525-1526)
+            self.kkt.solve(self.x, self.y, self.z)
+            yb[:p] = self.y.get()[:p]
+        else:
+            self.kkt.solve(self.x, self.z)
+        xb[:n] = self.x.get()[:n]
+        zb[:m] = self.z.get()[:m]
+
+
+def kkt_chol2(G, dims, A, mnl=0):
+    """KKT solver factory of the reference for sparse G (misc.py:1352-1567): returns factor(W, H=None, Df=None), which
+    returns solve(x, y, z) overwriting the right-hand side (bx, by, bz) with (ux, uy, W uz) of
+
+        [ H   A'  J' ] [ux]   [bx]
+        [ A   0   0  ] [uy] = [by],      J = [Df; G]  (Df: the mnl x n Jacobian block of cvxprog, absent for cone LPs / QPs).
+        [ J   0 -W'W ] [uz]   [bz]
+
+    Same contract as the reference: the first factor() call fixes the sparsity patterns (of G, Df, H -- hence of
+    S = J' W^-1 W^-T J + H) and analyses S once, later calls refactor numerically (misc.py:1405-1462); if the first S is not
+    positive definite, A'A is added to it from then on and the solves compensate (misc.py:1433-1447, 1525-1526); a failing
+    factorisation raises ArithmeticError.  Not the reference's program: everything between the host vectors of the caller
+    and the result runs in HBM on kvxopt_amd.lp's device classes -- S assembled by one gather kernel on a product map,
+    K = A S^-1 A' as a fixed-pattern assembly when S is diagonal and as a dense matrix otherwise (the reference rebuilds
+    Asct = L^-1 P A' by sparse triangular solves and re-analyses K at every call, misc.py:1483-1487), both Cholesky factors
+    resident between factor() and solve().  A dense A (the reference's "mixed" branch, misc.py:1476-1481) is accepted;
+    dense G, H or Df send the reference to LAPACK and are out of scope here."""
     if dims.get("q") or dims.get("s"):
         raise ValueError("kktsolver option 'kkt_chol2' is implemented only for problems with no "
                          "second-order or semidefinite cone constraints")
     if isinstance(G, matrix):
         raise NotImplementedError("kkt_chol2: the dense-G LAPACK branch (misc.py:1429,1467-1472) is out of scope")
     p, n = A.size
-    if isinstance(A, matrix):
-        # mixed branch of the reference (sparse S, dense A: misc.py:1476-1481 forms a dense K with LAPACK).  Here a dense A
-        # is A with every entry stored: Asct = L^-1 P A' and K = Asct' Asct come out of the same device kernels as for a
-        # sparse A, K is simply a full p x p pattern (one front).
+    if isinstance(A, matrix):                     # every entry stored: the same kernels, a full pattern
         Ad = np.asarray(A.a, dtype=np.float64).reshape(p, n)
         A = spmatrix.from_ccs(p, n, np.arange(n + 1, dtype=np.int64) * p, np.tile(np.arange(p, dtype=np.int64), n),
                               np.ascontiguousarray(Ad.T).reshape(-1))
-    ml = dims["l"]
-    F = {"firstcall": True, "singular": False}
+    state = {"dev": None}
 
     def factor(W, H=None, Df=None):
-        if F["firstcall"]:
-            gm, gn, gcp, gri, gv = base._as_ccs(G)
-            F["Gs"] = spmatrix.from_ccs(gm, gn, gcp.copy(), gri.copy(), np.zeros(gv.size))
-            if mnl:
-                if isinstance(Df, matrix) or not hasattr(Df, "CCS"):
-                    raise NotImplementedError("kkt_chol2: a dense Df takes the reference's LAPACK branch (out of scope)")
-                dm, dn, dcp, dri, dv = base._as_ccs(Df)
-                F["Dfs"] = spmatrix.from_ccs(dm, dn, dcp.copy(), dri.copy(), np.zeros(dv.size))
-            F["S"] = spmatrix([], [], [], (n, n))
-            F["K"] = spmatrix([], [], [], (p, p))
         if isinstance(H, matrix):
             raise NotImplementedError("kkt_chol2: a dense H takes the reference's LAPACK branch (out of scope)")
-        # Dfs = Wnl^{-1} * Df
-        if mnl:
-            base.gemm(base.spdiag(W["dnli"]), Df, F["Dfs"], partial=True)
-        # Gs = Wl^{-1} * G
-        base.gemm(base.spdiag(W["di"]), G, F["Gs"], partial=True)
-        if F["firstcall"]:
-            base.syrk(F["Gs"], F["S"], trans="T")
-            if mnl:
-                base.syrk(F["Dfs"], F["S"], trans="T", beta=1.0)
-            if H is not None:
-                F["S"] += H
+        if mnl and (isinstance(Df, matrix) or not hasattr(Df, "CCS")):
+            raise NotImplementedError("kkt_chol2: a dense Df takes the reference's LAPACK branch (out of scope)")
+        _lib.require_device()
+        if state["dev"] is None:
+            dev = _Chol2Device(G, A, mnl, Df, H, with_A_rows=False)
             try:
-                F["Sf"] = cholmod.symbolic(F["S"])
-                cholmod.numeric(F["S"], F["Sf"])
+                dev.refactor(W, H, Df)
             except ArithmeticError:
-                F["singular"] = True
-                base.syrk(F["Gs"], F["S"], trans="T")
-                if mnl:
-                    base.syrk(F["Dfs"], F["S"], trans="T", beta=1.0)
-                base.syrk(A, F["S"], trans="T", beta=1.0)
-                if H is not None:
-                    F["S"] += H
-                F["Sf"] = cholmod.symbolic(F["S"])
-                cholmod.numeric(F["S"], F["Sf"])
-            F["firstcall"] = False
+                if p == 0:
+                    raise
+                dev = _Chol2Device(G, A, mnl, Df, H, with_A_rows=True)      # S singular: S + A'A from now on
+                dev.refactor(W, H, Df)
+            state["dev"] = dev
         else:
-            base.syrk(F["Gs"], F["S"], trans="T", partial=True)
-            if mnl:
-                base.syrk(F["Dfs"], F["S"], trans="T", beta=1.0, partial=True)
-            if H is not None:
-                F["S"] += H
-            if F["singular"]:
-                base.syrk(A, F["S"], trans="T", beta=1.0, partial=True)
-            cholmod.numeric(F["S"], F["Sf"])
-        # Asct := L^{-1}*P*A'.  Factor K = Asct'*Asct.
-        Asct = cholmod.spsolve(F["Sf"], A.T, sys=7)
-        Asct = cholmod.spsolve(F["Sf"], Asct, sys=4)
-        F["K"] = spmatrix([], [], [], (p, p))
-        base.syrk(Asct, F["K"], trans="T")
-        Kf = cholmod.symbolic(F["K"])
-        cholmod.numeric(F["K"], Kf)
-
-        def solve(x, y, z):
-            # z := W^{-1} * z = W^{-1} * bz
-            scale(z, W, trans="T", inverse="I")
-            # x := L^{-1} * P * (x + Gs'*z (+ A'*y if singular))
-            if mnl:
-                base.gemv(F["Dfs"], z, x, trans="T", beta=1.0)
-            base.gemv(F["Gs"], z, x, offsetx=mnl, trans="T", beta=1.0)
-            if F["singular"]:
-                base.gemv(A, y, x, trans="T", beta=1.0)
-            cholmod.solve(F["Sf"], x, sys=7)
-            cholmod.solve(F["Sf"], x, sys=4)
-            # y := K^{-1} * (Asct'*x - y)
-            base.gemv(Asct, x, y, trans="T", beta=-1.0)
-            cholmod.solve(Kf, y)
-            # x := P' * L^{-T} * (x - Asct*y)
-            base.gemv(Asct, y, x, alpha=-1.0, beta=1.0)
-            cholmod.solve(F["Sf"], x, sys=5)
-            cholmod.solve(F["Sf"], x, sys=8)
-            # W*z := Gs*x - z
-            if mnl:
-                base.gemv(F["Dfs"], x, z, beta=-1.0)
-            base.gemv(F["Gs"], x, z, beta=-1.0, offsety=mnl)
-
-        return solve
+            state["dev"].refactor(W, H, Df)
+        return state["dev"].solve
 
     return factor

@@ -512,6 +512,63 @@ def g12_nonlinear_block():
     np.savez_compressed(os.path.join(HERE, "g12_nonlinear_block.npz"), **out)
 
 
+def g14_kkt_singular():
+    """misc.kkt_chol2 when S = G' W^-2 G is singular (G has a zero column) and A restores full rank: the reference's
+    fallback S + A'A (misc.py:1433-1447, 1525-1526), dense-G LAPACK branch = pure reference.  Also a p > 0 case with a
+    G that has ONE entry per row (diagonal S: standard-form LPs)."""
+    from kvxopt import matrix, misc, spmatrix
+    out = {}
+    rng = np.random.default_rng(1400)
+    ml, n, p = 14, 6, 2
+    Gd = rng.standard_normal((ml, n)) * (rng.uniform(size=(ml, n)) < 0.5)
+    Gd[:, 4] = 0.0                                        # column 4 never appears in an inequality
+    for j in range(n):
+        if j != 4 and not Gd[:, j].any():
+            Gd[j, j] = 1.0
+    Ad = rng.standard_normal((p, n)) * (rng.uniform(size=(p, n)) < 0.7)
+    Ad[0, 4] = 1.5; Ad[1, 0] = -0.5
+    I, J = np.nonzero(Gd); G = spmatrix(Gd[I, J].tolist(), I.tolist(), J.tolist(), (ml, n))
+    I, J = np.nonzero(Ad); A = spmatrix(Ad[I, J].tolist(), I.tolist(), J.tolist(), (p, n))
+    dims = {"l": ml, "q": [], "s": []}
+    bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(ml)
+    f = misc.kkt_chol2(matrix(G), dims, matrix(A))
+    sols = []
+    ds = [np.ones(ml), rng.uniform(0.5, 2.0, ml)]
+    for d in ds:
+        W = {"d": matrix(d), "di": matrix(1.0 / d), "v": [], "beta": [], "r": [], "rti": []}
+        solve = f(W)
+        x, y, z = matrix(bx.copy()), matrix(by.copy()), matrix(bz.copy())
+        solve(x, y, z)
+        sols.append((tolist(x), tolist(y), tolist(z)))
+    out["sing_G_cp"], out["sing_G_ri"], out["sing_G_v"] = ccs(G)
+    out["sing_A_cp"], out["sing_A_ri"], out["sing_A_v"] = ccs(A)
+    out["sing_d"] = ds[1]
+    out["sing_bx"], out["sing_by"], out["sing_bz"] = bx, by, bz
+    for i, (x, y, z) in enumerate(sols):
+        out["sing_x%d" % i], out["sing_y%d" % i], out["sing_z%d" % i] = x, y, z
+    # diagonal S with equality rows (G = -I stacked twice with different signs: one entry per row)
+    n2, p2 = 7, 3
+    ml2 = 2 * n2
+    G2 = spmatrix([-1.0] * n2 + [0.5] * n2, list(range(ml2)), list(range(n2)) * 2, (ml2, n2))
+    A2d = rng.standard_normal((p2, n2)) * (rng.uniform(size=(p2, n2)) < 0.6)
+    for i in range(p2):
+        A2d[i, i] = 1.0 + i
+    I, J = np.nonzero(A2d); A2 = spmatrix(A2d[I, J].tolist(), I.tolist(), J.tolist(), (p2, n2))
+    d2 = rng.uniform(0.5, 2.0, ml2)
+    bx2, by2, bz2 = rng.standard_normal(n2), rng.standard_normal(p2), rng.standard_normal(ml2)
+    f2 = misc.kkt_chol2(matrix(G2), {"l": ml2, "q": [], "s": []}, matrix(A2))
+    f2({"d": matrix(1.0, (ml2, 1)), "di": matrix(1.0, (ml2, 1)), "v": [], "beta": [], "r": [], "rti": []})
+    solve = f2({"d": matrix(d2), "di": matrix(1.0 / d2), "v": [], "beta": [], "r": [], "rti": []})
+    x, y, z = matrix(bx2.copy()), matrix(by2.copy()), matrix(bz2.copy())
+    solve(x, y, z)
+    out["diag_G_cp"], out["diag_G_ri"], out["diag_G_v"] = ccs(G2)
+    out["diag_A_cp"], out["diag_A_ri"], out["diag_A_v"] = ccs(A2)
+    out["diag_d"] = d2
+    out["diag_bx"], out["diag_by"], out["diag_bz"] = bx2, by2, bz2
+    out["diag_x"], out["diag_y"], out["diag_z"] = tolist(x), tolist(y), tolist(z)
+    np.savez_compressed(os.path.join(HERE, "g14_kkt_singular.npz"), **out)
+
+
 def g13_gemv_subblocks():
     """base.gemv (base.c:744-851 -> sparse.c:1073-1104) with the sub-block arguments m, n, offsetA and strides, sparse A."""
     from kvxopt import base, matrix, spmatrix
@@ -562,4 +619,5 @@ if __name__ == "__main__":
     g11_coneqp_initvals()
     g12_nonlinear_block()
     g13_gemv_subblocks()
+    g14_kkt_singular()
     print("goldens written to", HERE)

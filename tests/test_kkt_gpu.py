@@ -447,16 +447,6 @@ def test_conelp_equality_errors():
     A = spmatrix.from_ccs(L["p"], L["n"], L["Ap"], L["Ai"], L["Ax"])
     with pytest.raises(TypeError):
         lp.conelp(L["c"], G, L["h"], A=A, b=L["b"][:-1])
-    old = lp.KKTGenEqDev.MAX_P
-    lp.KKTGenEqDev.MAX_P = 0
-    try:
-        with pytest.raises(NotImplementedError):                        # S not diagonal and more equality rows than the dense-K path takes
-            P = workloads.lp_grid(6, 5)
-            G2 = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
-            A2 = spmatrix([1.0] * P["n"], [0] * P["n"], list(range(P["n"])), (1, P["n"]))
-            lp.conelp(P["c"], G2, P["h"], A=A2, b=np.ones(1))
-    finally:
-        lp.KKTGenEqDev.MAX_P = old
     with pytest.raises(NotImplementedError):
         lp.conelp(L["c"], G, L["h"], dims={"l": 0, "q": [L["ml"]], "s": []})
 
@@ -699,3 +689,63 @@ def test_numeric_checks_the_analysed_triangle_only():
     cholmod.numeric(A, F2)
     x2 = matrix(b.copy()); cholmod.solve(F2, x2)
     assert rel(x2._a, x._a) < 1e-13
+
+
+def test_kkt_chol2_singular_fallback_and_diagonal_S_golden(golden_dir):
+    """G14 (pure reference, dense-G LAPACK branch): (i) S = G' W^-2 G singular because a variable appears in no inequality,
+    the equality rows restore full rank -- the reference's fallback S + A'A (misc.py:1433-1447, 1525-1526), first call and a
+    refactorisation; (ii) a G with one entry per row (diagonal S, the standard-form branch with K on a fixed pattern)."""
+    g = np.load(os.path.join(golden_dir, "g14_kkt_singular.npz"))
+    ml, n, p = 14, 6, 2
+    G = spmatrix.from_ccs(ml, n, g["sing_G_cp"], g["sing_G_ri"], g["sing_G_v"])
+    A = spmatrix.from_ccs(p, n, g["sing_A_cp"], g["sing_A_ri"], g["sing_A_v"])
+    f = misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, A)
+    for i, d in enumerate((np.ones(ml), g["sing_d"])):
+        solve = f(W_of(d.copy(), 1.0 / d))
+        x, y, z = matrix(g["sing_bx"].copy()), matrix(g["sing_by"].copy()), matrix(g["sing_bz"].copy())
+        solve(x, y, z)
+        assert rel(x._a, g["sing_x%d" % i]) < 1e-10 and rel(y._a, g["sing_y%d" % i]) < 1e-10 and rel(z._a, g["sing_z%d" % i]) < 1e-10, i
+    n2, p2 = 7, 3
+    ml2 = 2 * n2
+    G2 = spmatrix.from_ccs(ml2, n2, g["diag_G_cp"], g["diag_G_ri"], g["diag_G_v"])
+    A2 = spmatrix.from_ccs(p2, n2, g["diag_A_cp"], g["diag_A_ri"], g["diag_A_v"])
+    f2 = misc.kkt_chol2(G2, {"l": ml2, "q": [], "s": []}, A2)
+    f2(W_of(np.ones(ml2), np.ones(ml2)))
+    solve = f2(W_of(g["diag_d"].copy(), 1.0 / g["diag_d"]))
+    x, y, z = matrix(g["diag_bx"].copy()), matrix(g["diag_by"].copy()), matrix(g["diag_bz"].copy())
+    solve(x, y, z)
+    assert rel(x._a, g["diag_x"]) < 1e-10 and rel(y._a, g["diag_y"]) < 1e-10 and rel(z._a, g["diag_z"]) < 1e-10
+    with pytest.raises(ArithmeticError):                   # p = 0: a singular S has no fallback (misc.py:1433 needs A)
+        misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, spmatrix([], [], [], (0, n)))(W_of(np.ones(ml), np.ones(ml)))
+
+
+def test_kkt_general_S_with_many_equality_rows():
+    """K = A S^-1 A' for a non-diagonal S and MORE equality rows than one column block of X = S^-1 A' holds (the p <= 2048
+    limit of round 1 is gone: X is formed and consumed block by block, K is a dense p x p front).  Checked against a sparse
+    direct solve of the whole KKT system on the host (SciPy), residual and solution."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    P = workloads.lp_grid(40, 30)
+    ml, n = P["ml"], P["n"]
+    p = 300
+    rng = np.random.default_rng(12)
+    Ad = sp.random(p, n, density=3.0 / n, random_state=5, format="csc") + sp.csc_matrix((np.ones(p), (np.arange(p), rng.permutation(n)[:p])), shape=(p, n))
+    Ad = Ad.tocsc(); Ad.sort_indices()
+    old = lp.KKTGenEqDev.BLOCK_BYTES
+    lp.KKTGenEqDev.BLOCK_BYTES = 8 * n * 64               # 64 columns per block: five blocks for p = 300
+    try:
+        kkt = lp.KKTGenEqDev(ml, n, P["Gp"], P["Gi"], P["Gx"], p, Ad.indptr.astype(np.int64), Ad.indices.astype(np.int64), Ad.data)
+        assert kkt.cols == 64
+        d = rng.uniform(0.5, 2.0, ml)
+        kkt.factor(lp.DVec(ml, 1.0 / d))
+        bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(ml)
+        x, y, z = lp.DVec(n, bx), lp.DVec(p, by), lp.DVec(ml, bz)
+        kkt.solve(x, y, z)
+    finally:
+        lp.KKTGenEqDev.BLOCK_BYTES = old
+    G = sp.csc_matrix((P["Gx"], P["Gi"], P["Gp"]), shape=(ml, n))
+    K = sp.bmat([[None, Ad.T, G.T], [Ad, None, None], [G, None, -sp.diags(d * d)]], format="csc")
+    K = K + sp.csc_matrix((n + p + ml, n + p + ml))
+    sol = spla.spsolve(K.tocsc(), np.concatenate([bx, by, bz]))
+    ux, uy, uz = sol[:n], sol[n:n + p], sol[n + p:]
+    assert rel(x.get(), ux) < 1e-8 and rel(y.get(), uy) < 1e-8 and rel(z.get(), d * uz) < 1e-8
