@@ -40,7 +40,10 @@ typedef struct {
                              * 1: LL' if flops / nnz(L) >= 40 (CHOLMOD's rule), else LDL'.  One set of kernels computes Lc with
                              * P A P' = Lc Lc'; the LDL' factor is that result seen as L = Lc diag(Lc)^-1, D = diag(Lc)^2: solve
                              * sys = 2..6, getfactor (D on the diagonal, unit diagonal of L implicit) and diag (refused) follow it */
-    int32_t ordering;       /* 0 = built-in nested-dissection/min-degree (when p == NULL); 1 = natural   */
+    int32_t ordering;       /* the library's own ordering (used when p == NULL, or compared with p when reserved[4] = 1):
+                             * 0 = best of nested dissection and, up to order reserved[5] (default 200 000), approximate minimum degree --
+                             * the one with the least fill, CHOLMOD's strategy of trying several methods (cholmod.c:65-76);
+                             * 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only (the role of AMD) */
     int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
     int32_t relax_small;    /* relaxed-amalgamation: always merge if merged width <= this (default 4)    */
     double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .05)     */
@@ -48,7 +51,9 @@ typedef struct {
     double  relax_z3;
     double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off: a pivot d <= 0 fails.  > 0: CHOLMOD's rule,
                              * L_kk < dbound is replaced by dbound; with reserved[3] = 1 by 1e64 (the row drops out of the solves) */
-    int32_t reserved[8];    /* [0] nd_leaf, [1] leaf_cols, [2] leaf_rows, [3] dbound mode                                       */
+    int32_t reserved[8];    /* [0] nd_leaf, [1] leaf_cols, [2] leaf_rows, [3] dbound mode, [4] 1 = a given p competes with the library's own
+                             * ordering(s) and the least fill wins (cholmod.options['nmethods'] = 0 or 2); 0 = p is used as given
+                             * (nmethods = 1), [5] largest order for the minimum-degree candidate of ordering 0                       */
 } kvx_chol_opts;
 
 void kvx_chol_default_opts(kvx_chol_opts *o);

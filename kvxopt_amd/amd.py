@@ -1,11 +1,11 @@
 """Drop-in for `kvxopt.amd` (src/C/amd.c:131-223): `order(A, uplo='L') -> p`, a fill-reducing permutation of a
 symmetric sparse matrix, as an 'i' matrix -- what `cholmod.symbolic(A, p)` and `misc` callers expect.
 
-Not SuiteSparse AMD: the permutation comes from this package's own host analysis (nested dissection on level
-structures + halo-aware minimum degree on the leaves, elimination-tree postorder; csrc/ordering.cpp, symbolic.cpp), the
-one the GPU Cholesky uses when no `p` is given.  Any valid permutation satisfies the reference's contract; its quality
-(fill) is what the tests compare.  Host-only: no GPU needed.  `options` is accepted and validated like amd.c:57-110
-(the AMD control parameters have no meaning here and are ignored).
+Not SuiteSparse AMD but the same algorithm family, written for this package (csrc/amd_order.cpp): approximate minimum
+degree on the quotient graph -- elements instead of explicit fill, approximate external degrees, element absorption, mass
+elimination of indistinguishable variables -- followed by the elimination-tree postorder of the analysis.  Fill is within a
+few per cent of SciPy/SuperLU's MMD on the reference's own test matrices (tests/test_symbolic.py).  Host-only: no GPU
+needed.  `options` is accepted and validated like amd.c:57-110 (the AMD control parameters are not used).
 """
 import numpy as np
 
@@ -27,5 +27,5 @@ def order(A, uplo="L"):
         raise TypeError("A must be a square sparse matrix")
     if uplo not in ("L", "U"):
         raise ValueError("possible values of uplo are: 'L', 'U'")
-    F = Factor(n, cp, ri, uplo)             # host analysis only (reads the `uplo` triangle, amd.c:161-203)
+    F = Factor(n, cp, ri, uplo, None, {"ordering": 3})   # host analysis only (reads the `uplo` triangle, amd.c:161-203)
     return matrix(F.perm(), (n, 1), tc="i")

@@ -29,6 +29,10 @@ class Factor:
                 o.reserved[1] = int(v) if int(v) > 0 else -1
             elif k == "leaf_rows":
                 o.reserved[2] = int(v)
+            elif k == "compare_given":      # a given perm is one candidate among the library's own orderings; least fill wins
+                o.reserved[4] = 1 if v else 0
+            elif k == "amd_auto_max":
+                o.reserved[5] = int(v)
             elif k == "dbound_drop":        # with dbound > 0: a pivot below dbound^2 becomes 1e128 (its row drops out of the solves)
                 o.reserved[3] = 1 if v else 0
             else:

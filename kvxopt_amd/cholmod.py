@@ -10,7 +10,7 @@ Cholesky of libkvxhip.so.  No CPU fallback: numeric calls raise RuntimeError wit
     splinsolve(A, B, p=None, uplo='L') -> X        cholmod.c:774-881
     diag(F) -> d                                   cholmod.c:900-945
     getfactor(F) -> L                              cholmod.c:948-985
-    options                                        dict, validated on every call (cholmod.c:87-129)
+    options                                        dict, validated on every call (cholmod.c:87-129); 'nmethods' as cholmod.c:65-76
 
 Differences kept on purpose: `numeric` raises ArithmeticError(minor) on a non-positive-
 definite matrix as DOCUMENTED (cholmod.c:308-310); the reference build tests a stale status there
@@ -49,7 +49,6 @@ def _check_options():
             raise ValueError("invalid value for CHOLMOD parameter: %-.20s" % k)
     if opts.get("supernodal", 2) not in (0, 1, 2):
         raise ValueError("invalid value for CHOLMOD parameter: supernodal")
-    opts.pop("nmethods", None)
     return opts
 
 
@@ -113,8 +112,17 @@ def symbolic(A, p=None, uplo="L"):
     if uplo not in ("L", "U"):
         raise ValueError("possible values of uplo are: 'L', 'U'")
     keep, tcp, tri = _triangle(n, cp, ri, uplo)
+    fopts = {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts}
+    # options['nmethods'] (cholmod.c:65-76): 1 = the given ordering and nothing else (no p: the natural order); 0 (default) and
+    # 2 = a given p competes with the library's own orderings (nested dissection / minimum degree), the least fill wins
+    nmethods = opts.get("nmethods", 0)
+    if nmethods == 1:
+        if q is None:
+            fopts["ordering"] = 1
+    elif q is not None:
+        fopts["compare_given"] = 1
     try:
-        fac = Factor(n, tcp, tri, uplo, q, {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts})
+        fac = Factor(n, tcp, tri, uplo, q, fopts)
     except ValueError as e:
         if "permutation" in str(e):
             raise ValueError("p is not a valid permutation")

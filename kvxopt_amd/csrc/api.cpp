@@ -731,6 +731,7 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
     kvx_chol_opts o;
     if (opts) o = *opts; else kvx_chol_default_opts(&o);
     if (o.supernodal < 0 || o.supernodal > 2) { set_err("options['supernodal'] must be 0, 1 or 2"); return KVX_EINVAL; }
+    if (o.ordering < 0 || o.ordering > 3) { set_err("ordering must be 0 (best of the library's own), 1 (natural), 2 (nested dissection) or 3 (minimum degree)"); return KVX_EINVAL; }
     kvx_chol *F = nullptr;
     try {
         F = new kvx_chol();
@@ -743,6 +744,8 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
         if (o.reserved[0] > 0) so.nd_leaf = o.reserved[0];
         if (o.reserved[1] != 0) so.leaf_cols = o.reserved[1] < 0 ? 0 : o.reserved[1];
         if (o.reserved[2] > 0) so.leaf_rows = o.reserved[2];
+        so.compare_given = o.reserved[4] == 1 ? 1 : 0;
+        if (o.reserved[5] > 0) so.amd_auto_max = o.reserved[5];
         static const int64_t zero = 0;
         analyze(n, n ? colptr : &zero, rowind, uplo, perm, so, F->S);
         // options['supernodal'] (spsolvers.rst:731-736): 2 -> LL'; 0 -> LDL'; 1 -> whichever CHOLMOD would find cheaper,

@@ -207,41 +207,97 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             if (Ai[p] < 0 || Ai[p] >= n) throw std::runtime_error("row index out of range");
     }
 
-    // ---- 1. initial permutation -------------------------------------------------------
-    std::vector<int64_t> perm0((size_t)n), iperm0((size_t)n, -1);
+    // ---- 1. initial permutation: candidates (user's, nested dissection, minimum degree), the least fill wins ----------
+    std::vector<std::vector<int64_t>> cand;
+    std::vector<const char *> cand_name;
     if (user_perm) {
+        std::vector<int64_t> pu((size_t)n);
+        std::vector<char> seen((size_t)n, 0);
         for (int64_t k = 0; k < n; k++) {
             int64_t q = user_perm[k];
-            if (q < 0 || q >= n || iperm0[q] != -1) throw std::invalid_argument("p is not a valid permutation");
-            perm0[k] = q;
-            iperm0[q] = k;
+            if (q < 0 || q >= n || seen[q]) throw std::invalid_argument("p is not a valid permutation");
+            seen[q] = 1;
+            pu[k] = q;
         }
-    } else if (opts.ordering == 1) {
-        std::iota(perm0.begin(), perm0.end(), 0);
-        iperm0 = perm0;
-    } else {
-        // full symmetric adjacency of the analysed triangle
-        std::vector<int64_t> aptr((size_t)n + 1, 0);
-        for (int64_t j = 0; j < n; j++)
-            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-                int64_t i = Ai[p];
-                if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
-                aptr[i + 1]++;
-                aptr[j + 1]++;
-            }
-        for (int64_t j = 0; j < n; j++) aptr[j + 1] += aptr[j];
-        std::vector<int32_t> adj((size_t)aptr[n]);
-        std::vector<int64_t> cur(aptr.begin(), aptr.end() - 1);
-        for (int64_t j = 0; j < n; j++)
-            for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
-                int64_t i = Ai[p];
-                if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
-                adj[(size_t)cur[i]++] = (int32_t)j;
-                adj[(size_t)cur[j]++] = (int32_t)i;
-            }
-        order_nd(n, aptr, adj, opts.nd_leaf, perm0);
-        for (int64_t k = 0; k < n; k++) iperm0[perm0[k]] = k;
+        cand.push_back(std::move(pu)); cand_name.push_back("given");
     }
+    if (!user_perm || opts.compare_given) {
+        if (opts.ordering == 1) {
+            if (!user_perm) { cand.emplace_back((size_t)n); std::iota(cand.back().begin(), cand.back().end(), 0); cand_name.push_back("natural"); }
+        } else if (n > 0) {
+            // full symmetric adjacency of the analysed triangle
+            std::vector<int64_t> aptr((size_t)n + 1, 0);
+            for (int64_t j = 0; j < n; j++)
+                for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                    int64_t i = Ai[p];
+                    if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                    aptr[i + 1]++;
+                    aptr[j + 1]++;
+                }
+            for (int64_t j = 0; j < n; j++) aptr[j + 1] += aptr[j];
+            std::vector<int32_t> adj((size_t)aptr[n]);
+            std::vector<int64_t> cur(aptr.begin(), aptr.end() - 1);
+            for (int64_t j = 0; j < n; j++)
+                for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
+                    int64_t i = Ai[p];
+                    if (i == j || (uplo == 'L' && i < j) || (uplo != 'L' && i > j)) continue;
+                    adj[(size_t)cur[i]++] = (int32_t)j;
+                    adj[(size_t)cur[j]++] = (int32_t)i;
+                }
+            if (opts.ordering != 3) {
+                cand.emplace_back();
+                order_nd(n, aptr, adj, opts.nd_leaf, cand.back());
+                cand_name.push_back("nested dissection");
+            }
+            if (opts.ordering == 3 || (opts.ordering == 0 && n <= opts.amd_auto_max)) {
+                // (duplicate entries of the caller's pattern would show up as repeated neighbours: harmless for the dissection,
+                // but the quotient graph wants clean lists)
+                std::vector<int64_t> aptr2((size_t)n + 1, 0);
+                std::vector<int32_t> adj2;
+                adj2.reserve(adj.size());
+                for (int64_t i = 0; i < n; i++) {
+                    const size_t b0 = adj2.size();
+                    adj2.insert(adj2.end(), adj.begin() + aptr[i], adj.begin() + aptr[i + 1]);
+                    std::sort(adj2.begin() + b0, adj2.end());
+                    adj2.erase(std::unique(adj2.begin() + b0, adj2.end()), adj2.end());
+                    aptr2[i + 1] = (int64_t)adj2.size();
+                }
+                cand.emplace_back();
+                order_amd(n, aptr2, adj2, cand.back());
+                cand_name.push_back("minimum degree");
+            }
+        } else if (!user_perm) {
+            cand.emplace_back(); cand_name.push_back("empty");
+        }
+    }
+    size_t pick = 0;
+    if (cand.size() > 1) {
+        // fill of a candidate: nnz(L) from the column counts (elimination tree + postorder + Gilbert-Ng-Peyton), no factor formed
+        double best = 0.0;
+        for (size_t c = 0; c < cand.size(); c++) {
+            std::vector<int64_t> ip((size_t)n), pp(cand[c]);
+            for (int64_t k = 0; k < n; k++) ip[pp[k]] = k;
+            LowerPattern Lc;
+            std::vector<int32_t> par, post, cc;
+            build_lower(n, Ap, Ai, uplo, ip, Lc);
+            etree_from_lower(n, Lc, par);
+            postorder(n, par, post);
+            std::vector<int32_t> ipost((size_t)n), np2((size_t)n);
+            for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
+            for (int64_t k = 0; k < n; k++) np2[k] = par[post[k]] >= 0 ? ipost[par[post[k]]] : -1;
+            for (int64_t k = 0; k < n; k++) ip[pp[post[k]]] = k;
+            build_lower(n, Ap, Ai, uplo, ip, Lc);
+            column_counts(n, Lc, np2, cc);
+            double lnz = 0.0;
+            for (int64_t j = 0; j < n; j++) lnz += cc[j];
+            if (pt.on) fprintf(stderr, "  analyze candidate %-18s nnz(L) = %.0f\n", cand_name[c], lnz);
+            if (c == 0 || lnz < best) { best = lnz; pick = c; }
+        }
+    }
+    std::vector<int64_t> perm0((size_t)n), iperm0((size_t)n, -1);
+    if (!cand.empty() && (int64_t)cand[pick].size() == n) perm0 = cand[pick];
+    else std::iota(perm0.begin(), perm0.end(), 0);
+    for (int64_t k = 0; k < n; k++) iperm0[perm0[k]] = k;
 
     pt.lap("1 ordering");
     // ---- 2. etree + postorder, fold the postorder into the permutation ---------------------

@@ -28,7 +28,11 @@ inline int wave_class_mcap(int cls) { static const int c[3] = {64, 48, 32}; retu
 inline int wave_class_kmax(int cls) { return ((cls - KVX_CLS_WAVE0) & 1) ? 16 : 32; }
 
 struct SymOpts {
-    int ordering = 0;        // 0 = built-in ND + minimum degree, 1 = natural
+    int ordering = 0;        // 0 = best of nested dissection and (n <= amd_auto_max) approximate minimum degree, by fill;
+                             // 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only
+    int compare_given = 0;   // with a user permutation: 1 = it is one candidate among the library's own (cholmod.options['nmethods']
+                             // 0 / 2, cholmod.c:65-76), the ordering with the least fill wins; 0 = it is used as given (nmethods = 1)
+    int64_t amd_auto_max = 200000;   // ordering 0: largest order for which the minimum-degree candidate is computed as well
     int postorder = 1;
     int relax_small = 4;
     double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
@@ -83,6 +87,9 @@ void analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
 // diagonal (adjptr[n+1], adj[]).  Returns perm (new -> old).
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
               int leaf, std::vector<int64_t> &perm);
+
+// Approximate minimum degree on the quotient graph (amd_order.cpp); same graph format as order_nd.
+void order_amd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj, std::vector<int64_t> &perm);
 
 // Sharding of ONE factorisation over nranks processes, host-only and deterministic: every rank computes the same map.
 // Proportional mapping of the elimination tree: front s is worked on by the contiguous rank range [glo[s], ghi[s]).  A range of

@@ -139,3 +139,67 @@ def test_amd_order_mirror(golden_dir):
         amd.order(A, uplo="X")
     with pytest.raises(TypeError):
         amd.order(matrix(np.eye(2)))
+
+
+def _scipy_fill(n, cp, ri, vx, spec):
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import splu
+    A = sp.csc_matrix((vx, ri, cp), shape=(n, n))
+    A = (A + sp.tril(A, -1).T).tocsc()
+    return splu(A, permc_spec=spec, diag_pivot_thresh=0.0, options={"SymmetricMode": True}).L.nnz
+
+
+def test_ordering_quality_against_scipy(golden_dir):
+    """Fill of the default ordering (the better of nested dissection and approximate minimum degree, CHOLMOD's `nmethods`
+    strategy) against SciPy/SuperLU's MMD(A'+A) and COLAMD on the reference's own unstructured test matrices, a random SPD
+    pattern and two grids: within 1.15x of the better SciPy ordering everywhere; the minimum-degree ordering alone
+    (`amd.order`, ordering = 3) within 1.05x of MMD on the unstructured ones."""
+    import os
+    import scipy.sparse as sp
+    cases = []
+    for nm in ("bcsstk13", "bcsstk24"):
+        z = np.load(os.path.join(golden_dir, nm + ".npz"))
+        cases.append((nm, int(z["n"]), z["colptr"], z["rowind"], z["values"], True))
+    M = sp.random(1500, 1500, 0.004, random_state=3, format="csc")
+    S = sp.tril((M @ M.T + sp.eye(1500) * 4.0).tocsc()).tocsc(); S.sort_indices()
+    cases.append(("random1500", 1500, S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data, True))
+    cases.append(("lap2d120",) + workloads.laplacian_2d(120) + (False,))
+    cases.append(("lap3d16",) + workloads.laplacian_3d(16) + (False,))
+    for nm, n, cp, ri, vx, unstructured in cases:
+        best_scipy = min(_scipy_fill(n, cp, ri, vx, s) for s in ("MMD_AT_PLUS_A", "COLAMD"))
+        auto = Factor(n, cp, ri).info()["lnz"]
+        nd = Factor(n, cp, ri, opts={"ordering": 2}).info()["lnz"]
+        amd = Factor(n, cp, ri, opts={"ordering": 3}).info()["lnz"]
+        assert auto == min(nd, amd), nm                               # the least fill wins
+        assert auto <= 1.15 * best_scipy, (nm, auto, best_scipy)
+        if unstructured:
+            assert amd <= 1.05 * _scipy_fill(n, cp, ri, vx, "MMD_AT_PLUS_A"), nm
+            assert amd < nd, nm
+
+
+def test_nmethods_semantics(golden_dir):
+    """cholmod.options['nmethods'] (cholmod.c:65-76): 1 = the given ordering and nothing else (no p: natural order); 0 / 2 =
+    a given p competes with the library's orderings and the least fill wins."""
+    import os
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import spmatrix, matrix
+    z = np.load(os.path.join(golden_dir, "bcsstk13.npz"))
+    n = int(z["n"])
+    A = spmatrix.from_ccs(n, n, z["colptr"], z["rowind"], z["values"])
+    ident = matrix(np.arange(n), (n, 1), tc="i")
+    try:
+        cholmod.options["nmethods"] = 1
+        f_given = cholmod.symbolic(A, ident).fac
+        assert np.array_equal(np.sort(f_given.perm()), np.arange(n))
+        nat = cholmod.symbolic(A).fac.info()["lnz"]                   # no p with nmethods = 1: the natural order
+        assert f_given.info()["lnz"] == nat
+        for nm in (0, 2):
+            cholmod.options["nmethods"] = nm
+            f_cmp = cholmod.symbolic(A, ident).fac                   # the stored order loses against minimum degree
+            assert f_cmp.info()["lnz"] < 0.7 * nat
+        cholmod.options.clear()
+        best = cholmod.symbolic(A).fac
+        good = matrix(best.perm(), (n, 1), tc="i")
+        assert cholmod.symbolic(A, good).fac.info()["lnz"] == best.info()["lnz"]    # a good p is kept
+    finally:
+        cholmod.options.clear()
