@@ -257,6 +257,25 @@ int kvx_vec_xmy_dev(int64_t n, double a, const double *x, const double *y, doubl
 int kvx_spmv_dev(int trans, int64_t m, int64_t n, const int64_t *Ap_dev, const int64_t *Ai_dev,
                  const double *Ax_dev, double alpha, const double *x_dev, double beta, double *y_dev);
 
+/* ---- second-order-cone ('q') blocks of the Nesterov-Todd scaling: the 'q' parts of
+ * misc.compute_scaling / update_scaling (misc.py:290-352, 467-580), misc_solvers.scale / scale2 / sprod / sinv
+ * (misc_solvers.c:144-186, 301-341, 671-700, 803-835), misc.ssqr (misc.py:951-959), max_step (misc_solvers.c:1073-1085).
+ * off_dev: nq + 1 cone boundaries [0, q0, q0 + q1, ...]; every vector pointer addresses the START of the 'q' section of its
+ * vector (i.e. the caller adds mnl + dims['l']); one workgroup per cone, all cones of a call in one launch (null stream). */
+int kvx_ntq_compute_scaling_dev(int64_t nq, const int64_t *off_dev, const double *s_dev, const double *z_dev, double *v_dev,
+                                double *beta_dev /* nq */, double *lmbda_dev);
+/* in place: s, z leave as st / a, zt / b (misc.py:517-523); v, beta, lmbda are updated */
+int kvx_ntq_update_scaling_dev(int64_t nq, const int64_t *off_dev, double *s_dev, double *z_dev, double *v_dev, double *beta_dev,
+                               double *lmbda_dev);
+/* x_k := beta_k (2 v_k v_k' - J) x_k for every column of x (leading dimension ldx), or the inverse scaling */
+int kvx_ntq_scale_dev(int64_t nq, const int64_t *off_dev, const double *v_dev, const double *beta_dev, double *x_dev, int64_t ldx,
+                      int64_t ncols, int inverse);
+int kvx_ntq_scale2_dev(int64_t nq, const int64_t *off_dev, const double *lmbda_dev, double *x_dev, int inverse);
+/* op 0: x := y o x (sprod);  1: x := y o\ x (sinv);  2: x := y o y (ssqr) */
+int kvx_ntq_prod_dev(int64_t nq, const int64_t *off_dev, double *x_dev, const double *y_dev, int op);
+/* out_dev[k] = |x_k1| - x_k0 (the caller takes the maximum) */
+int kvx_ntq_max_step_dev(int64_t nq, const int64_t *off_dev, const double *x_dev, double *out_dev);
+
 /* ---- dense helpers of the equality-constrained KKT solve with a general S (misc.py:1476-1487, 1545): K = A S^-1 A' formed
  * as a dense p x p matrix from X = S^-1 A' (kvx_chol_solve_dev with nrhs = p) when p is moderate ------------------------- */
 /* Y(j, c) = sum_i A(i, j) X(i, c) for the CCS matrix A with n columns and every column c < ncols of the dense X */

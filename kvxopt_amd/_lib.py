@@ -87,6 +87,12 @@ _SIGS = {
     "kvx_nt_sinv_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_nt_ssqr_dev": (ctypes.c_int, [i64, vp, vp]),
     "kvx_nt_sdot_dev": (ctypes.c_int, [i64, vp, vp, f64p]),
+    "kvx_ntq_compute_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, vp]),
+    "kvx_ntq_update_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, vp]),
+    "kvx_ntq_scale_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, i64, i64, ctypes.c_int]),
+    "kvx_ntq_scale2_dev": (ctypes.c_int, [i64, vp, vp, vp, ctypes.c_int]),
+    "kvx_ntq_prod_dev": (ctypes.c_int, [i64, vp, vp, vp, ctypes.c_int]),
+    "kvx_ntq_max_step_dev": (ctypes.c_int, [i64, vp, vp, vp]),
     "kvx_lp_newton_rhs_dev": (ctypes.c_int, [i64, vp, vp, f64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_step_post_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_update_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp, vp, vp]),

@@ -19,8 +19,32 @@ from .base import matrix, spmatrix
 
 
 def _only_l(dims, what):
-    if dims.get("q") or dims.get("s"):
-        raise NotImplementedError("%s: only the orthant ('l') cone is implemented on the GPU path" % what)
+    """The nonlinear, 'l' and 'q' blocks run on the GPU; semidefinite ('s') blocks are not built."""
+    if dims.get("s"):
+        raise NotImplementedError("%s: semidefinite ('s') blocks are not implemented on the GPU path "
+                                  "(nonlinear, 'l' and 'q' blocks are)" % what)
+
+
+def _q_offsets(q):
+    """Device table of the cone boundaries inside the 'q' section: [0, q0, q0 + q1, ...]."""
+    off = np.zeros(len(q) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(q, dtype=np.int64), out=off[1:])
+    return off, DeviceBuffer.from_array(off)
+
+
+def _q_apply(dims, m, call, *host_vecs):
+    """Run one 'q'-block kernel on the slices [m, m + sum(q)) of the host vectors: `call(nq, off_dev, *device slices)`;
+    the first vector is written back."""
+    q = list(dims.get("q") or [])
+    if not q:
+        return
+    off, doff = _q_offsets(q)
+    tot = int(off[-1])
+    bufs = [_buf(v)[0] for v in host_vecs]
+    devs = [_up(b[m:m + tot]) for b in bufs]
+    raise_for(call(len(q), doff.ptr, *[d.ptr for d in devs]))
+    _sync()
+    bufs[0][m:m + tot] = devs[0].download(np.float64, tot)
 
 
 def _buf(x):
@@ -36,8 +60,9 @@ def _sync():
 
 
 def compute_scaling(s, z, lmbda, dims, mnl=None):
-    """misc.py:250-287 (nonlinear and 'l' blocks): W['d'] = sqrt(s./z), W['di'] = 1./d, lmbda = sqrt(s.*z); with
-    mnl given (cvxprog), the first mnl entries make W['dnl'], W['dnli'] by the same formulas."""
+    """misc.py:250-352 (nonlinear, 'l' and 'q' blocks): W['d'] = sqrt(s./z), W['di'] = 1./d, lmbda = sqrt(s.*z); with
+    mnl given (cvxprog), the first mnl entries make W['dnl'], W['dnli'] by the same formulas; for every second-order cone
+    the unit-hyperbolic-norm vector W['v'][k] and W['beta'][k] with (beta_k (2 v_k v_k' - J)) z_k = lambda_k."""
     _only_l(dims, "compute_scaling")
     k = 0 if mnl is None else int(mnl)
     m = k + dims["l"]
@@ -56,6 +81,19 @@ def compute_scaling(s, z, lmbda, dims, mnl=None):
     W.update({"d": matrix(d[k:].copy(), (m - k, 1)), "di": matrix(di[k:].copy(), (m - k, 1)),
               "v": [], "beta": [], "r": [], "rti": []})
     lb[:m] = dl.download(np.float64, m)
+    q = list(dims.get("q") or [])
+    if q:
+        # 'q' blocks (misc.py:290-352): hyperbolic Householder scaling beta_k (2 v_k v_k' - J), one workgroup per cone
+        off, doff = _q_offsets(q)
+        tot = int(off[-1])
+        dsq, dzq = _up(sb[m:m + tot]), _up(zb[m:m + tot])
+        dv, dlq, db = DeviceBuffer(8 * tot), DeviceBuffer(8 * tot), DeviceBuffer(8 * len(q))
+        raise_for(lib().kvx_ntq_compute_scaling_dev(len(q), doff.ptr, dsq.ptr, dzq.ptr, dv.ptr, db.ptr, dlq.ptr))
+        _sync()
+        vall = dv.download(np.float64, tot)
+        W["v"] = [matrix(vall[off[i]:off[i + 1]].copy(), (q[i], 1)) for i in range(len(q))]
+        W["beta"] = [float(b) for b in db.download(np.float64, len(q))]
+        lb[m:m + tot] = dlq.download(np.float64, tot)
     return W
 
 
@@ -71,8 +109,8 @@ def _diag_of(W, inverse=False):
 def update_scaling(W, lmbda, s, z):
     """misc.py:422-464 (nonlinear and 'l' blocks), in place: s:=sqrt(s), z:=sqrt(z), d:=d.*s./z, di:=1./d,
     lmbda:=s.*z (W['dnl'], W['dnli'] likewise on the leading mnl entries)."""
-    if W.get("v") or W.get("r"):
-        raise NotImplementedError("update_scaling: only the orthant ('l') cone")
+    if W.get("r"):
+        raise NotImplementedError("update_scaling: semidefinite ('s') blocks are not implemented on the GPU path")
     dcat, k = _diag_of(W)
     m = dcat.size
     sb, _ = _buf(s)
@@ -92,21 +130,48 @@ def update_scaling(W, lmbda, s, z):
     _buf(W["d"])[0][:] = d[k:]
     _buf(W["di"])[0][:] = di[k:]
     lb[:m] = dl.download(np.float64, m)
+    if W.get("v"):
+        # 'q' blocks (misc.py:467-580): s, z leave as st / a, zt / b; v, beta, lambda are updated
+        q = [int(_buf(v)[1][0]) for v in W["v"]]
+        off, doff = _q_offsets(q)
+        tot = int(off[-1])
+        dsq, dzq, dlq = _up(sb[m:m + tot]), _up(zb[m:m + tot]), DeviceBuffer(8 * tot)
+        dv = _up(np.concatenate([np.asarray(_buf(v)[0], dtype=np.float64) for v in W["v"]]))
+        db = _up(np.asarray(W["beta"], dtype=np.float64))
+        raise_for(lib().kvx_ntq_update_scaling_dev(len(q), doff.ptr, dsq.ptr, dzq.ptr, dv.ptr, db.ptr, dlq.ptr))
+        _sync()
+        sb[m:m + tot] = dsq.download(np.float64, tot)
+        zb[m:m + tot] = dzq.download(np.float64, tot)
+        lb[m:m + tot] = dlq.download(np.float64, tot)
+        vall = dv.download(np.float64, tot)
+        for i, v in enumerate(W["v"]):
+            _buf(v)[0][:] = vall[off[i]:off[i + 1]]
+        W["beta"][:] = [float(b) for b in db.download(np.float64, len(q))]
 
 
 def scale(x, W, trans="N", inverse="N"):
     """misc_solvers.c:85-141 / misc.py:36-82 (nonlinear and 'l' blocks): x := [dnl; d].*x ('N') or [dnli; di].*x ('I')
     for every column of x; trans is irrelevant for a diagonal scaling."""
-    if W.get("v") or W.get("r"):
-        raise NotImplementedError("scale: only the orthant ('l') cone")
+    if W.get("r"):
+        raise NotImplementedError("scale: semidefinite ('s') blocks are not implemented on the GPU path")
     w, _ = _diag_of(W, inverse != "N")
     xb, size = _buf(x)
     m = w.size
-    if m == 0:
+    nq = len(W.get("v") or [])
+    if m == 0 and nq == 0:
         return
     _lib.require_device()
-    dx, dw = _up(xb), _up(w)
-    raise_for(lib().kvx_nt_scale_dev(m, size[1], size[0], dx.ptr, dw.ptr))
+    dx = _up(xb)
+    if m:
+        dw = _up(w)
+        raise_for(lib().kvx_nt_scale_dev(m, size[1], size[0], dx.ptr, dw.ptr))
+    if nq:
+        # 'q' blocks (misc_solvers.c:144-186): x_k := beta_k (2 v_k v_k' - J) x_k, or the inverse; symmetric, so `trans` is moot
+        q = [int(_buf(v)[1][0]) for v in W["v"]]
+        off, doff = _q_offsets(q)
+        dv = _up(np.concatenate([np.asarray(_buf(v)[0], dtype=np.float64) for v in W["v"]]))
+        db = _up(np.asarray(W["beta"], dtype=np.float64))
+        raise_for(lib().kvx_ntq_scale_dev(nq, doff.ptr, dv.ptr, db.ptr, dx.ptr + 8 * m, size[0], size[1], 1 if inverse != "N" else 0))
     _sync()
     xb[:] = dx.download(np.float64, xb.size)
 
@@ -117,13 +182,14 @@ def scale2(lmbda, x, dims, mnl=0, inverse="N"):
     m = mnl + dims["l"]
     lb, _ = _buf(lmbda)
     xb, _ = _buf(x)
-    if m == 0:
-        return
     _lib.require_device()
-    dx, dl = _up(xb[:m]), _up(lb[:m])
-    raise_for(lib().kvx_nt_scale2_dev(m, dl.ptr, dx.ptr, 1 if inverse == "I" else 0))
-    _sync()
-    xb[:m] = dx.download(np.float64, m)
+    if m:
+        dx, dl = _up(xb[:m]), _up(lb[:m])
+        raise_for(lib().kvx_nt_scale2_dev(m, dl.ptr, dx.ptr, 1 if inverse == "I" else 0))
+        _sync()
+        xb[:m] = dx.download(np.float64, m)
+    inv = 1 if inverse == "I" else 0                      # 'q' blocks: misc_solvers.c:301-341
+    _q_apply(dims, m, lambda nq, off, dxq, dlq: lib().kvx_ntq_scale2_dev(nq, off, dlq, dxq, inv), x, lmbda)
 
 
 def _binary(kernel, x, y, m):
@@ -142,24 +208,27 @@ def sprod(x, y, dims, mnl=0, diag="N"):
     """misc_solvers.c:634-669 ('l' block): x := x.*y."""
     _only_l(dims, "sprod")
     _binary(lib().kvx_nt_sprod_dev, x, y, mnl + dims["l"])
+    _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 0), x, y)   # misc_solvers.c:671-700
 
 
 def sinv(x, y, dims, mnl=0):
     """misc_solvers.c:775-800 ('l' block): x := x./y."""
     _only_l(dims, "sinv")
     _binary(lib().kvx_nt_sinv_dev, x, y, mnl + dims["l"])
+    _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 1), x, y)   # misc_solvers.c:803-835
 
 
 def ssqr(x, y, dims, mnl=0):
     """misc.py:945-952 ('l' block): x := y.*y."""
     _only_l(dims, "ssqr")
     _binary(lib().kvx_nt_ssqr_dev, x, y, mnl + dims["l"])
+    _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 2), x, y)   # misc.py:951-959
 
 
 def sdot(x, y, dims, mnl=0):
     """misc_solvers.c:991-1018 ('l' block): sum_i x_i*y_i."""
     _only_l(dims, "sdot")
-    m = mnl + dims["l"]
+    m = mnl + dims["l"] + sum(dims.get("q") or [])          # misc_solvers.c:1009-1012: one dot over the 'l' and 'q' entries
     xb, _ = _buf(x)
     yb, _ = _buf(y)
     if m == 0:
@@ -172,17 +241,29 @@ def sdot(x, y, dims, mnl=0):
 
 
 def max_step(x, dims, mnl=0, sigma=None):
-    """misc_solvers.c:1052-1071 ('l' block): max_i(-x_i)."""
+    """misc_solvers.c:1052-1085 (nonlinear, 'l' and 'q' blocks): max(max_i(-x_i), max_k(|x_k1| - x_k0)); 0.0 for an empty x
+    (misc_solvers.c:1099)."""
     _only_l(dims, "max_step")
     m = mnl + dims["l"]
+    q = list(dims.get("q") or [])
     xb, _ = _buf(x)
-    if m == 0:
-        return -np.finfo(np.float64).max
+    if m + sum(q) == 0:
+        return 0.0
     _lib.require_device()
-    dx = _up(xb[:m])
-    r = ctypes.c_double()
-    raise_for(lib().kvx_nt_max_step_dev(m, dx.ptr, ctypes.byref(r)))
-    return r.value
+    t = -np.finfo(np.float32).max                        # the reference starts from -FLT_MAX (misc_solvers.c:1063)
+    if m:
+        dx = _up(xb[:m])
+        r = ctypes.c_double()
+        raise_for(lib().kvx_nt_max_step_dev(m, dx.ptr, ctypes.byref(r)))
+        t = max(t, r.value)
+    if q:
+        off, doff = _q_offsets(q)
+        tot = int(off[-1])
+        dxq, dout = _up(xb[m:m + tot]), DeviceBuffer(8 * len(q))
+        raise_for(lib().kvx_ntq_max_step_dev(len(q), doff.ptr, dxq.ptr, dout.ptr))
+        _sync()
+        t = max(t, float(dout.download(np.float64, len(q)).max()))
+    return t
 
 
 class _Chol2Device:

@@ -569,6 +569,68 @@ def g14_kkt_singular():
     np.savez_compressed(os.path.join(HERE, "g14_kkt_singular.npz"), **out)
 
 
+def g15_q_cone_scaling():
+    """Nesterov-Todd scaling with second-order-cone blocks (dims = {'l': 4, 'q': [5, 1, 9], 's': []}, also with a nonlinear
+    block): misc.compute_scaling / update_scaling / ssqr and misc_solvers.scale / scale2 / sprod / sinv / sdot / max_step on
+    seeded interior points -- pure reference."""
+    from kvxopt import matrix, misc, misc_solvers
+    out = {}
+    for tag, mnl in (("a", None), ("b", 3)):
+        rng = np.random.default_rng(1500 + (mnl or 0))
+        k = mnl or 0
+        ml, q = 4, [5, 1, 9]
+        dims = {"l": ml, "q": q, "s": []}
+        N = k + ml + sum(q)
+
+        def interior():
+            x = rng.uniform(0.3, 2.0, N)
+            ind = k + ml
+            for m in q:
+                t = rng.standard_normal(m - 1)
+                x[ind + 1:ind + m] = t
+                x[ind] = np.linalg.norm(t) + rng.uniform(0.2, 1.5)
+                ind += m
+            return x
+        s, z = interior(), interior()
+        lm = matrix(0.0, (N, 1))
+        W = misc.compute_scaling(matrix(s), matrix(z), lm, dims, mnl)
+        out[tag + "_s"], out[tag + "_z"] = s, z
+        out[tag + "_lmbda"] = tolist(lm)
+        for key in ("d", "di") + (("dnl", "dnli") if mnl else ()):
+            out[tag + "_" + key] = tolist(W[key])
+        out[tag + "_beta"] = np.array(W["beta"])
+        out[tag + "_v"] = np.concatenate([tolist(v) for v in W["v"]])
+        X = rng.standard_normal((N, 2))
+        out[tag + "_X"] = X
+        for tr in "NT":
+            for inv in "NI":
+                x = matrix(X.copy(order="F"))
+                misc_solvers.scale(x, W, trans=tr, inverse=inv)
+                out["%s_scale_%s%s" % (tag, tr, inv)] = np.array(x)
+        x1, y1 = interior() * 0.7 + 0.1 * rng.standard_normal(N), interior()
+        out[tag + "_x1"], out[tag + "_y1"] = x1, y1
+        for name, fn in (("scale2_N", lambda a: misc_solvers.scale2(lm, a, dims, k)),
+                         ("scale2_I", lambda a: misc_solvers.scale2(lm, a, dims, k, inverse="I")),
+                         ("sprod", lambda a: misc_solvers.sprod(a, matrix(y1), dims, k)),
+                         ("sinv", lambda a: misc_solvers.sinv(a, matrix(y1), dims, k))):
+            a = matrix(x1.copy()); fn(a); out[tag + "_" + name] = tolist(a)
+        a = matrix(0.0, (N, 1)); misc.ssqr(a, matrix(y1), dims, k); out[tag + "_ssqr"] = tolist(a)
+        out[tag + "_sdot"] = np.array(misc_solvers.sdot(matrix(x1), matrix(y1), dims, k))
+        out[tag + "_max_step"] = np.array(misc_solvers.max_step(matrix(x1), dims, k))
+        # update_scaling: new iterates in the current scaling, close to lmbda (as the interior-point update produces them)
+        ns = np.array(lm).ravel() * (1.0 + 0.05 * rng.standard_normal(N))
+        nz = np.array(lm).ravel() * (1.0 + 0.05 * rng.standard_normal(N))
+        ms, mz = matrix(ns.copy()), matrix(nz.copy())
+        out[tag + "_us_s_in"], out[tag + "_us_z_in"] = ns, nz
+        misc.update_scaling(W, lm, ms, mz)
+        out[tag + "_us_s"], out[tag + "_us_z"], out[tag + "_us_lmbda"] = tolist(ms), tolist(mz), tolist(lm)
+        for key in ("d", "di") + (("dnl", "dnli") if mnl else ()):
+            out[tag + "_us_" + key] = tolist(W[key])
+        out[tag + "_us_beta"] = np.array(W["beta"])
+        out[tag + "_us_v"] = np.concatenate([tolist(v) for v in W["v"]])
+    np.savez(os.path.join(HERE, "g15_q_cone_scaling.npz"), **out)
+
+
 def g13_gemv_subblocks():
     """base.gemv (base.c:744-851 -> sparse.c:1073-1104) with the sub-block arguments m, n, offsetA and strides, sparse A."""
     from kvxopt import base, matrix, spmatrix
@@ -620,4 +682,5 @@ if __name__ == "__main__":
     g12_nonlinear_block()
     g13_gemv_subblocks()
     g14_kkt_singular()
+    g15_q_cone_scaling()
     print("goldens written to", HERE)

@@ -749,3 +749,50 @@ def test_kkt_general_S_with_many_equality_rows():
     sol = spla.spsolve(K.tocsc(), np.concatenate([bx, by, bz]))
     ux, uy, uz = sol[:n], sol[n:n + p], sol[n + p:]
     assert rel(x.get(), ux) < 1e-8 and rel(y.get(), uy) < 1e-8 and rel(z.get(), d * uz) < 1e-8
+
+
+@pytest.mark.parametrize("tag,mnl", [("a", None), ("b", 3)])
+def test_second_order_cone_scaling_golden(golden_dir, tag, mnl):
+    """G15 (pure reference): Nesterov-Todd scaling with second-order-cone blocks, dims = {'l': 4, 'q': [5, 1, 9]} without and
+    with a nonlinear block -- compute_scaling (W['v'], W['beta'], lambda), scale in all four trans / inverse combinations on
+    two columns, scale2, sprod, sinv, ssqr, sdot, max_step and update_scaling (s, z, lambda, v, beta in place).  Identical
+    formulas; the inner products are summed in a different order than BLAS: 1e-13."""
+    g = np.load(os.path.join(golden_dir, "g15_q_cone_scaling.npz"))
+    k = mnl or 0
+    ml, q = 4, [5, 1, 9]
+    dims = {"l": ml, "q": q, "s": []}
+    N = k + ml + sum(q)
+    tol = 1e-13
+    lm = matrix(0.0, (N, 1))
+    W = misc.compute_scaling(matrix(g[tag + "_s"].copy()), matrix(g[tag + "_z"].copy()), lm, dims, mnl)
+    assert rel(lm._a, g[tag + "_lmbda"]) < tol
+    assert rel(W["d"]._a, g[tag + "_d"]) < tol and rel(W["di"]._a, g[tag + "_di"]) < tol
+    if mnl:
+        assert rel(W["dnl"]._a, g[tag + "_dnl"]) < tol and rel(W["dnli"]._a, g[tag + "_dnli"]) < tol
+    assert len(W["v"]) == len(q) and [v.size for v in W["v"]] == [(m, 1) for m in q]
+    assert rel(np.concatenate([v._a for v in W["v"]]), g[tag + "_v"]) < tol and rel(W["beta"], g[tag + "_beta"]) < tol
+    for tr in "NT":
+        for inv in "NI":
+            x = matrix(g[tag + "_X"].copy(order="F"))
+            misc.scale(x, W, trans=tr, inverse=inv)
+            assert rel(x.a, g["%s_scale_%s%s" % (tag, tr, inv)]) < tol, (tr, inv)
+    x1, y1 = g[tag + "_x1"], g[tag + "_y1"]
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, k); assert rel(a._a, g[tag + "_scale2_N"]) < tol
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, k, inverse="I"); assert rel(a._a, g[tag + "_scale2_I"]) < tol
+    a = matrix(x1.copy()); misc.sprod(a, matrix(y1), dims, k); assert rel(a._a, g[tag + "_sprod"]) < tol
+    a = matrix(x1.copy()); misc.sinv(a, matrix(y1), dims, k); assert rel(a._a, g[tag + "_sinv"]) < tol
+    a = matrix(0.0, (N, 1)); misc.ssqr(a, matrix(y1), dims, k); assert rel(a._a, g[tag + "_ssqr"]) < tol
+    assert abs(misc.sdot(matrix(x1), matrix(y1), dims, k) - float(g[tag + "_sdot"])) <= 1e-12 * abs(float(g[tag + "_sdot"]))
+    assert abs(misc.max_step(matrix(x1), dims, k) - float(g[tag + "_max_step"])) <= 1e-13 * max(1.0, abs(float(g[tag + "_max_step"])))
+    ms, mz = matrix(g[tag + "_us_s_in"].copy()), matrix(g[tag + "_us_z_in"].copy())
+    misc.update_scaling(W, lm, ms, mz)
+    for got, name in ((ms, "us_s"), (mz, "us_z"), (lm, "us_lmbda"), (W["d"], "us_d"), (W["di"], "us_di")):
+        assert rel(got._a, g[tag + "_" + name]) < tol, name
+    assert rel(np.concatenate([v._a for v in W["v"]]), g[tag + "_us_v"]) < tol and rel(W["beta"], g[tag + "_us_beta"]) < tol
+    # inverse scaling undoes the scaling; W z = W^-T s = lambda holds for the 'q' blocks too
+    x = matrix(g[tag + "_X"].copy(order="F"))
+    misc.scale(x, W); misc.scale(x, W, inverse="I")
+    assert rel(x.a, g[tag + "_X"]) < 1e-12
+    assert misc.max_step(matrix(np.zeros(0)), {"l": 0, "q": [], "s": []}) == 0.0
+    with pytest.raises(NotImplementedError):
+        misc.compute_scaling(matrix(np.ones(4)), matrix(np.ones(4)), matrix(0.0, (2, 1)), {"l": 0, "q": [], "s": [2]})
