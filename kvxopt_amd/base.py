@@ -1,7 +1,8 @@
 """Host containers and sparse BLAS of the hot path, mirroring the subset of `kvxopt.base` that
 `misc.kkt_chol2` and the LP/QP drivers use (reference: src/C/base.c, dense.c, sparse.c).
 
-* `matrix`   : dense, column-major, typecode 'd' or 'i' (layout of src/C/kvxopt.h:48-56).
+* `matrix`   : dense, column-major, typecode 'd', 'i' or 'z' (layout of src/C/kvxopt.h:48-56; 'z' = complex128, accepted by
+  the linear solvers `cholmod` / `klu`, which solve complex systems through their real 2n x 2n embedding).
 * `spmatrix` : compressed-column storage with sorted rows (kvxopt.h:58-69, doc/source/c-api.rst:121-179).
 * `gemm(..., partial=True)`, `syrk(...)`, `gemv(...)` on sparse operands run on the GPU through the
   C ABI (kvx_atda_*, kvx_spmv_dev); there is no CPU arithmetic fallback for them.
@@ -46,9 +47,11 @@ class matrix:
                 arr = np.array(x)
                 size = size or (len(x), 1)
         if tc is None:
-            tc = "i" if arr.dtype.kind in "iu" else "d"
+            tc = "i" if arr.dtype.kind in "iu" else ("z" if arr.dtype.kind == "c" else "d")
+        if tc not in ("i", "d", "z"):
+            raise TypeError("tc must be 'i', 'd' or 'z'")
         self.typecode = tc
-        self._a = np.ascontiguousarray(arr, dtype=np.int64 if tc == "i" else np.float64).copy()
+        self._a = np.ascontiguousarray(arr, dtype={"i": np.int64, "d": np.float64, "z": np.complex128}[tc]).copy()
         self.size = (int(size[0]), int(size[1]))
         if self._a.size != self.size[0] * self.size[1]:
             raise TypeError("wrong number of elements")
@@ -67,11 +70,14 @@ class matrix:
     def __getitem__(self, idx):
         if isinstance(idx, tuple):
             r = self.a[idx]
-            return matrix(r) if isinstance(r, np.ndarray) else (int(r) if self.typecode == "i" else float(r))
+            return matrix(r) if isinstance(r, np.ndarray) else self._scalar(r)
         r = self._a[idx]
         if isinstance(r, np.ndarray):
             return matrix(r, (r.size, 1), self.typecode)
-        return int(r) if self.typecode == "i" else float(r)
+        return self._scalar(r)
+
+    def _scalar(self, r):
+        return int(r) if self.typecode == "i" else (complex(r) if self.typecode == "z" else float(r))
 
     def __setitem__(self, idx, v):
         v = v._a if isinstance(v, matrix) and not isinstance(idx, tuple) else (v.a if isinstance(v, matrix) else v)
@@ -121,8 +127,9 @@ def _as_ccs(A):
     if isinstance(A, spmatrix):
         return A.size[0], A.size[1], A.colptr, A.rowind, A.values
     cp, ri, v = A.CCS
+    v = np.array(v).reshape(-1)
     return (A.size[0], A.size[1], np.array(cp, dtype=np.int64).reshape(-1),
-            np.array(ri, dtype=np.int64).reshape(-1), np.array(v, dtype=np.float64).reshape(-1))
+            np.array(ri, dtype=np.int64).reshape(-1), v.astype(np.complex128 if v.dtype.kind == "c" else np.float64))
 
 
 class spmatrix:
@@ -135,8 +142,12 @@ class spmatrix:
         if isinstance(V, matrix):
             V = V._a
         if np.isscalar(V):
-            V = np.full(I.size, float(V))
-        V = np.asarray(V, dtype=np.float64).reshape(-1)
+            V = np.full(I.size, V)
+        V = np.asarray(V).reshape(-1)
+        if tc == "d" and V.dtype.kind == "c":
+            tc = "z"
+        vdt = np.complex128 if tc == "z" else np.float64
+        V = V.astype(vdt)
         if not (V.size == I.size == J.size):
             raise TypeError("V, I, J must have the same length")
         if size is None:
@@ -158,16 +169,17 @@ class spmatrix:
         np.add.at(self.colptr, J + 1, 1)
         np.cumsum(self.colptr, out=self.colptr)
         self.rowind = I.copy()
-        self.values = V.astype(np.float64).copy()
+        self.values = V.astype(vdt).copy()
 
     @classmethod
     def from_ccs(cls, m, n, colptr, rowind, values):
         S = cls.__new__(cls)
         S.size = (int(m), int(n))
-        S.typecode = "d"
+        values = np.asarray(values)
+        S.typecode = "z" if values.dtype.kind == "c" else "d"
         S.colptr = np.ascontiguousarray(colptr, dtype=np.int64)
         S.rowind = np.ascontiguousarray(rowind, dtype=np.int64)
-        S.values = np.ascontiguousarray(values, dtype=np.float64)
+        S.values = np.ascontiguousarray(values, dtype=np.complex128 if S.typecode == "z" else np.float64)
         return S
 
     @property
@@ -193,7 +205,7 @@ class spmatrix:
     def T(self):
         m, n = self.size
         cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(self.colptr))
-        return spmatrix(self.values, cols, self.rowind, (n, m))
+        return spmatrix(self.values, cols, self.rowind, (n, m), self.typecode)
 
     def __iadd__(self, o):
         """S += H on the union pattern (sparse.c:4299 spmatrix_iadd)."""
@@ -208,13 +220,13 @@ class spmatrix:
         return self
 
     def todense(self):
-        D = np.zeros(self.size)
+        D = np.zeros(self.size, dtype=self.values.dtype)
         cols = np.repeat(np.arange(self.size[1], dtype=np.int64), np.diff(self.colptr))
         D[self.rowind, cols] = self.values
         return D
 
     def __repr__(self):
-        return "<%dx%d sparse matrix, tc='d', nnz=%d>" % (self.size[0], self.size[1], self.values.size)
+        return "<%dx%d sparse matrix, tc='%s', nnz=%d>" % (self.size[0], self.size[1], self.typecode, self.values.size)
 
 
 def spdiag(x):
@@ -224,23 +236,24 @@ def spdiag(x):
     return spmatrix(v, np.arange(n), np.arange(n), (n, n))
 
 
-def _dense_buffer(B):
-    """Writable 1-D float64 numpy view of a dense matrix (ours or kvxopt's), column-major."""
+def _dense_buffer(B, tc="d"):
+    """Writable 1-D numpy view (float64, or complex128 for tc = 'z') of a dense matrix (ours or kvxopt's), column-major."""
+    want = np.complex128 if tc == "z" else np.float64
     if isinstance(B, matrix):
-        if B.typecode != "d":
-            raise TypeError("B must be a 'd' matrix")
+        if B.typecode != tc:
+            raise TypeError("B must be a '%s' matrix" % tc)
         return B._a, B.size
     if isinstance(B, np.ndarray):
-        if B.dtype != np.float64:
-            raise TypeError("B must be float64")
+        if B.dtype != want:
+            raise TypeError("B must be %s" % np.dtype(want).name)
         if B.ndim == 1:
             return B, (B.size, 1)
         if not B.flags.f_contiguous:
             raise TypeError("B must be column-major")
         return B.reshape(-1, order="F"), B.shape
     mv = memoryview(B)                                            # kvxopt matrix: buffer protocol (dense.c:1350-1385)
-    if mv.format != "d":
-        raise TypeError("B must be a 'd' matrix")
+    if mv.format != ("Zd" if tc == "z" else "d"):
+        raise TypeError("B must be a '%s' matrix" % tc)
     arr = np.asarray(mv)
     size = tuple(B.size)
     return arr.reshape(-1, order="F") if arr.ndim == 2 else arr, size

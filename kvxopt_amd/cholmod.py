@@ -19,6 +19,10 @@ options['supernodal'] (spsolvers.rst:731-736): 2 (default) gives P A P' = L L'; 
 CHOLMOD's flops / nnz(L) >= 40 rule.  One set of HIP kernels computes the LL' factor Lc; the LDL' factor is that result seen
 as L = Lc diag(Lc)^-1, D = diag(Lc)^2 -- `solve`/`spsolve` with sys = 2..6, `getfactor` (D on the diagonal) and `diag`
 (refused, cholmod.c:919-922) follow the reference's behaviour for such a factor.
+Complex Hermitian ('z') matrices (cholmod.c:144,153,463) are SOLVED -- symbolic / numeric / solve and spsolve with sys = 0,
+linsolve, splinsolve -- through the real symmetric 2n x 2n embedding [[Re A, -Im A], [Im A, Re A]] (positive definite exactly
+when A is) on the same real kernels; the partial systems (sys = 1..8), `diag` and `getfactor` of a complex factor are not
+available (the factor of the embedding is not the embedding of the complex factor) and raise NotImplementedError.
 """
 import numpy as np
 
@@ -62,6 +66,39 @@ class _F:
         self.keep = keep                # mask of its entries inside the `uplo` triangle (None: all of them)
         self.tri = tri                  # (colptr, rowind) of that triangle: what was analysed (cholmod.c:132-181 `pack`)
         self.name = "CHOLMOD SYM D FACTOR " + uplo
+
+
+def _embed_hermitian(n, cp, ri, v, uplo):
+    """Lower-triangular CCS (colptr, rowind, values, source map) of the real embedding [[B, -C], [C, B]] of the Hermitian
+    matrix A = B + iC given by its `uplo` triangle: every stored a_ij, i > j, lands in (i, j), (n+i, n+j) with Re a_ij and in
+    (n+i, j), (n+j, i) with +-Im a_ij; the (real part of the) diagonal in (i, i), (n+i, n+i).  Built once per pattern: the
+    returned gather turns a value array of A into the value array of the embedding."""
+    col = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp))
+    keep = ri >= col if uplo == "L" else ri <= col
+    idx = np.nonzero(keep)[0]
+    i, j = ri[idx], col[idx]
+    flip = np.zeros(idx.size, dtype=bool)
+    if uplo == "U":                                   # stored a_ij with i <= j: the lower entry is a_ji = conj(a_ij)
+        i, j = j, i
+        flip[:] = True
+    off = i > j
+    # entries: (row, col, source index, kind)  kind 0: Re, 1: +Im, 2: -Im (before the conjugation of an upper triangle)
+    rows = np.concatenate([i, n + i, n + i[off], n + j[off]])
+    cols = np.concatenate([j, n + j, j[off], i[off]])
+    src = np.concatenate([idx, idx, idx[off], idx[off]])
+    kind = np.concatenate([np.zeros(idx.size, np.int8), np.zeros(idx.size, np.int8), np.ones(off.sum(), np.int8),
+                           np.full(off.sum(), 2, np.int8)])
+    conj = np.concatenate([flip, flip, flip[off], flip[off]])
+    order = np.lexsort((rows, cols))
+    rows, cols, src, kind, conj = rows[order], cols[order], src[order], kind[order], conj[order]
+    cp2 = np.zeros(2 * n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=2 * n), out=cp2[1:])
+    sign = np.where(kind == 2, -1.0, 1.0) * np.where(conj & (kind > 0), -1.0, 1.0)
+
+    def values(vz):
+        vz = np.asarray(vz, dtype=np.complex128)
+        return np.where(kind == 0, vz.real[src], sign * vz.imag[src])
+    return cp2, np.ascontiguousarray(rows), values
 
 
 def _triangle(n, cp, ri, uplo):
@@ -111,7 +148,6 @@ def symbolic(A, p=None, uplo="L"):
     q = _perm(p, n)
     if uplo not in ("L", "U"):
         raise ValueError("possible values of uplo are: 'L', 'U'")
-    keep, tcp, tri = _triangle(n, cp, ri, uplo)
     fopts = {k: opts[k] for k in ("postorder", "dbound", "supernodal") if k in opts}
     # options['nmethods'] (cholmod.c:65-76): 1 = the given ordering and nothing else (no p: the natural order); 0 (default) and
     # 2 = a given p competes with the library's own orderings (nested dissection / minimum degree), the least fill wins
@@ -121,6 +157,20 @@ def symbolic(A, p=None, uplo="L"):
             fopts["ordering"] = 1
     elif q is not None:
         fopts["compare_given"] = 1
+    if v.dtype.kind == "c":
+        if q is not None:
+            q = np.concatenate([q, q + n])                  # the same symmetric permutation on both halves
+        ecp, eri, evals = _embed_hermitian(n, cp, ri, v, uplo)
+        try:
+            fac = Factor(2 * n, ecp, eri, "L", q, fopts)
+        except ValueError as e:
+            if "permutation" in str(e):
+                raise ValueError("p is not a valid permutation")
+            raise
+        F = _F(fac, uplo, (cp.copy(), ri.copy()), None, (ecp, eri))
+        F.name, F.complex, F.evals, F.n = "CHOLMOD SYM Z FACTOR " + uplo, True, evals, n
+        return F
+    keep, tcp, tri = _triangle(n, cp, ri, uplo)
     try:
         fac = Factor(n, tcp, tri, uplo, q, fopts)
     except ValueError as e:
@@ -137,6 +187,13 @@ def numeric(A, F):
         raise TypeError("A is not a sparse matrix")
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
+    if getattr(F, "complex", False) != (v.dtype.kind == "c"):
+        raise TypeError("F is not the CHOLMOD factor of a '%s' matrix" % ("z" if v.dtype.kind == "c" else "d"))
+    if getattr(F, "complex", False):
+        if n != F.n or ri.size != F.pattern[1].size or not np.array_equal(cp, F.pattern[0]) or not np.array_equal(ri, F.pattern[1]):
+            raise ValueError("factorization failed: A does not have the sparsity pattern of the symbolic factorization")
+        F.fac.factorize(F.evals(v))
+        return
     if n != F.fac.n:
         raise ValueError("factorization failed")
     # only the `uplo` triangle counts (cholmod.c:137-157): same full pattern as analysed -> reuse its mask; otherwise the
@@ -177,8 +234,12 @@ def solve(F, B, sys=0, nrhs=-1, ldB=0, offsetB=0):
         raise ArithmeticError("singular matrix")
     if sys < 0 or sys > 8:
         raise ValueError("invalid value for sys")
-    buf, size = base._dense_buffer(B)
-    n = F.fac.n
+    cplx = getattr(F, "complex", False)
+    try:
+        buf, size = base._dense_buffer(B, "z" if cplx else "d")
+    except TypeError:
+        raise TypeError("B must a dense matrix of the same numeric type as F")       # cholmod.c:461-465
+    n = F.n if cplx else F.fac.n
     if nrhs < 0:
         nrhs = size[1]
     if n == 0 or nrhs == 0:
@@ -191,6 +252,18 @@ def solve(F, B, sys=0, nrhs=-1, ldB=0, offsetB=0):
         raise ValueError("offsetB must be a nonnegative integer")
     if offsetB + (nrhs - 1) * ldB + n > buf.size:
         raise TypeError("length of B is too small")
+    if cplx:
+        if sys != 0:
+            raise NotImplementedError("complex factors solve A X = B (sys = 0) through their real embedding; the partial "
+                                      "systems sys = 1..8 are not available")
+        cols = [buf[offsetB + j * ldB: offsetB + j * ldB + n] for j in range(nrhs)]
+        R = np.empty((2 * n, nrhs), order="F")
+        for j, c in enumerate(cols):
+            R[:n, j], R[n:, j] = c.real, c.imag
+        F.fac.solve(R.reshape(-1, order="F"), sys=0, nrhs=nrhs, ldB=2 * n, offset=0)
+        for j, c in enumerate(cols):
+            c[:] = R[:n, j] + 1j * R[n:, j]
+        return
     F.fac.solve(buf, sys=sys, nrhs=nrhs, ldB=ldB, offset=offsetB)
 
 
@@ -206,6 +279,18 @@ def spsolve(F, B, sys=0):
     if sys < 0 or sys > 8:
         raise ValueError("invalid value for sys")
     m, ncol, cp, ri, v = _sp(B, "B")
+    if getattr(F, "complex", False):
+        if m != F.n:
+            raise ValueError("incompatible dimensions for B")
+        if sys != 0:
+            raise NotImplementedError("complex factors solve A X = B (sys = 0) only")
+        # columns of B as dense complex vectors through the embedding; exact zeros are dropped as CHOLMOD's own spsolve does
+        n = F.n
+        D = np.zeros((n, ncol), dtype=np.complex128, order="F")
+        D[ri, np.repeat(np.arange(ncol, dtype=np.int64), np.diff(cp))] = v
+        solve(F, D, 0)
+        I, J = np.nonzero(D.T != 0)
+        return spmatrix(D[J, I], J, I, (n, ncol), "z")
     if m != F.fac.n:
         raise ValueError("incompatible dimensions for B")
     if F.fac.n == 0 or ncol == 0:
@@ -219,7 +304,7 @@ def linsolve(A, B, p=None, uplo="L", nrhs=-1, ldB=0, offsetB=0):
     m, n, cp, ri, v = _sp(A)
     if m != n:
         raise TypeError("A is not a sparse matrix")
-    buf, size = base._dense_buffer(B)
+    buf, size = base._dense_buffer(B, "z" if v.dtype.kind == "c" else "d")
     if nrhs < 0:
         nrhs = size[1]
     if n == 0 or nrhs == 0:
@@ -246,6 +331,8 @@ def diag(F):
     _check_options()
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
+    if getattr(F, "complex", False):
+        raise NotImplementedError("diag of a complex factor (complex systems are solved through their real embedding)")
     inf = F.fac.info()
     if not inf["is_numeric"] or inf["minor"] < F.fac.n or not inf["is_ll"]:
         raise ValueError("F must be a nonsingular supernodal Cholesky factor")
@@ -256,6 +343,8 @@ def getfactor(F):
     _check_options()
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
+    if getattr(F, "complex", False):
+        raise NotImplementedError("getfactor of a complex factor (complex systems are solved through their real embedding)")
     if not F.fac.info()["is_numeric"]:
         raise ValueError("F must be a numeric Cholesky factor")
     Lp, Li, Lx = F.fac.get_factor()

@@ -9,7 +9,11 @@ No CPU fallback: numeric calls raise RuntimeError without a GPU.
     get_numeric(A, Fs, Fn) -> L, U, P, Q, R, F, r                klu.c:392-566   (R P A Q = L U + F)
     get_det(A, Fs, Fn) -> float                                  klu.c:707-828
 
-Real ('d') matrices only; complex ('z') raises TypeError (out of scope).  The factorisation has KLU's form
+Complex ('z') matrices (the reference's tests run every case with A + A*1j, tests/test_sparse_solvers.py:86-95) are SOLVED --
+`linsolve`, `symbolic`, `numeric`, `solve` with trans 'N', 'T', 'C' -- through the real 2n x 2n embedding [[Re A, -Im A],
+[Im A, Re A]] factored by the same real kernels (A^H is the transpose of the embedding; A^T x = b is conj(A^-H conj(b)));
+`get_numeric` / `get_det` of a complex factor are not available (the factors of the embedding are not embeddings of complex
+factors) and raise NotImplementedError.  The factorisation has KLU's form
 (block triangular permutation, L U of the diagonal blocks, off-diagonal part F, row scaling R) but not its algorithm:
 static multifrontal fronts with in-front threshold pivoting -- the identities the reference's tests check
 (tests/test_sparse_solvers.py:214-323) hold all the same.
@@ -41,12 +45,31 @@ class _Fn:
 def _sp(A, square=True, msg="A must be a square sparse matrix"):
     if not (isinstance(A, spmatrix) or hasattr(A, "CCS")):
         raise TypeError(msg)
-    if getattr(A, "typecode", "d") != "d":
-        raise TypeError("kvxopt_amd.klu implements real ('d') matrices only")
+    if getattr(A, "typecode", "d") not in ("d", "z"):
+        raise TypeError(msg)
     m, n, cp, ri, v = base._as_ccs(A)
     if square and m != n:
         raise TypeError(msg)
     return n, cp, ri, v
+
+
+def _embed(n, cp, ri, v):
+    """CCS of the real embedding [[Re A, -Im A], [Im A, Re A]] of a complex n x n CCS matrix (every stored entry keeps its
+    place in all four blocks, zero imaginary parts included: the pattern depends on A's pattern only)."""
+    nnz = ri.size
+    cnt = np.diff(cp)
+    cp2 = np.concatenate([2 * cp[:-1], 2 * nnz + 2 * cp]).astype(np.int64)
+    ri2 = np.empty(4 * nnz, dtype=np.int64)
+    v2 = np.empty(4 * nnz)
+    pos = np.arange(nnz, dtype=np.int64) - np.repeat(cp[:-1], cnt)          # position inside its column
+    base0 = 2 * np.repeat(cp[:-1], cnt)                                     # start of column j of the embedding
+    top, bot = base0 + pos, base0 + np.repeat(cnt, cnt) + pos
+    ri2[top], ri2[bot] = ri, ri + n
+    v2[top], v2[bot] = v.real, v.imag
+    top2, bot2 = 2 * nnz + top, 2 * nnz + bot                               # column n + j
+    ri2[top2], ri2[bot2] = ri, ri + n
+    v2[top2], v2[bot2] = -v.imag, v.real
+    return 2 * n, cp2, ri2, v2
 
 
 def _same_pattern(Fs, cp, ri):
@@ -58,6 +81,10 @@ def symbolic(A):
     n, cp, ri, v = _sp(A)
     if n == 0:
         raise ValueError("A must have at least one row and column")
+    if v.dtype.kind == "c":
+        Fs = _Fs(LuSymbolic(*_embed(n, cp, ri, v)), (cp.copy(), ri.copy()))
+        Fs.name, Fs.complex = "KLU SYM Z FACTOR", True
+        return Fs
     return _Fs(LuSymbolic(n, cp, ri, v), (cp.copy(), ri.copy()))
 
 
@@ -67,6 +94,10 @@ def numeric(A, Fs, Fn=None):
         raise TypeError("Fs is not the KLU symbolic factor of a 'd' matrix")
     if not _same_pattern(Fs, cp, ri):
         raise ValueError("KLU ERROR -3")                     # KLU_INVALID: not the analysed pattern
+    if (v.dtype.kind == "c") != bool(getattr(Fs, "complex", False)):
+        raise TypeError("Fs is not the KLU symbolic factor of a '%s' matrix" % ("z" if v.dtype.kind == "c" else "d"))
+    if v.dtype.kind == "c":
+        v = _embed(n, cp, ri, v)[3]
     if Fn is not None:
         if not isinstance(Fn, _Fn) or Fn.num.sym is not Fs.sym:
             raise TypeError("F is not the KLU numeric factor of a 'd' matrix")
@@ -75,10 +106,13 @@ def numeric(A, Fs, Fn=None):
     return _Fn(LuNumeric(Fs.sym, v))
 
 
-def _rhs_args(n, B, trans, nrhs, ldB, offsetB):
+def _rhs_args(n, B, trans, nrhs, ldB, offsetB, tc="d"):
     if not (isinstance(B, (matrix, np.ndarray)) or hasattr(B, "typecode")):
         raise TypeError("B must a dense matrix of the same numeric type as A")
-    buf, size = base._dense_buffer(B)
+    try:
+        buf, size = base._dense_buffer(B, tc)
+    except TypeError:
+        raise TypeError("B must a dense matrix of the same numeric type as A")
     if nrhs < 0:
         nrhs = size[1]
     if n == 0 or nrhs == 0:
@@ -102,15 +136,28 @@ def solve(A, Fs, F, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
         raise TypeError("F is not the KLU numeric factor of a 'd' matrix")
     if not isinstance(Fs, _Fs):
         raise TypeError("F is not the KLU symbolic factor of a 'd' matrix")
-    buf, nrhs, ldB = _rhs_args(n, B, trans, nrhs, ldB, offsetB)
+    cplx = v.dtype.kind == "c"
+    if cplx != bool(getattr(Fs, "complex", False)):
+        raise TypeError("F is not the KLU numeric factor of a '%s' matrix" % ("z" if cplx else "d"))
+    buf, nrhs, ldB = _rhs_args(n, B, trans, nrhs, ldB, offsetB, "z" if cplx else "d")
     if nrhs == 0:
         return
-    F.num.solve(buf, trans="N" if trans == "N" else "T", nrhs=nrhs, ldB=ldB, offset=offsetB)
+    if not cplx:
+        F.num.solve(buf, trans="N" if trans == "N" else "T", nrhs=nrhs, ldB=ldB, offset=offsetB)
+        return
+    # complex: [Re; Im] through the embedding.  'C': A^H = transpose of the embedding; 'T': A^T x = b  <=>  A^H conj(x) = conj(b)
+    cols = [buf[offsetB + j * ldB: offsetB + j * ldB + n] for j in range(nrhs)]
+    R = np.empty((2 * n, nrhs), order="F")
+    for j, c in enumerate(cols):
+        R[:n, j], R[n:, j] = c.real, (-c.imag if trans == "T" else c.imag)
+    F.num.solve(R.reshape(-1, order="F"), trans="N" if trans == "N" else "T", nrhs=nrhs, ldB=2 * n, offset=0)
+    for j, c in enumerate(cols):
+        c[:] = R[:n, j] + 1j * (-R[n:, j] if trans == "T" else R[n:, j])
 
 
 def linsolve(A, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
     n, cp, ri, v = _sp(A)
-    buf, nrhs_, ldB_ = _rhs_args(n, B, trans, nrhs, ldB, offsetB)
+    buf, nrhs_, ldB_ = _rhs_args(n, B, trans, nrhs, ldB, offsetB, "z" if v.dtype.kind == "c" else "d")
     if nrhs_ == 0:
         return 0 if n == 0 or nrhs == 0 else None
     Fs = symbolic(A)
@@ -124,6 +171,9 @@ def get_numeric(A, Fs, Fn):
         raise TypeError("F is not the KLU numeric factor of a 'd' matrix")
     if not isinstance(Fs, _Fs):
         raise TypeError("F is not the KLU symbolic factor of a 'd' matrix")
+    if getattr(Fs, "complex", False):
+        raise NotImplementedError("get_numeric of a complex factor: complex systems are solved through their real embedding, "
+                                  "whose factors are not the complex L, U")
     e = Fn.num.extract()
     L = spmatrix.from_ccs(n, n, *e["L"])
     U = spmatrix.from_ccs(n, n, *e["U"])
@@ -142,4 +192,6 @@ def get_det(A, Fs, Fn):
         raise TypeError("F is not the KLU numeric factor of a 'd' matrix")
     if not isinstance(Fs, _Fs):
         raise TypeError("F is not the KLU symbolic factor of a 'd' matrix")
+    if getattr(Fs, "complex", False):
+        raise NotImplementedError("get_det of a complex factor (the embedding only gives |det A|^2)")
     return Fn.num.det()

@@ -471,3 +471,49 @@ def test_device_pool_recycles_and_trims():
     assert np.abs(xs[0] - xs[1]).max() < 1e-12 * np.abs(xs[0]).max() and np.abs(xs[0] - xs[2]).max() < 1e-12 * np.abs(xs[0]).max()
     r = workloads.sym_matvec(n, cp, ri, v, xs[0]) - b
     assert np.abs(r).max() < 1e-12 * np.abs(b).max()
+
+
+def test_complex_hermitian_systems():
+    """cholmod with 'z' matrices (cholmod.c:144,153,463): Hermitian positive definite A given by either triangle, complex
+    right-hand sides -- symbolic / numeric / solve (sys = 0), linsolve, spsolve, splinsolve against dense numpy solves.  Runs
+    through the real symmetric 2n x 2n embedding; the partial systems, diag and getfactor of a complex factor are refused."""
+    import scipy.sparse as sp
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import matrix, spmatrix
+    rng = np.random.default_rng(11)
+    n = 60
+    M = (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * (rng.random((n, n)) < 0.08)
+    Ad = M @ M.conj().T + np.diag(rng.uniform(2.0, 4.0, n))
+    B = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    Xref = np.linalg.solve(Ad, B)
+    for uplo, T in (("L", np.tril(Ad)), ("U", np.triu(Ad))):
+        S = sp.csc_matrix(T); S.sort_indices()
+        A = spmatrix.from_ccs(n, n, S.indptr, S.indices, S.data)
+        assert A.typecode == "z"
+        F = cholmod.symbolic(A, uplo=uplo)
+        cholmod.numeric(A, F)
+        X = matrix(B.copy(order="F"))
+        cholmod.solve(F, X)
+        assert rel(np.array(X.a), Xref) < 1e-11, uplo
+        X2 = matrix(B.copy(order="F"))
+        cholmod.linsolve(A, X2, uplo=uplo)
+        assert rel(np.array(X2.a), Xref) < 1e-11
+        cholmod.numeric(spmatrix.from_ccs(n, n, S.indptr, S.indices, 2.0 * S.data), F)           # refactor, new values
+        X3 = matrix(B.copy(order="F")); cholmod.solve(F, X3)
+        assert rel(np.array(X3.a), Xref / 2.0) < 1e-11
+        Bs = spmatrix([1.0 + 2.0j, -1.0j, 3.0], [0, 7, 7], [0, 0, 1], (n, 2))
+        Xs = cholmod.splinsolve(A, Bs, uplo=uplo)
+        assert Xs.typecode == "z" and rel(Xs.todense(), np.linalg.solve(Ad, Bs.todense())) < 1e-11
+        with pytest.raises(NotImplementedError):
+            cholmod.solve(F, X, sys=4)
+        with pytest.raises(NotImplementedError):
+            cholmod.diag(F)
+        with pytest.raises(NotImplementedError):
+            cholmod.getfactor(F)
+        with pytest.raises(TypeError):
+            cholmod.solve(F, matrix(np.ones(n)))                       # real B with a complex factor (cholmod.c:461-465)
+    bad = Ad.copy(); bad[5, 5] = -1.0
+    S = sp.csc_matrix(np.tril(bad)); S.sort_indices()
+    Ab = spmatrix.from_ccs(n, n, S.indptr, S.indices, S.data)
+    with pytest.raises(ArithmeticError):
+        cholmod.numeric(Ab, cholmod.symbolic(Ab))
