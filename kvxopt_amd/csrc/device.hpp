@@ -187,8 +187,9 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
                        double *Lx, double *Uout, double *Linv, int *status);
 
+// sharded mode: rank-ob_len update with the panel [ob, ob + ob_len) of the columns in [c_from, c_to) that rank own_r owns
 void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,
-                            int own_ob, int own_g, int own_r, double *Lx, double *Uout);
+                            int own_ob, int own_g, int own_r, int c_from, int c_to, double *Lx, double *Uout);
 
 // solves: X is n x nrhs (ld = ldx) in PERMUTED order; W* are parity workspaces, each rhs
 // column uses a slice of wstride doubles.

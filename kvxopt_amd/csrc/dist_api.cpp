@@ -166,23 +166,42 @@ int factor_cyclic_front(Comm &C, int32_t s, int l)
     double *Y = F->d_Linv + F->linv_off_host[s];
     { ProfScope ps(F, FAM_ASSEMBLE); launch_assemble_big(st, F->ds, list, 1, m, F->d_Lx, Uch, Uout); }
     std::vector<Region> regs;
+    // the panel of a pivot block: the single-GPU chain restricted to the block (the update of panel jb also factors the
+    // diagonal block of panel jb + 64 while that is inside the block)
+    auto factor_panel = [&](int o, int nb) {
+        { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, 1, o, F->d_Lx, F->d_Linv, F->d_status); }
+        for (int jb = o; jb < o + nb; jb += KVX_NB) {
+            { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, 1, m, jb, F->d_Lx, F->d_Linv); }
+            { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, 1, m, jb, o + nb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+        }
+    };
+    auto update = [&](int o, int nb, int c_from, int c_to) {
+        ProfScope ps(F, FAM_SYRK);
+        launch_syrk_outer_dist(st, F->ds, list, m, o, nb, OB, g, r, c_from, c_to, F->d_Lx, Uout);
+    };
+    if (D.rank == lo) factor_panel(0, std::min(OB, k));
     int b = 0;
     for (int o = 0; o < k; o += OB, b++) {
         const int nb = std::min(OB, k - o), owner = lo + b % g;
-        if (D.rank == owner) {
-            { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, 1, o, F->d_Lx, F->d_Linv, F->d_status); }
-            for (int jb = o; jb < o + nb; jb += KVX_NB) {
-                // (the update of panel jb also factors the diagonal block of panel jb + 64 while it is inside this block)
-                { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, 1, m, jb, F->d_Lx, F->d_Linv); }
-                { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, 1, m, jb, o + nb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
-            }
-        }
         regs.clear();
         regs.push_back(Region{P + o + (int64_t)o * m, m, m - o, nb});
         regs.push_back(Region{Y + (int64_t)(o / KVX_NB) * KVX_NB * KVX_NB, KVX_NB * KVX_NB, KVX_NB * KVX_NB, (nb + KVX_NB - 1) / KVX_NB});
         int rc = bcast_regions(C, owner, lo, hi, regs);
         if (rc) return rc;
-        if (o + nb < m) { ProfScope ps(F, FAM_SYRK); launch_syrk_outer_dist(st, F->ds, list, m, o, nb, OB, g, r, F->d_Lx, Uout); }
+        if (o + nb >= m) break;
+        // Look-ahead: the owner of the NEXT pivot block brings that block up to date first, factors its panel, and only
+        // then joins the rest of this update -- with a stream-ordered collective (RCCL) its panel chain runs while the other
+        // ranks are still updating, and the next broadcast finds the panel ready.  Every entry still receives the same
+        // updates in the same order as without look-ahead: the factor is bitwise the same.
+        const int o2 = o + nb;
+        if (o2 < k && D.rank == lo + (b + 1) % g) {
+            const int nb2 = std::min(OB, k - o2);
+            update(o, nb, o2, o2 + nb2);
+            factor_panel(o2, nb2);
+            update(o, nb, o2 + nb2, m);
+        } else {
+            update(o, nb, o2, m);
+        }
     }
     HIPCHK(hipGetLastError());
     return KVX_OK;

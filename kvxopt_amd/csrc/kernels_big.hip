@@ -640,11 +640,11 @@ union SyrkLds {
 // own.g ranks -- the pivot columns from column 0, the update columns from column k on (so that the blocks of the update
 // matrix do not depend on k mod ob); this rank (own.r) updates only the columns it owns and the next diagonal block is
 // factored by a launch of its own (its owner is whoever owns the block, not this kernel's (0, 0) tile).
-struct ColOwner { int ob, g, r; };
+struct ColOwner { int ob, g, r, c_from, c_to; };   // + the columns [c_from, c_to) this launch may touch (look-ahead: the next pivot block first)
 __device__ __forceinline__ bool col_owned(const ColOwner &o, int c, int k, int nkb)
 {
     const int blk = c < k ? c / o.ob : nkb + (c - k) / o.ob;
-    return blk % o.g == o.r;
+    return blk % o.g == o.r && c >= o.c_from && c < o.c_to;
 }
 template <bool DIST>
 __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
     const int nkb = DIST ? (k + own.ob - 1) / own.ob : 0;
     if (DIST) {                                                    // workgroup-uniform: a tile without a column of this rank
         bool any = false;
-        for (int c = c0; c < min(c0 + SY_T, m) && !any; ) {
+        for (int c = max(c0, own.c_from); c < min(min(c0 + SY_T, m), own.c_to) && !any; ) {
             any = col_owned(own, c, k, nkb);
             const int step = c < k ? min(own.ob - c % own.ob, k - c) : own.ob - (c - k) % own.ob;   // first column of the next block
             c += step;
@@ -815,7 +815,7 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     const char *e = getenv("KVX_SYRK128_TILES");
     const int64_t big_limit = e ? atoll(e) : INT64_MAX;
     if (T * (T + 1) / 2 * count >= big_limit) {
-        hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0});
+        hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX});
     } else {                                          // latency regime: more, smaller workgroups
         hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
@@ -843,17 +843,17 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (count <= 0) return;
     int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0});
+    hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX});
 }
 
 // sharded mode: the rank-ob_len update of the columns this rank owns (block-cyclic, see ColOwner); no fused factorisation
 void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,
-                            int own_ob, int own_g, int own_r, double *Lx, double *Uout)
+                            int own_ob, int own_g, int own_r, int c_from, int c_to, double *Lx, double *Uout)
 {
     int rows = max_m - ob - 1;
-    if (rows <= 0) return;
+    if (rows <= 0 || c_from >= c_to) return;
     hipLaunchKernelGGL(k_syrk_trailing128<true>, syrk128_grid(rows, 1), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout,
-                       (double *)nullptr, (int *)nullptr, ColOwner{own_ob, own_g, own_r});
+                       (double *)nullptr, (int *)nullptr, ColOwner{own_ob, own_g, own_r, c_from, c_to});
 }
 
 // ------------------------------------------------------------------------------------------

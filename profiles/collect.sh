@@ -5,7 +5,7 @@
 # (FETCH_SIZE, WRITE_SIZE: the TCC block cannot hold both, MI355X_MICROARCH.md).  Summaries land in gpurun_out/<tag>_*;
 # profiles/summarize.py turns them into the small files committed under profiles/.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

@@ -295,6 +295,38 @@ def test_two_factors_of_one_symbolic_and_device_resident_solve():
     assert np.allclose(x, ref, rtol=1e-12)
 
 
+def test_device_entry_points_are_ordered_behind_the_callers_kernels(golden_dir):
+    """Stream contract (include/kvxhip.h): the *_dev entry points run on the library's own non-blocking streams and must order
+    them behind what the caller already submitted to the null stream.  Here the values / the right-hand side are produced by
+    kernels on the null stream IMMEDIATELY before the call, many times over a large buffer so that they are still running when
+    the call is made; a missing ordering reads stale data."""
+    A = load(golden_dir, "ACTIVSg2000")
+    n = A.size[0]
+    L = _lib.lib()
+    Fs = klu.symbolic(A)
+    Fn = klu.numeric(A, Fs)
+    nnz = A.values.size
+    big = _lib.DeviceBuffer.from_array(np.ones(1 << 24))              # keeps the null stream busy ahead of the small kernels
+    vals = _lib.DeviceBuffer.from_array(A.values)
+    b = np.random.default_rng(8).standard_normal(n)
+    rhs = _lib.DeviceBuffer.from_array(np.zeros(n))
+    src = _lib.DeviceBuffer.from_array(b)
+    for scale in (2.0, 0.5, 4.0):
+        for _ in range(20):
+            _lib.raise_for(L.kvx_vec_scal_dev(1 << 24, 1.0000001, big.ptr))
+        _lib.raise_for(L.kvx_vec_scal_dev(nnz, scale, vals.ptr))       # values := scale * values, then straight into the refactor
+        Fn.num.refactor_dev(vals.ptr, nnz)
+        for _ in range(20):
+            _lib.raise_for(L.kvx_vec_scal_dev(1 << 24, 0.9999999, big.ptr))
+        _lib.raise_for(L.kvx_vec_copy_dev(n, src.ptr, rhs.ptr))        # rhs := b on the null stream, then straight into the solve
+        Fn.num.solve_dev(rhs.ptr, "N", 1)
+        x = rhs.download(np.float64, n)
+        cur = vals.download(np.float64, nnz)
+        M = sp.csc_matrix((cur, A.rowind, A.colptr), shape=(n, n))
+        assert np.abs(M @ x - b).max() < 5e-8, scale
+        _lib.raise_for(L.kvx_vec_fill_dev(n, 0.0, rhs.ptr))
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_complex_matrices_as_the_reference_tests_build_them(golden_dir, name):
     """test_sparse_solvers.py:86-95, 238-284 with `_complex = True`: A := A + A*1j, b := b*1j, trans in 'N', 'T', 'C'; the
