@@ -356,14 +356,14 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         int nitems = 0;
         for (int c = KVX_CLS_LDS128; c < KVX_CLS_WAVE0; c++)
             if (P.cnt[c] > 0) {
-                const double slots = c == KVX_CLS_LDS128 ? 256.0 : 512.0;          // LDS image: one / two fronts per CU
+                const double slots = c == KVX_CLS_LDS128 ? 512.0 : 1024.0;         // packed LDS image: two / four fronts per CU
                 items[nitems++] = Item{c, P.cnt[c], P.off[c], (P.maxk[c] > 32 ? 80.0 : 45.0) * std::max(1.0, P.cnt[c] / slots), 0};
             }
         for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c += 2) {
             const int cnt = P.cnt[c] + P.cnt[c + 1];
             if (cnt == 0) continue;
             const int mcap = wave_class_mcap(c);
-            const double base = mcap == 64 ? 35.0 : (mcap == 48 ? 28.0 : 18.0), slots = mcap == 64 ? 1024.0 : (mcap == 48 ? 2048.0 : 4096.0);
+            const double base = mcap == 64 ? 35.0 : (mcap == 48 ? 28.0 : 18.0), slots = mcap == 64 ? 2048.0 : (mcap == 48 ? 4096.0 : 8192.0);
             items[nitems++] = Item{c, cnt, P.cnt[c] > 0 ? P.off[c] : P.off[c + 1], base * std::max(1.0, cnt / slots), 0};
         }
         std::sort(items, items + nitems, [](const Item &x, const Item &y) { return x.est > y.est; });

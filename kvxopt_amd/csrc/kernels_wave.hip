@@ -67,6 +67,11 @@ __device__ __forceinline__ void quad_col_steps(double (&a)[KMAX / 2], int k, int
     (quad_col_step<KMAX, Js>(a, k, row, p, status, col0, cb2, pr), ...);
 }
 
+// The LDS image of a front holds its LOWER TRIANGLE only, packed by columns: entry (row, col), row >= col, of a front of
+// order m sits at pk(row, col, m).  Half the footprint of a square image: two fronts of order 128 (66 KB each) share a CU
+// instead of one, nine wave fronts of order 64 instead of four -- these kernels are bound by occupancy x per-front latency.
+__device__ __forceinline__ int pk(int row, int col, int m) { return row + col * (m - 1) - ((col * (col - 1)) >> 1); }
+
 // Extend-add of one child's update matrix (lower triangle, uc x uc, ld = uc) into the LDS image F.
 // Thread (i = tid % RP, ph = tid / RP) owns child row i and the columns j = ph (mod NP); the HBM
 // loads of a batch of B columns are issued before any LDS update so that B loads are in flight.
@@ -87,7 +92,7 @@ __device__ __forceinline__ void extend_add_child(double *F, int m, const int *re
 #pragma unroll
         for (int q = 0; q < B; q++) {
             const int j = jb + ph + q * NP;
-            if (row_ok && j <= i) F[myrow + relsh[j] * m] += v[q];
+            if (row_ok && j <= i) F[pk(myrow, relsh[j], m)] += v[q];
         }
     }
 }
@@ -125,8 +130,8 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
     for (int ks = 0; ks < k; ks += 4) {
         const int kc = ks + lk;
         const bool kin = kc < k;
-        const double av = kvx_ld0(F, (k + cc) + kc * m, kin && cc < u);
-        const double bv = kvx_ld0(F, (k + rr) + kc * m, kin && rr < u);
+        const double av = kvx_ld0(F, pk(k + cc, kc, m), kin && cc < u);
+        const double bv = kvx_ld0(F, pk(k + rr, kc, m), kin && rr < u);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
     // lane holds D[i = lk + 4q][j = lr]: i <-> tile column, j <-> tile row
@@ -135,7 +140,7 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
         for (int q = 0; q < 4; q++) {
             const int c = 16 * tj + lk + 4 * q;
             if (c <= rr) {
-                const double base = kvx_ld0(F, (k + rr) + (k + c) * m, kids);
+                const double base = kvx_ld0(F, pk(k + rr, k + c, m), kids);
                 Uout[rr + (int64_t)c * u] = base - acc[q];
             }
         }
@@ -148,8 +153,8 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
-    extern __shared__ double F[];                  // m x m image of the front (ld = m), 2x64 column buffer, 64 ints
-    double *cb2 = F + mcap * mcap;
+    extern __shared__ double F[];                  // packed lower triangle of the front (pk), 2x64 column buffer, 64 ints
+    double *cb2 = F + mcap * (mcap + 1) / 2;
     int *relsh = (int *)(cb2 + 128);
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m, u = m - k, r = threadIdx.x;
@@ -161,11 +166,11 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
 #pragma unroll
     for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
     if (kids) {
-        const int mm = m * m;
+        const int mm = m * (m + 1) / 2;
         for (int i = r; i < mm; i += 64) F[i] = 0.0;
         extend_add_children<64, 64>(ds, fd, F, m, relsh, Uc, r);
 #pragma unroll
-        for (int j = 0; j < KMAX; j++) a[j] += kvx_ld0(F, r + j * m, j < k && r < m);
+        for (int j = 0; j < KMAX; j++) a[j] += kvx_ld0(F, pk(r, j, m), j < k && r < m && r >= j);
     }
     kvx_col_steps<KMAX>(a, k, r, status, fd.first, nullptr, cb2, make_piv_rule(ds), std::make_integer_sequence<int, KMAX>());
     if (r < m) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__r
         for (int j = 0; j < KMAX; j++)
             if (j < k) {
                 P[r + (int64_t)j * m] = a[j];
-                F[r + j * m] = a[j];
+                if (r >= j) F[pk(r, j, m)] = a[j];
             }
     }
     if (u == 0) return;
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
-    extern __shared__ double F[];                  // m x m image (ld = m), 2x128 column buffer, 128 ints
-    double *cb2 = F + mcap * mcap;
+    extern __shared__ double F[];                  // packed lower triangle (pk), 2x128 column buffer, 128 ints
+    double *cb2 = F + mcap * (mcap + 1) / 2;
     int *relsh = (int *)(cb2 + 256);
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m, u = m - k, tid = threadIdx.x;
@@ -203,17 +208,17 @@ __global__ __launch_bounds__(256) void k_front_lds(DevSym ds, const int32_t *__r
 #pragma unroll
     for (int t = 0; t < KMAX / 2; t++) a[t] = kvx_ld0(P, row + (int64_t)(2 * t + p) * m, 2 * t + p < k && row < m);
     if (kids) {
-        const int mm = m * m;
+        const int mm = m * (m + 1) / 2;
         for (int i = tid; i < mm; i += 256) F[i] = 0.0;
         extend_add_children<256, 128>(ds, fd, F, m, relsh, Uc, tid);
 #pragma unroll
-        for (int t = 0; t < KMAX / 2; t++) a[t] += kvx_ld0(F, row + (2 * t + p) * m, 2 * t + p < k && row < m);
+        for (int t = 0; t < KMAX / 2; t++) a[t] += kvx_ld0(F, pk(row, 2 * t + p, m), 2 * t + p < k && row < m && row >= 2 * t + p);
     }
     quad_col_steps<KMAX>(a, k, row, p, status, fd.first, cb2, make_piv_rule(ds), std::make_integer_sequence<int, KMAX>());
     if (row < m) {
 #pragma unroll
         for (int t = 0; t < KMAX / 2; t++)
-            if (2 * t + p < k) { F[row + (2 * t + p) * m] = a[t]; P[row + (int64_t)(2 * t + p) * m] = a[t]; }
+            if (2 * t + p < k) { if (row >= 2 * t + p) F[pk(row, 2 * t + p, m)] = a[t]; P[row + (int64_t)(2 * t + p) * m] = a[t]; }
     }
     if (u == 0) return;
     __syncthreads();
@@ -866,7 +871,7 @@ void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, con
                        double *Lx, const double *Uchild, double *Uout, int *status)
 {
     if (count <= 0) return;
-    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 128 * sizeof(double) + 64 * sizeof(int);
+    const size_t lds = (size_t)mcap * (mcap + 1) / 2 * sizeof(double) + 128 * sizeof(double) + 64 * sizeof(int);
     if (kmax <= 16)
         hipLaunchKernelGGL(k_front_wave<16>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     else
@@ -884,7 +889,7 @@ void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, co
         (void)hipFuncSetAttribute((const void *)k_front_lds<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
         attr_set = true;
     }
-    const size_t lds = (size_t)mcap * mcap * sizeof(double) + 256 * sizeof(double) + 128 * sizeof(int);
+    const size_t lds = (size_t)mcap * (mcap + 1) / 2 * sizeof(double) + 256 * sizeof(double) + 128 * sizeof(int);
     if (kmax <= 32)
         hipLaunchKernelGGL(k_front_lds<32>, dim3((unsigned)count), dim3(256), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     else
