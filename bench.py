@@ -396,10 +396,11 @@ def main():
     # HBM traffic of the dominant family from the committed PMC passes (profiles/, separate
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null when no profile matches.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_fetch_write_per_kernel.json")))
+        pmc_file = "r02_pmc_fetch_write_per_kernel.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
         if args.workload == "lap2d" and g == 1000 and nrhs == 1 and DF is None and dom in pmc.get("family_bytes_per_step", {}):
             roofline["traffic"] = pmc["family_bytes_per_step"][dom] / max(dom_launches, 1)
-            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/r01b_pmc_fetch_write_per_kernel.json)"
+            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/%s)" % pmc_file
             roofline["algorithmic_bytes_per_launch"] = (alg_bytes / max(dom_launches, 1)) if roofline["bound"] == "hbm" else None
     except Exception:
         pass

@@ -33,7 +33,7 @@ st = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), rec
 if st:
     rows = list(csv.DictReader(open(st[0])))
     with open(os.path.join(prof, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline  (12 factor+solve steps + 24 in the per-family timing loop)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline  (12 factor+solve steps + 27 in the per-family timing loop)\n")
         f.write("kernel,calls,total_us,avg_us,pct\n")
         for r in rows:
             f.write("%s,%s,%.1f,%.2f,%s\n" % (re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("kvx::", "").replace(",", ";"),
@@ -56,7 +56,7 @@ def pmc(dirname, counter):
 fa, fc = pmc(tag + "_pmc_fetch", "FETCH_SIZE")
 wa, wc = pmc(tag + "_pmc_write", "WRITE_SIZE")
 if fa or wa:
-    steps = 1 + 2 + 3 * 8          # warmup + timed + the per-family event-timing loop of bench.py (3 steps x 8 families)
+    steps = 1 + 2 + 3 * 9          # warmup + timed + the per-family event-timing loop of bench.py (3 steps x 9 families)
     per = {}
     for k in sorted(set(fa) | set(wa)):
         per[k] = {"dispatches": round(fc.get(k, wc.get(k, 0)) / steps, 1), "FETCH_SIZE_KB": round(fa.get(k, 0.0) / steps, 1),
