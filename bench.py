@@ -38,8 +38,8 @@ FP64_MFMA_PEAK_TF = 78.6     # MI355X FP64 matrix = vector peak; 2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, default=0, help="grid side (default: 1000 for the 5-pt Laplacian of config 2, 100 for --workload lap3d)")
     ap.add_argument("--workload", default="lap2d", choices=["lap2d", "lap3d"],
                     help="lap2d = BASELINE configs[1] (5-pt Laplacian, the headline); lap3d = 7-pt Laplacian on a cube (configs[4] is --grid 200)")
