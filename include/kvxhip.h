@@ -46,7 +46,7 @@ typedef struct {
                              * 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only (the role of AMD) */
     int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
     int32_t relax_small;    /* relaxed-amalgamation: always merge if merged width <= this (default 4)    */
-    double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .05)     */
+    double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .075)    */
     double  relax_z2;
     double  relax_z3;
     double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off: a pivot d <= 0 fails.  > 0: CHOLMOD's rule,

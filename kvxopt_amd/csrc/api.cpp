@@ -720,7 +720,11 @@ void kvx_chol_default_opts(kvx_chol_opts *o)
     o->relax_small = 4;
     o->relax_z1 = 0.8;
     o->relax_z2 = 0.1;
-    o->relax_z3 = 0.05;
+    o->relax_z3 = 0.075;    // (CHOLMOD's own default is 0.05: measured on MI355X, section 3 of DESIGN.md)
+    // (experiments: KVX_RELAX_Z1 / _Z2 / _Z3 override the defaults of every analysis in the process)
+    if (const char *e = getenv("KVX_RELAX_Z1")) o->relax_z1 = atof(e);
+    if (const char *e = getenv("KVX_RELAX_Z2")) o->relax_z2 = atof(e);
+    if (const char *e = getenv("KVX_RELAX_Z3")) o->relax_z3 = atof(e);
     o->dbound = 0.0;
 }
 

@@ -314,7 +314,7 @@ __device__ __forceinline__ void potrf_block(const DevSym &ds, const FrontDesc &f
     const int nbk = min(NB, k - jb);
     const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
     double *P = Lx + fd.px;
-    {
+    if (tid < 256) {                                // (workgroups of more than four waves: the others only keep the barriers company)
         double v[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void potrf_block(const DevSym &ds, const FrontDesc &f
     }
     __syncthreads();
     potrf_lds(lds, nbk, tid, status, fd.first + jb, make_piv_rule(ds));
-    potrf_store(lds, nbk, tid, P, m, jb, Linv + fd.linv + (int64_t)(jb / NB) * NB * NB);
+    if (tid < 256) potrf_store(lds, nbk, tid, P, m, jb, Linv + fd.linv + (int64_t)(jb / NB) * NB * NB);
 }
 
 __global__ __launch_bounds__(256) void k_potrf_blk(DevSym ds, const int32_t *__restrict__ list, int jb,
@@ -353,7 +353,8 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
 // trailing update (D[i][j]: i <-> panel column, j <-> row) so that stores run along rows.  All
 // operand loads of the 16 k-steps are branch-free; Linv is lower triangular, so k-groups above a
 // column tile are skipped.
-__device__ __forceinline__ void trsm_rows(const FrontDesc &fd, int jb, int rb, double *__restrict__ Lx, const double *__restrict__ Linv)
+__device__ __forceinline__ void trsm_rows(const FrontDesc &fd, int jb, int rb, double *__restrict__ Lx, const double *__restrict__ Linv,
+                                          const int lt)                  // lt: thread 0..255 of the four waves doing this row block
 {
     const int k = fd.k, m = fd.m;
     const int nbk = min(NB, k - jb);
@@ -361,7 +362,7 @@ __device__ __forceinline__ void trsm_rows(const FrontDesc &fd, int jb, int rb, d
     if (r0 >= m) return;
     double *P = Lx + fd.px;
     const double *Y = Linv + fd.linv + (int64_t)(jb / NB) * NB * NB;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+    const int w = lt >> 6, l = lt & 63, lr = l & 15, lk = l >> 4;
     const int rr = r0 + 16 * w + lr;
     const bool rin = rr < m;
     d4 acc[4];
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void k_trsm_blk(DevSym ds, const int32_t *__re
 {
     const FrontDesc fd = ds.fd[list[blockIdx.y]];
     if (jb >= fd.k) return;
-    trsm_rows(fd, jb, (int)blockIdx.x, Lx, Linv);
+    trsm_rows(fd, jb, (int)blockIdx.x, Lx, Linv, (int)threadIdx.x);
 }
 
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
@@ -522,13 +523,14 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 // Here a front costs its own time only, the fronts of a level run side by side on the CUs (50 KB of LDS: three per CU), and
 // the chain of the few larger fronts runs beside them on the main stream.  Same arithmetic, same order of operations per
 // entry as the multi-workgroup kernels (bitwise identical factors).
-__device__ __forceinline__ void syrk_tile(const FrontDesc &fd, int jb, int ti, int tj, double *__restrict__ P, double *__restrict__ U)
+__device__ __forceinline__ void syrk_tile(const FrontDesc &fd, int jb, int ti, int tj, double *__restrict__ P, double *__restrict__ U,
+                                          const int lt)
 {
     const int k = fd.k, m = fd.m, u = m - k;
     const int nbk = min(NB, k - jb);
     const int t0 = jb + nbk;
     const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, lr = l & 15, lk = l >> 4;
+    const int w = lt >> 6, l = lt & 63, lr = l & 15, lk = l >> 4;
     d4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
@@ -577,15 +579,17 @@ __device__ __forceinline__ void syrk_tile(const FrontDesc &fd, int jb, int ti, i
             if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
 }
 
-__global__ __launch_bounds__(256) void k_front_mid(DevSym ds, const int32_t *__restrict__ list, double *__restrict__ Lx,
-                                                   const double *__restrict__ Uc, double *__restrict__ Uo,
-                                                   double *__restrict__ Linv, int *status)
+constexpr int MID_NT = 512;                         // eight waves: two teams of four, one tile / row block per team at a time (sixteen waves spill: 128 VGPRs each)
+__global__ __launch_bounds__(MID_NT) void k_front_mid(DevSym ds, const int32_t *__restrict__ list, double *__restrict__ Lx,
+                                                      const double *__restrict__ Uc, double *__restrict__ Uo,
+                                                      double *__restrict__ Linv, int *status)
 {
     __shared__ PotrfLds lds;
     const FrontDesc fd = ds.fd[list[blockIdx.x]];
     const int k = fd.k, m = fd.m;
     double *P = Lx + fd.px;
     double *U = Uo + fd.ux;
+    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), lt = threadIdx.x & 255;
     // (the extend-add stays with the multi-workgroup kernel, all big fronts of the level in one launch: done by ONE
     // workgroup it is a chain of dependent index loads per 16-column tile, 130 us for a front of order 256)
     (void)Uc;
@@ -597,10 +601,12 @@ __global__ __launch_bounds__(256) void k_front_mid(DevSym ds, const int32_t *__r
         const int rows = m - jb - nbk;
         if (rows <= 0) break;
         const int T = (rows + KVX_TILE - 1) / KVX_TILE;
-        for (int rb = 0; rb < T; rb++) trsm_rows(fd, jb, rb, Lx, Linv);
+        for (int rb = team; rb < T; rb += MID_NT / 256) trsm_rows(fd, jb, rb, Lx, Linv, lt);
         __syncthreads();
+        int t = 0;
         for (int ti = 0; ti < T; ti++)
-            for (int tj = 0; tj <= ti; tj++) syrk_tile(fd, jb, ti, tj, P, U);
+            for (int tj = 0; tj <= ti; tj++, t++)
+                if ((t & (MID_NT / 256 - 1)) == team) syrk_tile(fd, jb, ti, tj, P, U, lt);
         __syncthreads();
     }
 }
@@ -609,7 +615,7 @@ void launch_front_mid(hipStream_t st, const DevSym &ds, const int32_t *list, int
                       double *Uout, double *Linv, int *status)
 {
     if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_mid, dim3((unsigned)count), dim3(256), 0, st, ds, list, Lx, Uchild, Uout, Linv, status);
+    hipLaunchKernelGGL(k_front_mid, dim3((unsigned)count), dim3(MID_NT), 0, st, ds, list, Lx, Uchild, Uout, Linv, status);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -35,7 +35,9 @@ struct SymOpts {
     int64_t amd_auto_max = 200000;   // ordering 0: largest order for which the minimum-degree candidate is computed as well
     int postorder = 1;
     int relax_small = 4;
-    double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.05;
+    double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.075;   // zero fractions tolerated when a chain supernode joins its parent
+                             // (merged width <= 16, <= 48, any); CHOLMOD uses 0.8 / 0.1 / 0.05 -- 0.075 for wide supernodes removes five of the
+                             // sixteen levels that hold big fronts on config 2 (each costs an extend-add + a first diagonal block + a join)
     int nd_leaf = 96;        // nested-dissection leaf size
     int leaf_cols = 32;      // leaf-subtree amalgamation: fuse while pivots <= leaf_cols ...
     int leaf_rows = 64;      // ... and front order <= leaf_rows (0 cols = off)
