@@ -24,6 +24,9 @@ linsolve, splinsolve -- through the real symmetric 2n x 2n embedding [[Re A, -Im
 when A is) on the same real kernels; the partial systems (sys = 1..8), `diag` and `getfactor` of a complex factor are not
 available (the factor of the embedding is not the embedding of the complex factor) and raise NotImplementedError.
 """
+import collections
+import os
+
 import numpy as np
 
 from . import base
@@ -299,6 +302,28 @@ def spsolve(F, B, sys=0):
     return spmatrix.from_ccs(m, ncol, Xp, Xi, Xx)
 
 
+# linsolve / splinsolve analyse the matrix at every call in the reference (cholmod.c:663, 811).  The symbolic factors of the last few
+# (pattern, p, uplo, options) combinations are kept here: a repeated call is a numeric refactorisation + solve; the host analysis
+# (0.2 s at n = 1e6) is 98 % of a one-shot call otherwise.
+_SYMBOLIC_CACHE = collections.OrderedDict()
+_SYMBOLIC_CACHE_MAX = int(os.environ.get("KVX_LINSOLVE_CACHE", "4"))      # 0 turns the cache off (every kept factor holds device memory)
+
+
+def _cached_symbolic(A, p, uplo, n, cp, ri, v):
+    q = _perm(p, n)
+    key = (n, uplo, v.dtype.kind, None if q is None else q.tobytes(), cp.tobytes(), ri.tobytes(),
+           tuple(sorted((k, repr(val)) for k, val in options.items())))
+    if _SYMBOLIC_CACHE_MAX <= 0:
+        return symbolic(A, p, uplo)
+    F = _SYMBOLIC_CACHE.pop(key, None)
+    if F is None:
+        F = symbolic(A, p, uplo)
+    _SYMBOLIC_CACHE[key] = F
+    while len(_SYMBOLIC_CACHE) > _SYMBOLIC_CACHE_MAX:
+        _SYMBOLIC_CACHE.popitem(last=False)
+    return F
+
+
 def linsolve(A, B, p=None, uplo="L", nrhs=-1, ldB=0, offsetB=0):
     _check_options()
     m, n, cp, ri, v = _sp(A)
@@ -309,7 +334,7 @@ def linsolve(A, B, p=None, uplo="L", nrhs=-1, ldB=0, offsetB=0):
         nrhs = size[1]
     if n == 0 or nrhs == 0:
         return
-    F = symbolic(A, p, uplo)
+    F = _cached_symbolic(A, p, uplo, n, cp, ri, v)
     numeric(A, F)
     solve(F, B, 0, nrhs, ldB, offsetB)
 
@@ -322,7 +347,7 @@ def splinsolve(A, B, p=None, uplo="L"):
     bm = B.size[0]
     if bm != n:
         raise ValueError("incompatible dimensions for B")
-    F = symbolic(A, p, uplo)
+    F = _cached_symbolic(A, p, uplo, n, cp, ri, v)
     numeric(A, F)
     return spsolve(F, B, 0)
 

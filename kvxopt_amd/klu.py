@@ -18,6 +18,9 @@ factors) and raise NotImplementedError.  The factorisation has KLU's form
 static multifrontal fronts with in-front threshold pivoting -- the identities the reference's tests check
 (tests/test_sparse_solvers.py:214-323) hold all the same.
 """
+import collections
+import os
+
 import numpy as np
 
 from . import base
@@ -155,13 +158,34 @@ def solve(A, Fs, F, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
         c[:] = R[:n, j] + 1j * (-R[n:, j] if trans == "T" else R[n:, j])
 
 
+# linsolve re-analyses and re-factors at every call in the reference (klu.c:142-198).  Here the symbolic and numeric factors of the
+# last few sparsity patterns are kept: a repeated call with a known pattern is a numeric REfactorisation (same pivot sequence,
+# full factorisation as fall-back, doc/source/spsolvers.rst:377-388) plus a solve -- the host analysis (matching, block
+# triangular form, ordering: 4-5 ms on ACTIVSg2000) is what made a one-shot call slower than a host SuperLU.
+_LINSOLVE_CACHE = collections.OrderedDict()
+_LINSOLVE_CACHE_MAX = int(os.environ.get("KVX_LINSOLVE_CACHE", "8"))      # 0 turns the cache off (every kept factor holds device memory)
+
+
 def linsolve(A, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
     n, cp, ri, v = _sp(A)
     buf, nrhs_, ldB_ = _rhs_args(n, B, trans, nrhs, ldB, offsetB, "z" if v.dtype.kind == "c" else "d")
     if nrhs_ == 0:
         return 0 if n == 0 or nrhs == 0 else None
-    Fs = symbolic(A)
-    Fn = numeric(A, Fs)
+    key = (n, v.dtype.kind, cp.tobytes(), ri.tobytes())
+    hit = _LINSOLVE_CACHE.pop(key, None) if _LINSOLVE_CACHE_MAX > 0 else None
+    if hit is not None:
+        Fs, Fn = hit
+        try:
+            Fn = numeric(A, Fs, Fn)
+        except ArithmeticError:
+            hit = None                                    # (singular with these values: start over below and report from there)
+    if hit is None:
+        Fs = symbolic(A)
+        Fn = numeric(A, Fs)
+    if _LINSOLVE_CACHE_MAX > 0:
+        _LINSOLVE_CACHE[key] = (Fs, Fn)
+    while len(_LINSOLVE_CACHE) > _LINSOLVE_CACHE_MAX:
+        _LINSOLVE_CACHE.popitem(last=False)
     solve(A, Fs, Fn, B, trans, nrhs, ldB, offsetB)
 
 
