@@ -192,7 +192,7 @@ int ensure_device(kvx_chol *F)
     }
     Symbolic &S = F->S;
     analyze_subtrees(F);
-    { const char *e = getenv("KVX_CHAIN_PRIO"); F->prio_stream = !(e && e[0] == '0'); }
+    { const char *e = getenv("KVX_CHAIN_PRIO"); F->prio_stream = e && e[0] == '1'; }
     HIPCHK(pool_stream_get(&F->stream, F->prio_stream));
     for (int i = 0; i < 4; i++) HIPCHK(pool_event_get(&F->ev[i], true));
     for (int i = 0; i < 4; i++) {

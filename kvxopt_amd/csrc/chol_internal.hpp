@@ -50,7 +50,9 @@ struct kvx_chol {
     bool diag_valid = false;
     int64_t minor = 0;
     hipStream_t stream = nullptr;
-    bool prio_stream = true;   // the main stream (the pivot chain) has the highest stream priority (KVX_CHAIN_PRIO=0: default priority)
+    bool prio_stream = false;  // KVX_CHAIN_PRIO=1: the main stream (the pivot chain) gets the highest stream priority.  OFF by default: nothing on
+                               // config 2 (4.31 vs 4.26 ms) and -22 % on the interior-point loop (313 vs 400 iterations/s: the loop hops between
+                               // the null stream and the factor's stream through events, which a high-priority queue serves more slowly)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
