@@ -276,6 +276,50 @@ int kvx_ntq_prod_dev(int64_t nq, const int64_t *off_dev, double *x_dev, const do
 /* out_dev[k] = |x_k1| - x_k0 (the caller takes the maximum) */
 int kvx_ntq_max_step_dev(int64_t nq, const int64_t *off_dev, const double *x_dev, double *out_dev);
 
+/* ---- semidefinite ('s') blocks of the Nesterov-Todd scaling: the 's' parts of misc.compute_scaling /
+ * update_scaling (misc.py:354-419, 582-634), misc_solvers.scale / scale2 / sprod / sinv / sdot / max_step
+ * (misc_solvers.c:188-240, 343-397, 700-770, 845-882, 1029-1046, 1086-1160) and pack / unpack / symm / trisc / triusc
+ * (misc_solvers.c:412-632, 887-988).  Block k has order m_k; off2_dev: ns + 1 offsets of the blocks in the 's' section of a
+ * vector [0, m0^2, m0^2 + m1^2, ...]; off1_dev: ns + 1 offsets of their diagonals / eigenvalues [0, m0, m0 + m1, ...].  Vector
+ * pointers address the START of the 's' section (r, rti: the blocks W['r'][k], W['rti'][k] back to back; lmbda: its 's' part).
+ * One workgroup per block, all blocks of a call in one launch (null stream).  work_dev: scratch, sizes given per entry. */
+/* r_k' z_k r_k = r_k^-1 s_k r_k^-T = diag(lmbda_k), rti_k = r_k^-T; lmbda_k descending as lapack.gesvd returns it.
+ * work: 4 sum m_k^2 doubles.  status_dev: int, preset to INT_MAX; a block that is not positive definite stores its failing
+ * column with atomicMin (the reference's lapack.potrf raises ArithmeticError). */
+int kvx_nts_compute_scaling_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, const double *s_dev,
+                                const double *z_dev, double *r_dev, double *rti_dev, double *lmbda_dev, double *work_dev,
+                                int *status_dev);
+/* in place (misc.py:582-634): on entry s_k, z_k hold the factors Ls, Lz of the new iterates in the current scaling, on return
+ * the singular vectors U and V' of Lz' Ls; r, rti, lmbda are updated.  work: 4 sum m_k^2 doubles */
+int kvx_nts_update_scaling_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, double *s_dev, double *z_dev,
+                               double *r_dev, double *rti_dev, double *lmbda_dev, double *work_dev);
+/* x_k := R_k' X_k R_k (form 0) or R_k X_k R_k' (form 1) for every column of x (leading dimension ldx); X_k is the symmetric
+ * matrix stored in the lower triangle of x_k and only that triangle is written.  R = r or rti as the reference chooses by
+ * (trans, inverse).  work: ncols * wstride doubles, wstride >= sum m_k^2 */
+int kvx_nts_scale_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, const double *R_dev, double *x_dev,
+                      int64_t ldx, int64_t ncols, int form, double *work_dev, int64_t wstride);
+/* x_k(i, j) := x_k(i, j) / (sqrt(l_i) sqrt(l_j)) (inverse 0) or times it (inverse 1), all entries of the block */
+int kvx_nts_scale2_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, const double *lmbda_dev, double *x_dev,
+                       int inverse);
+/* op 0: x := y o x with full 's' blocks in y (the upper triangles of y are filled by mirroring, as the reference does;
+ * work: sum m_k^2);  op 1 / 2: sprod / sinv with DIAGONAL 's' blocks -- y_dev then addresses the diagonals (off1 layout) */
+int kvx_nts_prod_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, double *x_dev, double *y_dev, int op,
+                     double *work_dev);
+/* out_dev[k] = trace inner product of the symmetric matrices stored in the lower triangles of x_k, y_k (the caller adds) */
+int kvx_nts_dot_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, const double *x_dev, const double *y_dev,
+                    double *out_dev);
+/* out_dev[k] = -(smallest eigenvalue of x_k); with sigma_dev != NULL the eigenvalues (ascending) are stored there and the
+ * eigenvectors replace x_k (misc_solvers.c:1128-1133), otherwise x is not modified.  work: 3 sum m_k^2 + 2 sum m_k */
+int kvx_nts_max_step_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, double *x_dev, double *sigma_dev,
+                         double *out_dev, double *work_dev);
+/* mode 0 symm (upper := mirror of lower), 1 trisc (upper := 0, strict lower *= 2), 2 triusc (strict lower *= 0.5) */
+int kvx_nts_tri_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, double *x_dev, int mode);
+/* dir 0 pack: packed (offp_dev: ns offsets [0, m0 (m0 + 1) / 2, ...]) := lower triangles of the blocks by columns, off-diagonal
+ * entries times sqrt(2) (dir 2: pack2's form, which copies the diagonal instead of dividing and multiplying it by sqrt(2));
+ * dir 1 unpack: the reverse into the lower triangles (the strict upper triangles are not touched) */
+int kvx_nts_pack_dev(int64_t ns, const int64_t *off2_dev, const int64_t *off1_dev, const int64_t *offp_dev, double *full_dev,
+                     double *packed_dev, int dir);
+
 /* ---- dense helpers of the equality-constrained KKT solve with a general S (misc.py:1476-1487, 1545): K = A S^-1 A' formed
  * as a dense p x p matrix from X = S^-1 A' (kvx_chol_solve_dev with nrhs = p) when p is moderate ------------------------- */
 /* Y(j, c) = sum_i A(i, j) X(i, c) for the CCS matrix A with n columns and every column c < ncols of the dense X */

@@ -93,6 +93,15 @@ _SIGS = {
     "kvx_ntq_scale2_dev": (ctypes.c_int, [i64, vp, vp, vp, ctypes.c_int]),
     "kvx_ntq_prod_dev": (ctypes.c_int, [i64, vp, vp, vp, ctypes.c_int]),
     "kvx_ntq_max_step_dev": (ctypes.c_int, [i64, vp, vp, vp]),
+    "kvx_nts_compute_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "kvx_nts_update_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "kvx_nts_scale_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, i64, i64, ctypes.c_int, vp, i64]),
+    "kvx_nts_scale2_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, ctypes.c_int]),
+    "kvx_nts_prod_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, ctypes.c_int, vp]),
+    "kvx_nts_dot_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
+    "kvx_nts_max_step_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, vp]),
+    "kvx_nts_tri_dev": (ctypes.c_int, [i64, vp, vp, vp, ctypes.c_int]),
+    "kvx_nts_pack_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp, ctypes.c_int]),
     "kvx_lp_newton_rhs_dev": (ctypes.c_int, [i64, vp, vp, f64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_step_post_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_update_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp, vp, vp]),

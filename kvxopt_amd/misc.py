@@ -1,9 +1,9 @@
-"""Orthant ('l' cone) subset of `kvxopt.misc` / `kvxopt.misc_solvers` on MI355X, plus the KKT solver
-factory `kkt_chol2` -- same names, argument meaning and in-place semantics as the reference
-(src/python/misc.py, src/C/misc_solvers.c).  Second-order-cone and semidefinite blocks are out of
-scope (kkt_chol2 rejects them in the reference too, misc.py:1381-1384).  The nonlinear block of
-cvxprog (`mnl` leading entries scaled by W['dnl'], misc.py:262-270, 432-442, 48-60) IS covered: it is
-one more diagonal block in front of the 'l' block, so every kernel simply runs over mnl + ml entries.
+"""`kvxopt.misc` / `kvxopt.misc_solvers` on MI355X -- the Nesterov-Todd scaling operations for the nonlinear, 'l', 'q' and
+'s' blocks and the storage helpers of the 's' blocks -- plus the KKT solver factory `kkt_chol2`: same names, argument
+meaning and in-place semantics as the reference (src/python/misc.py, src/C/misc_solvers.c).  kkt_chol2 itself takes
+'l' (and nonlinear) blocks only, as in the reference (misc.py:1381-1384).  The nonlinear block of cvxprog (`mnl` leading
+entries scaled by W['dnl'], misc.py:262-270, 432-442, 48-60) is one more diagonal block in front of the 'l' block, so
+every kernel simply runs over mnl + ml entries.
 
 Host-array compatibility layer: arguments are host `matrix` objects (ours or kvxopt's); every
 operation runs through the HIP kernels of libkvxhip.so (upload, kernel, download).  The device-
@@ -18,11 +18,37 @@ from ._lib import DeviceBuffer, lib, raise_for
 from .base import matrix, spmatrix
 
 
-def _only_l(dims, what):
-    """The nonlinear, 'l' and 'q' blocks run on the GPU; semidefinite ('s') blocks are not built."""
-    if dims.get("s"):
-        raise NotImplementedError("%s: semidefinite ('s') blocks are not implemented on the GPU path "
-                                  "(nonlinear, 'l' and 'q' blocks are)" % what)
+class _SBlocks:
+    """Device tables of the 's' section of a vector: offsets of the m_k x m_k blocks, of their diagonals / eigenvalues and
+    of their packed lower triangles (csrc/kkt_s.hip: one workgroup per block, all blocks in one launch)."""
+
+    def __init__(self, sdims):
+        self.dims = [int(m) for m in sdims]
+        self.ns = len(self.dims)
+        d = np.asarray(self.dims, dtype=np.int64)
+        self.off2, self.off1, self.offp = (np.zeros(self.ns + 1, dtype=np.int64) for _ in range(3))
+        np.cumsum(d * d, out=self.off2[1:])
+        np.cumsum(d, out=self.off1[1:])
+        np.cumsum(d * (d + 1) // 2, out=self.offp[1:])
+        self.tot2, self.tot1, self.totp = int(self.off2[-1]), int(self.off1[-1]), int(self.offp[-1])
+        self.d2, self.d1, self.dp = (DeviceBuffer.from_array(a) for a in (self.off2, self.off1, self.offp))
+
+    def split(self, flat):
+        """list of m_k x m_k matrices from the concatenated blocks"""
+        return [matrix(flat[self.off2[k]:self.off2[k + 1]].copy(), (m, m)) for k, m in enumerate(self.dims)]
+
+
+def _s_blocks(dims):
+    sd = [int(m) for m in (dims.get("s") or [])]
+    return _SBlocks(sd) if sd and sum(sd) else None
+
+
+def _cat(mats):
+    return np.concatenate([np.asarray(_buf(a)[0], dtype=np.float64) for a in mats]) if mats else np.zeros(0)
+
+
+def _scratch(n):
+    return DeviceBuffer(8 * max(int(n), 1))
 
 
 def _q_offsets(q):
@@ -63,7 +89,6 @@ def compute_scaling(s, z, lmbda, dims, mnl=None):
     """misc.py:250-352 (nonlinear, 'l' and 'q' blocks): W['d'] = sqrt(s./z), W['di'] = 1./d, lmbda = sqrt(s.*z); with
     mnl given (cvxprog), the first mnl entries make W['dnl'], W['dnli'] by the same formulas; for every second-order cone
     the unit-hyperbolic-norm vector W['v'][k] and W['beta'][k] with (beta_k (2 v_k v_k' - J)) z_k = lambda_k."""
-    _only_l(dims, "compute_scaling")
     k = 0 if mnl is None else int(mnl)
     m = k + dims["l"]
     sb, _ = _buf(s)
@@ -94,7 +119,25 @@ def compute_scaling(s, z, lmbda, dims, mnl=None):
         W["v"] = [matrix(vall[off[i]:off[i + 1]].copy(), (q[i], 1)) for i in range(len(q))]
         W["beta"] = [float(b) for b in db.download(np.float64, len(q))]
         lb[m:m + tot] = dlq.download(np.float64, tot)
+    S = _s_blocks(dims)
+    if S is not None:
+        # 's' blocks (misc.py:354-419): r_k' z_k r_k = r_k^-1 s_k r_k^-T = diag(lambda_k), rti_k = r_k^-T; lambda_k is the
+        # vector of singular values of Lz' Ls (descending), stored behind the 'q' part of lmbda
+        ind = m + sum(q)
+        dss, dzs = _up(sb[ind:ind + S.tot2]), _up(zb[ind:ind + S.tot2])
+        dr, drt, dls, wk = _scratch(S.tot2), _scratch(S.tot2), _scratch(S.tot1), _scratch(4 * S.tot2)
+        st = DeviceBuffer.from_array(np.array([_NOFAIL], dtype=np.int32))
+        raise_for(lib().kvx_nts_compute_scaling_dev(S.ns, S.d2.ptr, S.d1.ptr, dss.ptr, dzs.ptr, dr.ptr, drt.ptr, dls.ptr, wk.ptr, st.ptr))
+        _sync()
+        bad = int(st.download(np.int32, 1)[0])
+        if bad != _NOFAIL:
+            raise ArithmeticError(bad + 1)                  # lapack.potrf on a block that is not positive definite
+        W["r"], W["rti"] = S.split(dr.download(np.float64, S.tot2)), S.split(drt.download(np.float64, S.tot2))
+        lb[ind:ind + S.tot1] = dls.download(np.float64, S.tot1)
     return W
+
+
+_NOFAIL = 2 ** 31 - 1
 
 
 def _diag_of(W, inverse=False):
@@ -107,10 +150,8 @@ def _diag_of(W, inverse=False):
 
 
 def update_scaling(W, lmbda, s, z):
-    """misc.py:422-464 (nonlinear and 'l' blocks), in place: s:=sqrt(s), z:=sqrt(z), d:=d.*s./z, di:=1./d,
-    lmbda:=s.*z (W['dnl'], W['dnli'] likewise on the leading mnl entries)."""
-    if W.get("r"):
-        raise NotImplementedError("update_scaling: semidefinite ('s') blocks are not implemented on the GPU path")
+    """misc.py:422-634, in place.  Nonlinear and 'l' blocks: s:=sqrt(s), z:=sqrt(z), d:=d.*s./z, di:=1./d, lmbda:=s.*z
+    (W['dnl'], W['dnli'] likewise on the leading mnl entries); 'q' and 's' blocks below."""
     dcat, k = _diag_of(W)
     m = dcat.size
     sb, _ = _buf(s)
@@ -147,18 +188,35 @@ def update_scaling(W, lmbda, s, z):
         for i, v in enumerate(W["v"]):
             _buf(v)[0][:] = vall[off[i]:off[i + 1]]
         W["beta"][:] = [float(b) for b in db.download(np.float64, len(q))]
+    if W.get("r"):
+        # 's' blocks (misc.py:582-634): s_k, z_k hold the Cholesky factors Ls, Lz of the new iterates in the current scaling;
+        # with Lz' Ls = U diag(lambda_k) V':  r_k := r_k Ls V diag(lambda_k)^-1/2, rti_k := rti_k Lz U diag(lambda_k)^-1/2;
+        # s_k, z_k leave as U and V' (what lapack.gesvd stores there)
+        S = _SBlocks([int(_buf(r)[1][0]) for r in W["r"]])
+        ind = m + sum(int(_buf(v)[1][0]) for v in (W.get("v") or []))
+        dss, dzs = _up(sb[ind:ind + S.tot2]), _up(zb[ind:ind + S.tot2])
+        dr, drt = _up(_cat(W["r"])), _up(_cat(W["rti"]))
+        dls, wk = _scratch(S.tot1), _scratch(4 * S.tot2)
+        raise_for(lib().kvx_nts_update_scaling_dev(S.ns, S.d2.ptr, S.d1.ptr, dss.ptr, dzs.ptr, dr.ptr, drt.ptr, dls.ptr, wk.ptr))
+        _sync()
+        sb[ind:ind + S.tot2] = dss.download(np.float64, S.tot2)
+        zb[ind:ind + S.tot2] = dzs.download(np.float64, S.tot2)
+        lb[ind:ind + S.tot1] = dls.download(np.float64, S.tot1)
+        rall, tall = dr.download(np.float64, S.tot2), drt.download(np.float64, S.tot2)
+        for i in range(S.ns):
+            _buf(W["r"][i])[0][:] = rall[S.off2[i]:S.off2[i + 1]]
+            _buf(W["rti"][i])[0][:] = tall[S.off2[i]:S.off2[i + 1]]
 
 
 def scale(x, W, trans="N", inverse="N"):
-    """misc_solvers.c:85-141 / misc.py:36-82 (nonlinear and 'l' blocks): x := [dnl; d].*x ('N') or [dnli; di].*x ('I')
-    for every column of x; trans is irrelevant for a diagonal scaling."""
-    if W.get("r"):
-        raise NotImplementedError("scale: semidefinite ('s') blocks are not implemented on the GPU path")
+    """misc_solvers.c:85-240 / misc.py:36-164.  Nonlinear and 'l' blocks: x := [dnl; d].*x ('N') or [dnli; di].*x ('I') for
+    every column of x (trans is irrelevant for a diagonal scaling); 'q' and 's' blocks below."""
     w, _ = _diag_of(W, inverse != "N")
     xb, size = _buf(x)
     m = w.size
     nq = len(W.get("v") or [])
-    if m == 0 and nq == 0:
+    nsb = len(W.get("r") or [])
+    if m == 0 and nq == 0 and nsb == 0:
         return
     _lib.require_device()
     dx = _up(xb)
@@ -172,13 +230,22 @@ def scale(x, W, trans="N", inverse="N"):
         dv = _up(np.concatenate([np.asarray(_buf(v)[0], dtype=np.float64) for v in W["v"]]))
         db = _up(np.asarray(W["beta"], dtype=np.float64))
         raise_for(lib().kvx_ntq_scale_dev(nq, doff.ptr, dv.ptr, db.ptr, dx.ptr + 8 * m, size[0], size[1], 1 if inverse != "N" else 0))
+    if nsb:
+        # 's' blocks (misc_solvers.c:188-240): x_k := r' X r ('N','N'), r X r' ('T','N'), rti X rti' ('N','I'), rti' X rti
+        # ('T','I'), X the symmetric matrix in the lower triangle of x_k; only the lower triangle is written
+        R = W["r"] if inverse == "N" else W["rti"]
+        S = _SBlocks([int(_buf(r)[1][0]) for r in R])
+        ind = m + sum(int(_buf(v)[1][0]) for v in (W.get("v") or []))
+        dR, wk = _up(_cat(R)), _scratch(S.tot2 * size[1])
+        form = 1 if (inverse == "N") == (trans == "T") else 0
+        raise_for(lib().kvx_nts_scale_dev(S.ns, S.d2.ptr, S.d1.ptr, dR.ptr, dx.ptr + 8 * ind, size[0], size[1], form, wk.ptr, S.tot2))
     _sync()
     xb[:] = dx.download(np.float64, xb.size)
 
 
 def scale2(lmbda, x, dims, mnl=0, inverse="N"):
-    """misc_solvers.c:256-298 ('l' block): x := x./lmbda ('N') or x.*lmbda ('I')."""
-    _only_l(dims, "scale2")
+    """misc_solvers.c:256-397.  Nonlinear and 'l' blocks: x := x./lmbda ('N') or x.*lmbda ('I'); 'q' blocks: the hyperbolic
+    form (:301-341); 's' blocks: x_k(i, j) divided ('N') or multiplied ('I') by sqrt(l_i) sqrt(l_j) (:343-397)."""
     m = mnl + dims["l"]
     lb, _ = _buf(lmbda)
     xb, _ = _buf(x)
@@ -190,6 +257,13 @@ def scale2(lmbda, x, dims, mnl=0, inverse="N"):
         xb[:m] = dx.download(np.float64, m)
     inv = 1 if inverse == "I" else 0                      # 'q' blocks: misc_solvers.c:301-341
     _q_apply(dims, m, lambda nq, off, dxq, dlq: lib().kvx_ntq_scale2_dev(nq, off, dlq, dxq, inv), x, lmbda)
+    S = _s_blocks(dims)
+    if S is not None:
+        ind = m + sum(dims.get("q") or [])
+        dxs, dls = _up(xb[ind:ind + S.tot2]), _up(lb[ind:ind + S.tot1])
+        raise_for(lib().kvx_nts_scale2_dev(S.ns, S.d2.ptr, S.d1.ptr, dls.ptr, dxs.ptr, inv))
+        _sync()
+        xb[ind:ind + S.tot2] = dxs.download(np.float64, S.tot2)
 
 
 def _binary(kernel, x, y, m):
@@ -205,49 +279,92 @@ def _binary(kernel, x, y, m):
 
 
 def sprod(x, y, dims, mnl=0, diag="N"):
-    """misc_solvers.c:634-669 ('l' block): x := x.*y."""
-    _only_l(dims, "sprod")
+    """misc_solvers.c:634-770: x := y o x.  'l' block: x.*y; 'q' blocks :671-700; 's' blocks :700-770: the lower triangle of
+    (Y X + X Y) / 2, with y holding full blocks (diag 'N'; their upper triangles are filled in as the reference does) or
+    only their diagonals (diag 'D')."""
     _binary(lib().kvx_nt_sprod_dev, x, y, mnl + dims["l"])
     _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 0), x, y)   # misc_solvers.c:671-700
+    S = _s_blocks(dims)
+    if S is not None:
+        ind = mnl + dims["l"] + sum(dims.get("q") or [])
+        xb, yb = _buf(x)[0], _buf(y)[0]
+        dxs = _up(xb[ind:ind + S.tot2])
+        if diag == "N":
+            dys, wk = _up(yb[ind:ind + S.tot2]), _scratch(S.tot2)
+            raise_for(lib().kvx_nts_prod_dev(S.ns, S.d2.ptr, S.d1.ptr, dxs.ptr, dys.ptr, 0, wk.ptr))
+            _sync()
+            yb[ind:ind + S.tot2] = dys.download(np.float64, S.tot2)
+        else:
+            dys = _up(yb[ind:ind + S.tot1])
+            raise_for(lib().kvx_nts_prod_dev(S.ns, S.d2.ptr, S.d1.ptr, dxs.ptr, dys.ptr, 1, None))
+            _sync()
+        xb[ind:ind + S.tot2] = dxs.download(np.float64, S.tot2)
 
 
 def sinv(x, y, dims, mnl=0):
-    """misc_solvers.c:775-800 ('l' block): x := x./y."""
-    _only_l(dims, "sinv")
+    """misc_solvers.c:775-882: the inverse of x := y o x.  'l' block: x./y; 'q' blocks :803-835; 's' blocks :845-882 (y holds
+    only the diagonals): the lower triangle of x_k divided entrywise by (y_i + y_j) / 2."""
     _binary(lib().kvx_nt_sinv_dev, x, y, mnl + dims["l"])
     _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 1), x, y)   # misc_solvers.c:803-835
+    S = _s_blocks(dims)
+    if S is not None:
+        ind = mnl + dims["l"] + sum(dims.get("q") or [])
+        xb, yb = _buf(x)[0], _buf(y)[0]
+        dxs, dys = _up(xb[ind:ind + S.tot2]), _up(yb[ind:ind + S.tot1])
+        raise_for(lib().kvx_nts_prod_dev(S.ns, S.d2.ptr, S.d1.ptr, dxs.ptr, dys.ptr, 2, None))
+        _sync()
+        xb[ind:ind + S.tot2] = dxs.download(np.float64, S.tot2)
 
 
 def ssqr(x, y, dims, mnl=0):
-    """misc.py:945-952 ('l' block): x := y.*y."""
-    _only_l(dims, "ssqr")
+    """misc.py:945-959: x := y o y; the 's' components of x and y are diagonal and only the diagonals are stored, so they are
+    squared entrywise like the 'l' block."""
     _binary(lib().kvx_nt_ssqr_dev, x, y, mnl + dims["l"])
     _q_apply(dims, mnl + dims["l"], lambda nq, off, dx, dy: lib().kvx_ntq_prod_dev(nq, off, dx, dy, 2), x, y)   # misc.py:951-959
+    ns1 = sum(int(m) for m in (dims.get("s") or []))
+    if ns1:
+        ind = mnl + dims["l"] + sum(dims.get("q") or [])
+        xb, yb = _buf(x)[0], _buf(y)[0]
+        dxs, dys = _up(xb[ind:ind + ns1]), _up(yb[ind:ind + ns1])
+        raise_for(lib().kvx_nt_ssqr_dev(ns1, dxs.ptr, dys.ptr))
+        _sync()
+        xb[ind:ind + ns1] = dxs.download(np.float64, ns1)
 
 
 def sdot(x, y, dims, mnl=0):
-    """misc_solvers.c:991-1018 ('l' block): sum_i x_i*y_i."""
-    _only_l(dims, "sdot")
+    """misc_solvers.c:991-1046: sum_i x_i*y_i over the nonlinear, 'l' and 'q' entries plus, per 's' block, the trace inner
+    product of the symmetric matrices stored in the lower triangles (diagonal + twice the strict lower part)."""
     m = mnl + dims["l"] + sum(dims.get("q") or [])          # misc_solvers.c:1009-1012: one dot over the 'l' and 'q' entries
     xb, _ = _buf(x)
     yb, _ = _buf(y)
-    if m == 0:
+    S = _s_blocks(dims)
+    if m == 0 and S is None:
         return 0.0
     _lib.require_device()
-    dx, dy = _up(xb[:m]), _up(yb[:m])
-    r = ctypes.c_double()
-    raise_for(lib().kvx_nt_sdot_dev(m, dx.ptr, dy.ptr, ctypes.byref(r)))
-    return r.value
+    a = 0.0
+    if m:
+        dx, dy = _up(xb[:m]), _up(yb[:m])
+        r = ctypes.c_double()
+        raise_for(lib().kvx_nt_sdot_dev(m, dx.ptr, dy.ptr, ctypes.byref(r)))
+        a = r.value
+    if S is not None:
+        dxs, dys, dout = _up(xb[m:m + S.tot2]), _up(yb[m:m + S.tot2]), _scratch(S.ns)
+        raise_for(lib().kvx_nts_dot_dev(S.ns, S.d2.ptr, S.d1.ptr, dxs.ptr, dys.ptr, dout.ptr))
+        _sync()
+        for v in dout.download(np.float64, S.ns):          # block after block, as the reference accumulates
+            a += float(v)
+    return a
 
 
 def max_step(x, dims, mnl=0, sigma=None):
-    """misc_solvers.c:1052-1085 (nonlinear, 'l' and 'q' blocks): max(max_i(-x_i), max_k(|x_k1| - x_k0)); 0.0 for an empty x
-    (misc_solvers.c:1099)."""
-    _only_l(dims, "max_step")
+    """misc_solvers.c:1052-1160: min {t | x + t e >= 0} = max(max_i(-x_i), max_k(|x_k1| - x_k0), max_k(-lambda_min(x_k)));
+    0.0 for an empty x (misc_solvers.c:1099).  With `sigma` the eigenvalues of the 's' blocks (ascending) are stored there and
+    their eigenvectors replace the blocks of x (:1128-1133)."""
     m = mnl + dims["l"]
     q = list(dims.get("q") or [])
     xb, _ = _buf(x)
-    if m + sum(q) == 0:
+    S = _s_blocks(dims)
+    if m + sum(q) == 0 and S is None:
         return 0.0
     _lib.require_device()
     t = -np.finfo(np.float32).max                        # the reference starts from -FLT_MAX (misc_solvers.c:1063)
@@ -263,7 +380,98 @@ def max_step(x, dims, mnl=0, sigma=None):
         raise_for(lib().kvx_ntq_max_step_dev(len(q), doff.ptr, dxq.ptr, dout.ptr))
         _sync()
         t = max(t, float(dout.download(np.float64, len(q)).max()))
+    if S is not None:
+        ind = m + sum(q)
+        dxs, dout, wk = _up(xb[ind:ind + S.tot2]), _scratch(S.ns), _scratch(3 * S.tot2 + 2 * S.tot1)
+        dsg = _scratch(S.tot1) if sigma is not None else None
+        raise_for(lib().kvx_nts_max_step_dev(S.ns, S.d2.ptr, S.d1.ptr, dxs.ptr, dsg.ptr if dsg else None, dout.ptr, wk.ptr))
+        _sync()
+        t = max(t, float(dout.download(np.float64, S.ns).max()))
+        if sigma is not None:
+            _buf(sigma)[0][:S.tot1] = dsg.download(np.float64, S.tot1)
+            xb[ind:ind + S.tot2] = dxs.download(np.float64, S.tot2)
     return t
+
+
+# ---- storage helpers of the 's' blocks (misc_solvers.c:412-632, 887-988) -------------------------------------------------
+def _s_section(dims, mnl):
+    return mnl + dims["l"] + sum(dims.get("q") or [])
+
+
+def pack(x, y, dims, mnl=0, offsetx=0, offsety=0):
+    """misc_solvers.c:412-468: y := x with the 's' blocks in packed storage (lower triangles by columns, off-diagonal
+    entries scaled by sqrt(2))."""
+    xb, yb = _buf(x)[0], _buf(y)[0]
+    nlq = _s_section(dims, mnl)
+    yb[offsety:offsety + nlq] = xb[offsetx:offsetx + nlq]
+    S = _s_blocks(dims)
+    if S is None:
+        return
+    _lib.require_device()
+    dfull, dpk = _up(xb[offsetx + nlq:offsetx + nlq + S.tot2]), _scratch(S.totp)
+    raise_for(lib().kvx_nts_pack_dev(S.ns, S.d2.ptr, S.d1.ptr, S.dp.ptr, dfull.ptr, dpk.ptr, 0))
+    _sync()
+    yb[offsety + nlq:offsety + nlq + S.totp] = dpk.download(np.float64, S.totp)
+
+
+def pack2(x, dims, mnl=0):
+    """misc_solvers.c:476-544: in-place pack of every column of the matrix x (the diagonal entries are copied as they are)."""
+    xb, size = _buf(x)
+    S = _s_blocks(dims)
+    if S is None:
+        return
+    _lib.require_device()
+    nlq = _s_section(dims, mnl)
+    X = xb.reshape(size, order="F")
+    for c in range(size[1]):
+        col = X[:, c]
+        dfull, dpk = _up(col[nlq:nlq + S.tot2]), _scratch(S.totp)
+        raise_for(lib().kvx_nts_pack_dev(S.ns, S.d2.ptr, S.d1.ptr, S.dp.ptr, dfull.ptr, dpk.ptr, 2))
+        _sync()
+        col[nlq:nlq + S.totp] = dpk.download(np.float64, S.totp)
+
+
+def unpack(x, y, dims, mnl=0, offsetx=0, offsety=0):
+    """misc_solvers.c:552-608: y := x with the 's' blocks unpacked into the lower triangles (off-diagonal entries scaled by
+    1/sqrt(2)); the strict upper triangles of y are not touched."""
+    xb, yb = _buf(x)[0], _buf(y)[0]
+    nlq = _s_section(dims, mnl)
+    yb[offsety:offsety + nlq] = xb[offsetx:offsetx + nlq]
+    S = _s_blocks(dims)
+    if S is None:
+        return
+    _lib.require_device()
+    dfull, dpk = _up(yb[offsety + nlq:offsety + nlq + S.tot2]), _up(xb[offsetx + nlq:offsetx + nlq + S.totp])
+    raise_for(lib().kvx_nts_pack_dev(S.ns, S.d2.ptr, S.d1.ptr, S.dp.ptr, dfull.ptr, dpk.ptr, 1))
+    _sync()
+    yb[offsety + nlq:offsety + nlq + S.tot2] = dfull.download(np.float64, S.tot2)
+
+
+def _tri(x, sdims, offset, mode):
+    S = _SBlocks(sdims) if sdims and sum(sdims) else None
+    if S is None:
+        return
+    _lib.require_device()
+    xb = _buf(x)[0]
+    d = _up(xb[offset:offset + S.tot2])
+    raise_for(lib().kvx_nts_tri_dev(S.ns, S.d2.ptr, S.d1.ptr, d.ptr, mode))
+    _sync()
+    xb[offset:offset + S.tot2] = d.download(np.float64, S.tot2)
+
+
+def symm(x, n, offset=0):
+    """misc_solvers.c:610-632: fills in the upper triangle of the n x n symmetric matrix stored at x[offset:] ('L' storage)."""
+    _tri(x, [int(n)], offset, 0)
+
+
+def trisc(x, dims, offset=0):
+    """misc_solvers.c:887-938: upper triangles of the 's' blocks := 0, strict lower triangles scaled by 2."""
+    _tri(x, [int(m) for m in (dims.get("s") or [])], offset + dims["l"] + sum(dims.get("q") or []), 1)
+
+
+def triusc(x, dims, offset=0):
+    """misc_solvers.c:940-988: strict lower triangles of the 's' blocks scaled by 1/2."""
+    _tri(x, [int(m) for m in (dims.get("s") or [])], offset + dims["l"] + sum(dims.get("q") or []), 2)
 
 
 class _Chol2Device:

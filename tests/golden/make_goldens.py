@@ -631,6 +631,101 @@ def g15_q_cone_scaling():
     np.savez(os.path.join(HERE, "g15_q_cone_scaling.npz"), **out)
 
 
+def g16_s_cone_scaling():
+    """Nesterov-Todd scaling with semidefinite blocks (dims = {'l': 3, 'q': [4], 's': [3, 1, 6]}, also with a nonlinear block):
+    misc.compute_scaling / update_scaling / ssqr, misc_solvers.scale / scale2 / sprod (both forms) / sinv / sdot / max_step (with
+    and without sigma) and the storage helpers pack / pack2 / unpack / symm / trisc / triusc on seeded interior points -- pure
+    reference (LAPACK potrf / gesvd / syevd / syevr of the OpenBLAS that ships in scipy)."""
+    from kvxopt import matrix, misc, misc_solvers
+    out = {}
+    for tag, mnl in (("a", None), ("b", 2)):
+        rng = np.random.default_rng(1600 + (mnl or 0))
+        k = mnl or 0
+        ml, q, sd = 3, [4], [3, 1, 6]
+        dims = {"l": ml, "q": q, "s": sd}
+        nlq = k + ml + sum(q)
+        N = nlq + sum(m * m for m in sd)
+        Nd = nlq + sum(sd)                                   # length with diagonal 's' storage
+
+        def spd(m, spread=1.0):
+            B = rng.standard_normal((m, m))
+            return B @ B.T / m + np.diag(rng.uniform(0.3, 0.3 + spread, m))
+
+        def interior():
+            x = rng.uniform(0.3, 2.0, N)
+            ind = k + ml
+            for m in q:
+                t = rng.standard_normal(m - 1)
+                x[ind + 1:ind + m] = t
+                x[ind] = np.linalg.norm(t) + rng.uniform(0.2, 1.5)
+                ind += m
+            for m in sd:
+                x[ind:ind + m * m] = spd(m).reshape(-1, order="F")
+                ind += m * m
+            return x
+        s, z = interior(), interior()
+        lm = matrix(0.0, (Nd, 1))
+        W = misc.compute_scaling(matrix(s), matrix(z), lm, dims, mnl)
+        out[tag + "_s"], out[tag + "_z"] = s, z
+        out[tag + "_lmbda"] = tolist(lm)
+        out[tag + "_r"] = np.concatenate([tolist(r) for r in W["r"]])
+        out[tag + "_rti"] = np.concatenate([tolist(r) for r in W["rti"]])
+        X = rng.standard_normal((N, 2))                      # 's' blocks: nonsymmetric on purpose (only the lower triangle is read)
+        out[tag + "_X"] = X
+        for tr in "NT":
+            for inv in "NI":
+                x = matrix(X.copy(order="F"))
+                misc_solvers.scale(x, W, trans=tr, inverse=inv)
+                out["%s_scale_%s%s" % (tag, tr, inv)] = np.array(x)
+        x1 = interior() * 0.7 + 0.1 * rng.standard_normal(N)
+        y1 = interior()
+        out[tag + "_x1"], out[tag + "_y1"] = x1, y1
+        for name, inv in (("scale2_N", "N"), ("scale2_I", "I")):
+            a = matrix(x1.copy()); misc_solvers.scale2(lm, a, dims, k, inverse=inv); out[tag + "_" + name] = tolist(a)
+        a, b = matrix(x1.copy()), matrix(y1.copy())
+        misc_solvers.sprod(a, b, dims, k)
+        out[tag + "_sprod"], out[tag + "_sprod_y_after"] = tolist(a), tolist(b)
+        yd = np.concatenate([y1[:nlq], rng.uniform(0.4, 2.0, sum(sd))])       # diagonal 's' storage
+        out[tag + "_yd"] = yd
+        a = matrix(x1.copy()); misc_solvers.sprod(a, matrix(yd), dims, k, diag="D"); out[tag + "_sprod_D"] = tolist(a)
+        a = matrix(x1.copy()); misc_solvers.sinv(a, matrix(yd), dims, k); out[tag + "_sinv"] = tolist(a)
+        a = matrix(0.0, (Nd, 1)); misc.ssqr(a, matrix(yd), dims, k); out[tag + "_ssqr"] = tolist(a)
+        out[tag + "_sdot"] = np.array(misc_solvers.sdot(matrix(x1), matrix(y1), dims, k))
+        out[tag + "_max_step"] = np.array(misc_solvers.max_step(matrix(x1), dims, k))
+        xs, sg = matrix(x1.copy()), matrix(0.0, (sum(sd), 1))
+        out[tag + "_max_step_sigma_t"] = np.array(misc_solvers.max_step(xs, dims, k, sg))
+        out[tag + "_max_step_sigma"], out[tag + "_max_step_x"] = tolist(sg), tolist(xs)
+        # storage helpers
+        npk = nlq + sum(m * (m + 1) // 2 for m in sd)
+        yp = matrix(0.0, (npk + 3, 1)); misc_solvers.pack(matrix(x1), yp, dims, k, 0, 2); out[tag + "_pack"] = tolist(yp)
+        yu = matrix(7.0, (N + 1, 1)); misc_solvers.unpack(yp, yu, dims, k, 2, 1); out[tag + "_unpack"] = tolist(yu)
+        x2 = matrix(np.column_stack([x1, y1]).copy(order="F")); misc_solvers.pack2(x2, dims, k); out[tag + "_pack2"] = np.array(x2)
+        if mnl is None:
+            a = matrix(x1.copy()); misc_solvers.trisc(a, dims); out[tag + "_trisc"] = tolist(a)
+            a = matrix(x1.copy()); misc_solvers.triusc(a, dims); out[tag + "_triusc"] = tolist(a)
+            a = matrix(x1.copy()); misc_solvers.symm(a, 6, nlq + 10); out[tag + "_symm"] = tolist(a)
+        # update_scaling: new iterates in the current scaling, close to lmbda; their 's' components arrive as Cholesky factors
+        lmv = np.array(lm).ravel()
+        ns_ = np.zeros(N); nz_ = np.zeros(N)
+        ns_[:nlq] = lmv[:nlq] * (1.0 + 0.05 * rng.standard_normal(nlq))
+        nz_[:nlq] = lmv[:nlq] * (1.0 + 0.05 * rng.standard_normal(nlq))
+        ind, il = nlq, nlq
+        for m in sd:
+            for vec in (ns_, nz_):
+                E = 0.05 * rng.standard_normal((m, m))
+                M = np.diag(lmv[il:il + m]) + 0.5 * (E + E.T)
+                vec[ind:ind + m * m] = np.linalg.cholesky(M).reshape(-1, order="F")
+            ind += m * m
+            il += m
+        ms, mz = matrix(ns_.copy()), matrix(nz_.copy())
+        out[tag + "_us_s_in"], out[tag + "_us_z_in"] = ns_, nz_
+        misc.update_scaling(W, lm, ms, mz)
+        out[tag + "_us_s"], out[tag + "_us_z"], out[tag + "_us_lmbda"] = tolist(ms), tolist(mz), tolist(lm)
+        out[tag + "_us_r"] = np.concatenate([tolist(r) for r in W["r"]])
+        out[tag + "_us_rti"] = np.concatenate([tolist(r) for r in W["rti"]])
+    np.savez(os.path.join(HERE, "g16_s_cone_scaling.npz"), **out)
+
+
 def g13_gemv_subblocks():
     """base.gemv (base.c:744-851 -> sparse.c:1073-1104) with the sub-block arguments m, n, offsetA and strides, sparse A."""
     from kvxopt import base, matrix, spmatrix
@@ -683,4 +778,5 @@ if __name__ == "__main__":
     g13_gemv_subblocks()
     g14_kkt_singular()
     g15_q_cone_scaling()
+    g16_s_cone_scaling()
     print("goldens written to", HERE)

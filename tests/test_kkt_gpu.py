@@ -794,5 +794,154 @@ def test_second_order_cone_scaling_golden(golden_dir, tag, mnl):
     misc.scale(x, W); misc.scale(x, W, inverse="I")
     assert rel(x.a, g[tag + "_X"]) < 1e-12
     assert misc.max_step(matrix(np.zeros(0)), {"l": 0, "q": [], "s": []}) == 0.0
-    with pytest.raises(NotImplementedError):
-        misc.compute_scaling(matrix(np.ones(4)), matrix(np.ones(4)), matrix(0.0, (2, 1)), {"l": 0, "q": [], "s": [2]})
+
+
+def _col_signs(got, ref, m):
+    """Singular / eigen-vectors are defined up to the sign of each column: flip the columns of `got` (m x m, flat column-major)
+    to the orientation of `ref`."""
+    G, R = got.reshape((m, m), order="F").copy(), ref.reshape((m, m), order="F")
+    for j in range(m):
+        if np.dot(G[:, j], R[:, j]) < 0:
+            G[:, j] = -G[:, j]
+    return G.reshape(-1, order="F")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,mnl", [("a", None), ("b", 2)])
+def test_s_cone_scaling_against_reference(golden_dir, tag, mnl):
+    """Golden G16 (pure reference: misc.compute_scaling / update_scaling / ssqr, misc_solvers.scale / scale2 / sprod / sinv / sdot /
+    max_step, pack / pack2 / unpack / symm / trisc / triusc) on dims = {'l': 3, 'q': [4], 's': [3, 1, 6]}, also with a nonlinear
+    block.  The reference goes through LAPACK's gesvd / syevd, the GPU through one-sided Jacobi: singular values / eigenvalues
+    agree to 1e-12, the vectors up to the sign of each column (compared after aligning the signs; the products r r', rti rti'
+    -- the scaling itself -- are compared as they are).  Layout helpers are bit-exact."""
+    g = np.load(os.path.join(golden_dir, "g16_s_cone_scaling.npz"))
+    k = mnl or 0
+    ml, q, sd = 3, [4], [3, 1, 6]
+    dims = {"l": ml, "q": q, "s": sd}
+    nlq = k + ml + sum(q)
+    N = nlq + sum(m * m for m in sd)
+    Nd = nlq + sum(sd)
+    off2 = np.concatenate([[0], np.cumsum([m * m for m in sd])])
+    tol = 1e-12
+    lm = matrix(0.0, (Nd, 1))
+    W = misc.compute_scaling(matrix(g[tag + "_s"].copy()), matrix(g[tag + "_z"].copy()), lm, dims, mnl)
+    assert rel(lm._a, g[tag + "_lmbda"]) < tol
+    assert [r.size for r in W["r"]] == [(m, m) for m in sd] and [r.size for r in W["rti"]] == [(m, m) for m in sd]
+    for i, m in enumerate(sd):
+        rr, rt = g[tag + "_r"][off2[i]:off2[i + 1]], g[tag + "_rti"][off2[i]:off2[i + 1]]
+        R, Rr = W["r"][i].a, rr.reshape((m, m), order="F")
+        T, Tr = W["rti"][i].a, rt.reshape((m, m), order="F")
+        assert rel(R @ R.T, Rr @ Rr.T) < tol and rel(T @ T.T, Tr @ Tr.T) < tol
+        assert rel(_col_signs(W["r"][i]._a, rr, m), rr) < 1e-10 and rel(_col_signs(W["rti"][i]._a, rt, m), rt) < 1e-10
+        assert rel(R.T @ T, np.eye(m)) < tol                                   # rti = r^-T
+        # the defining identities (misc.py:354-366): r' z r = r^-1 s r^-T = diag(lambda)
+        ind = nlq + off2[i]
+        Z = g[tag + "_z"][ind:ind + m * m].reshape((m, m), order="F")
+        Sm = g[tag + "_s"][ind:ind + m * m].reshape((m, m), order="F")
+        il = nlq + sum(sd[:i])
+        assert rel(R.T @ Z @ R, np.diag(lm._a[il:il + m])) < 1e-11 and rel(T.T @ Sm @ T, np.diag(lm._a[il:il + m])) < 1e-11
+    # x_k := r' X r lives in the basis r defines, so the goldens of scale are taken with the reference's own r, rti
+    Wref = dict(W)
+    Wref["r"] = [matrix(g[tag + "_r"][off2[i]:off2[i + 1]].copy(), (m, m)) for i, m in enumerate(sd)]
+    Wref["rti"] = [matrix(g[tag + "_rti"][off2[i]:off2[i + 1]].copy(), (m, m)) for i, m in enumerate(sd)]
+    for tr in "NT":
+        for inv in "NI":
+            x = matrix(g[tag + "_X"].copy(order="F"))
+            misc.scale(x, Wref, trans=tr, inverse=inv)
+            assert rel(x.a, g["%s_scale_%s%s" % (tag, tr, inv)]) < tol, (tr, inv)       # incl. the untouched upper triangles
+    x = matrix(g[tag + "_X"].copy(order="F"))                  # with the GPU's own r: scaling and inverse scaling cancel
+    misc.scale(x, W); misc.scale(x, W, inverse="I")
+    low = np.concatenate([np.arange(nlq)] + [nlq + off2[i] + np.array([r + c * m for c in range(m) for r in range(c, m)])
+                                             for i, m in enumerate(sd)])
+    assert rel(x.a[low], g[tag + "_X"][low]) < 1e-11
+    x1, y1, yd = g[tag + "_x1"], g[tag + "_y1"], g[tag + "_yd"]
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, k); assert rel(a._a, g[tag + "_scale2_N"]) < tol
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, k, inverse="I"); assert rel(a._a, g[tag + "_scale2_I"]) < tol
+    a, b = matrix(x1.copy()), matrix(y1.copy())
+    misc.sprod(a, b, dims, k)
+    assert rel(a._a, g[tag + "_sprod"]) < tol and np.array_equal(b._a[nlq:], g[tag + "_sprod_y_after"][nlq:])
+    a = matrix(x1.copy()); misc.sprod(a, matrix(yd), dims, k, diag="D"); assert rel(a._a, g[tag + "_sprod_D"]) < tol
+    a = matrix(x1.copy()); misc.sinv(a, matrix(yd), dims, k); assert rel(a._a, g[tag + "_sinv"]) < tol
+    a = matrix(0.0, (Nd, 1)); misc.ssqr(a, matrix(yd), dims, k); assert rel(a._a, g[tag + "_ssqr"]) < tol
+    assert abs(misc.sdot(matrix(x1), matrix(y1), dims, k) - float(g[tag + "_sdot"])) <= 1e-12 * abs(float(g[tag + "_sdot"]))
+    assert abs(misc.max_step(matrix(x1), dims, k) - float(g[tag + "_max_step"])) <= 1e-12 * max(1.0, abs(float(g[tag + "_max_step"])))
+    xs, sg = matrix(x1.copy()), matrix(0.0, (sum(sd), 1))
+    t = misc.max_step(xs, dims, k, sg)
+    assert abs(t - float(g[tag + "_max_step_sigma_t"])) <= 1e-12 * max(1.0, abs(t))
+    assert np.max(np.abs(sg._a - g[tag + "_max_step_sigma"])) <= 1e-12 * max(1.0, np.max(np.abs(sg._a)))
+    assert np.array_equal(xs._a[:nlq], x1[:nlq])
+    for i, m in enumerate(sd):
+        ind = nlq + off2[i]
+        ref = g[tag + "_max_step_x"][ind:ind + m * m]
+        assert rel(_col_signs(xs._a[ind:ind + m * m], ref, m), ref) < 1e-9
+    # storage helpers: pure data movement and one scaling per entry -- bit for bit
+    npk = nlq + sum(m * (m + 1) // 2 for m in sd)
+    yp = matrix(0.0, (npk + 3, 1)); misc.pack(matrix(x1), yp, dims, k, 0, 2); assert np.array_equal(yp._a, g[tag + "_pack"])
+    yu = matrix(7.0, (N + 1, 1)); misc.unpack(yp, yu, dims, k, 2, 1); assert np.array_equal(yu._a, g[tag + "_unpack"])
+    x2 = matrix(np.column_stack([x1, y1]).copy(order="F")); misc.pack2(x2, dims, k); assert np.array_equal(x2.a, g[tag + "_pack2"])
+    if mnl is None:
+        a = matrix(x1.copy()); misc.trisc(a, dims); assert np.array_equal(a._a, g[tag + "_trisc"])
+        a = matrix(x1.copy()); misc.triusc(a, dims); assert np.array_equal(a._a, g[tag + "_triusc"])
+        a = matrix(x1.copy()); misc.symm(a, 6, nlq + 10); assert np.array_equal(a._a, g[tag + "_symm"])
+    # update_scaling: lambda and the scaling (r r', rti rti') against the reference; s_k, z_k leave as U and V' (up to signs)
+    ms, mz = matrix(g[tag + "_us_s_in"].copy()), matrix(g[tag + "_us_z_in"].copy())
+    lm = matrix(g[tag + "_lmbda"].copy())
+    misc.update_scaling(Wref, lm, ms, mz)
+    W = Wref
+    assert rel(lm._a, g[tag + "_us_lmbda"]) < tol
+    assert rel(ms._a[:nlq], g[tag + "_us_s"][:nlq]) < 1e-13 and rel(mz._a[:nlq], g[tag + "_us_z"][:nlq]) < 1e-13
+    for i, m in enumerate(sd):
+        rr, rt = g[tag + "_us_r"][off2[i]:off2[i + 1]], g[tag + "_us_rti"][off2[i]:off2[i + 1]]
+        R, Rr = W["r"][i].a, rr.reshape((m, m), order="F")
+        T, Tr = W["rti"][i].a, rt.reshape((m, m), order="F")
+        assert rel(R @ R.T, Rr @ Rr.T) < 1e-11 and rel(T @ T.T, Tr @ Tr.T) < 1e-11
+        assert rel(R.T @ T, np.eye(m)) < 1e-11
+        ind = nlq + off2[i]
+        U, Ur = ms._a[ind:ind + m * m], g[tag + "_us_s"][ind:ind + m * m]
+        assert rel(_col_signs(U, Ur, m), Ur) < 1e-9
+        Vt = mz._a[ind:ind + m * m].reshape((m, m), order="F")
+        Vtr = g[tag + "_us_z"][ind:ind + m * m].reshape((m, m), order="F")
+        assert rel(np.abs(np.sum(Vt * Vtr, axis=1)), np.ones(m)) < 1e-9           # rows of V' match up to sign
+    # a block that is not positive definite: lapack.potrf's ArithmeticError
+    bad = g[tag + "_s"].copy(); bad[nlq] = -1.0
+    with pytest.raises(ArithmeticError):
+        misc.compute_scaling(matrix(bad), matrix(g[tag + "_z"].copy()), matrix(0.0, (Nd, 1)), dims, mnl)
+
+
+@pytest.mark.gpu
+def test_s_cone_scaling_larger_blocks_against_numpy():
+    """'s' blocks of orders the Jacobi sweeps have to work for (odd, one wavefront, more than one wavefront of rows): lambda
+    against numpy's SVD of Lz' Ls, the defining identities of the scaling, max_step against numpy's eigvalsh."""
+    rng = np.random.default_rng(77)
+    sd = [33, 64, 1, 90]
+    dims = {"l": 0, "q": [], "s": sd}
+    blocks_s, blocks_z = [], []
+    for m in sd:
+        for lst in (blocks_s, blocks_z):
+            B = rng.standard_normal((m, m))
+            lst.append(B @ B.T / m + np.diag(rng.uniform(0.2, 1.5, m)))
+    s = np.concatenate([b.reshape(-1, order="F") for b in blocks_s])
+    z = np.concatenate([b.reshape(-1, order="F") for b in blocks_z])
+    lm = matrix(0.0, (sum(sd), 1))
+    W = misc.compute_scaling(matrix(s), matrix(z), lm, dims)
+    il = 0
+    for i, m in enumerate(sd):
+        Ls, Lz = np.linalg.cholesky(blocks_s[i]), np.linalg.cholesky(blocks_z[i])
+        sv = np.linalg.svd(Lz.T @ Ls, compute_uv=False)
+        assert rel(lm._a[il:il + m], sv) < 1e-12
+        R, T = W["r"][i].a, W["rti"][i].a
+        assert rel(R.T @ blocks_z[i] @ R, np.diag(sv)) < 1e-10 and rel(T.T @ blocks_s[i] @ T, np.diag(sv)) < 1e-10
+        assert rel(R.T @ T, np.eye(m)) < 1e-10
+        il += m
+    x = np.concatenate([(0.5 * (B + B.T)).reshape(-1, order="F") for B in (rng.standard_normal((m, m)) for m in sd)])
+    off2 = np.concatenate([[0], np.cumsum([m * m for m in sd])])
+    ev = [np.linalg.eigvalsh(x[off2[i]:off2[i + 1]].reshape((m, m), order="F")) for i, m in enumerate(sd)]
+    t = misc.max_step(matrix(x), dims)
+    assert abs(t - max(-e[0] for e in ev)) <= 1e-12 * max(1.0, abs(t))
+    xs, sg = matrix(x.copy()), matrix(0.0, (sum(sd), 1))
+    misc.max_step(xs, dims, 0, sg)
+    assert np.max(np.abs(sg._a - np.concatenate(ev))) <= 1e-12 * np.max(np.abs(np.concatenate(ev)))
+    for i, m in enumerate(sd):                                   # Q diag(sigma) Q' = x_k
+        Q = xs._a[off2[i]:off2[i + 1]].reshape((m, m), order="F")
+        X = x[off2[i]:off2[i + 1]].reshape((m, m), order="F")
+        assert rel(Q @ np.diag(ev[i]) @ Q.T, X) < 1e-10 and rel(Q.T @ Q, np.eye(m)) < 1e-11
