@@ -175,6 +175,7 @@ int build_subtrees(kvx_chol *F)
     F->d_subs = nullptr; F->d_cd_woff = nullptr; F->d_lists_sw = nullptr; F->d_depth = nullptr;
     if ((rc = upload(&F->d_subs, subs))) return rc;
     if ((rc = upload(&F->d_cd_woff, cd_woff))) return rc;
+    F->lsw_host = lsw;
     if ((rc = upload(&F->d_lists_sw, lsw))) return rc;
     std::vector<int32_t> dep(S.depth.begin(), S.depth.end());
     if (dep.empty()) dep.push_back(0);
@@ -872,6 +873,175 @@ int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
     return guarded([&] { return kvx_chol_solve_impl(F, sys, B, nrhs, ldB); });
 }
 
+// Sparse right-hand sides, forward systems (L x = b, L D x = b): only the REACH of a block of columns is swept -- the fronts
+// that hold a nonzero row of the block and their ancestors in the supernodal elimination tree (the supernodal form of
+// CHOLMOD's sparse-rhs solve, cholmod.c:524-587; misc.kkt_chol2 forms L^-1 P A' this way, misc.py:1483-1487).  Everything
+// outside the reach is zero and is neither computed nor copied back.  Per block of up to 64 columns: host marks the reach
+// (leaf subtrees are taken whole: they are one launch anyway), uploads the filtered level lists, the device sweeps them with
+// the ordinary forward kernels (the update vectors of children outside the reach are cleared first -- the parents pull them),
+// and only the rows of the swept fronts come back.
+static int spsolve_forward_reach(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
+                                 std::vector<int64_t> &xp, std::vector<int64_t> &xi, std::vector<double> &xx)
+{
+    Symbolic &S = F->S;
+    const int64_t n = S.n, ns = S.nsuper;
+    hipStream_t st = F->stream;
+    if (F->col2sn.empty()) {
+        F->col2sn.resize((size_t)n);
+        for (int64_t s = 0; s < ns; s++)
+            for (int64_t c = S.super[s]; c < S.super[s + 1]; c++) F->col2sn[(size_t)c] = (int32_t)s;
+        F->sub_of.assign((size_t)ns, -1);
+        for (size_t i = 0; i < F->subs_host.size(); i++)
+            for (int q = F->subs_host[i].lo; q <= F->subs_host[i].hi; q++) F->sub_of[(size_t)q] = (int32_t)i;
+    }
+    const bool subs_on = F->nsub > 0;
+    const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
+    const int64_t chunk = 64;
+    std::vector<uint8_t> mark((size_t)ns, 0), submark(F->subs_host.size(), 0);
+    std::vector<int32_t> touched;                            // fronts marked in this block (for the reset)
+    std::vector<int64_t> pos;
+    std::vector<double> val, back;
+    std::vector<int32_t> lists, rows;
+    std::vector<int64_t> slots;
+    std::vector<SubDesc> subs;
+    int rc;
+    for (int64_t c0 = 0; c0 < ncol; c0 += chunk) {
+        const int nc = (int)std::min<int64_t>(chunk, ncol - c0);
+        touched.clear(); pos.clear(); val.clear();
+        std::vector<size_t> touched_subs;
+        for (int j = 0; j < nc; j++) {
+            const size_t first = pos.size();
+            for (int64_t p = Bp[c0 + j]; p < Bp[c0 + j + 1]; p++) {
+                const int64_t r = Bi[p];
+                if (r < 0 || r >= n) { set_err("row index out of range in B"); return KVX_EINVAL; }
+                bool dup = false;
+                for (size_t q = first; q < pos.size() && !dup; q++)       // (columns are short; duplicates are summed as the dense path does)
+                    if (pos[q] == r + (int64_t)j * n) { val[q] += Bx[p]; dup = true; }
+                if (!dup) { pos.push_back(r + (int64_t)j * n); val.push_back(Bx[p]); }
+                for (int32_t f = F->col2sn[(size_t)r]; f >= 0 && !mark[(size_t)f]; f = S.sparent[(size_t)f]) {
+                    mark[(size_t)f] = 1;
+                    touched.push_back(f);
+                }
+            }
+        }
+        if (subs_on)
+            for (size_t t = 0, e = touched.size(); t < e; t++) {                  // a touched subtree is swept whole
+                const int32_t sb = F->sub_of[(size_t)touched[t]];
+                if (sb < 0 || submark[(size_t)sb]) continue;
+                submark[(size_t)sb] = 1;
+                touched_subs.push_back((size_t)sb);
+                for (int q = F->subs_host[(size_t)sb].lo; q <= F->subs_host[(size_t)sb].hi; q++)
+                    if (!mark[(size_t)q]) { mark[(size_t)q] = 1; touched.push_back(q); }
+            }
+        // filtered lists: per level [big | lds (unmerged mode only) | small], the slots to clear, the subtrees, the rows to fetch
+        struct Lv { int64_t big, lds, sw, zs; int nbig, nlds, nsw, nz; };
+        std::vector<Lv> lv((size_t)S.nlevels);
+        lists.clear(); slots.clear(); subs.clear(); rows.clear();
+        for (size_t sb : touched_subs) subs.push_back(F->subs_host[sb]);
+        for (int l = 0; l < S.nlevels; l++) {
+            const LevelPlan &P = F->plan[l];
+            Lv &v = lv[(size_t)l];
+            auto take = [&](const int32_t *src, int cnt, int64_t &off, int &out) {
+                off = (int64_t)lists.size();
+                for (int i = 0; i < cnt; i++)
+                    if (mark[(size_t)src[i]]) lists.push_back(src[i]);
+                out = (int)((int64_t)lists.size() - off);
+            };
+            take(S.levellist.data() + P.soff[0], P.scnt[0], v.big, v.nbig);
+            if (F->solve_merged) { v.lds = 0; v.nlds = 0; }
+            else take(S.levellist.data() + P.soff[1], P.scnt[1], v.lds, v.nlds);
+            take(F->lsw_host.data() + F->sw_off[l], F->sw_cnt[l], v.sw, v.nsw);
+            v.zs = (int64_t)slots.size() / 2;
+            for (int64_t q = v.big; q < (int64_t)lists.size(); q++) {
+                const int32_t f = lists[(size_t)q];
+                for (int64_t c = S.childptr[f]; c < S.childptr[f + 1]; c++) {
+                    const int32_t ch = S.children[(size_t)c];
+                    if (!mark[(size_t)ch] && S.sn_m[ch] > S.sn_k[ch]) { slots.push_back(S.wx[ch]); slots.push_back(S.sn_m[ch] - S.sn_k[ch]); }
+                }
+            }
+            v.nz = (int)((int64_t)slots.size() / 2 - v.zs);
+        }
+        std::sort(touched.begin(), touched.end());
+        for (int32_t f : touched)
+            for (int64_t c = S.super[f]; c < S.super[f + 1]; c++) rows.push_back((int32_t)c);
+        const int64_t nrow = (int64_t)rows.size();
+        // device side
+        if ((rc = ensure_solve_ws(F, nc))) return rc;
+        int32_t *d_l = nullptr, *d_rows = nullptr;
+        int64_t *d_slots = nullptr, *d_pos = nullptr;
+        double *d_val = nullptr, *d_back = nullptr;
+        SubDesc *d_sb = nullptr;
+        auto release = [&] {
+            for (void *q : {(void *)d_l, (void *)d_rows, (void *)d_slots, (void *)d_pos, (void *)d_val, (void *)d_back, (void *)d_sb})
+                if (q) (void)pool_free(q);
+        };
+        auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+            HIPCHK(pool_malloc(dst, std::max<size_t>(bytes, 8)));
+            if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+            return KVX_OK;
+        };
+        rc = up((void **)&d_l, lists.data(), lists.size() * sizeof(int32_t));
+        if (!rc) rc = up((void **)&d_rows, rows.data(), rows.size() * sizeof(int32_t));
+        if (!rc) rc = up((void **)&d_slots, slots.data(), slots.size() * sizeof(int64_t));
+        if (!rc) rc = up((void **)&d_pos, pos.data(), pos.size() * sizeof(int64_t));
+        if (!rc) rc = up((void **)&d_val, val.data(), val.size() * sizeof(double));
+        if (!rc) rc = up((void **)&d_sb, subs.data(), subs.size() * sizeof(SubDesc));
+        if (!rc && hipSuccess != pool_malloc((void **)&d_back, std::max<size_t>((size_t)(nrow * nc), 1) * sizeof(double))) rc = KVX_EDEVICE;
+        if (rc) { release(); return rc; }
+        auto body = [&]() -> int {
+            HIPCHK(hipMemsetAsync(F->d_X, 0, (size_t)n * nc * sizeof(double), st));
+            launch_scatter_entries(st, d_pos, d_val, (int64_t)pos.size(), F->d_X);
+            HIPCHK(hipMemcpyAsync(F->d_X0, F->d_X, (size_t)n * nc * sizeof(double), hipMemcpyDeviceToDevice, st));
+            if (!subs.empty())
+                launch_fwd_subtree(st, F->ds, d_sb, (int)subs.size(), F->d_cd_woff, F->d_Lx, F->d_X, n, nc, F->d_W[0], F->d_W[1], wstride, F->d_depth);
+            for (int l = S.nlevels - 1; l >= 0; l--) {
+                const LevelPlan &P = F->plan[l];
+                const Lv &v = lv[(size_t)l];
+                if (v.nbig + v.nlds + v.nsw == 0) continue;
+                double *Wch = F->d_W[(l + 1) & 1], *Wout = F->d_W[l & 1];
+                launch_zero_slots(st, d_slots + 2 * v.zs, v.nz, nc, Wch, wstride);
+                if (v.nsw > 0) {
+                    if (F->solve_merged) launch_fwd_lds(st, F->ds, d_l + v.sw, v.nsw, F->sw_kmax[l], F->d_Lx, F->d_X, n, nc, Wch, Wout, wstride);
+                    else launch_fwd_wave(st, F->ds, d_l + v.sw, v.nsw, 32, F->d_Lx, F->d_X, n, nc, Wch, Wout, wstride);
+                }
+                if (v.nlds > 0)
+                    launch_fwd_lds(st, F->ds, d_l + v.lds, v.nlds, std::max(P.maxk[KVX_CLS_LDS128], P.maxk[KVX_CLS_LDS96]), F->d_Lx, F->d_X,
+                                   n, nc, Wch, Wout, wstride);
+                if (v.nbig > 0)
+                    launch_fwd_big(st, F->ds, d_l + v.big, v.nbig, P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv, F->d_X, F->d_X0, n, nc,
+                                   F->d_WK, S.n, Wch, Wout, wstride);
+            }
+            if (!F->is_ll) {                                      // LDL' view: L D x = b -> diag^-1 Lc^-1 b;  L x = b -> diag Lc^-1 b
+                if (!F->diag_valid) {
+                    if (!F->d_diag) HIPCHK(pool_malloc((void **)&F->d_diag, (size_t)n * sizeof(double)));
+                    launch_extract_diag(st, F->ds, S.nsuper, F->d_Lx, F->d_diag);
+                    F->diag_valid = true;
+                }
+                launch_diag_scale(st, n, nc, F->d_diag, F->d_X, n, sys == 2 ? 1 : 0);
+            }
+            launch_perm_gather(st, d_rows, nrow, nc, F->d_X, n, d_back, nrow);
+            HIPCHK(hipGetLastError());
+            back.resize((size_t)(nrow * nc));
+            if (nrow * nc) HIPCHK(hipMemcpyAsync(back.data(), d_back, back.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            return KVX_OK;
+        };
+        rc = body();
+        release();
+        if (rc) return rc;
+        for (int j = 0; j < nc; j++) {
+            for (int64_t i = 0; i < nrow; i++) {
+                const double v = back[(size_t)(i + (int64_t)j * nrow)];
+                if (v != 0.0) { xi.push_back(rows[(size_t)i]); xx.push_back(v); }
+            }
+            xp[(size_t)(c0 + j + 1)] = (int64_t)xi.size();
+        }
+        for (int32_t f : touched) mark[(size_t)f] = 0;
+        for (size_t sb : touched_subs) submark[sb] = 0;
+    }
+    return KVX_OK;
+}
+
 static int kvx_chol_spsolve_impl(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,
                      int64_t **Xp, int64_t **Xi, double **Xx)
 {
@@ -884,6 +1054,22 @@ static int kvx_chol_spsolve_impl(kvx_chol *F, int sys, int64_t ncol, const int64
     if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ESINGULAR; }
     std::vector<int64_t> xp((size_t)ncol + 1, 0), xi;
     std::vector<double> xx;
+    auto deliver = [&]() -> int {
+        for (int64_t j = 0; j < ncol; j++) xp[j + 1] = std::max(xp[j + 1], xp[j]);
+        *Xp = (int64_t *)malloc(sizeof(int64_t) * (ncol + 1));
+        *Xi = (int64_t *)malloc(sizeof(int64_t) * std::max<size_t>(xi.size(), 1));
+        *Xx = (double *)malloc(sizeof(double) * std::max<size_t>(xx.size(), 1));
+        if (!*Xp || !*Xi || !*Xx) { free(*Xp); free(*Xi); free(*Xx); return KVX_ENOMEM; }
+        memcpy(*Xp, xp.data(), sizeof(int64_t) * (ncol + 1));
+        if (!xi.empty()) { memcpy(*Xi, xi.data(), sizeof(int64_t) * xi.size()); memcpy(*Xx, xx.data(), sizeof(double) * xx.size()); }
+        return KVX_OK;
+    };
+    // forward systems: only the reach of the columns is swept (KVX_SPSOLVE_DENSE=1: the dense column blocks below, for comparison)
+    if ((sys == 2 || sys == 4) && n > 0 && ncol > 0 && F->dist_nranks == 1 && !getenv("KVX_SPSOLVE_DENSE")) {
+        if ((rc = wait_for_caller(F))) return rc;
+        if ((rc = spsolve_forward_reach(F, sys, ncol, Bp, Bi, Bx, xp, xi, xx))) return rc;
+        return deliver();
+    }
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(ncol, (int64_t)(1 << 26) / std::max<int64_t>(n, 1)));
     std::vector<double> dense;
     for (int64_t c0 = 0; c0 < ncol && n > 0; c0 += chunk) {
@@ -904,14 +1090,7 @@ static int kvx_chol_spsolve_impl(kvx_chol *F, int sys, int64_t ncol, const int64
             xp[(size_t)(c0 + j + 1)] = (int64_t)xi.size();
         }
     }
-    for (int64_t j = 0; j < ncol; j++) xp[j + 1] = std::max(xp[j + 1], xp[j]);
-    *Xp = (int64_t *)malloc(sizeof(int64_t) * (ncol + 1));
-    *Xi = (int64_t *)malloc(sizeof(int64_t) * std::max<size_t>(xi.size(), 1));
-    *Xx = (double *)malloc(sizeof(double) * std::max<size_t>(xx.size(), 1));
-    if (!*Xp || !*Xi || !*Xx) { free(*Xp); free(*Xi); free(*Xx); return KVX_ENOMEM; }
-    memcpy(*Xp, xp.data(), sizeof(int64_t) * (ncol + 1));
-    if (!xi.empty()) { memcpy(*Xi, xi.data(), sizeof(int64_t) * xi.size()); memcpy(*Xx, xx.data(), sizeof(double) * xx.size()); }
-    return KVX_OK;
+    return deliver();
 }
 
 int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi, const double *Bx,

@@ -100,6 +100,8 @@ struct kvx_chol {
     std::vector<SubDesc> subs_host;
     std::vector<int32_t> cd_woff_host;
     std::vector<uint8_t> in_sub;
+    std::vector<int32_t> lsw_host;             // host copy of d_lists_sw
+    std::vector<int32_t> col2sn, sub_of;       // sparse right-hand sides (spsolve): front of a permuted column, subtree of a front (-1: none)
     std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
     std::vector<int> sw_cnt, sw_kmax;
     bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)

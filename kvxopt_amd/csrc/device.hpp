@@ -225,6 +225,8 @@ void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs
                         double *out, int64_t ldo);
 void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
                          double *out, int64_t ldo);
+void launch_zero_slots(hipStream_t st, const int64_t *slots, int count, int nrhs, double *W, int64_t wstride);
+void launch_scatter_entries(hipStream_t st, const int64_t *pos, const double *val, int64_t count, double *X);
 void launch_mask_rows(hipStream_t st, const uint8_t *keep, int64_t n, int nrhs, double *X, int64_t ldx);
 void launch_extract_diag(hipStream_t st, const DevSym &ds, int64_t nsuper, const double *Lx, double *d);
 void launch_diag_scale(hipStream_t st, int64_t n, int nrhs, const double *d, double *X, int64_t ldx, int mode);

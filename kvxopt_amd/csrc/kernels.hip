@@ -218,6 +218,31 @@ void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrh
     hipLaunchKernelGGL(k_perm_scatter, grid, dim3(256), 0, st, perm, n, in, ldi, out, ldo);
 }
 
+// Sparse right-hand sides (kvx_chol_spsolve, reach-restricted forward sweep).
+// zero the update vectors of the listed fronts: slots[2 i] = offset in the parity buffer, slots[2 i + 1] = length
+__global__ void k_zero_slots(const int64_t *__restrict__ slots, double *__restrict__ W, int64_t wstride)
+{
+    const int64_t off = slots[2 * blockIdx.x], len = slots[2 * blockIdx.x + 1];
+    double *w = W + (int64_t)blockIdx.y * wstride + off;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) w[i] = 0.0;
+}
+void launch_zero_slots(hipStream_t st, const int64_t *slots, int count, int nrhs, double *W, int64_t wstride)
+{
+    if (count <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_zero_slots, dim3((unsigned)count, (unsigned)nrhs), dim3(64), 0, st, slots, W, wstride);
+}
+// X[pos[i]] = val[i] (the entries of a block of sparse columns; duplicates were summed on the host)
+__global__ void k_scatter_entries(const int64_t *__restrict__ pos, const double *__restrict__ val, int64_t count, double *__restrict__ X)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) X[pos[i]] = val[i];
+}
+void launch_scatter_entries(hipStream_t st, const int64_t *pos, const double *val, int64_t count, double *X)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_scatter_entries, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, pos, val, count, X);
+}
+
 // x[i] := keep[i] ? x[i] : 0 (sharded solves: every entry of x is reported by exactly one rank, the sum over ranks is x)
 __global__ void k_mask_rows(const uint8_t *__restrict__ keep, int64_t n, double *__restrict__ X, int64_t ldx)
 {

@@ -517,3 +517,48 @@ def test_complex_hermitian_systems():
     Ab = spmatrix.from_ccs(n, n, S.indptr, S.indices, S.data)
     with pytest.raises(ArithmeticError):
         cholmod.numeric(Ab, cholmod.symbolic(Ab))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g,h,supernodal", [(160, 150, 2), (37, 41, 2), (60, 50, 0)])
+def test_spsolve_forward_systems_sweep_only_the_reach(g, h, supernodal, monkeypatch):
+    """spsolve with sys = 4 (L x = b) and 2 (L D x = b) on sparse right-hand sides (cholmod.c:524-587; what misc.kkt_chol2 uses to
+    form L^-1 P A', misc.py:1483-1487) sweeps only the fronts that hold a nonzero row of a column block and their ancestors.
+    The result must be what the dense column-block path gives (KVX_SPSOLVE_DENSE=1: every front swept) -- the same kernels on
+    the same data, so bit for bit, pattern included -- for 150 columns (three blocks, one ragged), empty columns, a duplicate
+    entry and columns that reach the root through different subtrees; the 160 x 150 grid has big-class fronts."""
+    n, cp, ri, v = workloads.laplacian_2d(g, h)
+    F = Factor(n, cp, ri, opts={"supernodal": supernodal})
+    F.factorize(v + 0.0)
+    rng = np.random.default_rng(g)
+    ncol = 150
+    Bp, Bi, Bx = [0], [], []
+    for j in range(ncol):
+        cnt = 0 if j in (3, 77) else int(rng.integers(1, 4))
+        rows = np.sort(rng.choice(n, size=cnt, replace=False))
+        if j == 5 and cnt:
+            rows = np.concatenate([rows, rows[:1]])              # a duplicate entry: summed
+        Bi.extend(int(r) for r in rows)
+        Bx.extend(rng.standard_normal(rows.size))
+        Bp.append(len(Bi))
+    Bp, Bi, Bx = np.array(Bp, dtype=np.int64), np.array(Bi, dtype=np.int64), np.array(Bx)
+    for sys in (4, 2):
+        monkeypatch.delenv("KVX_SPSOLVE_DENSE", raising=False)
+        got = F.spsolve(ncol, Bp, Bi, Bx, sys=sys)
+        monkeypatch.setenv("KVX_SPSOLVE_DENSE", "1")
+        ref = F.spsolve(ncol, Bp, Bi, Bx, sys=sys)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), sys
+        assert got[0][-1] < 0.5 * n * ncol                       # L^-1 b is sparse here: the reach, not the whole vector
+    # and against the definition, through a dense solve of one block
+    monkeypatch.delenv("KVX_SPSOLVE_DENSE", raising=False)
+    Xp, Xi, Xx = F.spsolve(ncol, Bp, Bi, Bx, sys=4)
+    D = np.zeros((n, 8), order="F")
+    for j in range(8):
+        np.add.at(D[:, j], Bi[Bp[j]:Bp[j + 1]], Bx[Bp[j]:Bp[j + 1]])
+    Y = D.copy(order="F")
+    F.solve(Y, sys=4)
+    for j in range(8):
+        col = np.zeros(n)
+        col[Xi[Xp[j]:Xp[j + 1]]] = Xx[Xp[j]:Xp[j + 1]]
+        assert np.array_equal(col, Y[:, j])
