@@ -157,9 +157,9 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
     // pseudo-peripheral root: repeat BFS from a min-degree vertex of the last level
     int32_t root = st.verts[t.lo];
     int32_t nlev = 0;
-    int64_t cnt = 0;
+    int64_t cnt = bfs(st, queue, t.rid, root, nlev);
     for (int iter = 0; iter < 4; iter++) {
-        cnt = bfs(st, queue, t.rid, root, nlev);
+        // (the level structure of `root` is in place here: a deeper candidate of the previous round is not swept again)
         int32_t cand = -1;
         int64_t cdeg = INT64_MAX;
         for (int64_t i = cnt - 1; i >= 0 && st.level[queue[i]] == nlev - 1; i--) {
@@ -177,7 +177,6 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
             if (nlev < old_nlev) { reset_levels(st, queue, cnt); root = old_root; cnt = bfs(st, queue, t.rid, root, nlev); }
             break;
         }
-        reset_levels(st, queue, cnt);
     }
     // queue[0..cnt) holds one connected component in BFS order with levels set
     if (cnt < sz) {
