@@ -19,6 +19,7 @@
 // Reference role: cholmod_l_factorize (src/C/cholmod.c:362) for these supernodes.
 #include "device.hpp"
 
+#include <cstdlib>
 #include <utility>
 
 namespace kvx {
@@ -148,8 +149,11 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
 }
 
 // ------------------------------------------------------------------------------------------
-template <int KMAX>
-__global__ __launch_bounds__(64) void k_front_wave(DevSym ds, const int32_t *__restrict__ list,
+// OCC: wavefronts per SIMD the register allocation must leave room for.  The levels that hold thousands of these fronts are bound
+// by (fronts in flight) x (latency of one front); left alone the compiler takes 129 + 8 registers for KMAX = 32 -- three waves per
+// SIMD -- where 128 (four waves, no spill) serve as well, and 96 + 8 for KMAX = 16 (four waves; 95: five).
+template <int KMAX, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_front_wave(DevSym ds, const int32_t *__restrict__ list,
                                                    double *__restrict__ Lx, const double *__restrict__ Uc,
                                                    double *__restrict__ Uo, int *status, int mcap)
 {
@@ -872,10 +876,14 @@ void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, con
 {
     if (count <= 0) return;
     const size_t lds = (size_t)mcap * (mcap + 1) / 2 * sizeof(double) + 128 * sizeof(double) + 64 * sizeof(int);
-    if (kmax <= 16)
-        hipLaunchKernelGGL(k_front_wave<16>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
-    else
-        hipLaunchKernelGGL(k_front_wave<32>, dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+    static const bool tight = [] { const char *e = getenv("KVX_WAVE_OCC"); return !(e && e[0] == '0'); }();   // KVX_WAVE_OCC=0: the compiler's own allocation
+    if (kmax <= 16) {
+        if (tight) hipLaunchKernelGGL((k_front_wave<16, 5>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+        else hipLaunchKernelGGL((k_front_wave<16, 1>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+    } else {
+        if (tight) hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+        else hipLaunchKernelGGL((k_front_wave<32, 1>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
+    }
 }
 
 // LDS kernel: mcap = 96 or 128; kmax = 32 or 64 (k of every front in the list must be <= kmax)
