@@ -202,6 +202,7 @@ int ensure_device(kvx_chol *F)
     }
     HIPCHK(pool_event_get(&F->ev_fork, false));
     HIPCHK(pool_event_get(&F->ev_fork2, false));
+    for (int i = 0; i < 2; i++) HIPCHK(pool_event_get(&F->ev_la[i], false));
     HIPCHK(pool_event_get(&F->ev_in, false));
     HIPCHK(pool_event_get(&F->ev_out, false));
     int rc;
@@ -291,6 +292,7 @@ int ensure_device(kvx_chol *F)
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
+    { const char *e = getenv("KVX_LOOKAHEAD"); F->lookahead = e && e[0] == '1'; }
     { const char *e = getenv("KVX_OUTER_BLOCK"); if (e && atoi(e) >= 64) F->outer_block = atoi(e) / 64 * 64; }
     F->dev_ready = true;
     return KVX_OK;
@@ -424,13 +426,37 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 // block, so it is used for very large fronts only; look-ahead (outer update of block b beside the panel
                 // chain of block b + 1) is the missing piece
                 const int OB = F->outer_block;
+                // Look-ahead (opt-in, KVX_LOOKAHEAD=1): the outer update of block ob is split -- the strip of the next outer block (with the
+                // next diagonal block factored in its (0, 0) tile) stays on the chain's stream, everything right of it runs on side[3]
+                // beside the panel chain of block ob + OB, which only touches that strip; the next strip update waits for it.
+                // Measured on MI355X (100^3 Laplacian, factor 116.6 ms): 128 ms with the strip first, 125 ms with both parts started
+                // together (then they share the CUs and finish together) -- the panel chain of a front this wide is itself a few
+                // hundred workgroups per launch and waits for CU slots behind the bulk update (a high-priority chain stream: 129 ms).
+                // Off by default.
+                const bool la = F->lookahead && F->prof_family < 0;
+                bool bulk_pending = false;
                 for (int ob = 0; ob < P.chain_maxk; ob += OB) {
                     for (int jb = ob; jb < std::min(ob + OB, P.chain_maxk); jb += KVX_NB) {
                         { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
                         { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, ob + OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
                     }
-                    { ProfScope ps(F, FAM_SYRK); launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                    if (!la) {
+                        ProfScope ps(F, FAM_SYRK);
+                        launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status);
+                        continue;
+                    }
+                    // the strip of the next block first (behind the previous bulk update, which wrote these columns too) ...
+                    if (bulk_pending) HIPCHK(hipStreamWaitEvent(st, F->ev_la[1], 0));
+                    launch_syrk_outer_cols(st, F->ds, list, nbig, bigm, ob, OB, 0, ob + 2 * OB, 1, F->d_Lx, Uout, F->d_Linv, F->d_status);   // (from column 0: a front whose pivots end inside this block starts its update matrix left of ob + OB)
+                    // ... then the bulk update on the side stream, beside the panel chain of the next block (started together, the two
+                    // launches share the CUs and the strip finishes with the bulk: measured)
+                    HIPCHK(hipEventRecord(F->ev_la[0], st));
+                    HIPCHK(hipStreamWaitEvent(F->side[3], F->ev_la[0], 0));
+                    launch_syrk_outer_cols(F->side[3], F->ds, list, nbig, bigm, ob, OB, ob + 2 * OB, INT_MAX, 0, F->d_Lx, Uout, F->d_Linv, F->d_status);
+                    HIPCHK(hipEventRecord(F->ev_la[1], F->side[3]));
+                    bulk_pending = true;
                 }
+                if (bulk_pending) HIPCHK(hipStreamWaitEvent(st, F->ev_la[1], 0));
             } else {
                 for (int jb = 0; jb < P.chain_maxk; jb += KVX_NB) {
                     // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
@@ -1282,6 +1308,8 @@ void kvx_chol_free(kvx_chol *F)
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
         if (F->ev_fork2) pool_event_put(F->ev_fork2, false);
+        for (int i = 0; i < 2; i++)
+            if (F->ev_la[i]) pool_event_put(F->ev_la[i], false);
         if (F->ev_in) pool_event_put(F->ev_in, false);
         if (F->ev_out) pool_event_put(F->ev_out, false);
         if (F->stream) pool_stream_put(F->stream, F->prio_stream);

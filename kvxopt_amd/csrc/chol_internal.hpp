@@ -91,6 +91,8 @@ struct kvx_chol {
     int mid_m = 0;             // big-class fronts up to this order: one workgroup per front (k_front_mid).  OFF by default: measured on
                                // config 2, factor 4.37 ms -> 4.55 (256) / 4.42 (192) / 5.49 (384): a lone workgroup needs ~100 us per front
                                // (dependent L2 round trips tile after tile), the batched chain amortises them.  KVX_MID_M=<order> turns it on
+    bool lookahead = false;    // two-level blocking: the update right of the NEXT outer block runs on side[3] beside that block's panel chain (KVX_LOOKAHEAD=1; measured slower)
+    hipEvent_t ev_la[2] = {nullptr, nullptr};
     int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
     // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
     SubDesc *d_subs = nullptr;

@@ -187,6 +187,9 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
                        double *Lx, double *Uout, double *Linv, int *status);
 
+// look-ahead: the rank-ob_len update of the columns [c_from, c_to) only; fuse = 1: tile (0, 0) factors the next diagonal block
+void launch_syrk_outer_cols(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
+                            int c_from, int c_to, int fuse, double *Lx, double *Uout, double *Linv, int *status);
 // sharded mode: rank-ob_len update with the panel [ob, ob + ob_len) of the columns in [c_from, c_to) that rank own_r owns
 void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,
                             int own_ob, int own_g, int own_r, int c_from, int c_to, double *Lx, double *Uout);

@@ -646,7 +646,8 @@ union SyrkLds {
 // own.g ranks -- the pivot columns from column 0, the update columns from column k on (so that the blocks of the update
 // matrix do not depend on k mod ob); this rank (own.r) updates only the columns it owns and the next diagonal block is
 // factored by a launch of its own (its owner is whoever owns the block, not this kernel's (0, 0) tile).
-struct ColOwner { int ob, g, r, c_from, c_to; };   // + the columns [c_from, c_to) this launch may touch (look-ahead: the next pivot block first)
+struct ColOwner { int ob, g, r, c_from, c_to, fuse; };   // + the columns [c_from, c_to) this launch may touch (look-ahead: the next pivot block first);
+                                                          // fuse: the (0, 0) tile still factors the next diagonal block (single-GPU look-ahead, ob = g = 1)
 __device__ __forceinline__ bool col_owned(const ColOwner &o, int c, int k, int nkb)
 {
     const int blk = c < k ? c / o.ob : nkb + (c - k) / o.ob;
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(512, 4) void k_syrk_trailing128(DevSym ds, const in
         // iteration writes it before its own barrier, so one barrier per chunk suffices
     }
     // epilogue: lane holds C[row = .. + 16 s2 + lr][col = .. + 16 t + lk + 4 q]; branch-free RMW in batches of 16
-    const bool fuse = !DIST && ti == 0 && tj == 0 && t0 < k;      // workgroup-uniform
+    const bool fuse = (!DIST || own.fuse) && ti == 0 && tj == 0 && t0 < k;      // workgroup-uniform
     const int nb2 = min(NB, k - t0);
     if (fuse) __syncthreads();                                     // staging buffers are about to become the potrf image
     if (active) {
@@ -821,7 +822,7 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     const char *e = getenv("KVX_SYRK128_TILES");
     const int64_t big_limit = e ? atoll(e) : INT64_MAX;
     if (T * (T + 1) / 2 * count >= big_limit) {
-        hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX});
+        hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
     } else {                                          // latency regime: more, smaller workgroups
         hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
@@ -849,7 +850,20 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (count <= 0) return;
     int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX});
+    hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
+}
+
+// look-ahead (two-level blocking on one GPU): the same rank-ob_len update restricted to the columns [c_from, c_to) of the
+// fronts.  The strip of the NEXT outer block goes first on the pivot chain's stream (fuse = 1: its (0, 0) tile factors the next
+// diagonal block), the rest beside the next block's panel chain on another stream.
+void launch_syrk_outer_cols(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
+                            int c_from, int c_to, int fuse, double *Lx, double *Uout, double *Linv, int *status)
+{
+    if (count <= 0 || c_from >= c_to) return;
+    int rows = max_m - ob - 1;
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_syrk_trailing128<true>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status,
+                       ColOwner{1, 1, 0, c_from, c_to, fuse});
 }
 
 // sharded mode: the rank-ob_len update of the columns this rank owns (block-cyclic, see ColOwner); no fused factorisation
@@ -859,7 +873,7 @@ void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *lis
     int rows = max_m - ob - 1;
     if (rows <= 0 || c_from >= c_to) return;
     hipLaunchKernelGGL(k_syrk_trailing128<true>, syrk128_grid(rows, 1), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout,
-                       (double *)nullptr, (int *)nullptr, ColOwner{own_ob, own_g, own_r, c_from, c_to});
+                       (double *)nullptr, (int *)nullptr, ColOwner{own_ob, own_g, own_r, c_from, c_to, 0});
 }
 
 // ------------------------------------------------------------------------------------------

@@ -244,6 +244,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
                     adj[(size_t)cur[i]++] = (int32_t)j;
                     adj[(size_t)cur[j]++] = (int32_t)i;
                 }
+            pt.lap("1a adjacency");
             if (opts.ordering != 3) {
                 cand.emplace_back();
                 order_nd(n, aptr, adj, opts.nd_leaf, cand.back());
