@@ -93,6 +93,13 @@ void analyze_subtrees(kvx_chol *F)
     }
     int64_t extra[2] = {0, 0};
     const int64_t base[2] = {S.wrk_size[0], S.wrk_size[1]};
+    // factorisation: every front of a subtree gets a slot of its parity buffer that no other front reuses (the level schedule
+    // recycles the buffers level by level; subtrees are factored before the level loop, at all depths at once)
+    int64_t uextra[2] = {0, 0};
+    const int64_t ubase[2] = {S.upd_size[0], S.upd_size[1]};
+    // (opt-in, KVX_FACTOR_SUBTREES=1 -- measured slower than the level schedule, see build_subtrees: the slots cost
+    // sum u^2 doubles over the subtree fronts, 270 MB on config 2)
+    const bool uniq = [] { const char *e = getenv("KVX_FACTOR_SUBTREES"); return e && e[0] == '1'; }();
     for (int64_t s = ns - 1; s >= 0; s--) {
         if (!ok[s] || F->in_sub[s]) continue;
         if (S.sparent[s] >= 0 && ok[S.sparent[s]]) continue;      // not maximal
@@ -112,6 +119,12 @@ void analyze_subtrees(kvx_chol *F)
         for (int64_t q = lo; q <= s; q++) {
             F->in_sub[q] = 1;
             for (int64_t c = S.childptr[q]; c < S.childptr[q + 1]; c++) F->cd_woff_host[c] = (int32_t)woff[S.children[c] - lo];
+            if (uniq) {
+                const int pq = S.depth[q] & 1;
+                const int64_t uq = S.sn_m[q] - S.sn_k[q];
+                S.ux[q] = ubase[pq] + uextra[pq];
+                uextra[pq] += uq * uq;
+            }
         }
         F->subs_host.push_back(SubDesc{(int32_t)lo, (int32_t)s, (int32_t)S.super[lo], (int32_t)(S.super[s + 1] - S.super[lo])});
         const int p = S.depth[s] & 1;
@@ -120,6 +133,8 @@ void analyze_subtrees(kvx_chol *F)
     }
     S.wrk_size[0] = base[0] + extra[0];
     S.wrk_size[1] = base[1] + extra[1];
+    S.upd_size[0] = ubase[0] + uextra[0];
+    S.upd_size[1] = ubase[1] + uextra[1];
 }
 
 // per-level solve lists without the subtree fronts, and the subtree tables, on the device
@@ -177,6 +192,37 @@ int build_subtrees(kvx_chol *F)
     if ((rc = upload(&F->d_cd_woff, cd_woff))) return rc;
     F->lsw_host = lsw;
     if ((rc = upload(&F->d_lists_sw, lsw))) return rc;
+    // factorisation: the subtrees grouped by the LDS image their largest front needs (32 / 48 / 64 rows), and level lists without
+    // their fronts (the fplan / d_flists pair the sharded mode uses for its own filtered lists; it keeps subtrees off)
+    // Opt-in (KVX_FACTOR_SUBTREES=1).  Measured on MI355X, config 2: the two large groups of subtrees take 0.49 / 0.55 ms side by
+    // side and the level loop reaches its first big front at 0.86 ms instead of 0.81; factor 3.69 -> 4.00 ms.  A front costs a
+    // wavefront ~30 us under load either way (pivot sweeps are issue-bound FP64, the rest memory latency); the level schedule
+    // keeps every front of a level in flight, a walk only one front per subtree.
+    { const char *e = getenv("KVX_FACTOR_SUBTREES"); F->factor_subtrees = enabled && F->dist == nullptr && e && e[0] == '1'; }
+    F->nsubf[0] = F->nsubf[1] = F->nsubf[2] = 0;
+    if (F->factor_subtrees) {
+        std::vector<SubDesc> fs;
+        for (int g = 0; g < 3; g++)
+            for (const SubDesc &d : F->subs_host) {
+                int mm = 0;
+                for (int q = d.lo; q <= d.hi; q++) mm = std::max(mm, S.sn_m[q]);
+                if ((mm <= 32 ? 0 : (mm <= 48 ? 1 : 2)) == g) { fs.push_back(d); F->nsubf[g]++; }
+            }
+        if (fs.empty()) fs.push_back(SubDesc{0, -1, 0, 0});
+        if (F->d_subs_f) { (void)pool_free(F->d_subs_f); F->d_subs_f = nullptr; }
+        if ((rc = upload(&F->d_subs_f, fs))) return rc;
+        std::vector<int32_t> fl;
+        std::vector<int64_t> flp((size_t)S.nlevels + 1, 0);
+        for (int l = 0; l < S.nlevels; l++) {
+            for (int64_t q = F->lptr_host[l]; q < F->lptr_host[l + 1]; q++)
+                if (!F->in_sub[F->lists_host[q]]) fl.push_back(F->lists_host[q]);
+            flp[l + 1] = (int64_t)fl.size();
+        }
+        if (F->d_flists) { (void)pool_free(F->d_flists); F->d_flists = nullptr; }
+        if ((rc = upload(&F->d_flists, fl))) return rc;
+        build_plan_from(S, fl, flp, F->fplan, F->mid_m);
+        F->fplan_on = true;
+    }
     std::vector<int32_t> dep(S.depth.begin(), S.depth.end());
     if (dep.empty()) dep.push_back(0);
     if ((rc = upload(&F->d_depth, dep))) return rc;
@@ -343,6 +389,28 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
     }
     if (lfrom < 0) lfrom = S.nlevels - 1;
+    if (F->factor_subtrees && prologue && lfrom == S.nlevels - 1) {
+        // the leaf subtrees: one wavefront each, all depths at once, the three LDS sizes on three streams
+        const int caps[3] = {32, 48, 64};
+        hipStream_t ss[3] = {st, F->side[0], F->side[1]};
+        const bool fork[3] = {false, F->nsubf[1] > 0, F->nsubf[2] > 0};
+        if (fork[1] || fork[2]) {
+            HIPCHK(hipEventRecord(F->ev_fork, st));
+            for (int g = 1; g < 3; g++)
+                if (fork[g]) HIPCHK(hipStreamWaitEvent(ss[g], F->ev_fork, 0));
+        }
+        int64_t off = 0;
+        // (largest images first: they hold the fewest subtrees per CU)
+        int64_t offs[3] = {0, F->nsubf[0], F->nsubf[0] + F->nsubf[1]};
+        (void)off;
+        for (int g = 2; g >= 0; g--) {
+            if (F->nsubf[g] == 0) continue;
+            ProfScope ps(F, FAM_SMALL, ss[g]);
+            launch_factor_subtree(ss[g], caps[g], F->ds, F->d_subs_f + offs[g], F->nsubf[g], F->d_depth, F->d_Lx, F->d_U[0], F->d_U[1], F->d_status);
+        }
+        for (int g = 1; g < 3; g++)
+            if (fork[g]) { HIPCHK(hipEventRecord(F->ev_join[g - 1], ss[g])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[g - 1], 0)); }
+    }
     const int32_t *lbase = F->fplan_on ? F->d_flists : F->d_lists;
     for (int l = lfrom; l >= lto; l--) {
         const LevelPlan &P = F->fplan_on ? F->fplan[l] : F->plan[l];
@@ -1304,7 +1372,7 @@ void kvx_chol_free(kvx_chol *F)
         if (F->d_keep) (void)pool_free(F->d_keep);
         if (F->d_flists) (void)pool_free(F->d_flists);
         dist_release(F);
-        for (void *p : {(void *)F->d_subs, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
+        for (void *p : {(void *)F->d_subs, (void *)F->d_subs_f, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
         if (F->ev_fork2) pool_event_put(F->ev_fork2, false);

@@ -96,6 +96,9 @@ struct kvx_chol {
     int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
     // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
     SubDesc *d_subs = nullptr;
+    SubDesc *d_subs_f = nullptr;               // the same subtrees grouped by LDS image size (32 / 48 / 64 rows) for the factorisation
+    int nsubf[3] = {0, 0, 0};
+    bool factor_subtrees = false;              // opt-in KVX_FACTOR_SUBTREES=1: the subtrees are factored by one wavefront each before the level loop (measured slower)
     int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
     int nsub = 0, nsub32 = 0;                  // subtrees; the first nsub32 hold only fronts of order <= 32
     bool use_subtrees = true;

@@ -166,6 +166,9 @@ void launch_front_small(hipStream_t st, int mcap, int kmax, const DevSym &ds, co
 // wave-per-front kernel (kernels_wave.hip): m <= mcap (32/48/64), k <= kmax (16/32)
 void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, const int32_t *list, int count,
                        double *Lx, const double *Uchild, double *Uout, int *status);
+// leaf subtrees of the factorisation (kernels_wave.hip): one wavefront factors a whole subtree; U0 / U1: the parity buffers
+void launch_factor_subtree(hipStream_t st, int mcap, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *depth,
+                           double *Lx, double *U0, double *U1, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
 // one workgroup per front, one launch: extend-add + the whole panel loop (big-class fronts of order <= KVX_MID_M)

@@ -149,19 +149,14 @@ __device__ __forceinline__ void schur_tile(const double *F, int m, int k, int u,
 }
 
 // ------------------------------------------------------------------------------------------
-// OCC: wavefronts per SIMD the register allocation must leave room for.  The levels that hold thousands of these fronts are bound
-// by (fronts in flight) x (latency of one front); left alone the compiler takes 129 + 8 registers for KMAX = 32 -- three waves per
-// SIMD -- where 128 (four waves, no spill) serve as well, and 96 + 8 for KMAX = 16 (four waves; 95: five).
-template <int KMAX, int OCC>
-__global__ __launch_bounds__(64, OCC) void k_front_wave(DevSym ds, const int32_t *__restrict__ list,
-                                                   double *__restrict__ Lx, const double *__restrict__ Uc,
-                                                   double *__restrict__ Uo, int *status, int mcap)
+// One wave-class front (m <= 64, k <= 32) by one wavefront: the body shared by the one-front-per-wavefront kernel of the level
+// schedule and by the leaf-subtree walk.  F: packed LDS image of the front, cb2: 2 x 64 column buffer, relsh: 64 ints.
+template <int KMAX>
+__device__ __forceinline__ void front_wave_body(const DevSym &ds, const FrontDesc &fd, double *__restrict__ Lx,
+                                                const double *__restrict__ Uc, double *__restrict__ Uo, int *status,
+                                                double *F, double *cb2, int *relsh, const int r)
 {
-    extern __shared__ double F[];                  // packed lower triangle of the front (pk), 2x64 column buffer, 64 ints
-    double *cb2 = F + mcap * (mcap + 1) / 2;
-    int *relsh = (int *)(cb2 + 128);
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
-    const int k = fd.k, m = fd.m, u = m - k, r = threadIdx.x;
+    const int k = fd.k, m = fd.m, u = m - k;
     double *P = Lx + fd.px;
     const bool kids = fd.nchild > 0;
     // the panel goes straight from HBM to registers (all KMAX loads in flight while the children are
@@ -191,6 +186,50 @@ __global__ __launch_bounds__(64, OCC) void k_front_wave(DevSym ds, const int32_t
     const int T = (u + 15) >> 4;
     for (int ti = 0; ti < T; ti++)
         for (int tj = 0; tj <= ti; tj++) schur_tile(F, m, k, u, ti, tj, kids, Uout, r);
+}
+
+// OCC: wavefronts per SIMD the register allocation must leave room for.  The levels that hold thousands of these fronts are bound
+// by (fronts in flight) x (latency of one front); left alone the compiler takes 129 + 8 registers for KMAX = 32 -- three waves per
+// SIMD -- where 128 (four waves, no spill) serve as well, and 96 + 8 for KMAX = 16 (four waves; 95: five).
+template <int KMAX, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_front_wave(DevSym ds, const int32_t *__restrict__ list,
+                                                        double *__restrict__ Lx, const double *__restrict__ Uc,
+                                                        double *__restrict__ Uo, int *status, int mcap)
+{
+    extern __shared__ double F[];                  // packed lower triangle of the front (pk), 2x64 column buffer, 64 ints
+    double *cb2 = F + mcap * (mcap + 1) / 2;
+    int *relsh = (int *)(cb2 + 128);
+    const FrontDesc fd = ds.fd[list[blockIdx.x]];
+    front_wave_body<KMAX>(ds, fd, Lx, Uc, Uo, status, F, cb2, relsh, (int)threadIdx.x);
+}
+
+// Leaf subtrees in the FACTORISATION: the bottom of the elimination tree is thousands of small independent subtrees whose fronts
+// are all wave-class.  Level by level they cost one launch + one stream join per level for a few microseconds of work per front
+// (config 2: eight levels, 0.7 ms, before the first big front starts).  Here ONE wavefront factors a whole subtree, its fronts in
+// postorder, before the level loop starts: the next front's descriptor is fetched while the current one is factored, and a parent
+// finds its children's update matrices where the level schedule would have put them -- every front of a subtree owns a slot of
+// the parity buffers that no other front reuses (analyze_subtrees), so subtrees at different depths cannot collide.  Same
+// arithmetic per front as k_front_wave (the same body): bitwise the same factor.
+template <int KMAX, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_factor_subtree(DevSym ds, const SubDesc *__restrict__ subs, const int32_t *__restrict__ depth,
+                                                            double *__restrict__ Lx, double *__restrict__ U0, double *__restrict__ U1,
+                                                            int *status, int mcap)
+{
+    extern __shared__ double F[];
+    double *cb2 = F + mcap * (mcap + 1) / 2;
+    int *relsh = (int *)(cb2 + 128);
+    const SubDesc sd = subs[blockIdx.x];
+    FrontDesc nxt = ds.fd[sd.lo];
+    int ndep = depth[sd.lo];
+    for (int s = sd.lo; s <= sd.hi; s++) {
+        const FrontDesc fd = nxt;
+        const int dp = ndep;
+        if (s < sd.hi) { nxt = ds.fd[s + 1]; ndep = depth[s + 1]; }
+        double *Uo = (dp & 1) ? U1 : U0;
+        const double *Uc = (dp & 1) ? U0 : U1;
+        front_wave_body<KMAX>(ds, fd, Lx, Uc, Uo, status, F, cb2, relsh, (int)threadIdx.x);
+        __syncthreads();                           // the LDS image is reused; the update matrix just stored is a child's of a later front
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -884,6 +923,15 @@ void launch_front_wave(hipStream_t st, int mcap, int kmax, const DevSym &ds, con
         if (tight) hipLaunchKernelGGL((k_front_wave<32, 4>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
         else hipLaunchKernelGGL((k_front_wave<32, 1>), dim3((unsigned)count), dim3(64), lds, st, ds, list, Lx, Uchild, Uout, status, mcap);
     }
+}
+
+// leaf subtrees of the factorisation: one wavefront per subtree; mcap = LDS image capacity of the largest front of these subtrees
+void launch_factor_subtree(hipStream_t st, int mcap, const DevSym &ds, const SubDesc *subs, int nsub, const int32_t *depth,
+                           double *Lx, double *U0, double *U1, int *status)
+{
+    if (nsub <= 0) return;
+    const size_t lds = (size_t)mcap * (mcap + 1) / 2 * sizeof(double) + 128 * sizeof(double) + 64 * sizeof(int);
+    hipLaunchKernelGGL((k_factor_subtree<32, 3>), dim3((unsigned)nsub), dim3(64), lds, st, ds, subs, depth, Lx, U0, U1, status, mcap);
 }
 
 // LDS kernel: mcap = 96 or 128; kmax = 32 or 64 (k of every front in the list must be <= kmax)

@@ -562,3 +562,25 @@ def test_spsolve_forward_systems_sweep_only_the_reach(g, h, supernodal, monkeypa
         col = np.zeros(n)
         col[Xi[Xp[j]:Xp[j + 1]]] = Xx[Xp[j]:Xp[j + 1]]
         assert np.array_equal(col, Y[:, j])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["config2", "stencil21"])
+def test_full_size_against_the_host_supernodal_oracle(which):
+    """BASELINE.json configs[1] (5-point Laplacian 1000 x 1000, n = 1e6) and the north star's "~20 nnz/row" system (21-point
+    stencil on the same grid) AT FULL SIZE against a CPU oracle: oracle/kvx_supernodal.c factors the same matrix on the same
+    supernodes and permutation with OpenBLAS inside the fronts (different kernels, different summation order, the host's
+    cores).  Solutions agree to 1e-10 relative (north_star), the diagonals of L to 1e-11."""
+    from oracle.kvx_oracle import OracleSupernodal
+    n, cp, ri, vx = workloads.laplacian_2d(1000) if which == "config2" else workloads.stencil21_2d(1000)
+    F = Factor(n, cp, ri)
+    F.factorize(vx)
+    b = np.random.default_rng(2).standard_normal(n)
+    x = b.copy()
+    F.solve(x)
+    O = OracleSupernodal.from_factor(n, cp, ri, F)
+    O.factorize(vx)
+    xo = b.copy()
+    O.solve(xo)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-10
+    assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - b) / np.linalg.norm(b) < 1e-10
