@@ -570,7 +570,7 @@ def test_full_size_against_the_host_supernodal_oracle(which):
     """BASELINE.json configs[1] (5-point Laplacian 1000 x 1000, n = 1e6) and the north star's "~20 nnz/row" system (21-point
     stencil on the same grid) AT FULL SIZE against a CPU oracle: oracle/kvx_supernodal.c factors the same matrix on the same
     supernodes and permutation with OpenBLAS inside the fronts (different kernels, different summation order, the host's
-    cores).  Solutions agree to 1e-10 relative (north_star), the diagonals of L to 1e-11."""
+    cores).  Solutions agree to 1e-10 relative (north_star)."""
     from oracle.kvx_oracle import OracleSupernodal
     n, cp, ri, vx = workloads.laplacian_2d(1000) if which == "config2" else workloads.stencil21_2d(1000)
     F = Factor(n, cp, ri)
@@ -584,3 +584,24 @@ def test_full_size_against_the_host_supernodal_oracle(which):
     O.solve(xo)
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-10
     assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - b) / np.linalg.norm(b) < 1e-10
+
+
+@pytest.mark.gpu
+def test_factor_subtree_walk_gives_the_same_factor(monkeypatch):
+    """KVX_FACTOR_SUBTREES=1 (opt-in, measured slower): the leaf subtrees are factored by one wavefront each before the level
+    loop, every front of a subtree in a slot of the update buffers of its own.  Same arithmetic per front: the factor and the
+    solution are bit-identical to the level schedule's."""
+    n, cp, ri, vx = workloads.laplacian_2d(220, 190)
+    b = np.random.default_rng(5).standard_normal(n)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("KVX_FACTOR_SUBTREES", flag)
+        F = Factor(n, cp, ri)
+        F.factorize(vx)
+        x = b.copy()
+        F.solve(x)
+        out.append((F.diag(), x))
+        F.factorize(vx)                                     # graph replay from the second call on
+        F.factorize(vx)
+        assert np.array_equal(F.diag(), out[-1][0])
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
