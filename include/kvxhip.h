@@ -93,7 +93,10 @@ int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_
 int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
 
 /* spsolve(F, B, sys) -- cholmod.c:524-587.  B is n x ncol CCS; the result is returned as a
- * newly malloc'ed CCS triple the caller frees with kvx_free(). */
+ * newly malloc'ed CCS triple the caller frees with kvx_free() (entries that are exactly zero are dropped, as
+ * cholmod_spsolve does on a supernodal factor).  The forward systems (sys 2: L D x = b, 4: L x = b) sweep only the reach
+ * of each block of 64 columns in the supernodal elimination tree -- the fronts that hold a nonzero row of the block and
+ * their ancestors -- and copy back only the rows of those fronts; the other codes solve dense column blocks. */
 int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, const int64_t *Bi,
                      const double *Bx, int64_t **Xp, int64_t **Xi, double **Xx);
 
