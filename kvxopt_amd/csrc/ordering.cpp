@@ -180,18 +180,45 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
     }
     // queue[0..cnt) holds one connected component in BFS order with levels set
     if (cnt < sz) {
-        // disconnected: peel this component off as its own task, no separator
-        int32_t ra = st.next_region.fetch_add(2, std::memory_order_relaxed), rb = ra + 1;
-        for (int64_t i = 0; i < cnt; i++) st.region[queue[i]] = ra;
-        int64_t a = t.lo, b = t.lo + cnt;
+        // disconnected: every connected component of the slice becomes a task of its own, no separator.  One sweep labels them
+        // all (a slice that falls apart into hundreds of pieces -- power grids, LP bases -- used to be peeled one component per
+        // step, each step rewriting the rest of the slice); the layout is the one the peeling produced: components in the order
+        // of their first vertex in the slice, every component in slice order.
+        reset_levels(st, queue, cnt);
         std::vector<int32_t> tmp(st.verts.begin() + t.lo, st.verts.begin() + t.hi);
-        reset_levels(st, queue, cnt);              // (before the slice is rewritten: queue aliases nothing in verts)
-        for (int32_t v : tmp) {
-            if (st.region[v] == ra) st.verts[a++] = v;
-            else { st.region[v] = rb; st.verts[b++] = v; }
+        std::vector<int32_t> rid_of;                 // region id of component c
+        std::vector<int64_t> csize;
+        for (int32_t v0 : tmp) {
+            if (st.region[v0] != t.rid) continue;    // already in a component
+            const int32_t rc = st.next_region.fetch_add(1, std::memory_order_relaxed);
+            const int32_t ci = (int32_t)rid_of.size();
+            rid_of.push_back(rc);
+            int64_t head = 0, tail = 0;
+            queue[tail++] = v0;
+            st.region[v0] = rc;
+            st.level[v0] = ci;                       // (component index, cleared below)
+            while (head < tail) {
+                const int32_t v = queue[head++];
+                for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1]; p++) {
+                    const int32_t u = st.g.adj[p];
+                    if (st.region[u] != t.rid) continue;
+                    st.region[u] = rc;
+                    st.level[u] = ci;
+                    queue[tail++] = u;
+                }
+            }
+            csize.push_back(tail);
         }
-        out.push_back(NDTask{t.lo + cnt, t.hi, rb});
-        out.push_back(NDTask{t.lo, t.lo + cnt, ra});
+        std::vector<int64_t> pos(csize.size() + 1, t.lo);
+        for (size_t c = 0; c < csize.size(); c++) pos[c + 1] = pos[c] + csize[c];
+        {
+            std::vector<int64_t> cur(pos.begin(), pos.end() - 1);
+            for (int32_t v : tmp) {
+                st.verts[(size_t)cur[(size_t)(int32_t)st.level[v]]++] = v;
+                st.level[v] = -1;
+            }
+        }
+        for (size_t c = csize.size(); c-- > 0;) out.push_back(NDTask{pos[c], pos[c + 1], rid_of[c]});   // (LIFO: the first component is taken first)
         return;
     }
     if (nlev < 3) {
