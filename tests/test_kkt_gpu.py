@@ -933,8 +933,19 @@ def test_s_cone_scaling_larger_blocks_against_numpy():
         assert rel(R.T @ blocks_z[i] @ R, np.diag(sv)) < 1e-10 and rel(T.T @ blocks_s[i] @ T, np.diag(sv)) < 1e-10
         assert rel(R.T @ T, np.eye(m)) < 1e-10
         il += m
-    x = np.concatenate([(0.5 * (B + B.T)).reshape(-1, order="F") for B in (rng.standard_normal((m, m)) for m in sd)])
     off2 = np.concatenate([[0], np.cumsum([m * m for m in sd])])
+    # W z = W^-T s = lambda (coneprog.py:1031-1043 relies on it): scale(z, W) and scale(s, W, trans='T', inverse='I') give
+    # diag(lambda_k) in every block (lower triangles)
+    zz, ss = matrix(z.copy()), matrix(s.copy())
+    misc.scale(zz, W)
+    misc.scale(ss, W, trans="T", inverse="I")
+    il = 0
+    for i, m in enumerate(sd):
+        for got in (zz, ss):
+            Bk = np.tril(got._a[off2[i]:off2[i + 1]].reshape((m, m), order="F"))
+            assert rel(Bk, np.diag(lm._a[il:il + m])) < 1e-10
+        il += m
+    x = np.concatenate([(0.5 * (B + B.T)).reshape(-1, order="F") for B in (rng.standard_normal((m, m)) for m in sd)])
     ev = [np.linalg.eigvalsh(x[off2[i]:off2[i + 1]].reshape((m, m), order="F")) for i, m in enumerate(sd)]
     t = misc.max_step(matrix(x), dims)
     assert abs(t - max(-e[0] for e in ev)) <= 1e-12 * max(1.0, abs(t))
