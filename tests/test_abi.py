@@ -67,3 +67,31 @@ def test_lu_abi_argument_checks_need_no_gpu():
     assert L.kvx_lu_det(None, None) == _lib.KVX_EINVAL
     L.kvx_lu_free_symbolic(h)
     L.kvx_lu_free_numeric(None)
+
+
+def test_cone_block_operations_fail_loudly_without_gpu():
+    """The 'q' / 's' block operations of kvxopt_amd.misc have no host arithmetic behind them: without a HIP device they raise
+    (a vector without such blocks needs no device for the storage helpers -- plain copies -- and the argument checks of the C ABI
+    answer on any box)."""
+    if _lib.lib().kvx_device_count() > 0:
+        pytest.skip("GPU present")
+    from kvxopt_amd import misc
+    from kvxopt_amd.base import matrix
+    dims = {"l": 2, "q": [], "s": []}
+    x, y = matrix(np.arange(4.0)), matrix(0.0, (6, 1))
+    misc.pack(x, y, dims, 1, 1, 2)                       # mnl = 1: three leading entries copied, nothing else touched
+    assert np.array_equal(y._a, [0.0, 0.0, 1.0, 2.0, 3.0, 0.0])
+    misc.unpack(y, x, dims, 1, 2, 1)
+    assert np.array_equal(x._a, [0.0, 1.0, 2.0, 3.0])
+    dims_s = {"l": 0, "q": [], "s": [2]}
+    for call in (lambda: misc.pack(matrix(np.ones(4)), matrix(0.0, (3, 1)), dims_s),
+                 lambda: misc.compute_scaling(matrix(np.eye(2).reshape(-1)), matrix(np.eye(2).reshape(-1)), matrix(0.0, (2, 1)), dims_s),
+                 lambda: misc.max_step(matrix(np.ones(4)), dims_s),
+                 lambda: misc.trisc(matrix(np.ones(4)), dims_s)):
+        with pytest.raises(RuntimeError):
+            call()
+    L = _lib.lib()
+    assert L.kvx_nts_scale_dev(-1, None, None, None, None, 1, 1, 0, None, 0) == _lib.KVX_EINVAL
+    assert L.kvx_nts_scale_dev(1, None, None, None, None, 1, 1, 2, None, 0) == _lib.KVX_EINVAL      # form is 0 or 1
+    assert L.kvx_nts_pack_dev(0, None, None, None, None, None, 0) == _lib.KVX_OK                     # no blocks: nothing to do
+    assert L.kvx_nts_prod_dev(1, None, None, None, None, 3, None) == _lib.KVX_EINVAL
