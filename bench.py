@@ -410,13 +410,13 @@ def main():
 
     # --- CPU baselines on the same system and permutation (rank 0, host cores of this box) -------
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # (the contract: rank 0 at N = 1 only)
         cpu = cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x)
 
     # --- the other half of BASELINE.json's metric: IPM iterations/s of the device-resident conelp on configs[3]
     # (inequality form), rank 0 only, a few hundred ms; never part of `value`
     ipm = None
-    if rank == 0 and not args.no_ipm:
+    if rank == 0 and world == 1 and not args.no_ipm:
         try:
             ipm = ipm_leg(args, torch)
         except Exception as e:                      # the headline line must not depend on this leg
