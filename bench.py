@@ -410,7 +410,7 @@ def main():
 
     # --- CPU baselines on the same system and permutation (rank 0, host cores of this box) -------
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:          # (the contract: rank 0 at N = 1 only)
+    if rank == 0 and (world == 1 or DF is not None) and not args.no_cpu_baseline:   # (replicas: rank 0 at N = 1 only; one sharded system: beside every N)
         cpu = cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x)
 
     # --- the other half of BASELINE.json's metric: IPM iterations/s of the device-resident conelp on configs[3]
