@@ -585,6 +585,20 @@ class _Chol2Device:
         zb[:m] = self.z.get()[:m]
 
 
+def _full_pattern(M, lower=False):
+    """A dense `matrix` as an spmatrix with every entry (or every entry of the lower triangle) stored; anything else unchanged."""
+    if not isinstance(M, matrix):
+        return M
+    r, c = M.size
+    D = np.asarray(M.a, dtype=np.float64).reshape(r, c)
+    if lower:
+        I, J = np.nonzero(np.tril(np.ones((r, c), dtype=bool)).T)       # column by column
+        I, J = J, I
+        return spmatrix(D[I, J], I, J, (r, c))
+    return spmatrix.from_ccs(r, c, np.arange(c + 1, dtype=np.int64) * r, np.tile(np.arange(r, dtype=np.int64), c),
+                             np.ascontiguousarray(D.T).reshape(-1))
+
+
 def kkt_chol2(G, dims, A, mnl=0):
     """KKT solver factory of the reference for sparse G (misc.py:1352-1567): returns factor(W, H=None, Df=None), which
     returns solve(x, y, z) overwriting the right-hand side (bx, by, bz) with (ux, uy, W uz) of
@@ -600,25 +614,24 @@ def kkt_chol2(G, dims, A, mnl=0):
     and the result runs in HBM on kvxopt_amd.lp's device classes -- S assembled by one gather kernel on a product map,
     K = A S^-1 A' as a fixed-pattern assembly when S is diagonal and as a dense matrix otherwise (the reference rebuilds
     Asct = L^-1 P A' by sparse triangular solves and re-analyses K at every call, misc.py:1483-1487), both Cholesky factors
-    resident between factor() and solve().  A dense A (the reference's "mixed" branch, misc.py:1476-1481) is accepted;
-    dense G, H or Df send the reference to LAPACK and are out of scope here."""
+    resident between factor() and solve().  Dense G, A, H or Df (the reference's LAPACK branches) are taken as matrices with
+    every entry stored and run through the same kernels."""
     if dims.get("q") or dims.get("s"):
         raise ValueError("kktsolver option 'kkt_chol2' is implemented only for problems with no "
                          "second-order or semidefinite cone constraints")
-    if isinstance(G, matrix):
-        raise NotImplementedError("kkt_chol2: the dense-G LAPACK branch (misc.py:1429,1467-1472) is out of scope")
     p, n = A.size
-    if isinstance(A, matrix):                     # every entry stored: the same kernels, a full pattern
-        Ad = np.asarray(A.a, dtype=np.float64).reshape(p, n)
-        A = spmatrix.from_ccs(p, n, np.arange(n + 1, dtype=np.int64) * p, np.tile(np.arange(p, dtype=np.int64), n),
-                              np.ascontiguousarray(Ad.T).reshape(-1))
+    # dense operands (the reference's LAPACK branches, misc.py:1401-1404, 1428-1429, 1464-1481): every entry stored, the same
+    # kernels on a full pattern -- S is then one dense front
+    G = _full_pattern(G)
+    A = _full_pattern(A)
     state = {"dev": None}
 
     def factor(W, H=None, Df=None):
-        if isinstance(H, matrix):
-            raise NotImplementedError("kkt_chol2: a dense H takes the reference's LAPACK branch (out of scope)")
-        if mnl and (isinstance(Df, matrix) or not hasattr(Df, "CCS")):
-            raise NotImplementedError("kkt_chol2: a dense Df takes the reference's LAPACK branch (out of scope)")
+        H = _full_pattern(H, lower=True)          # (the lower triangle is what the factorisation reads)
+        if mnl:
+            Df = _full_pattern(Df)
+            if not hasattr(Df, "CCS"):
+                raise TypeError("Df must be a 'd' matrix or spmatrix")
         _lib.require_device()
         if state["dev"] is None:
             dev = _Chol2Device(G, A, mnl, Df, H, with_A_rows=False)

@@ -105,6 +105,15 @@ def test_kkt_chol2_golden(golden_dir, tag, p):
         x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
         solve(x, y, z)
         assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(y._a, g[tag + "_y"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
+    # a DENSE G (the branch the golden itself was produced with in the reference, misc.py:1401-1404, 1464-1472) and a dense A
+    f = misc.kkt_chol2(matrix(G.todense()), dims, matrix(A.todense()) if p else A)
+    f(W_of(np.ones(ml), np.ones(ml)))
+    solve = f(W_of(g[tag + "_d"].copy(), 1.0 / g[tag + "_d"]))
+    x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
+    solve(x, y, z)
+    assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
+    if p:
+        assert rel(y._a, g[tag + "_y"]) < 1e-10
 
 
 def test_nonlinear_block_scaling_golden(golden_dir):
@@ -156,8 +165,18 @@ def test_kkt_chol2_nonlinear_block_golden(golden_dir, tag, p):
     assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
     if p:
         assert rel(y._a, g[tag + "_y"]) < 1e-10
-    with pytest.raises(NotImplementedError):                  # dense Df: the reference's LAPACK branch, out of scope
-        misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, A, mnl)(Ws[0], H[0], matrix(Df[0].todense()))
+    # dense Df and H (the reference's LAPACK branches): every entry stored, the same kernels, the same triple
+    def sym_full(Hs):
+        D = Hs.todense()
+        return matrix(D + np.tril(D, -1).T)
+    f = misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, A, mnl)
+    f(Ws[0], sym_full(H[0]), matrix(Df[0].todense()))
+    solve = f(Ws[1], sym_full(H[1]), matrix(Df[1].todense()))
+    x, y, z = matrix(g[tag + "_bx"].copy()), matrix(g[tag + "_by"].copy(), (p, 1)), matrix(g[tag + "_bz"].copy())
+    solve(x, y, z)
+    assert rel(x._a, g[tag + "_x"]) < 1e-10 and rel(z._a, g[tag + "_z"]) < 1e-10
+    if p:
+        assert rel(y._a, g[tag + "_y"]) < 1e-10
 
 
 def test_kkt_chol2_rejects_other_cones():
