@@ -401,7 +401,7 @@ __global__ __launch_bounds__(NT) void k_s_max_step(const int64_t *__restrict__ o
         fro = __builtin_fma(v, v, fro);
     }
     fro = sqrt(block_sum1(fro, shd));
-    const double c = 1.5 * fro + 2.2250738585072014e-308;
+    const double c = fro > 0.0 ? 1.5 * fro : 1.0;                     // (the zero matrix: any positive shift)
     for (int i = threadIdx.x; i < m; i += NT) B[i + (int64_t)i * m] += c;
     __syncthreads();
     jacobi_sweeps(B, nullptr, m, sh);

@@ -975,3 +975,24 @@ def test_s_cone_scaling_larger_blocks_against_numpy():
         Q = xs._a[off2[i]:off2[i + 1]].reshape((m, m), order="F")
         X = x[off2[i]:off2[i + 1]].reshape((m, m), order="F")
         assert rel(Q @ np.diag(ev[i]) @ Q.T, X) < 1e-10 and rel(Q.T @ Q, np.eye(m)) < 1e-11
+
+
+@pytest.mark.gpu
+def test_s_cone_scaling_with_repeated_singular_values():
+    """Degenerate spectra: s = z = I (every singular value of Lz' Ls equals 1: any orthonormal basis serves) and s = 4 z
+    (W = 2 I): the scaling point r r' and lambda are still what the definition gives, the Jacobi sweeps terminate at once."""
+    m = 7
+    dims = {"l": 0, "q": [], "s": [m]}
+    I = np.eye(m).reshape(-1, order="F")
+    lm = matrix(0.0, (m, 1))
+    W = misc.compute_scaling(matrix(I.copy()), matrix(I.copy()), lm, dims)
+    assert rel(lm._a, np.ones(m)) < 1e-14 and rel(W["r"][0].a @ W["r"][0].a.T, np.eye(m)) < 1e-14
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((m, m))
+    Z = B @ B.T + m * np.eye(m)
+    W = misc.compute_scaling(matrix((4.0 * Z).reshape(-1, order="F")), matrix(Z.reshape(-1, order="F")), lm, dims)
+    R = W["r"][0].a
+    assert rel(R @ R.T, 2.0 * np.eye(m)) < 1e-12                    # W = r r' = (s z^-1)^(1/2) = 2 I
+    assert rel(np.sort(lm._a), np.sort(2.0 * np.linalg.eigvalsh(Z))) < 1e-12
+    t = misc.max_step(matrix(np.zeros(m * m)), dims)                 # the zero matrix: every eigenvalue 0
+    assert t == 0.0
