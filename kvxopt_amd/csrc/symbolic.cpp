@@ -245,54 +245,93 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
                     adj[(size_t)cur[j]++] = (int32_t)i;
                 }
             pt.lap("1a adjacency");
-            if (opts.ordering != 3) {
-                cand.emplace_back();
-                order_nd(n, aptr, adj, opts.nd_leaf, cand.back());
-                cand_name.push_back("nested dissection");
+            // the two orderings are independent: the minimum-degree candidate runs on a thread of its own beside the dissection
+            // (an exception of either is carried to the caller; the result does not depend on the overlap)
+            const bool want_nd = opts.ordering != 3;
+            const bool want_md = opts.ordering == 3 || (opts.ordering == 0 && n <= opts.amd_auto_max);
+            std::vector<int64_t> perm_nd, perm_md;
+            std::exception_ptr md_err;
+            auto run_md = [&] {
+                try {
+                    // (duplicate entries of the caller's pattern would show up as repeated neighbours: harmless for the
+                    // dissection, but the quotient graph wants clean lists)
+                    std::vector<int64_t> aptr2((size_t)n + 1, 0);
+                    std::vector<int32_t> adj2;
+                    adj2.reserve(adj.size());
+                    for (int64_t i = 0; i < n; i++) {
+                        const size_t b0 = adj2.size();
+                        adj2.insert(adj2.end(), adj.begin() + aptr[i], adj.begin() + aptr[i + 1]);
+                        std::sort(adj2.begin() + b0, adj2.end());
+                        adj2.erase(std::unique(adj2.begin() + b0, adj2.end()), adj2.end());
+                        aptr2[i + 1] = (int64_t)adj2.size();
+                    }
+                    order_amd(n, aptr2, adj2, perm_md);
+                } catch (...) { md_err = std::current_exception(); }
+            };
+            std::thread md_thread;
+            bool md_async = false;
+            if (want_md && want_nd && analyze_threads() > 1) {
+                try { md_thread = std::thread(run_md); md_async = true; } catch (...) { md_async = false; }
             }
-            if (opts.ordering == 3 || (opts.ordering == 0 && n <= opts.amd_auto_max)) {
-                // (duplicate entries of the caller's pattern would show up as repeated neighbours: harmless for the dissection,
-                // but the quotient graph wants clean lists)
-                std::vector<int64_t> aptr2((size_t)n + 1, 0);
-                std::vector<int32_t> adj2;
-                adj2.reserve(adj.size());
-                for (int64_t i = 0; i < n; i++) {
-                    const size_t b0 = adj2.size();
-                    adj2.insert(adj2.end(), adj.begin() + aptr[i], adj.begin() + aptr[i + 1]);
-                    std::sort(adj2.begin() + b0, adj2.end());
-                    adj2.erase(std::unique(adj2.begin() + b0, adj2.end()), adj2.end());
-                    aptr2[i + 1] = (int64_t)adj2.size();
-                }
-                cand.emplace_back();
-                order_amd(n, aptr2, adj2, cand.back());
-                cand_name.push_back("minimum degree");
+            try {
+                if (want_nd) order_nd(n, aptr, adj, opts.nd_leaf, perm_nd);
+            } catch (...) {
+                if (md_async) md_thread.join();
+                throw;
             }
+            if (md_async) md_thread.join();
+            else if (want_md) run_md();
+            if (md_err) std::rethrow_exception(md_err);
+            if (want_nd) { cand.push_back(std::move(perm_nd)); cand_name.push_back("nested dissection"); }
+            if (want_md) { cand.push_back(std::move(perm_md)); cand_name.push_back("minimum degree"); }
         } else if (!user_perm) {
             cand.emplace_back(); cand_name.push_back("empty");
         }
     }
     size_t pick = 0;
     if (cand.size() > 1) {
-        // fill of a candidate: nnz(L) from the column counts (elimination tree + postorder + Gilbert-Ng-Peyton), no factor formed
+        // fill of a candidate: nnz(L) from the column counts (elimination tree + postorder + Gilbert-Ng-Peyton), no factor formed;
+        // the candidates are evaluated side by side (independent work on private vectors)
+        std::vector<double> fill(cand.size(), 0.0);
+        std::vector<std::exception_ptr> ferr(cand.size());
+        auto eval = [&](size_t c) {
+            try {
+                std::vector<int64_t> ip((size_t)n), pp(cand[c]);
+                for (int64_t k = 0; k < n; k++) ip[pp[k]] = k;
+                LowerPattern Lc;
+                std::vector<int32_t> par, post, cc;
+                build_lower(n, Ap, Ai, uplo, ip, Lc);
+                etree_from_lower(n, Lc, par);
+                postorder(n, par, post);
+                std::vector<int32_t> ipost((size_t)n), np2((size_t)n);
+                for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
+                for (int64_t k = 0; k < n; k++) np2[k] = par[post[k]] >= 0 ? ipost[par[post[k]]] : -1;
+                for (int64_t k = 0; k < n; k++) ip[pp[post[k]]] = k;
+                build_lower(n, Ap, Ai, uplo, ip, Lc);
+                column_counts(n, Lc, np2, cc);
+                double lnz = 0.0;
+                for (int64_t j = 0; j < n; j++) lnz += cc[j];
+                fill[c] = lnz;
+            } catch (...) { ferr[c] = std::current_exception(); }
+        };
+        {
+            std::vector<std::thread> th;
+            if (analyze_threads() > 1) {
+                try {
+                    for (size_t c = 1; c < cand.size(); c++) th.emplace_back(eval, c);
+                } catch (...) { }
+            }
+            const size_t started = th.size();
+            eval(0);
+            for (size_t c = 1 + started; c < cand.size(); c++) eval(c);
+            for (auto &t : th) t.join();
+        }
+        for (auto &e : ferr)
+            if (e) std::rethrow_exception(e);
         double best = 0.0;
         for (size_t c = 0; c < cand.size(); c++) {
-            std::vector<int64_t> ip((size_t)n), pp(cand[c]);
-            for (int64_t k = 0; k < n; k++) ip[pp[k]] = k;
-            LowerPattern Lc;
-            std::vector<int32_t> par, post, cc;
-            build_lower(n, Ap, Ai, uplo, ip, Lc);
-            etree_from_lower(n, Lc, par);
-            postorder(n, par, post);
-            std::vector<int32_t> ipost((size_t)n), np2((size_t)n);
-            for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
-            for (int64_t k = 0; k < n; k++) np2[k] = par[post[k]] >= 0 ? ipost[par[post[k]]] : -1;
-            for (int64_t k = 0; k < n; k++) ip[pp[post[k]]] = k;
-            build_lower(n, Ap, Ai, uplo, ip, Lc);
-            column_counts(n, Lc, np2, cc);
-            double lnz = 0.0;
-            for (int64_t j = 0; j < n; j++) lnz += cc[j];
-            if (pt.on) fprintf(stderr, "  analyze candidate %-18s nnz(L) = %.0f\n", cand_name[c], lnz);
-            if (c == 0 || lnz < best) { best = lnz; pick = c; }
+            if (pt.on) fprintf(stderr, "  analyze candidate %-18s nnz(L) = %.0f\n", cand_name[c], fill[c]);
+            if (c == 0 || fill[c] < best) { best = fill[c]; pick = c; }
         }
     }
     std::vector<int64_t> perm0((size_t)n), iperm0((size_t)n, -1);
