@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE ONLY -- ctypes/numpy front-end of the CPU oracle.
 
-Restates (for the orthant 'l' cone only) what the reference computes on the KKT
-factor/solve hot path; every function cites the reference lines it follows.
+Restates what the reference computes on the KKT factor/solve hot path (orthant 'l' cone) and, for
+the widening row SURVEY 8(f)4, the Nesterov-Todd scaling operations of the 'q' and 's' blocks;
+every function cites the reference lines it follows.
 Never imported by kvxopt_amd/ (the product path fails loudly without its HIP
 library instead of falling back to this).
 """
@@ -235,6 +236,129 @@ def max_step_l(x):
     """misc_solvers.c:1065-1071: max_i(-x_i)  (-inf... the reference starts from
     -FLT_MAX; for ml>0 this is max(-x))."""
     return float(np.max(-x)) if x.size else -np.finfo(np.float64).max
+
+
+# --- second-order-cone ('q') blocks, one cone at a time (numpy vectors) ----------------
+def _jnrm2(x):
+    """misc.py:848-856: sqrt(x0 - |x1|) * sqrt(x0 + |x1|)."""
+    a = np.linalg.norm(x[1:])
+    return np.sqrt(x[0] - a) * np.sqrt(x[0] + a)
+
+
+def compute_scaling_q(s, z):
+    """misc.py:290-352 for one cone: returns v, beta, lmbda with (beta (2 v v' - J)) z = lmbda."""
+    aa, bb = _jnrm2(s), _jnrm2(z)
+    beta = np.sqrt(aa / bb)
+    cc = np.sqrt((np.dot(s, z) / aa / bb + 1.0) / 2.0)
+    v = -z / bb
+    v[0] *= -1.0
+    v += s / aa
+    v *= 1.0 / 2.0 / cc
+    v[0] += 1.0
+    v *= 1.0 / np.sqrt(2.0 * v[0])
+    lm = np.empty_like(s)
+    lm[0] = cc
+    dd = 2 * cc + s[0] / aa + z[0] / bb
+    lm[1:] = (cc + z[0] / bb) / dd / aa * s[1:] + (cc + s[0] / aa) / dd / bb * z[1:]
+    lm *= np.sqrt(aa * bb)
+    return v, float(beta), lm
+
+
+def scale_q(x, v, beta, inverse="N"):
+    """misc_solvers.c:144-186 for one cone and one column: x := beta (2 v v' - J) x, or its inverse (1/beta)(2 J v v' J - J) x."""
+    x = x.copy()
+    if inverse == "I":
+        x[0] *= -1.0
+    w = np.dot(v, x)
+    x[0] *= -1.0
+    x += 2.0 * w * v
+    if inverse == "I":
+        x[0] *= -1.0
+        return x / beta
+    return x * beta
+
+
+def sprod_q(x, y):
+    """misc_solvers.c:671-700 for one cone: (y o x)_0 = y'x, (y o x)_1 = y0 x1 + x0 y1."""
+    out = y[0] * x + x[0] * y
+    out[0] = np.dot(x, y)
+    return out
+
+
+def max_step_q(x):
+    """misc_solvers.c:1073-1085 for one cone: |x1| - x0."""
+    return float(np.linalg.norm(x[1:]) - x[0])
+
+
+# --- semidefinite ('s') blocks, one block at a time (m x m numpy matrices) --------------
+def compute_scaling_s(S, Z):
+    """misc.py:354-419 for one block: r, rti, lmbda with r' Z r = r^-1 S r^-T = diag(lmbda); lmbda = singular values of
+    Lz' Ls in descending order.  (The signs of the columns of r are those of numpy's SVD -- any choice is a valid scaling.)"""
+    Ls, Lz = np.linalg.cholesky(S), np.linalg.cholesky(Z)
+    U, lm, _ = np.linalg.svd(Lz.T @ Ls)
+    r = np.linalg.solve(Lz.T, U) * np.sqrt(lm)
+    rti = (Lz @ U) / np.sqrt(lm)
+    return r, rti, lm
+
+
+def update_scaling_s(r, rti, Ls, Lz):
+    """misc.py:582-634 for one block: returns the new r, rti, lmbda (Ls, Lz: the blocks of s and z on entry)."""
+    U, lm, Vt = np.linalg.svd(Lz.T @ Ls)
+    return (r @ Ls @ Vt.T) / np.sqrt(lm), (rti @ Lz @ U) / np.sqrt(lm), lm
+
+
+def scale_s(X, r, rti, trans="N", inverse="N"):
+    """misc_solvers.c:188-240 for one block and one column: the lower triangle of r' Xs r ('N','N'), r Xs r' ('T','N'),
+    rti Xs rti' ('N','I'), rti' Xs rti ('T','I') with Xs the symmetric matrix stored in the lower triangle of X; the strict
+    upper triangle of X is returned unchanged."""
+    Xs = np.tril(X) + np.tril(X, -1).T
+    R = r if inverse == "N" else rti
+    Y = (R @ Xs @ R.T) if (inverse == "N") == (trans == "T") else (R.T @ Xs @ R)
+    return np.tril(Y) + np.triu(X, 1)
+
+
+def scale2_s(lm, X, inverse="N"):
+    """misc_solvers.c:343-397 for one block: X(i, j) / (sqrt(l_i) sqrt(l_j)) ('N') or times it ('I'), every entry."""
+    c = np.outer(np.sqrt(lm), np.sqrt(lm))
+    return X / c if inverse == "N" else X * c
+
+
+def sprod_s(X, Y, diag="N"):
+    """misc_solvers.c:700-770 for one block: the lower triangle of (Y X + X Y) / 2 (X, Y symmetric from their lower triangles;
+    diag 'D': Y = diag(y)); the strict upper triangle of X unchanged."""
+    Xs = np.tril(X) + np.tril(X, -1).T
+    Ys = np.diag(Y) if diag == "D" else np.tril(Y) + np.tril(Y, -1).T
+    return np.tril(0.5 * (Ys @ Xs + Xs @ Ys)) + np.triu(X, 1)
+
+
+def sinv_s(X, y):
+    """misc_solvers.c:845-882 for one block: lower triangle of X divided entrywise by (y_i + y_j) / 2."""
+    c = 0.5 * (y[:, None] + y[None, :])
+    return np.tril(X / c) + np.triu(X, 1)
+
+
+def sdot_s(X, Y):
+    """misc_solvers.c:1029-1046 for one block: trace inner product of the symmetric matrices in the lower triangles."""
+    return float(np.sum(np.diag(X) * np.diag(Y)) + 2.0 * np.sum(np.tril(X, -1) * np.tril(Y, -1)))
+
+
+def max_step_s(X):
+    """misc_solvers.c:1086-1160 for one block: -lambda_min of the symmetric matrix in the lower triangle, and its eigenvalues
+    (ascending)."""
+    ev = np.linalg.eigvalsh(np.tril(X) + np.tril(X, -1).T)
+    return float(-ev[0]), ev
+
+
+def pack_s(X):
+    """misc_solvers.c:412-468 for one block: the lower triangle by columns, off-diagonal entries times sqrt(2) (the diagonal is
+    divided and multiplied by sqrt(2) as the reference does)."""
+    m = X.shape[0]
+    out = []
+    for k in range(m):
+        col = X[k:, k].copy()
+        col[0] /= np.sqrt(2.0)
+        out.append(col)
+    return np.concatenate(out) * np.sqrt(2.0)
 
 
 class OracleKLU:

@@ -200,3 +200,84 @@ def test_cpu_conelp_restatement_reproduces_the_reference_traces(golden_dir):
     sol = lp_oracle.conelp_l(np.array([-1.0, 0.5]), 2, 2, Gp, Gi, Gx, np.array([0.0, 0.0]))
     assert sol["status"] == "dual infeasible" and sol["iterations"] == meta["dual_infeasible"]["iterations"]
     assert np.allclose(sol["x"], meta["dual_infeasible"]["x"], rtol=1e-9)
+
+
+def _blocks(vec, off, dims):
+    out, o = [], off
+    for m in dims:
+        out.append(vec[o:o + m * m].reshape((m, m), order="F"))
+        o += m * m
+    return out
+
+
+def test_cone_block_restatements_against_the_reference_goldens():
+    """oracle/kvx_oracle.py restates the 'q' and 's' parts of the Nesterov-Todd scaling (misc.py:290-419, 582-634;
+    misc_solvers.c:144-240, 343-397, 671-770, 845-882, 1029-1160) in numpy; pinned here on the goldens G15 / G16 the reference
+    itself produced (values to 1e-12; the singular vectors of an 's' block up to the sign of each column, so r and rti are
+    compared through r r', rti rti' and through scale() with the reference's own r)."""
+    import os
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    from oracle import kvx_oracle as orc
+    rel = lambda a, b: np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(np.asarray(b))), 1e-300)
+    # --- 'q' (G15): dims = {'l': 4, 'q': [5, 1, 9]}
+    g = np.load(os.path.join(gd, "g15_q_cone_scaling.npz"))
+    for tag, k in (("a", 0), ("b", 3)):
+        ind, iv = k + 4, 0
+        for m in (5, 1, 9):
+            v, beta, lm = orc.compute_scaling_q(g[tag + "_s"][ind:ind + m].copy(), g[tag + "_z"][ind:ind + m].copy())
+            assert rel(v, g[tag + "_v"][iv:iv + m]) < 1e-12 and rel(lm, g[tag + "_lmbda"][ind:ind + m]) < 1e-12
+            bidx = [5, 1, 9].index(m)
+            assert abs(beta - g[tag + "_beta"][bidx]) < 1e-12 * beta
+            for inv in "NI":
+                for c in range(2):
+                    got = orc.scale_q(g[tag + "_X"][ind:ind + m, c], v, beta, inv)
+                    assert rel(got, g["%s_scale_N%s" % (tag, inv)][ind:ind + m, c]) < 1e-12
+            assert rel(orc.sprod_q(g[tag + "_x1"][ind:ind + m], g[tag + "_y1"][ind:ind + m]), g[tag + "_sprod"][ind:ind + m]) < 1e-12
+            ind += m
+            iv += m
+    # --- 's' (G16): dims = {'l': 3, 'q': [4], 's': [3, 1, 6]}
+    g = np.load(os.path.join(gd, "g16_s_cone_scaling.npz"))
+    sd = [3, 1, 6]
+    for tag, k in (("a", 0), ("b", 2)):
+        nlq = k + 3 + 4
+        Sb, Zb = _blocks(g[tag + "_s"], nlq, sd), _blocks(g[tag + "_z"], nlq, sd)
+        Rb, Tb = _blocks(g[tag + "_r"], 0, sd), _blocks(g[tag + "_rti"], 0, sd)
+        X1, Y1 = _blocks(g[tag + "_x1"], nlq, sd), _blocks(g[tag + "_y1"], nlq, sd)
+        il, sdot, tmax = nlq, float(np.dot(g[tag + "_x1"][:nlq], g[tag + "_y1"][:nlq])), -np.inf
+        for i, m in enumerate(sd):
+            r, rti, lm = orc.compute_scaling_s(Sb[i], Zb[i])
+            assert rel(lm, g[tag + "_lmbda"][il:il + m]) < 1e-12
+            assert rel(r @ r.T, Rb[i] @ Rb[i].T) < 1e-11 and rel(rti @ rti.T, Tb[i] @ Tb[i].T) < 1e-11
+            for tr in "NT":
+                for inv in "NI":
+                    for c in range(2):
+                        Xc = _blocks(g[tag + "_X"][:, c], nlq, sd)[i]
+                        want = _blocks(g["%s_scale_%s%s" % (tag, tr, inv)][:, c], nlq, sd)[i]
+                        assert rel(orc.scale_s(Xc, Rb[i], Tb[i], tr, inv), want) < 1e-12, (tr, inv)
+            lmk = g[tag + "_lmbda"][il:il + m]
+            assert rel(orc.scale2_s(lmk, X1[i], "N"), _blocks(g[tag + "_scale2_N"], nlq, sd)[i]) < 1e-12
+            assert rel(orc.scale2_s(lmk, X1[i], "I"), _blocks(g[tag + "_scale2_I"], nlq, sd)[i]) < 1e-12
+            assert rel(orc.sprod_s(X1[i], Y1[i]), _blocks(g[tag + "_sprod"], nlq, sd)[i]) < 1e-12
+            yd = g[tag + "_yd"][il:il + m]
+            assert rel(orc.sprod_s(X1[i], yd, "D"), _blocks(g[tag + "_sprod_D"], nlq, sd)[i]) < 1e-12
+            assert rel(orc.sinv_s(X1[i], yd), _blocks(g[tag + "_sinv"], nlq, sd)[i]) < 1e-12
+            sdot += orc.sdot_s(X1[i], Y1[i])
+            t, ev = orc.max_step_s(X1[i])
+            tmax = max(tmax, t)
+            assert rel(ev, g[tag + "_max_step_sigma"][il - nlq:il - nlq + m]) < 1e-12
+            il += m
+        assert abs(sdot - float(g[tag + "_sdot"])) < 1e-12 * abs(sdot)
+        x1 = g[tag + "_x1"]
+        tq = orc.max_step_q(x1[k + 3:k + 7])
+        assert abs(max(tmax, tq, float(np.max(-x1[:k + 3]))) - float(g[tag + "_max_step"])) < 1e-12
+        packed = np.concatenate([orc.pack_s(B) for B in X1])
+        assert np.array_equal(packed, g[tag + "_pack"][2 + nlq:2 + nlq + packed.size])
+        # update_scaling: lambda and the new scaling point through r r', rti rti'
+        Ls, Lz = _blocks(g[tag + "_us_s_in"], nlq, sd), _blocks(g[tag + "_us_z_in"], nlq, sd)
+        Rn, Tn = _blocks(g[tag + "_us_r"], 0, sd), _blocks(g[tag + "_us_rti"], 0, sd)
+        il = nlq
+        for i, m in enumerate(sd):
+            r2, t2, lm2 = orc.update_scaling_s(Rb[i], Tb[i], Ls[i], Lz[i])
+            assert rel(lm2, g[tag + "_us_lmbda"][il:il + m]) < 1e-12
+            assert rel(r2 @ r2.T, Rn[i] @ Rn[i].T) < 1e-11 and rel(t2 @ t2.T, Tn[i] @ Tn[i].T) < 1e-11
+            il += m
