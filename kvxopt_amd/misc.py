@@ -24,6 +24,8 @@ class _SBlocks:
 
     def __init__(self, sdims):
         self.dims = [int(m) for m in sdims]
+        if any(m < 0 or m > 4096 for m in self.dims):
+            raise ValueError("semidefinite blocks must have an order between 0 and 4096 (one workgroup per block)")
         self.ns = len(self.dims)
         d = np.asarray(self.dims, dtype=np.int64)
         self.off2, self.off1, self.offp = (np.zeros(self.ns + 1, dtype=np.int64) for _ in range(3))
