@@ -192,14 +192,23 @@ def ipm_leg(args, torch):
     Pl = workloads.lp_grid(250, 200)
     ml, nl = Pl["ml"], Pl["n"]
     Gl = spmatrix.from_ccs(ml, nl, Pl["Gp"], Pl["Gi"], Pl["Gx"])
-    kvx_lp.conelp(Pl["c"], Gl, Pl["h"], options={"maxiters": 2})
+    kvx_lp.conelp(Pl["c"], Gl, Pl["h"], options={"maxiters": 2})       # code objects, pools
+    kvx_lp.clear_cache()
+    t00 = time.perf_counter()
+    s0 = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])                           # a NEW constraint structure: analysis, set-up, graph capture
+    t0c = time.perf_counter() - t00
     tl0 = time.perf_counter()
-    sl = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])
+    sl = kvx_lp.conelp(Pl["c"], Gl, Pl["h"])                           # the same structure again: KKT objects kept (lp._kkt_for)
     tl = time.perf_counter() - tl0
     ipm = {"metric": "IPM iterations/s", "value": sl["iterations"] / sl["loop seconds"], "unit": "iterations/s",
            "workload": "conelp, grid LP 250x200: ml=200000 inequalities, n=50000 (BASELINE configs[3], inequality form)",
+           "measured": "interior-point loop (coneprog.py:859-1436 equivalent) of a call on a constraint structure seen before -- the "
+                       "steady state of a sequence of LPs on fixed patterns, as the headline step reuses its symbolic analysis; "
+                       "first_call = a new structure (analysis, device set-up and launch-graph capture inside the call)",
            "iterations": sl["iterations"], "status": sl["status"], "loop_s": sl["loop seconds"], "whole_call_s": tl,
-           "value_whole_call": sl["iterations"] / tl}
+           "value_whole_call": sl["iterations"] / tl,
+           "first_call": {"value": s0["iterations"] / s0["loop seconds"], "loop_s": s0["loop seconds"], "whole_call_s": t0c,
+                          "value_whole_call": s0["iterations"] / t0c, "iterations": s0["iterations"]}}
     # roofline of the assembly kernel: S = G' diag(w) G on the fixed pattern, launched back to back on the null stream
     L = _lib.lib()
     h = ctypes.c_void_p()

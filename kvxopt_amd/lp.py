@@ -13,8 +13,12 @@ libkvxhip.so.  No CPU fallback.
 Equality constraints (p > 0, K = A S^{-1} A') are device-resident too: KKTDiagEqDev (diagonal S, sparse K on a fixed
 pattern) and KKTGenEqDev (general S, dense K in HBM, any p).  `kvxopt_amd.misc.kkt_chol2` is built on the same classes.
 """
+import collections
 import ctypes
+import hashlib
+import json
 import math
+import os
 import time
 
 import numpy as np
@@ -191,6 +195,16 @@ class KKTChol2Dev:
             lib().kvx_atda_free(self._plan)
             self._plan = None
 
+    def reset(self, Gx, Px=None):
+        """New values of G (and H) on the patterns given at construction: the object -- product map, analysis of S, captured
+        launch graphs -- serves another problem of the same structure (see `_kkt_for`)."""
+        self.G.set_values(Gx)
+        if Px is not None:
+            self.set_hessian(Px)
+        self.di = None
+        self.nfactor = 0
+        self.async_solves = False
+
     def set_hessian(self, Px):
         """New values of H on the pattern given at construction (cvxprog: H changes at every iteration)."""
         if self.Px is not None and len(Px):
@@ -259,6 +273,7 @@ class KKTDiagEqDev:
         Ap = np.asarray(Ap, dtype=np.int64); Ai = np.asarray(Ai, dtype=np.int64); Ax = np.asarray(Ax, dtype=np.float64)
         cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
         order = np.lexsort((cols, Ai))
+        self._at_order = order
         ATi, ATx = cols[order], Ax[order]
         ATp = np.zeros(p + 1, dtype=np.int64)
         np.add.at(ATp, Ai + 1, 1)
@@ -294,6 +309,18 @@ class KKTDiagEqDev:
         if getattr(self, "_plan", None):
             lib().kvx_atda_free(self._plan)
             self._plan = None
+
+    def reset(self, Gx, Ax):
+        """New values of G and A on the patterns given at construction (see `_kkt_for`)."""
+        Gx = np.asarray(Gx, dtype=np.float64); Ax = np.asarray(Ax, dtype=np.float64)
+        self.G.set_values(Gx); self.G2.set_values(Gx ** 2)
+        self.A.set_values(Ax); self.A2.set_values(Ax ** 2)
+        if Ax.size:
+            self.ATx.set(Ax[self._at_order])
+        self.kscale = 1.0
+        self.di = None
+        self.nfactor = 0
+        self.async_solves = False
 
     def factor(self, di, sync=True):
         self.w.sqr_of(di)
@@ -375,6 +402,7 @@ class KKTGenEqDev:
         Ap = np.asarray(Ap, dtype=np.int64); Ai = np.asarray(Ai, dtype=np.int64); Ax = np.asarray(Ax, dtype=np.float64)
         cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(Ap))
         order = np.lexsort((cols, Ai))
+        self._at_order = order
         ATp = np.zeros(p + 1, dtype=np.int64)
         np.add.at(ATp, Ai + 1, 1)
         np.cumsum(ATp, out=ATp)
@@ -394,6 +422,17 @@ class KKTGenEqDev:
         self.di = None
         self.nfactor = 0
         self._async = False
+
+    def reset(self, Gx, Ax, Px=None):
+        """New values of G, A (and H) on the patterns given at construction (see `_kkt_for`)."""
+        Ax = np.asarray(Ax, dtype=np.float64)
+        self.S.reset(Gx, Px)
+        self.A.set_values(Ax)
+        self.AT.set_values(Ax[self._at_order])
+        self.kscale = 1.0
+        self.di = None
+        self.nfactor = 0
+        self.async_solves = False
 
     @property
     def async_solves(self):
@@ -452,6 +491,44 @@ class KKTGenEqDev:
         self.solve(xb, yb, zb)
 
 
+# The KKT objects of the last few constraint structures are kept: a sequence of cone programs on the same patterns of G, A (and
+# P) -- the usual way an interior-point solver is deployed: receding-horizon control, parameter sweeps, branch and bound -- pays
+# for the product map, the analysis of S (and K), the device set-up and the capture of the launch graphs once; only the values
+# are refreshed.  cholmod.linsolve / klu.linsolve keep their analyses the same way.  `clear_cache()` releases them.
+_KKT_CACHE = collections.OrderedDict()
+_KKT_CACHE_MAX = 4
+
+
+def clear_cache():
+    """Release the cached KKT objects (device memory, analyses, launch graphs)."""
+    _KKT_CACHE.clear()
+
+
+def _pattern_key(*arrays):
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        h.update(a.shape[0].to_bytes(8, "little"))
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def _kkt_for(kind, dims_key, patterns, chol_opts, build, refresh):
+    """The cached KKT object of this structure with its values refreshed, or a new one (build())."""
+    if os.environ.get("KVX_LP_NO_CACHE") == "1":
+        return build()
+    key = (kind, dims_key, _pattern_key(*patterns), json.dumps(chol_opts or {}, sort_keys=True))
+    kkt = _KKT_CACHE.pop(key, None)
+    if kkt is None:
+        kkt = build()
+    else:
+        refresh(kkt)
+    _KKT_CACHE[key] = kkt
+    while len(_KKT_CACHE) > _KKT_CACHE_MAX:
+        _KKT_CACHE.popitem(last=False)
+    return kkt
+
+
 def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, primalstart=None, dualstart=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
     (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints either G has at most one entry per
@@ -493,7 +570,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     if p > 0:
         Gi64 = np.asarray(Gi, dtype=np.int64)
         diag_s = not (Gi64.size and np.bincount(Gi64, minlength=ml).max() > 1)
-        kkt = (KKTDiagEqDev if diag_s else KKTGenEqDev)(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts)
+        cls = KKTDiagEqDev if diag_s else KKTGenEqDev
+        kkt = _kkt_for(cls.__name__, (ml, n, p), (Gp, Gi, Ap, Ai), chol_opts,
+                       lambda: cls(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts), lambda k: k.reset(Gx, Ax))
         Ad = kkt.A
         bv = DVec(p, b_h)
         y, dy, y1, ry, hry = (DVec(p) for _ in range(5))
@@ -502,7 +581,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
     else:
-        kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts)
+        kkt = _kkt_for("KKTChol2Dev", (ml, n, 0), (Gp, Gi), chol_opts,
+                       lambda: KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts), lambda k: k.reset(Gx))
         bv = y = dy = y1 = ry = hry = _NoY()
         def ksolve(xx, yy, zz):
             kkt.solve(xx, zz)
@@ -802,7 +882,8 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         if b_h.size != p:
             raise TypeError("'b' must have length %d" % p)
     if p > 0:
-        kkt = KKTGenEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts, Pp, Pi, Px)
+        kkt = _kkt_for("KKTGenEqDev+P", (ml, n, p), (Gp, Gi, Ap, Ai, Pp, Pi), chol_opts,
+                       lambda: KKTGenEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts, Pp, Pi, Px), lambda k: k.reset(Gx, Ax, Px))
         Ad = kkt.A
         bv = DVec(p, b_h)
         y, dy, ry = DVec(p), DVec(p), DVec(p)
@@ -811,7 +892,8 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         resy0 = max(1.0, bv.nrm2())
         ksolve = kkt.solve
     else:
-        kkt = KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px)
+        kkt = _kkt_for("KKTChol2Dev+P", (ml, n, 0), (Gp, Gi, Pp, Pi), chol_opts,
+                       lambda: KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px), lambda k: k.reset(Gx, Px))
         y = dy = ry = wy = wy2 = None
         resy0 = 1.0
         def ksolve(xx, yy, zz):

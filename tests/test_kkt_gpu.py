@@ -996,3 +996,37 @@ def test_s_cone_scaling_with_repeated_singular_values():
     assert rel(np.sort(lm._a), np.sort(2.0 * np.linalg.eigvalsh(Z))) < 1e-12
     t = misc.max_step(matrix(np.zeros(m * m)), dims)                 # the zero matrix: every eigenvalue 0
     assert t == 0.0
+
+
+@pytest.mark.gpu
+def test_conelp_reuses_kkt_objects_of_a_known_structure(monkeypatch):
+    """lp.conelp / lp.coneqp keep the KKT device objects of the last constraint structures (lp._kkt_for): a second problem on
+    the same patterns of G (and A, P) with OTHER values must be solved exactly as by a fresh object -- bit for bit, the runs
+    being reproducible -- with or without equality rows, and clear_cache() must forget everything."""
+    for build in (lambda: workloads.lp_grid(30, 24), lambda: workloads.lp_grid_eq(30, 24, 5)):
+        P1 = build()
+        # the second problem: the rows of G x <= h scaled by a positive diagonal (same patterns, other values, still feasible)
+        P2 = dict(P1)
+        dscale = np.random.default_rng(12).uniform(0.5, 2.0, P1["ml"])
+        P2["Gx"] = P1["Gx"] * dscale[P1["Gi"]]
+        P2["h"] = P1["h"] * dscale
+        assert not np.array_equal(P1["Gx"], P2["Gx"])
+        def run(P):
+            G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+            if "p" in P and P["p"]:
+                A = spmatrix.from_ccs(P["p"], P["n"], P["Ap"], P["Ai"], P["Ax"])
+                return lp.conelp(P["c"], G, P["h"], A=A, b=P["b"])
+            return lp.conelp(P["c"], G, P["h"])
+        lp.clear_cache()
+        run(P1)
+        assert len(lp._KKT_CACHE) == 1
+        warm = run(P2)                                   # cached structure, refreshed values
+        assert len(lp._KKT_CACHE) == 1
+        monkeypatch.setenv("KVX_LP_NO_CACHE", "1")
+        cold = run(P2)
+        monkeypatch.delenv("KVX_LP_NO_CACHE")
+        assert warm["status"] == cold["status"] == "optimal" and warm["iterations"] == cold["iterations"]
+        for key in ("x", "s", "z"):
+            assert np.array_equal(np.asarray(warm[key]), np.asarray(cold[key])), key
+    lp.clear_cache()
+    assert len(lp._KKT_CACHE) == 0
