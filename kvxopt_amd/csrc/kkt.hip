@@ -241,7 +241,56 @@ void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, dou
     hipLaunchKernelGGL(k_reduce1<true>, dim3(RED_BLOCKS), dim3(256), 0, st, n, x, x, part);
     hipLaunchKernelGGL(k_reduce2<true>, dim3(1), dim3(64), 0, st, RED_BLOCKS, part, out);
 }
-int reduce_scratch_doubles() { return RED_BLOCKS + 1; }
+// Several reductions in two launches (kvx_nt_reduce_multi_dev: the residual norms and objectives of an interior-point iteration):
+// blockIdx.y = reduction; per reduction the same chunking and summation order as k_reduce1 / k_reduce2, so the values are the
+// single launches' bit for bit.
+__global__ __launch_bounds__(256) void k_reduce1_multi(MultiRed mr, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    const int r = blockIdx.y;
+    const bool mx = mr.kind[r] != 0;
+    const int64_t n = mr.n[r];
+    const double *x = mr.x[r], *y = mr.y[r];
+    double acc = mx ? -1.7976931348623157e308 : 0.0;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t b0 = per * blockIdx.x, b1 = min(n, b0 + per);
+    if (mx) {
+        for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) acc = fmax(acc, -x[i]);
+        acc = wave_red<true>(acc);
+    } else {
+        for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) acc += x[i] * y[i];
+        acc = wave_red<false>(acc);
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+        for (int w = 1; w < 4; w++) t = mx ? fmax(t, sh[w]) : t + sh[w];
+        part[(int64_t)r * RED_BLOCKS + blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(64) void k_reduce2_multi(MultiRed mr, const double *__restrict__ part, double *__restrict__ out)
+{
+    const int r = blockIdx.x;
+    const bool mx = mr.kind[r] != 0;
+    const double *pr = part + (int64_t)r * RED_BLOCKS;
+    double acc = mx ? -1.7976931348623157e308 : 0.0;
+    if (mx) {
+        for (int i = threadIdx.x; i < RED_BLOCKS; i += 64) acc = fmax(acc, pr[i]);
+        acc = wave_red<true>(acc);
+    } else {
+        for (int i = threadIdx.x; i < RED_BLOCKS; i += 64) acc = acc + pr[i];
+        acc = wave_red<false>(acc);
+    }
+    if (threadIdx.x == 0) out[r] = acc;
+}
+void launch_reduce_multi(hipStream_t st, const MultiRed &mr, double *part, double *out)
+{
+    if (mr.count <= 0) return;
+    hipLaunchKernelGGL(k_reduce1_multi, dim3(RED_BLOCKS, (unsigned)mr.count), dim3(256), 0, st, mr, part);
+    hipLaunchKernelGGL(k_reduce2_multi, dim3((unsigned)mr.count), dim3(64), 0, st, mr, part, out);
+}
+int reduce_scratch_doubles() { return 32 * RED_BLOCKS + 1; }
 
 // ---- S = G' diag(w) G (+ P) on a fixed pattern ----------------------------------------------------
 // One thread per stored S entry e: sum over its product list [pp[e], pp[e+1]) of

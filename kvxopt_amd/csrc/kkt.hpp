@@ -4,6 +4,15 @@
 #include <cstdint>
 
 namespace kvx {
+// up to 32 reductions in two launches: kind 0 = dot(x, y), 1 = max(-x)
+struct MultiRed {
+    int count;
+    int kind[32];
+    int64_t n[32];
+    const double *x[32];
+    const double *y[32];
+};
+void launch_reduce_multi(hipStream_t st, const MultiRed &mr, double *part, double *out);
 void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const double *z, double *d, double *di, double *lm);
 void launch_update_scaling(hipStream_t st, int64_t n, double *s, double *z, double *d, double *di, double *lm);
 void launch_lp_newton_rhs(hipStream_t st, int64_t n, const double *lsq, const double *ws3, double shift, double scale,

@@ -306,16 +306,18 @@ int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, co
     int rc = ensure_scratch();
     if (rc) return rc;
     Scratch &s = scratch();
+    MultiRed mr;
+    mr.count = count;
+    for (int i = 0; i < 32; i++) { mr.kind[i] = 0; mr.n[i] = 0; mr.x[i] = nullptr; mr.y[i] = nullptr; }
     for (int i = 0; i < count; i++) {
-        if (kind[i] == 0) {
-            if (!y) return KVX_EINVAL;
-            launch_dot(nullptr, n[i], x[i], y[i], s.part, s.multi + i);
-        } else if (kind[i] == 1) {
-            launch_maxneg(nullptr, n[i], x[i], s.part, s.multi + i);
-        } else {
-            return KVX_EINVAL;
-        }
+        if (kind[i] != 0 && kind[i] != 1) return KVX_EINVAL;
+        if (kind[i] == 0 && (!y || !y[i])) return KVX_EINVAL;
+        mr.kind[i] = kind[i];
+        mr.n[i] = n[i];
+        mr.x[i] = x[i];
+        mr.y[i] = kind[i] == 0 ? y[i] : x[i];
     }
+    launch_reduce_multi(nullptr, mr, s.part, s.multi);              // all of them in two launches
     HIPCHK(hipMemcpy(s.host, s.multi, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < count; i++) out_host[i] = s.host[i];
     return KVX_OK;
