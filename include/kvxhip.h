@@ -247,7 +247,9 @@ int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, co
 
 /* ---- BLAS-1 glue on device vectors: replaces the blas.axpy / scal / copy calls and elementwise
  * products the interior-point loop makes between KKT solves (coneprog.py:1126-1433). ------------- */
-int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y);     /* y += alpha x        */
+int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y);
+/* z := a x + b y in one pass (blas.copy + blas.axpy / blas.scal pairs of coneprog.py:861-896, 1295-1298); b == 0: z := a x */
+int kvx_vec_lincomb_dev(int64_t n, double a, const double *x_dev, double b, const double *y_dev, double *z_dev);     /* y += alpha x        */
 int kvx_vec_scal_dev(int64_t n, double alpha, double *x);                       /* x *= alpha          */
 int kvx_vec_addc_dev(int64_t n, double c, double *x);                           /* x += c              */
 int kvx_vec_fill_dev(int64_t n, double c, double *x);                           /* x := c              */

@@ -162,6 +162,11 @@ __global__ void k_fill(int64_t n, double c, double *__restrict__ x) { GS_LOOP(i,
 // z := a * (x .* y) + b * z
 __global__ void k_xmy(int64_t n, double a, const double *__restrict__ x, const double *__restrict__ y, double b, double *__restrict__ z)
 { GS_LOOP(i, n) z[i] = a * (x[i] * y[i]) + (b == 0.0 ? 0.0 : b * z[i]); }
+// z := a * x + b * y (b == 0: z := a * x, y is not read); z may be x or y
+__global__ void k_lincomb(int64_t n, double a, const double *x, double b, const double *y, double *z)
+{ GS_LOOP(i, n) z[i] = (b == 0.0) ? a * x[i] : __builtin_fma(b, y[i], a * x[i]); }
+void launch_lincomb(hipStream_t st, int64_t n, double a, const double *x, double b, const double *y, double *z)
+{ if (n > 0) hipLaunchKernelGGL(k_lincomb, dim3(grid_for(n)), dim3(256), 0, st, n, a, x, b, y, z); }
 void launch_axpy(hipStream_t st, int64_t n, double alpha, const double *x, double *y)
 { if (n > 0) hipLaunchKernelGGL(k_axpy, dim3(grid_for(n)), dim3(256), 0, st, n, alpha, x, y); }
 void launch_vscal(hipStream_t st, int64_t n, double alpha, double *x)

@@ -355,6 +355,8 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
 // ---- BLAS-1 glue of the interior-point loop on device vectors (blas.axpy/scal/copy/dot calls of coneprog.py) ----
 int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y)
 { launch_axpy(nullptr, n, alpha, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_vec_lincomb_dev(int64_t n, double a, const double *x, double b, const double *y, double *z)
+{ launch_lincomb(nullptr, n, a, x, b, y, z); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_vec_scal_dev(int64_t n, double alpha, double *x)
 { launch_vscal(nullptr, n, alpha, x); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_vec_addc_dev(int64_t n, double c, double *x)

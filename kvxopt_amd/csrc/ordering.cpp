@@ -312,7 +312,7 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
     // Host threads: subdomains are independent once their separator is numbered.  Tasks of at least `cutoff` vertices go
     // through a shared pool (their two halves become new pool tasks); smaller ones are finished depth-first by whoever takes
     // them.  The result does not depend on the thread count (see NDState).  KVX_ND_THREADS = 1 runs the whole tree in place.
-    int nthreads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    int nthreads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("KVX_ND_THREADS")) nthreads = std::max(1, std::min(64, atoi(e)));
     const int64_t cutoff = 8192;
     if (n < 4 * cutoff) nthreads = 1;

@@ -12,7 +12,7 @@ namespace kvx {
 
 inline int analyze_threads()
 {
-    int t = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    int t = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("KVX_ANALYZE_THREADS")) t = std::max(1, std::min(64, atoi(e)));
     return t;
 }

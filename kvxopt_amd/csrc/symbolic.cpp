@@ -87,6 +87,27 @@ void etree_from_lower(int64_t n, const LowerPattern &Lo, std::vector<int32_t> &p
         }
 }
 
+// The same tree from the full symmetric adjacency (original labels) and the permutation: no permuted pattern is formed.
+void etree_from_adjacency(int64_t n, const std::vector<int64_t> &aptr, const std::vector<int32_t> &adj,
+                          const std::vector<int64_t> &perm, const std::vector<int64_t> &iperm, std::vector<int32_t> &parent)
+{
+    parent.assign((size_t)n, -1);
+    std::vector<int32_t> anc((size_t)n, -1), ip32((size_t)n);
+    for (int64_t v = 0; v < n; v++) ip32[(size_t)v] = (int32_t)iperm[(size_t)v];
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t v = perm[(size_t)k];
+        for (int64_t p = aptr[(size_t)v]; p < aptr[(size_t)v + 1]; p++) {
+            int32_t i = ip32[(size_t)adj[(size_t)p]];
+            while (i != -1 && i < k) {
+                const int32_t nxt = anc[i];
+                anc[i] = (int32_t)k;
+                if (nxt == -1) parent[i] = (int32_t)k;
+                i = nxt;
+            }
+        }
+    }
+}
+
 // Postorder of a forest given by parent[] (parent[j] > j or -1).  Children are visited
 // in increasing subtree size so that the heaviest child ends adjacent to its parent
 // (it is the amalgamation candidate).
@@ -210,6 +231,8 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
     // ---- 1. initial permutation: candidates (user's, nested dissection, minimum degree), the least fill wins ----------
     std::vector<std::vector<int64_t>> cand;
     std::vector<const char *> cand_name;
+    std::vector<int64_t> aptr;             // full symmetric adjacency (built when an ordering is computed here; phase 2 reuses it)
+    std::vector<int32_t> adj;
     if (user_perm) {
         std::vector<int64_t> pu((size_t)n);
         std::vector<char> seen((size_t)n, 0);
@@ -226,7 +249,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             if (!user_perm) { cand.emplace_back((size_t)n); std::iota(cand.back().begin(), cand.back().end(), 0); cand_name.push_back("natural"); }
         } else if (n > 0) {
             // full symmetric adjacency of the analysed triangle
-            std::vector<int64_t> aptr((size_t)n + 1, 0);
+            aptr.assign((size_t)n + 1, 0);
             for (int64_t j = 0; j < n; j++)
                 for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
                     int64_t i = Ai[p];
@@ -235,7 +258,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
                     aptr[j + 1]++;
                 }
             for (int64_t j = 0; j < n; j++) aptr[j + 1] += aptr[j];
-            std::vector<int32_t> adj((size_t)aptr[n]);
+            adj.resize((size_t)aptr[n]);
             std::vector<int64_t> cur(aptr.begin(), aptr.end() - 1);
             for (int64_t j = 0; j < n; j++)
                 for (int64_t p = Ap[j]; p < Ap[j + 1]; p++) {
@@ -343,26 +366,20 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
     // ---- 2. etree + postorder, fold the postorder into the permutation ---------------------
     LowerPattern Lo;
     std::vector<int32_t> parent;
-    build_lower(n, Ap, Ai, uplo, iperm0, Lo);
-    etree_from_lower(n, Lo, parent);
-    bool need_post = false;
-    {
-        // a tree is already postordered when every subtree is a contiguous index range
-        std::vector<int64_t> size((size_t)n, 1);
-        for (int64_t j = 0; j < n; j++)
-            if (parent[j] >= 0) size[parent[j]] += size[j];
-        // children of p must tile [p - size[p] + 1, p - 1]; check via first-descendant
-        std::vector<int64_t> fd((size_t)n);
-        for (int64_t j = 0; j < n; j++) fd[j] = j;
-        for (int64_t j = 0; j < n; j++)
-            if (parent[j] >= 0) fd[parent[j]] = std::min(fd[parent[j]], fd[j]);
-        for (int64_t j = 0; j < n && !need_post; j++) need_post = (fd[j] != j - size[j] + 1);
+    bool lower_built = false;
+    if (!adj.empty() || (n > 0 && !aptr.empty() && aptr[n] == 0)) {
+        // the adjacency of the ordering phase is at hand: Liu's algorithm straight from it (row k of the permuted matrix = the
+        // neighbours of perm0[k] that come earlier), no permuted pattern and no row lists for this pass
+        etree_from_adjacency(n, aptr, adj, perm0, iperm0, parent);
+    } else {
+        build_lower(n, Ap, Ai, uplo, iperm0, Lo);
+        etree_from_lower(n, Lo, parent);
+        lower_built = true;
     }
     S.perm = perm0;
     S.iperm = iperm0;
     // Supernodes need contiguous subtrees, so the postorder is always applied (CHOLMOD's
     // supernodal analysis does the same whatever options['postorder'] says).
-    (void)need_post;
     {
         std::vector<int32_t> post;
         postorder(n, parent, post);
@@ -377,8 +394,11 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
             for (int64_t k = 0; k < n; k++) np[k] = parent[post[k]] >= 0 ? ipost[parent[post[k]]] : -1;
             parent.swap(np);
+            lower_built = true;
         }
     }
+    if (!lower_built) build_lower(n, Ap, Ai, uplo, S.iperm, Lo);
+    { std::vector<int64_t>().swap(aptr); std::vector<int32_t>().swap(adj); }
 
     pt.lap("2 etree+postorder");
     // ---- 3. column counts ---------------------------------------------------------------

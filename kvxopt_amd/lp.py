@@ -60,6 +60,10 @@ class DVec:
     def axpy(self, x, alpha=1.0):                       # self += alpha * x
         raise_for(lib().kvx_vec_axpy_dev(self.n, float(alpha), x.ptr, self.ptr)); return self
 
+    def lincomb(self, a, x, b=0.0, y=None):             # self := a * x + b * y (one pass; copy + axpy / copy + scal)
+        raise_for(lib().kvx_vec_lincomb_dev(self.n, float(a), x.ptr, float(b) if y is not None else 0.0,
+                                            (y if y is not None else x).ptr, self.ptr)); return self
+
     def scal(self, alpha):
         raise_for(lib().kvx_vec_scal_dev(self.n, float(alpha), self.ptr)); return self
 
@@ -684,11 +688,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         # residuals (coneprog.py:861-896); their norms and the objectives come back in one reduction call
         Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
         Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=1.0)
-        rx.copy_from(hrx).axpy(cv, -tau)
+        rx.lincomb(1.0, hrx, -tau, cv)
         Af(x, hry, trans="N")
-        ry.copy_from(hry).axpy(bv, -tau)
+        ry.lincomb(1.0, hry, -tau, bv)
         Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
-        rz.copy_from(hrz).axpy(hv, -tau)
+        rz.lincomb(1.0, hrz, -tau, hv)
         (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = reduce_multi(
             [("dot", hrx, hrx), ("dot", rx, rx), ("dot", hry, hry), ("dot", ry, ry), ("dot", hrz, hrz), ("dot", rz, rz),
              ("dot", cv, x), ("dot", bv, y), ("dot", hv, z), ("dot", lmbda, lmbda)])
@@ -746,8 +750,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             # ds := -(lmbdasq (+ ws3 - sigma mu)) o\ lmbda,  dz := -((1 - sigma) rz + W' ds): one fused kernel
             raise_for(lib().kvx_lp_newton_rhs_dev(ml, lmbdasq.ptr, ws3.ptr if i == 1 else None, sigma * mu if i == 1 else 0.0,
                                                   1.0 - sigma, rz.ptr, lmbda.ptr, d.ptr, ds.ptr, dz.ptr))
-            dx.copy_from(rx).scal(1.0 - sigma)
-            dy.copy_from(ry).scal(-(1.0 - sigma))
+            dx.lincomb(1.0 - sigma, rx)
+            dy.lincomb(-(1.0 - sigma), ry)
             st8["dtau"] = (1.0 - sigma) * rt
             st8["dkappa"] = dkappa
 
@@ -755,7 +759,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         # one two-column triangular solve with the new factor
         try:
             kkt.factor(di, sync=False)                   # a failed factorisation surfaces in the solve right below
-            x1.copy_from(cv).scal(-1.0)
+            x1.lincomb(-1.0, cv)
             y1.copy_from(bv)
             z1.copy_from(hv)
             newton_rhs(0)
@@ -985,7 +989,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         Gd.gemv(ux, vz, trans="N", alpha=-1.0, beta=1.0)
         tmp.xmy(1.0, us, d)
         vz.axpy(tmp, -1.0)
-        tmp.copy_from(us).axpy(uz)
+        tmp.lincomb(1.0, us, 1.0, uz)
         tmp.mul(lmbda)
         vs.axpy(tmp, -1.0)
 
@@ -1015,7 +1019,7 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
             ry.copy_from(bv)
             Ad.gemv(x, ry, trans="N", alpha=1.0, beta=-1.0)      # ry = A x - b
         Gd.gemv(z, rx, trans="T", alpha=1.0, beta=1.0)
-        rz.copy_from(s).axpy(hv, -1.0)
+        rz.lincomb(1.0, s, -1.0, hv)
         Gd.gemv(x, rz, trans="N", alpha=1.0, beta=1.0)
         xPq, xq, v_rx, v_rz, zrz, v_ry, yry = reduce_multi([("dot", x, tmpx), ("dot", x, qv), ("dot", rx, rx), ("dot", rz, rz),
                                                              ("dot", z, rz), ("dot", ry, ry), ("dot", y, ry)])
@@ -1056,10 +1060,10 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
             if correction and i == 1:
                 ds.axpy(ws3, -1.0)
             ds.axpy(lmbdasq, -1.0).addc(sigma * mu)
-            dx.copy_from(rx).scal(-1.0 + eta)
+            dx.lincomb(-1.0 + eta, rx)
             if p:
-                dy.copy_from(ry).scal(-1.0 + eta)
-            dz.copy_from(rz).scal(-1.0 + eta)
+                dy.lincomb(-1.0 + eta, ry)
+            dz.lincomb(-1.0 + eta, rz)
             f4(dx, dy, dz, ds)
             dsdz = ds.dot(dz)
             if correction and i == 0:
