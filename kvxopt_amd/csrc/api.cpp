@@ -336,6 +336,7 @@ int ensure_device(kvx_chol *F)
     { const char *e = getenv("KVX_NO_SUBTREES"); F->use_subtrees = !(e && e[0] == '1'); }
     if ((rc = build_subtrees(F))) return rc;
     { const char *e = getenv("KVX_NO_GRAPH"); F->use_graph = !(e && e[0] == '1'); }
+    { const char *e = getenv("KVX_WIDE_FROM"); if (e) F->wide_from = std::max(0, atoi(e)); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
     { const char *e = getenv("KVX_LOOKAHEAD"); F->lookahead = e && e[0] == '1'; }
@@ -701,6 +702,103 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int l
     }
 }
 
+// ---- many right-hand sides: rhs-major blocks of 64 (kernels_wide.hip) ---------------------------------------------------------
+// The inverse of the relative indices: for every row of every front, the rows of its children's update vectors that are added to
+// it, children in list order (the order the single-rhs kernels add them in).  Host pass over the tree, once per analysis.
+int ensure_wide(kvx_chol *F)
+{
+    if (F->wide_state != 0) return KVX_OK;
+    Symbolic &S = F->S;
+    F->wide_state = -1;
+    if (F->dist_nranks != 1 || S.sum_m >= INT32_MAX - 1 || (int64_t)S.rel.size() >= INT32_MAX) return KVX_OK;
+    if (std::max(S.wrk_size[0], S.wrk_size[1]) >= INT32_MAX) return KVX_OK;
+    const int64_t nrow = S.rowptr[S.nsuper];
+    std::vector<int32_t> ptr((size_t)nrow + 1, 0);
+    for (int64_t s = 0; s < S.nsuper; s++)
+        for (int64_t ci = S.childptr[s]; ci < S.childptr[s + 1]; ci++) {
+            const int32_t c = S.children[ci];
+            const int64_t kc = S.sn_k[c], uc = S.sn_m[c] - kc;
+            const int32_t *rel = S.rel.data() + S.rowptr[c] + kc;
+            for (int64_t i = 0; i < uc; i++) ptr[(size_t)(S.rowptr[s] + rel[i]) + 1]++;
+        }
+    for (int64_t r = 0; r < nrow; r++) ptr[(size_t)r + 1] += ptr[(size_t)r];
+    std::vector<int32_t> src((size_t)std::max<int64_t>(ptr[(size_t)nrow], 1), 0);
+    {
+        std::vector<int32_t> cur(ptr.begin(), ptr.end() - 1);
+        for (int64_t s = 0; s < S.nsuper; s++)
+            for (int64_t ci = S.childptr[s]; ci < S.childptr[s + 1]; ci++) {
+                const int32_t c = S.children[ci];
+                const int64_t kc = S.sn_k[c], uc = S.sn_m[c] - kc;
+                const int32_t *rel = S.rel.data() + S.rowptr[c] + kc;
+                for (int64_t i = 0; i < uc; i++) src[(size_t)cur[(size_t)(S.rowptr[s] + rel[i])]++] = (int32_t)(S.wx[c] + i);
+            }
+    }
+    int rc;
+    if ((rc = upload(&F->d_inv_ptr, ptr))) return rc;
+    if ((rc = upload(&F->d_inv_src, src))) return rc;
+    F->wide_state = 1;
+    return KVX_OK;
+}
+
+// the small fronts of a level: the LDS classes (k <= 64) and the wave classes (k <= 32), each with the largest pivot count it holds
+static void small_lists(const LevelPlan &P, int64_t off[2], int cnt[2], int kmax[2])
+{
+    off[0] = P.soff[1]; cnt[0] = P.scnt[1]; kmax[0] = std::max(P.maxk[KVX_CLS_LDS128], P.maxk[KVX_CLS_LDS96]);
+    off[1] = P.soff[2]; cnt[1] = P.scnt[2]; kmax[1] = 0;
+    for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c++) kmax[1] = std::max(kmax[1], P.maxk[c]);
+}
+
+void enqueue_fwd_wide(kvx_chol *F, double *XT, int nchunk)
+{
+    Symbolic &S = F->S;
+    const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
+    for (int l = S.nlevels - 1; l >= 0; l--) {
+        const LevelPlan &P = F->plan[l];
+        const double *Wch = F->d_W[(l + 1) & 1];
+        double *Wout = F->d_W[l & 1];
+        int64_t off[2]; int cnt[2], kmax[2];
+        small_lists(P, off, cnt, kmax);
+        if (cnt[0] == 0 && cnt[1] == 0 && P.scnt[0] == 0) continue;
+        LevelStreams ls(F, P.scnt[0] > 0, cnt[0] > 0, cnt[1] > 0);
+        for (int g = 0; g < 2; g++)
+            if (cnt[g] > 0) {
+                hipStream_t sg = g == 0 ? ls.lds : ls.wave;
+                ProfScope ps(F, FAM_FWD, sg);
+                launch_wide_fwd_small(sg, F->ds, F->d_lists + off[g], cnt[g], kmax[g], nchunk, F->d_Lx, XT, S.n, Wch, Wout, wstride,
+                                      F->d_inv_ptr, F->d_inv_src);
+            }
+        if (P.scnt[0] > 0) {
+            ProfScope ps(F, FAM_FWD);
+            launch_wide_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, nchunk, F->d_Lx, F->d_Linv,
+                                XT, S.n, Wch, Wout, wstride, F->d_inv_ptr, F->d_inv_src);
+        }
+        ls.join();
+    }
+}
+
+void enqueue_bwd_wide(kvx_chol *F, double *XT, int nchunk)
+{
+    Symbolic &S = F->S;
+    for (int l = 0; l < S.nlevels; l++) {
+        const LevelPlan &P = F->plan[l];
+        int64_t off[2]; int cnt[2], kmax[2];
+        small_lists(P, off, cnt, kmax);
+        if (cnt[0] == 0 && cnt[1] == 0 && P.scnt[0] == 0) continue;
+        LevelStreams ls(F, P.scnt[0] > 0, cnt[0] > 0, cnt[1] > 0);
+        for (int g = 0; g < 2; g++)
+            if (cnt[g] > 0) {
+                hipStream_t sg = g == 0 ? ls.lds : ls.wave;
+                ProfScope ps(F, FAM_BWD, sg);
+                launch_wide_bwd_small(sg, F->ds, F->d_lists + off[g], cnt[g], kmax[g], nchunk, F->d_Lx, XT, S.n);
+            }
+        if (P.scnt[0] > 0) {
+            ProfScope ps(F, FAM_BWD);
+            launch_wide_bwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.big_maxk, nchunk, F->d_Lx, F->d_Linv, XT, S.n);
+        }
+        ls.join();
+    }
+}
+
 // B_dev: n x nrhs, leading dimension ldB, device memory.
 int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool async = false)
 {
@@ -729,12 +827,44 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
         F->diag_valid = true;
     }
     // wstride: both parity buffers are allocated with wrk_size[p]*x_cap; use a common stride
-    const int chunk_max = 65535;
+    // many right-hand sides of a plain LL' system: rhs-major blocks of 64 (kernels_wide.hip)
+    const int kind0 = (sys == 0 || sys == 1) ? 0 : ((sys == 2 || sys == 4) ? 1 : ((sys == 3 || sys == 5) ? 2 : -1));
+    bool wide = kind0 >= 0 && !ldl && F->wide_from > 0 && nrhs >= F->wide_from && F->prof_family < 0;
+    if (wide) {
+        if ((rc = ensure_wide(F))) return rc;
+        wide = F->wide_state == 1;
+    }
+    const int chunk_max = wide ? 1024 : 65535;
     for (int64_t r0 = 0; r0 < nrhs; r0 += chunk_max) {
         int nr = (int)std::min<int64_t>(chunk_max, nrhs - r0);
         double *Bc = B + r0 * ldB;
-        if ((rc = ensure_solve_ws(F, nr))) return rc;
+        if ((rc = ensure_solve_ws(F, wide ? (int64_t)((nr + 63) / 64) * 64 : nr))) return rc;
         HIPCHK(hipEventRecord(F->ev[2], st));
+        if (wide) {
+            const int nchunk = (nr + 63) / 64;
+            launch_wide_gather(st, sys == 0 ? F->d_perm : nullptr, n, nr, Bc, ldB, F->d_X);
+            auto body = [&]() -> int {
+                if (kind0 == 0 || kind0 == 1) enqueue_fwd_wide(F, F->d_X, nchunk);
+                if (kind0 == 0 || kind0 == 2) enqueue_bwd_wide(F, F->d_X, nchunk);
+                return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
+            };
+            hipGraphExec_t exec = nullptr;
+            if (F->use_graph) {
+                kvx_chol::SolveGraph *slot = nullptr;
+                for (auto &g : F->g_solve)
+                    if (g.kind == kind0 + 8 && g.nrhs == nchunk) slot = &g;
+                if (!slot) { F->g_solve.push_back({kind0 + 8, nchunk, 0, nullptr}); slot = &F->g_solve.back(); }
+                slot->calls++;
+                if (!slot->exec && slot->calls >= 2 && F->g_solve.size() <= 16) slot->exec = capture_graph(F, body);
+                exec = slot->exec;
+            }
+            if (exec) HIPCHK(hipGraphLaunch(exec, st));
+            else if ((rc = body())) return rc;
+            launch_wide_scatter(st, sys == 0 ? F->d_perm : nullptr, n, nr, F->d_X, Bc, ldB);
+            HIPCHK(hipEventRecord(F->ev[3], st));
+            HIPCHK(hipGetLastError());
+            continue;
+        }
         // every system is solved on the staging block d_X (n x nr, ld = n): fixed pointers, so the
         // triangular sweeps can be replayed from a captured graph
         const int kind = (sys == 0 || sys == 1) ? 0 : ((sys == 2 || sys == 4) ? 1 : ((sys == 3 || sys == 5) ? 2 : -1));
@@ -1369,6 +1499,8 @@ void kvx_chol_free(kvx_chol *F)
             if (F->side[i]) pool_stream_put(F->side[i]);
             if (F->ev_join[i]) pool_event_put(F->ev_join[i], false);
         }
+        if (F->d_inv_ptr) (void)pool_free(F->d_inv_ptr);
+        if (F->d_inv_src) (void)pool_free(F->d_inv_src);
         if (F->d_keep) (void)pool_free(F->d_keep);
         if (F->d_flists) (void)pool_free(F->d_flists);
         dist_release(F);

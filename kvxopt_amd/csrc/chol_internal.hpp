@@ -109,6 +109,10 @@ struct kvx_chol {
     std::vector<int32_t> col2sn, sub_of;       // sparse right-hand sides (spsolve): front of a permuted column, subtree of a front (-1: none)
     std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
     std::vector<int> sw_cnt, sw_kmax;
+    // many right-hand sides (kernels_wide.hip): per front row, the children's update rows that land on it (built at the first such solve)
+    int32_t *d_inv_ptr = nullptr, *d_inv_src = nullptr;
+    int wide_state = 0;                        // 0 = not built yet, 1 = ready, -1 = not available for this factor (sharded mode, index range)
+    int wide_from = 64;                        // right-hand sides from which the rhs-major path is used (KVX_WIDE_FROM; 0 = never)
     bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;

@@ -231,6 +231,19 @@ void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs
                         double *out, int64_t ldo);
 void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
                          double *out, int64_t ldo);
+// many right-hand sides, rhs-major blocks of 64 (kernels_wide.hip): XT[chunk][row][64]; W*: [chunk][wstride rows][64]
+void launch_wide_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT);
+void launch_wide_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB);
+void launch_wide_fwd_small(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax, int nchunk, const double *Lx,
+                           double *XT, int64_t n, const double *Wch, double *Wout, int64_t wstride, const int32_t *inv_ptr,
+                           const int32_t *inv_src);
+void launch_wide_bwd_small(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax, int nchunk, const double *Lx,
+                           double *XT, int64_t n);
+void launch_wide_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k, int nchunk,
+                         const double *Lx, const double *Linv, double *XT, int64_t n, const double *Wch, double *Wout,
+                         int64_t wstride, const int32_t *inv_ptr, const int32_t *inv_src);
+void launch_wide_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_k, int nchunk, const double *Lx,
+                         const double *Linv, double *XT, int64_t n);
 void launch_zero_slots(hipStream_t st, const int64_t *slots, int count, int nrhs, double *W, int64_t wstride);
 void launch_scatter_entries(hipStream_t st, const int64_t *pos, const double *val, int64_t count, double *X);
 void launch_mask_rows(hipStream_t st, const uint8_t *keep, int64_t n, int nrhs, double *X, int64_t ldx);
