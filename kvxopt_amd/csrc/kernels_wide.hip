@@ -76,17 +76,58 @@ __global__ __launch_bounds__(256) void k_wide_scatter(const int32_t *__restrict_
 }
 
 // ---- small fronts (k <= KMAX <= 64, m <= 128): one wavefront per (front, chunk) ----------------------------------------------
-// Forward: row blocks of 16 from the top.  A block first collects its right-hand side (pivot rows: x; every row: the children's
-// update rows the inverse map names), then subtracts L(block, earlier pivots) * y (MFMA), then -- inside the pivot rows -- runs
-// the 16 x 16 substitution.  Rows past the pivots are the front's update vector.
+// Everything stays in the accumulator layout of the MFMA: a block of 16 rows x 64 right-hand sides is four d4 registers per lane,
+// D[q1][q] = (row 16 b + lk + 4 q, rhs 16 q1 + lr).  That layout IS the B operand of the four k-steps that multiply with those 16
+// rows (B[kk = lk][n = lr] of step s is D[q1][s]), so the solved pivot blocks of a front never leave the registers: no LDS image
+// of y, no layout change.  The 16 x 16 substitution runs in the same layout: the pivot row's values travel from their lane group
+// to the other three through the LDS crossbar (ds_bpermute), the multipliers are four LDS reads per step from the 2 KB image
+// of the diagonal block.  The children's update rows are pulled per lane group through the inverse map.
+
+// rows r0 + lk + 4 q of the front's right-hand side: x for the pivot rows + the children's update rows (forward sweep)
+__device__ __forceinline__ void wide_assemble(d4 (&D)[4], int r0, int k, int m, int first, int lk, int lr, const double *__restrict__ xt,
+                                              const double *__restrict__ wc, const int32_t *__restrict__ ip,
+                                              const int32_t *__restrict__ inv_src)
+{
+    int e0[4], e1[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = r0 + lk + 4 * q;
+        const int rc = min(r, m - 1);
+        e0[q] = ip[rc];
+        e1[q] = r < m ? ip[rc + 1] : e0[q];
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) D[q1][q] = kvx_ld0(xt, (int64_t)(first + r) * 64 + 16 * q1 + lr, r < k);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        for (int e = e0[q]; e < e1[q]; e++) {
+            const double *src = wc + (int64_t)inv_src[e] * 64 + lr;
+#pragma unroll
+            for (int q1 = 0; q1 < 4; q1++) D[q1][q] += src[16 * q1];
+        }
+}
+
+// image of the 16 x 16 diagonal block at (r0, r0) (column-major, zero above the diagonal and past the pivots) + reciprocal diagonal
+__device__ __forceinline__ void wide_diag_image(const double *__restrict__ P, int r0, int k, int m, int l, double *Ld, double *Ldi)
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int idx = l + 64 * t, ii = idx & 15, jj = idx >> 4;
+        Ld[idx] = kvx_ld0(P, (r0 + ii) + (int64_t)(r0 + jj) * m, r0 + ii < m && r0 + jj < k && jj <= ii);
+    }
+    if (l < 16) {
+        const double dg = kvx_ld0(P, (r0 + l) + (int64_t)(r0 + l) * m, r0 + l < k);
+        Ldi[l] = 1.0 / (r0 + l < k ? dg : 1.0);
+    }
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(64) void k_wide_fwd_small(DevSym ds, const int32_t *__restrict__ list, const double *__restrict__ Lx,
                                                        double *__restrict__ XT, int64_t n, const double *__restrict__ Wch,
                                                        double *__restrict__ Wout, int64_t wstride,
                                                        const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_src)
 {
-    __shared__ double Ysh[KMAX * 64];
-    __shared__ double conv[16 * 64];
+    constexpr int KB = KMAX / 16;
     __shared__ double Ld[16 * 16];
     __shared__ double Ldi[16];
     unsigned fi, ch;
@@ -99,114 +140,99 @@ __global__ __launch_bounds__(64) void k_wide_fwd_small(DevSym ds, const int32_t 
     const double *wc = Wch + (int64_t)ch * wstride * 64;
     double *wo = Wout + ((int64_t)ch * wstride + fd.wx) * 64;
     const int32_t *ip = inv_ptr + fd.rowptr;
-    for (int r0 = 0; r0 < m; r0 += 16) {
-        double v[16];
+    d4 Y[KB][4];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int r = r0 + i;
-            double val = 0.0;
-            if (r < m) {                           // wave-uniform
-                if (r < k) val = xt[(int64_t)(first + r) * 64 + l];
-                const int e1 = ip[r + 1];
-                for (int e = ip[r]; e < e1; e++) val += wc[(int64_t)inv_src[e] * 64 + l];
-            }
-            v[i] = val;
-        }
-        const int jmax = min(k, r0);               // pivots above this block
-        const bool tri = r0 < k;
-        if (jmax > 0) {
+    for (int b = 0; b < KB; b++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) conv[sw(i, l)] = v[i];
-            __syncthreads();
+        for (int q1 = 0; q1 < 4; q1++) Y[b][q1] = (d4){0.0, 0.0, 0.0, 0.0};
+    // ---- the pivot blocks
+#pragma unroll
+    for (int b = 0; b < KB; b++) {
+        const int r0 = 16 * b;
+        if (r0 < k) {                              // wave-uniform
+            wide_diag_image(P, r0, k, m, l, Ld, Ldi);
             d4 D[4];
-#pragma unroll
-            for (int q1 = 0; q1 < 4; q1++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) D[q1][q] = conv[sw(lk + 4 * q, 16 * q1 + lr)];
+            wide_assemble(D, r0, k, m, first, lk, lr, xt, wc, ip, inv_src);
             const bool rin = r0 + lr < m;
-            for (int j0 = 0; j0 < jmax; j0 += 16) {
+#pragma unroll
+            for (int pb = 0; pb < b; pb++) {
                 double av[4];
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int j = j0 + 4 * s + lk;
-                    av[s] = -kvx_ld0(P, (r0 + lr) + (int64_t)j * m, rin && j < jmax);
-                }
+                for (int s = 0; s < 4; s++) av[s] = -kvx_ld0(P, (r0 + lr) + (int64_t)(16 * pb + 4 * s + lk) * m, rin);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int j = j0 + 4 * s + lk;
-                    const bool jin = j < jmax;
+                for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int q1 = 0; q1 < 4; q1++) {
-                        const double bv = Ysh[sw(jin ? j : 0, 16 * q1 + lr)];
-                        D[q1] = mfma(av[s], jin ? bv : 0.0, D[q1]);
-                    }
-                }
-            }
-            if (tri) {
-                __syncthreads();
-#pragma unroll
-                for (int q1 = 0; q1 < 4; q1++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) conv[sw(lk + 4 * q, 16 * q1 + lr)] = D[q1][q];
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 16; i++) v[i] = conv[sw(i, l)];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int r = r0 + lk + 4 * q;
-                    if (r < m) {
-#pragma unroll
-                        for (int q1 = 0; q1 < 4; q1++) wo[(int64_t)(r - k) * 64 + 16 * q1 + lr] = D[q1][q];
-                    }
-                }
-            }
-        }
-        if (tri) {
-            // the diagonal block L(r0 .. r0 + 15, r0 .. r0 + 15), column-major, and the reciprocals of its diagonal
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int idx = l + 64 * t, ii = idx & 15, jj = idx >> 4;
-                Ld[idx] = kvx_ld0(P, (r0 + ii) + (int64_t)(r0 + jj) * m, r0 + ii < m && r0 + jj < k && jj <= ii);
-            }
-            if (l < 16) {
-                const double dg = kvx_ld0(P, (r0 + l) + (int64_t)(r0 + l) * m, r0 + l < k);
-                Ldi[l] = 1.0 / (r0 + l < k ? dg : 1.0);
+                    for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], Y[pb][q1][s], D[q1]);
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (r0 + i < k) {                  // wave-uniform
-                    const double y = v[i] * Ldi[i];
-                    v[i] = y;
-                    Ysh[sw(r0 + i, l)] = y;
+                    const int gi = i & 3, qi = i >> 2;
+                    const double ri = Ldi[i];
+                    double mult[4];
 #pragma unroll
-                    for (int i2 = i + 1; i2 < 16; i2++) v[i2] = __builtin_fma(-Ld[i * 16 + i2], y, v[i2]);
+                    for (int q = 0; q < 4; q++) mult[q] = (lk + 4 * q > i) ? Ld[i * 16 + lk + 4 * q] : 0.0;
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) {
+                        const double y = __shfl(D[q1][qi] * ri, gi * 16 + lr);
+                        D[q1][qi] = (lk == gi) ? y : D[q1][qi];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) D[q1][q] = __builtin_fma(-mult[q], y, D[q1][q]);
+                    }
                 }
             }
+            __syncthreads();                       // (the image is rewritten by the next block)
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int r = r0 + i;
-                if (r < k) xt[(int64_t)(first + r) * 64 + l] = v[i];
-                else if (r < m) wo[(int64_t)(r - k) * 64 + l] = v[i];
+            for (int q = 0; q < 4; q++) {
+                const int r = r0 + lk + 4 * q;
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) {
+                    if (r < k) xt[(int64_t)(first + r) * 64 + 16 * q1 + lr] = D[q1][q];
+                    else if (r < m) wo[(int64_t)(r - k) * 64 + 16 * q1 + lr] = D[q1][q];
+                    Y[b][q1][q] = r < k ? D[q1][q] : 0.0;
+                }
             }
-        } else if (jmax == 0) {                    // k == 0 cannot happen (every front has a pivot); kept for completeness
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                if (r0 + i < m) wo[(int64_t)(r0 + i - k) * 64 + l] = v[i];
         }
-        __syncthreads();
+    }
+    // ---- the rows past the last pivot block: update rows only
+    for (int r0 = 16 * ((k + 15) / 16); r0 < m; r0 += 16) {
+        d4 D[4];
+        wide_assemble(D, r0, k, m, first, lk, lr, xt, wc, ip, inv_src);
+        const bool rin = r0 + lr < m;
+#pragma unroll
+        for (int pb = 0; pb < KB; pb++) {
+            if (16 * pb < k) {                     // wave-uniform
+                double av[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int j = 16 * pb + 4 * s + lk;
+                    av[s] = -kvx_ld0(P, (r0 + lr) + (int64_t)j * m, rin && j < k);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], Y[pb][q1][s], D[q1]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = r0 + lk + 4 * q;
+            if (r < m) {
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) wo[(int64_t)(r - k) * 64 + 16 * q1 + lr] = D[q1][q];
+            }
+        }
     }
 }
 
-// Backward: pivot blocks of 16 from the last.  t = y - L(rows below the block, block)' x (MFMA; x of the front's own later pivots
-// from LDS, of the rows past the pivots gathered from XT), then the 16 x 16 back substitution.
+// Backward: pivot blocks of 16 from the last.  t = y - L(rows below the block, block)' x: the front's own later pivot blocks from
+// registers, the rows past the pivots gathered from XT; then the 16 x 16 back substitution.
 template <int KMAX>
 __global__ __launch_bounds__(64) void k_wide_bwd_small(DevSym ds, const int32_t *__restrict__ list, const double *__restrict__ Lx,
                                                        double *__restrict__ XT, int64_t n)
 {
-    __shared__ double Xsh[KMAX * 64];
-    __shared__ double conv[16 * 64];
+    constexpr int KB = KMAX / 16;
     __shared__ double Ld[16 * 16];
     __shared__ double Ldi[16];
     unsigned fi, ch;
@@ -217,69 +243,91 @@ __global__ __launch_bounds__(64) void k_wide_bwd_small(DevSym ds, const int32_t 
     const double *P = Lx + fd.px;
     double *xt = XT + (int64_t)ch * n * 64;
     const int32_t *rows = ds.rowidx + fd.rowptr;
-    for (int p0 = 16 * ((k - 1) / 16); p0 >= 0; p0 -= 16) {
-        d4 D[4];
+    d4 X[KB][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int p = p0 + lk + 4 * q;
+    for (int b = 0; b < KB; b++)
 #pragma unroll
-            for (int q1 = 0; q1 < 4; q1++) D[q1][q] = kvx_ld0(xt, (int64_t)(first + p) * 64 + 16 * q1 + lr, p < k);
-        }
-        const bool pin = p0 + lr < k;
-        const double *Pc = P + (int64_t)(pin ? p0 + lr : 0) * m;
-        // (a last, partial pivot block shares its 16 rows with the first rows past the pivots: they take part here)
-        for (int rr0 = (p0 + 16 <= k) ? p0 + 16 : p0; rr0 < m; rr0 += 16) {
-            double av[4];
-            int gr[4];
+        for (int q1 = 0; q1 < 4; q1++) X[b][q1] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int r = rr0 + 4 * s + lk;
-                av[s] = -kvx_ld0(Pc, r, pin && r < m && (r >= p0 + 16 || r >= k));
-                gr[s] = rows[min(r, m - 1)];
+    for (int b = KB - 1; b >= 0; b--) {
+        const int p0 = 16 * b;
+        if (p0 < k) {                              // wave-uniform
+            wide_diag_image(P, p0, k, m, l, Ld, Ldi);
+            d4 D[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = p0 + lk + 4 * q;
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) D[q1][q] = kvx_ld0(xt, (int64_t)(first + p) * 64 + 16 * q1 + lr, p < k);
             }
+            const bool pin = p0 + lr < k;
+            const double *Pc = P + (int64_t)(pin ? p0 + lr : 0) * m;
+            // later pivot blocks of this front
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int r = rr0 + 4 * s + lk;
-                const bool rin = r < m && (r >= p0 + 16 || r >= k), own = r < k;
+            for (int lb = b + 1; lb < KB; lb++) {
+                if (16 * lb < k) {                 // wave-uniform
+                    double av[4];
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const int r = 16 * lb + 4 * s + lk;
+                        av[s] = -kvx_ld0(Pc, r, pin && r < k);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; s++)
+#pragma unroll
+                        for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], X[lb][q1][s], D[q1]);
+                }
+            }
+            // rows past the pivots (the block that holds row k may start inside the pivots: masked)
+            for (int rr0 = 16 * (k / 16); rr0 < m; rr0 += 16) {
+                double av[4];
+                int gr[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int r = rr0 + 4 * s + lk;
+                    av[s] = -kvx_ld0(Pc, r, pin && r >= k && r < m);
+                    gr[s] = rows[min(r, m - 1)];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int r = rr0 + 4 * s + lk;
+                    const bool rin = r >= k && r < m;
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) {
+                        const double xg = xt[(int64_t)gr[s] * 64 + 16 * q1 + lr];
+                        D[q1] = mfma(av[s], rin ? xg : 0.0, D[q1]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 15; i >= 0; i--) {
+                if (p0 + i < k) {                  // wave-uniform
+                    const int gi = i & 3, qi = i >> 2;
+                    const double ri = Ldi[i];
+                    double mult[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) mult[q] = (lk + 4 * q < i) ? Ld[(lk + 4 * q) * 16 + i] : 0.0;
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) {
+                        const double x = __shfl(D[q1][qi] * ri, gi * 16 + lr);
+                        D[q1][qi] = (lk == gi) ? x : D[q1][qi];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) D[q1][q] = __builtin_fma(-mult[q], x, D[q1][q]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = p0 + lk + 4 * q;
 #pragma unroll
                 for (int q1 = 0; q1 < 4; q1++) {
-                    const double xl = Xsh[sw(own ? r : 0, 16 * q1 + lr)];
-                    const double xg = xt[(int64_t)gr[s] * 64 + 16 * q1 + lr];
-                    D[q1] = mfma(av[s], rin ? (own ? xl : xg) : 0.0, D[q1]);
+                    if (p < k) xt[(int64_t)(first + p) * 64 + 16 * q1 + lr] = D[q1][q];
+                    X[b][q1][q] = p < k ? D[q1][q] : 0.0;
                 }
             }
         }
-#pragma unroll
-        for (int q1 = 0; q1 < 4; q1++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) conv[sw(lk + 4 * q, 16 * q1 + lr)] = D[q1][q];
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int idx = l + 64 * t, ii = idx & 15, jj = idx >> 4;
-            Ld[idx] = kvx_ld0(P, (p0 + ii) + (int64_t)(p0 + jj) * m, p0 + ii < k && jj <= ii);
-        }
-        if (l < 16) {
-            const double dg = kvx_ld0(P, (p0 + l) + (int64_t)(p0 + l) * m, p0 + l < k);
-            Ldi[l] = 1.0 / (p0 + l < k ? dg : 1.0);
-        }
-        __syncthreads();
-        double v[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) v[i] = conv[sw(i, l)];
-#pragma unroll
-        for (int i = 15; i >= 0; i--) {
-            if (p0 + i < k) {                      // wave-uniform
-                const double x = v[i] * Ldi[i];
-                v[i] = x;
-                Xsh[sw(p0 + i, l)] = x;
-#pragma unroll
-                for (int i2 = 0; i2 < i; i2++) v[i2] = __builtin_fma(-Ld[i2 * 16 + i], x, v[i2]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            if (p0 + i < k) xt[(int64_t)(first + p0 + i) * 64 + l] = v[i];
-        __syncthreads();
     }
 }
 
@@ -292,26 +340,29 @@ __global__ __launch_bounds__(64) void k_wide_bwd_small(DevSym ds, const int32_t 
 
 // y = Linv_blk * w (TRANS = false) or x = Linv_blk' * t (TRANS = true) for the 64-row block held in Bf (rows past nb zero); wave w
 // computes rows 16 w .. 16 w + 15 for all 64 right-hand sides.  The result replaces Bf and goes to XT rows `dst`.
+// the 16 A operands of a wave (loaded early by the caller: their latency hides behind the caller's own work)
 template <bool TRANS>
-__device__ __forceinline__ void wide_diag_solve(const double *__restrict__ Yi, int nb, double *Bf, double *dst, int w, int lr, int lk)
+__device__ __forceinline__ void wide_diag_load(const double *__restrict__ Yi, int nb, int w, int lr, int lk, double (&av)[16])
+{
+    const int ri = 16 * w + lr;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int c = 4 * s + lk;
+        av[s] = TRANS ? kvx_ld0(Yi, c + ri * 64, c < nb && ri < nb && c >= ri) : kvx_ld0(Yi, ri + c * 64, ri < nb && c <= ri);
+    }
+}
+template <bool TRANS>
+__device__ __forceinline__ void wide_diag_solve(const double (&av)[16], int nb, double *Bf, double *dst, int w, int lr, int lk)
 {
     d4 D[4];
 #pragma unroll
     for (int q1 = 0; q1 < 4; q1++) D[q1] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int ri = 16 * w + lr;
-    if (!TRANS) {
-        for (int j0 = 0; j0 < 16 * (w + 1); j0 += 4) {
-            const int c = j0 + lk;
-            const double av = kvx_ld0(Yi, ri + c * 64, ri < nb && c <= ri);
 #pragma unroll
-            for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av, Bf[sw(c, 16 * q1 + lr)], D[q1]);
-        }
-    } else {
-        for (int j0 = 16 * w; j0 < 64; j0 += 4) {
-            const int c = j0 + lk;
-            const double av = kvx_ld0(Yi, c + ri * 64, c < nb && ri < nb && c >= ri);
+    for (int s = 0; s < 16; s++) {
+        if (TRANS ? (4 * s + 3 >= 16 * w) : (4 * s < 16 * (w + 1))) {       // wave-uniform: the triangle of the block
+            const int c = 4 * s + lk;
 #pragma unroll
-            for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av, Bf[sw(c, 16 * q1 + lr)], D[q1]);
+            for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], Bf[sw(c, 16 * q1 + lr)], D[q1]);
         }
     }
     __syncthreads();
@@ -358,11 +409,13 @@ __global__ __launch_bounds__(256) void k_wide_fwd_big_asm(DevSym ds, const int32
         }
     }
     if (bx != 0) return;
-    __syncthreads();
     const int nb = min(64, k);
+    double dv[16];
+    wide_diag_load<false>(Linv + fd.linv, nb, w, lr, lk, dv);
+    __syncthreads();
     for (int i = w; i < 64; i += 4) Bf[sw(i, l)] = kvx_ld0(xt, (int64_t)(first + i) * 64 + l, i < nb);
     __syncthreads();
-    wide_diag_solve<false>(Linv + fd.linv, nb, Bf, xt + (int64_t)first * 64, w, lr, lk);
+    wide_diag_solve<false>(dv, nb, Bf, xt + (int64_t)first * 64, w, lr, lk);
 }
 
 // Forward, block jb: every workgroup stages y_blk and takes it off its 64 rows below the block; workgroup 0's rows are the next
@@ -385,6 +438,10 @@ __global__ __launch_bounds__(256) void k_wide_fwd_big_step(DevSym ds, const int3
     const double *P = Lx + fd.px;
     double *xt = XT + (int64_t)ch * n * 64;
     double *wo = Wout + ((int64_t)ch * wstride + fd.wx) * 64;
+    const bool next = bx == 0 && jb + nb < k;       // this workgroup's 64 rows are the next pivot block: it solves it at the end
+    const int jn = jb + nb, nb2 = min(64, k - jn);
+    double dv[16];
+    if (next) wide_diag_load<false>(Linv + fd.linv + (int64_t)(jn / 64) * 4096, nb2, w, lr, lk, dv);
     for (int i = w; i < 64; i += 4) Bf[sw(i, l)] = kvx_ld0(xt, (int64_t)(first + jb + i) * 64 + l, i < nb);
     const int r0 = rbeg + 16 * w;
     d4 D[4];
@@ -410,7 +467,6 @@ __global__ __launch_bounds__(256) void k_wide_fwd_big_step(DevSym ds, const int3
 #pragma unroll
         for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], Bf[sw(j, 16 * q1 + lr)], D[q1]);
     }
-    const bool next = bx == 0 && jb + nb < k;       // these 64 rows are the next pivot block: solve it here
     if (!next) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -420,7 +476,6 @@ __global__ __launch_bounds__(256) void k_wide_fwd_big_step(DevSym ds, const int3
             }
         return;
     }
-    const int jn = jb + nb, nb2 = min(64, k - jn);
     __syncthreads();                                // every wave is done with y_blk
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -433,7 +488,7 @@ __global__ __launch_bounds__(256) void k_wide_fwd_big_step(DevSym ds, const int3
         }
     }
     __syncthreads();
-    wide_diag_solve<false>(Linv + fd.linv + (int64_t)(jn / 64) * 4096, nb2, Bf, xt + (int64_t)(first + jn) * 64, w, lr, lk);
+    wide_diag_solve<false>(dv, nb2, Bf, xt + (int64_t)(first + jn) * 64, w, lr, lk);
 }
 
 // Backward, first launch of a level: t = y - L21' x_below for 64 pivots per workgroup (a wave = 16 of them; the rows of x are
@@ -453,6 +508,10 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_head(DevSym ds, const int3
     double *xt = XT + (int64_t)ch * n * 64;
     const int32_t *rows = ds.rowidx + fd.rowptr;
     const int p0 = (int)bx * 64 + 16 * w;
+    const bool last = ((int)bx + 1) * 64 >= k;
+    const int jb = (int)bx * 64, nb = k - jb;
+    double dv[16];
+    if (last) wide_diag_load<true>(Linv + fd.linv + (int64_t)(jb / 64) * 4096, nb, w, lr, lk, dv);
     d4 D[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -483,7 +542,6 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_head(DevSym ds, const int3
             }
         }
     }
-    const bool last = ((int)bx + 1) * 64 >= k;
     if (!last) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -495,7 +553,6 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_head(DevSym ds, const int3
         }
         return;
     }
-    const int jb = (int)bx * 64, nb = k - jb;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int i = 16 * w + lk + 4 * q;
@@ -503,7 +560,7 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_head(DevSym ds, const int3
         for (int q1 = 0; q1 < 4; q1++) Bf[sw(i, 16 * q1 + lr)] = i < nb ? D[q1][q] : 0.0;
     }
     __syncthreads();
-    wide_diag_solve<true>(Linv + fd.linv + (int64_t)(jb / 64) * 4096, nb, Bf, xt + (int64_t)(first + jb) * 64, w, lr, lk);
+    wide_diag_solve<true>(dv, nb, Bf, xt + (int64_t)(first + jb) * 64, w, lr, lk);
 }
 
 // Backward, step s: block b = (blocks of the front) - 1 - s holds its x; workgroup c < b takes L(b, c)' x_b off its 64 pivots, and
@@ -524,6 +581,8 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_step(DevSym ds, const int3
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const double *P = Lx + fd.px;
     double *xt = XT + (int64_t)ch * n * 64;
+    double dv[16];
+    if ((int)bx == b - 1) wide_diag_load<true>(Linv + fd.linv + (int64_t)(b - 1) * 4096, 64, w, lr, lk, dv);
     for (int i = w; i < 64; i += 4) Bf[sw(i, l)] = kvx_ld0(xt, (int64_t)(first + jb + i) * 64 + l, i < nb);
     const int p0 = (int)bx * 64 + 16 * w;           // < jb: whole blocks of pivots
     d4 D[4];
@@ -558,7 +617,7 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_step(DevSym ds, const int3
 #pragma unroll
         for (int q1 = 0; q1 < 4; q1++) Bf[sw(16 * w + lk + 4 * q, 16 * q1 + lr)] = D[q1][q];
     __syncthreads();
-    wide_diag_solve<true>(Linv + fd.linv + (int64_t)(b - 1) * 4096, 64, Bf, xt + (int64_t)(first + 64 * (b - 1)) * 64, w, lr, lk);
+    wide_diag_solve<true>(dv, 64, Bf, xt + (int64_t)(first + 64 * (b - 1)) * 64, w, lr, lk);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
