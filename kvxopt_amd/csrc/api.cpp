@@ -734,6 +734,9 @@ int ensure_wide(kvx_chol *F)
             }
     }
     int rc;
+    std::vector<int32_t> ip32((size_t)S.n);
+    for (int64_t j = 0; j < S.n; j++) ip32[(size_t)j] = (int32_t)S.iperm[(size_t)j];
+    if ((rc = upload(&F->d_iperm, ip32))) return rc;
     if ((rc = upload(&F->d_inv_ptr, ptr))) return rc;
     if ((rc = upload(&F->d_inv_src, src))) return rc;
     F->wide_state = 1;
@@ -842,7 +845,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
         HIPCHK(hipEventRecord(F->ev[2], st));
         if (wide) {
             const int nchunk = (nr + 63) / 64;
-            launch_wide_gather(st, sys == 0 ? F->d_perm : nullptr, n, nr, Bc, ldB, F->d_X);
+            launch_wide_gather(st, sys == 0 ? F->d_iperm : nullptr, n, nr, Bc, ldB, F->d_X);
             auto body = [&]() -> int {
                 if (kind0 == 0 || kind0 == 1) enqueue_fwd_wide(F, F->d_X, nchunk);
                 if (kind0 == 0 || kind0 == 2) enqueue_bwd_wide(F, F->d_X, nchunk);
@@ -860,7 +863,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
             }
             if (exec) HIPCHK(hipGraphLaunch(exec, st));
             else if ((rc = body())) return rc;
-            launch_wide_scatter(st, sys == 0 ? F->d_perm : nullptr, n, nr, F->d_X, Bc, ldB);
+            launch_wide_scatter(st, sys == 0 ? F->d_iperm : nullptr, n, nr, F->d_X, Bc, ldB);
             HIPCHK(hipEventRecord(F->ev[3], st));
             HIPCHK(hipGetLastError());
             continue;
@@ -1499,6 +1502,7 @@ void kvx_chol_free(kvx_chol *F)
             if (F->side[i]) pool_stream_put(F->side[i]);
             if (F->ev_join[i]) pool_event_put(F->ev_join[i], false);
         }
+        if (F->d_iperm) (void)pool_free(F->d_iperm);
         if (F->d_inv_ptr) (void)pool_free(F->d_inv_ptr);
         if (F->d_inv_src) (void)pool_free(F->d_inv_src);
         if (F->d_keep) (void)pool_free(F->d_keep);

@@ -110,7 +110,7 @@ struct kvx_chol {
     std::vector<int64_t> sw_off;               // per level: the wave-class fronts NOT in a subtree (offset, count into d_lists_sw)
     std::vector<int> sw_cnt, sw_kmax;
     // many right-hand sides (kernels_wide.hip): per front row, the children's update rows that land on it (built at the first such solve)
-    int32_t *d_inv_ptr = nullptr, *d_inv_src = nullptr;
+    int32_t *d_inv_ptr = nullptr, *d_inv_src = nullptr, *d_iperm = nullptr;   // d_iperm: position of every caller row in the permuted order
     int wide_state = 0;                        // 0 = not built yet, 1 = ready, -1 = not available for this factor (sharded mode, index range)
     int wide_from = 64;                        // right-hand sides from which the rhs-major path is used (KVX_WIDE_FROM; 0 = never)
     bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)

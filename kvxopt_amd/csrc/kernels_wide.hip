@@ -34,45 +34,50 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_
 }  // namespace
 
 // ---- layout changes ---------------------------------------------------------------------------------------------------------
-// XT[chunk][k][b] = B[perm[k] + (64 chunk + b) ldB]   (perm == nullptr: identity); right-hand sides past nrhs are zero
-__global__ __launch_bounds__(256) void k_wide_gather(const int32_t *__restrict__ perm, int64_t n, int nrhs,
+// XT[chunk][iperm[j]][b] = B[j + (64 chunk + b) ldB]: driven by the CALLER's row index j, so the reads of B run down its columns
+// (coalesced) and every write is one whole 512-byte row of XT wherever the permutation sends it.  iperm == nullptr: identity.
+// Right-hand sides past nrhs are zero.
+__global__ __launch_bounds__(256) void k_wide_gather(const int32_t *__restrict__ iperm, int64_t n, int nrhs,
                                                      const double *__restrict__ B, int64_t ldB, double *__restrict__ XT)
 {
     __shared__ double tile[64][65];
+    __shared__ int dst[64];
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int c = blockIdx.y;
     const int nv = min(64, nrhs - 64 * c);
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t row = row0 + i;
     const bool rin = row < n;
-    const int64_t src = rin ? (perm ? (int64_t)perm[row] : row) : 0;
+    if (g == 0) dst[i] = rin ? (iperm ? iperm[row] : (int)row) : 0;
     for (int b = g; b < 64; b += 4) {
         const bool ok = rin && b < nv;
-        const double v = B[ok ? src + (int64_t)(64 * c + b) * ldB : 0];
+        const double v = B[ok ? row + (int64_t)(64 * c + b) * ldB : 0];
         tile[i][b] = ok ? v : 0.0;
     }
     __syncthreads();
-    double *out = XT + ((int64_t)c * n + row0) * 64;
+    double *out = XT + (int64_t)c * n * 64;
     for (int r = g; r < 64; r += 4)
-        if (row0 + r < n) out[r * 64 + i] = tile[r][i];
+        if (row0 + r < n) out[(int64_t)dst[r] * 64 + i] = tile[r][i];
 }
 
-// B[perm[k] + (64 chunk + b) ldB] = XT[chunk][k][b]
-__global__ __launch_bounds__(256) void k_wide_scatter(const int32_t *__restrict__ perm, int64_t n, int nrhs,
+// B[j + (64 chunk + b) ldB] = XT[chunk][iperm[j]][b]
+__global__ __launch_bounds__(256) void k_wide_scatter(const int32_t *__restrict__ iperm, int64_t n, int nrhs,
                                                       const double *__restrict__ XT, double *__restrict__ B, int64_t ldB)
 {
     __shared__ double tile[64][65];
+    __shared__ int src[64];
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     const int c = blockIdx.y;
     const int nv = min(64, nrhs - 64 * c);
     const int i = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const double *in = XT + ((int64_t)c * n + row0) * 64;
-    for (int r = g; r < 64; r += 4) tile[r][i] = (row0 + r < n) ? in[r * 64 + i] : 0.0;
-    __syncthreads();
     const int64_t row = row0 + i;
+    if (g == 0) src[i] = row < n ? (iperm ? iperm[row] : (int)row) : 0;
+    __syncthreads();
+    const double *in = XT + (int64_t)c * n * 64;
+    for (int r = g; r < 64; r += 4) tile[r][i] = (row0 + r < n) ? in[(int64_t)src[r] * 64 + i] : 0.0;
+    __syncthreads();
     if (row >= n) return;
-    const int64_t dst = perm ? (int64_t)perm[row] : row;
-    for (int b = g; b < nv; b += 4) B[dst + (int64_t)(64 * c + b) * ldB] = tile[i][b];
+    for (int b = g; b < nv; b += 4) B[row + (int64_t)(64 * c + b) * ldB] = tile[i][b];
 }
 
 // ---- small fronts (k <= KMAX <= 64, m <= 128): one wavefront per (front, chunk) ----------------------------------------------
@@ -122,7 +127,7 @@ __device__ __forceinline__ void wide_diag_image(const double *__restrict__ P, in
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(64) void k_wide_fwd_small(DevSym ds, const int32_t *__restrict__ list, const double *__restrict__ Lx,
+__global__ __launch_bounds__(64, KMAX <= 32 ? 3 : 2) void k_wide_fwd_small(DevSym ds, const int32_t *__restrict__ list, const double *__restrict__ Lx,
                                                        double *__restrict__ XT, int64_t n, const double *__restrict__ Wch,
                                                        double *__restrict__ Wout, int64_t wstride,
                                                        const int32_t *__restrict__ inv_ptr, const int32_t *__restrict__ inv_src)
@@ -279,24 +284,34 @@ __global__ __launch_bounds__(64) void k_wide_bwd_small(DevSym ds, const int32_t 
                 }
             }
             // rows past the pivots (the block that holds row k may start inside the pivots: masked)
+            double avn[4];
+            int grn[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int r = 16 * (k / 16) + 4 * s + lk;
+                avn[s] = -kvx_ld0(Pc, r, pin && r >= k && r < m);
+                grn[s] = rows[min(r, m - 1)];
+            }
             for (int rr0 = 16 * (k / 16); rr0 < m; rr0 += 16) {
-                double av[4];
-                int gr[4];
+                double av[4], xg[4][4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const int r = rr0 + 4 * s + lk;
-                    av[s] = -kvx_ld0(Pc, r, pin && r >= k && r < m);
-                    gr[s] = rows[min(r, m - 1)];
+                    av[s] = avn[s];
+#pragma unroll
+                    for (int q1 = 0; q1 < 4; q1++) xg[s][q1] = xt[(int64_t)grn[s] * 64 + 16 * q1 + lr];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int r = rr0 + 16 + 4 * s + lk;
+                    avn[s] = -kvx_ld0(Pc, r, pin && r >= k && r < m);
+                    grn[s] = rows[min(r, m - 1)];
                 }
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int r = rr0 + 4 * s + lk;
                     const bool rin = r >= k && r < m;
 #pragma unroll
-                    for (int q1 = 0; q1 < 4; q1++) {
-                        const double xg = xt[(int64_t)gr[s] * 64 + 16 * q1 + lr];
-                        D[q1] = mfma(av[s], rin ? xg : 0.0, D[q1]);
-                    }
+                    for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], rin ? xg[s][q1] : 0.0, D[q1]);
                 }
             }
             __syncthreads();
@@ -522,23 +537,49 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_head(DevSym ds, const int3
     if (p0 < k) {                                  // wave-uniform
         const bool pin = p0 + lr < k;
         const double *Pc = P + (int64_t)(pin ? p0 + lr : 0) * m;
+        // (the row indices and panel entries of the NEXT 16 rows are fetched while the gathered rows of x of this step arrive)
+        double avn[4];
+        int grn[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int r = k + 4 * s + lk;
+            avn[s] = -kvx_ld0(Pc, r, pin && r < m);
+            grn[s] = rows[min(r, m - 1)];
+        }
+        // two steps deep: the gathered rows of step i + 1 and the indices of step i + 2 are in flight during the MFMAs of step i
+        double xgn[4][4], av1[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            av1[s] = avn[s];
+#pragma unroll
+            for (int q1 = 0; q1 < 4; q1++) xgn[s][q1] = xt[(int64_t)grn[s] * 64 + 16 * q1 + lr];
+            const int r = k + 16 + 4 * s + lk;
+            avn[s] = -kvx_ld0(Pc, r, pin && r < m);
+            grn[s] = rows[min(r, m - 1)];
+        }
         for (int r0 = k; r0 < m; r0 += 16) {
-            double av[4];
-            int gr[4];
+            double av[4], xg[4][4];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const int r = r0 + 4 * s + lk;
-                av[s] = -kvx_ld0(Pc, r, pin && r < m);
-                gr[s] = rows[min(r, m - 1)];
+                av[s] = av1[s];
+                av1[s] = avn[s];
+#pragma unroll
+                for (int q1 = 0; q1 < 4; q1++) {
+                    xg[s][q1] = xgn[s][q1];
+                    xgn[s][q1] = xt[(int64_t)grn[s] * 64 + 16 * q1 + lr];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int r = r0 + 32 + 4 * s + lk;
+                avn[s] = -kvx_ld0(Pc, r, pin && r < m);
+                grn[s] = rows[min(r, m - 1)];
             }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const bool rin = r0 + 4 * s + lk < m;
 #pragma unroll
-                for (int q1 = 0; q1 < 4; q1++) {
-                    const double xg = xt[(int64_t)gr[s] * 64 + 16 * q1 + lr];
-                    D[q1] = mfma(av[s], rin ? xg : 0.0, D[q1]);
-                }
+                for (int q1 = 0; q1 < 4; q1++) D[q1] = mfma(av[s], rin ? xg[s][q1] : 0.0, D[q1]);
             }
         }
     }
@@ -621,15 +662,15 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_step(DevSym ds, const int3
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
-void launch_wide_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT)
+void launch_wide_gather(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT)
 {
     if (n <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_wide_gather, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, perm, n, nrhs, B, ldB, XT);
+    hipLaunchKernelGGL(k_wide_gather, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, B, ldB, XT);
 }
-void launch_wide_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB)
+void launch_wide_scatter(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB)
 {
     if (n <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_wide_scatter, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, perm, n, nrhs, XT, B, ldB);
+    hipLaunchKernelGGL(k_wide_scatter, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, XT, B, ldB);
 }
 void launch_wide_fwd_small(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax, int nchunk, const double *Lx,
                            double *XT, int64_t n, const double *Wch, double *Wout, int64_t wstride, const int32_t *inv_ptr,
