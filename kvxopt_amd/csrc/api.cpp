@@ -385,8 +385,16 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
     Symbolic &S = F->S;
     hipStream_t st = F->stream;
     if (prologue) {
-        HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
-        HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+        // Plain kernels, not memset nodes: replayed from a captured graph under the HIP runtime that ships inside the PyTorch wheel
+        // (7.0.51831, the one a process gets once torch is imported), the memset nodes of a SMALL factor were not ordered before
+        // the kernels behind them -- a dense 200 x 200 K of misc.kkt_chol2 failed at column 0 in 28 of 30 replays
+        // (scratch/graph_stress.py; ROCm 7.2's own runtime replays them correctly).  KVX_DBG_MEMSET_NODES=1 restores the nodes.
+        if (getenv("KVX_DBG_MEMSET_NODES")) {
+            HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
+            HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+        } else {
+            launch_clear_factor(st, F->d_Lx, S.lsize, F->d_status);
+        }
         { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
     }
     if (lfrom < 0) lfrom = S.nlevels - 1;
@@ -563,13 +571,16 @@ int enqueue_factor(kvx_chol *F)
     if (F->dist_nranks > 1) { set_err("sharded factor: use kvx_chol_dist_factorize"); return KVX_EINVAL; }
     hipStream_t st = F->stream;
     HIPCHK(hipEventRecord(F->ev[0], st));
-    const bool graph_ok = F->use_graph && F->prof_family < 0;
+    const char *dbg_ng = getenv("KVX_DBG_NO_FACTOR_GRAPH");      // debugging: "1" = no factor graphs at all, "<n>" = none for factors of order n
+    const bool graph_ok = F->use_graph && F->prof_family < 0 && !(dbg_ng && (atoll(dbg_ng) == 1 || atoll(dbg_ng) == F->S.n));
     F->factor_calls++;
     F->diag_valid = false;
     if (graph_ok && !F->g_factor && F->factor_calls >= 2)
         F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });   // (sharded mode drives the body itself)
     if (graph_ok && F->g_factor) {
+        if (const char *e = getenv("KVX_DBG_GRAPH_SYNC")) { if (atoi(e) & 1) HIPCHK(hipStreamSynchronize(st)); }
         HIPCHK(hipGraphLaunch(F->g_factor, st));
+        if (const char *e = getenv("KVX_DBG_GRAPH_SYNC")) { if (atoi(e) & 2) HIPCHK(hipStreamSynchronize(st)); }
     } else {
         int rc = enqueue_factor_body(F);
         if (rc) return rc;
@@ -852,7 +863,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
                 return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
             };
             hipGraphExec_t exec = nullptr;
-            if (F->use_graph) {
+            if (F->use_graph && !getenv("KVX_DBG_NO_SOLVE_GRAPH")) {
                 kvx_chol::SolveGraph *slot = nullptr;
                 for (auto &g : F->g_solve)
                     if (g.kind == kind0 + 8 && g.nrhs == nchunk) slot = &g;
@@ -881,14 +892,14 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
                 if (kind == 0 || kind == 1) {
                     // the first forward step of a big front is spread over workgroups that all read the front's
                     // pivot entries of the rhs while one of them overwrites them with y: they read this copy
-                    (void)hipMemcpyAsync(F->d_X0, F->d_X, (size_t)n * nr * sizeof(double), hipMemcpyDeviceToDevice, F->stream);
+                    launch_copy_d(F->stream, F->d_X0, F->d_X, n * (int64_t)nr);         // (a kernel, not a memcpy node: see enqueue_factor_body)
                     enqueue_fwd(F, F->d_X, n, nr);
                 }
                 if (kind == 0 || kind == 2) enqueue_bwd(F, F->d_X, n, nr);
                 return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
             };
             hipGraphExec_t exec = nullptr;
-            if (F->use_graph && F->prof_family < 0) {
+            if (F->use_graph && F->prof_family < 0 && !getenv("KVX_DBG_NO_SOLVE_GRAPH")) {
                 kvx_chol::SolveGraph *slot = nullptr;
                 for (auto &g : F->g_solve)
                     if (g.kind == kind && g.nrhs == nr) slot = &g;

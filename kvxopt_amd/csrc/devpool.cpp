@@ -38,7 +38,22 @@ void release_all_locked()
 }
 }  // namespace
 
+static hipError_t pool_malloc_impl(void **p, size_t bytes);
+// KVX_DBG_POISON=1: every block handed out is filled with 0xFF bytes (NaN as doubles, -1 as integers) -- a read of memory the
+// library never wrote shows up in the results whatever the allocator happened to leave there
 hipError_t pool_malloc(void **p, size_t bytes)
+{
+    static const bool poison = [] { const char *e = getenv("KVX_DBG_POISON"); return e && e[0] == '1'; }();
+    hipError_t e = pool_malloc_impl(p, bytes);
+    if (e == hipSuccess && poison) {
+        (void)hipDeviceSynchronize();
+        e = hipMemset(*p, 0xFF, std::max<size_t>((bytes + 255) & ~(size_t)255, 256));
+        (void)hipDeviceSynchronize();
+    }
+    return e;
+}
+
+static hipError_t pool_malloc_impl(void **p, size_t bytes)
 {
     if (!p) return hipErrorInvalidValue;
     bytes = (bytes + 255) & ~(size_t)255;

@@ -13,6 +13,8 @@
 //     atomics and the result is bitwise reproducible.
 #include "device.hpp"
 
+#include <algorithm>
+
 namespace kvx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -30,6 +32,39 @@ __global__ void k_scatter_a(const double *__restrict__ Ax, const int64_t *__rest
         int64_t d = amap[i];
         if (d >= 0) Lx[d] = Ax[i];
     }
+}
+
+// zero the panels and reset the status word: plain kernels instead of memset nodes (see enqueue_factor_body)
+__global__ __launch_bounds__(256) void k_clear_factor(double2 *__restrict__ Lx2, int64_t n2, double *__restrict__ Lx, int64_t n, int *status)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (i == 0) *status = 0x7f7f7f7f;
+    if (i == 0 && (n & 1)) Lx[n - 1] = 0.0;
+    for (; i < n2; i += stride) Lx2[i] = make_double2(0.0, 0.0);
+}
+void launch_clear_factor(hipStream_t st, double *Lx, int64_t n, int *status)
+{
+    const int64_t n2 = n / 2;                       // (pool blocks are 256-byte aligned)
+    int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n2 + 255) / 256, 8192));
+    hipLaunchKernelGGL(k_clear_factor, dim3((unsigned)blocks), dim3(256), 0, st, (double2 *)Lx, n2, Lx, n, status);
+}
+
+// dst := src (n doubles, both 16-byte aligned): a kernel instead of a memcpy node inside the captured solve sweeps
+__global__ __launch_bounds__(256) void k_copy_d(double2 *__restrict__ dst2, const double2 *__restrict__ src2, int64_t n2,
+                                                double *__restrict__ dst, const double *__restrict__ src, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (i == 0 && (n & 1)) dst[n - 1] = src[n - 1];
+    for (; i < n2; i += stride) dst2[i] = src2[i];
+}
+void launch_copy_d(hipStream_t st, double *dst, const double *src, int64_t n)
+{
+    if (n <= 0) return;
+    const int64_t n2 = n / 2;
+    int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((n2 + 255) / 256, 8192));
+    hipLaunchKernelGGL(k_copy_d, dim3((unsigned)blocks), dim3(256), 0, st, (double2 *)dst, (const double2 *)src, n2, dst, src, n);
 }
 
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx)

@@ -655,3 +655,19 @@ def test_factor_subtree_walk_gives_the_same_factor(monkeypatch):
         F.factorize(vx)
         assert np.array_equal(F.diag(), out[-1][0])
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_torch", ["0", "1"])
+def test_graph_replay_with_the_hip_runtime_of_the_torch_wheel(with_torch):
+    """A process that imports torch before this library runs on the HIP runtime bundled with the wheel (bench.py does).  Under that
+    runtime the memset nodes of a captured factorisation were not ordered before the kernels behind them when a SMALL factor was
+    replayed (the dense K of misc.kkt_chol2: `Terminated (singular KKT matrix)` from the second conelp call on); the prologue
+    is kernels now.  A child process refactorises a sparse and a small dense factor alternately through their graphs and checks
+    every solve, once per runtime."""
+    import subprocess, sys
+    env = dict(os.environ, WITH_TORCH=with_torch)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_replay_child.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "done, failures: 0" in out.stdout, out.stdout[-2000:]
