@@ -85,7 +85,9 @@ int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the facto
  * L', D, P, P' (:437-439) with D = I for an LL' factor (spsolvers.rst:640-668).  B (n x nrhs, leading dimension ldB >= max(1,n)) is
  * overwritten.  The caller applies offsetB to the pointer.  After kvx_chol_factorize_async_dev the solve
  * is queued behind the factorisation without a host round trip; a failed factorisation is then reported by
- * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456). */
+ * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456).
+ * From 64 right-hand sides on (KVX_WIDE_FROM) an LL' solve works on rhs-major blocks of 64 with GEMM-shaped panel products (FP64 MFMA):
+ * its columns agree with single-rhs solves to rounding, not bit for bit -- CHOLMOD's BLAS-3 solves do not either. */
 int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB);
 int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
 /* Enqueue only: no host synchronisation; work the caller submits to the null stream afterwards is ordered behind the
