@@ -13,6 +13,7 @@
             metric = IPM iterations per second (wall time of the whole conelp call, analysis included),
             plus the per-iteration cost of one KKT factor (assembly + numeric Cholesky) and one KKT solve.
 
+  chol5x64, chol5x256 : config 2 with 64 / 256 right-hand sides (solves on rhs-major blocks, csrc/kernels_wide.hip)
   lp4c    : lp4b plus 200 random equality rows: general G and A together (dense K = A S^-1 A', lp.KKTGenEqDev)
   klu3    : BASELINE.json configs[2]: klu.linsolve on the ACTIVSg2000 power-flow Jacobian (4000 x 4000, 29 336 entries,
             tests/golden/ACTIVSg2000.npz), nrhs = 3: symbolic, first numeric, steady-state refactorisation and solve times,
@@ -237,6 +238,10 @@ def main():
     for case in args.cases.split(","):
         if case == "chol5":
             out = chol_case("chol5 nrhs=3", *workloads.laplacian_2d(args.grid), 3, args.steps, args.warmup)
+        elif case == "chol5x64":                  # many right-hand sides: the rhs-major MFMA path (kernels_wide.hip)
+            out = chol_case("chol5 nrhs=64", *workloads.laplacian_2d(args.grid), 64, max(3, args.steps // 2), 2)
+        elif case == "chol5x256":
+            out = chol_case("chol5 nrhs=256", *workloads.laplacian_2d(args.grid), 256, max(3, args.steps // 2), 2)
         elif case == "chol21":
             out = chol_case("chol21 (21-point stencil)", *workloads.stencil21_2d(args.grid), 1, args.steps, args.warmup)
         elif case == "lap3d":

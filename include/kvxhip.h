@@ -86,7 +86,7 @@ int kvx_chol_status(kvx_chol *F, int64_t *minor);      /* synchronises the facto
  * overwritten.  The caller applies offsetB to the pointer.  After kvx_chol_factorize_async_dev the solve
  * is queued behind the factorisation without a host round trip; a failed factorisation is then reported by
  * the solve (KVX_ESINGULAR, B undefined), as the reference's solve does on a failed factor (cholmod.c:456).
- * From 64 right-hand sides on (KVX_WIDE_FROM) an LL' solve works on rhs-major blocks of 64 with GEMM-shaped panel products (FP64 MFMA):
+ * With many right-hand sides (48, or 8 when nrhs * n >= 6e6; KVX_WIDE_FROM) an LL' solve works on rhs-major blocks of 64 with GEMM-shaped panel products (FP64 MFMA):
  * its columns agree with single-rhs solves to rounding, not bit for bit -- CHOLMOD's BLAS-3 solves do not either. */
 int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB);
 int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);

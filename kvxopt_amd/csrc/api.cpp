@@ -843,7 +843,10 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     // wstride: both parity buffers are allocated with wrk_size[p]*x_cap; use a common stride
     // many right-hand sides of a plain LL' system: rhs-major blocks of 64 (kernels_wide.hip)
     const int kind0 = (sys == 0 || sys == 1) ? 0 : ((sys == 2 || sys == 4) ? 1 : ((sys == 3 || sys == 5) ? 2 : -1));
-    bool wide = kind0 >= 0 && !ldl && F->wide_from > 0 && nrhs >= F->wide_from && F->prof_family < 0;
+    // A block of 64 costs the same whatever it holds, the older kernels grow with every right-hand side: measured break-even
+    // (scratch/wide_thresh.py, 2-D grids) at 48 right-hand sides for n = 5e4, ~22 for n = 2.5e5, ~9 for n = 1e6.
+    const bool wide_by_size = nrhs >= 48 || (nrhs >= 8 && (double)nrhs * (double)n >= 6e6);
+    bool wide = kind0 >= 0 && !ldl && F->prof_family < 0 && (F->wide_from < 0 ? wide_by_size : (F->wide_from > 0 && nrhs >= F->wide_from));
     if (wide) {
         if ((rc = ensure_wide(F))) return rc;
         wide = F->wide_state == 1;

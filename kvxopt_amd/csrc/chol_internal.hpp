@@ -112,7 +112,7 @@ struct kvx_chol {
     // many right-hand sides (kernels_wide.hip): per front row, the children's update rows that land on it (built at the first such solve)
     int32_t *d_inv_ptr = nullptr, *d_inv_src = nullptr, *d_iperm = nullptr;   // d_iperm: position of every caller row in the permuted order
     int wide_state = 0;                        // 0 = not built yet, 1 = ready, -1 = not available for this factor (sharded mode, index range)
-    int wide_from = 64;                        // right-hand sides from which the rhs-major path is used (KVX_WIDE_FROM; 0 = never)
+    int wide_from = -1;                        // right-hand sides from which the rhs-major path is used (KVX_WIDE_FROM; 0 = never; -1 = by size, see solve_dev)
     bool solve_merged = false;                 // sw lists hold every small front outside the subtrees (one launch per level)
     int side_spread = 1;      // spread the small-front launches of a level over the streams (KVX_SIDE_SPREAD=0: one stream)
     std::vector<LevelPlan> plan;

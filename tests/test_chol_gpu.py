@@ -671,3 +671,48 @@ def test_graph_replay_with_the_hip_runtime_of_the_torch_wheel(with_torch):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "done, failures: 0" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_rhs_major_blocks_edge_cases():
+    """The rhs-major path beyond its plain use: more right-hand sides than one pass of the workspace takes (1024: 1100 go in two
+    passes), a natural ordering (a deep, thin tree: hundreds of levels, mostly chains of small fronts), a user permutation,
+    a leading dimension larger than n; in an LDL' view (options['supernodal'] = 0) the systems with D (sys 2, 3, 6) keep the older
+    kernels (bit-identical columns), A x = b and L D L' x = b are the same sweeps as for LL'."""
+    n, cp, ri, v = workloads.laplacian_2d(30, 22)
+    rng = np.random.default_rng(3)
+    for opts, perm in (({}, None), ({"ordering": 1}, None), ({}, rng.permutation(n))):
+        F = Factor(n, cp, ri, "L", perm, opts)
+        F.factorize(v)
+        O = OracleChol(n, cp, ri, "L", F.perm())
+        O.factorize(v)
+        nrhs = 1100 if not opts and perm is None else 80
+        B = rng.standard_normal((n, nrhs))
+        X = np.asfortranarray(B.copy())
+        F.solve(X)
+        Xo = np.asfortranarray(B.copy())
+        O.solve(Xo)
+        assert np.abs(X - Xo).max() / np.abs(Xo).max() < 1e-11
+    # leading dimension > n
+    ld = n + 7
+    Bl = np.zeros((ld, 70), order="F")
+    Bl[:n] = rng.standard_normal((n, 70))
+    keep = Bl.copy()
+    F.solve(Bl.reshape(-1, order="F"), nrhs=70, ldB=ld)
+    Xo = np.asfortranarray(keep[:n].copy())
+    O.solve(Xo)
+    assert np.abs(Bl[:n] - Xo).max() / np.abs(Xo).max() < 1e-11 and np.array_equal(Bl[n:], keep[n:])
+    # LDL' view
+    Fl = Factor(n, cp, ri, opts={"supernodal": 0})
+    Fl.factorize(v)
+    B = rng.standard_normal((n, 66))
+    for sys in (0, 1, 2, 3, 6):
+        X = np.asfortranarray(B.copy())
+        Fl.solve(X, sys=sys)
+        for j in (0, 65):
+            xj = B[:, j].copy()
+            Fl.solve(xj, sys=sys)
+            if sys >= 2:
+                assert np.array_equal(xj, X[:, j]), (sys, j)
+            else:
+                assert np.abs(xj - X[:, j]).max() <= 1e-12 * np.abs(xj).max(), (sys, j)
