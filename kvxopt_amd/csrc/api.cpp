@@ -851,7 +851,9 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
         if ((rc = ensure_wide(F))) return rc;
         wide = F->wide_state == 1;
     }
-    const int chunk_max = wide ? 1024 : 65535;
+    // rhs-major passes: at most 1024 right-hand sides, fewer on very large systems (the workspace is a few blocks of n x pass doubles)
+    const int wide_pass = (int)std::max<int64_t>(64, std::min<int64_t>(1024, ((int64_t)(1e9 / (double)std::max<int64_t>(n, 1)) / 64) * 64));
+    const int chunk_max = wide ? wide_pass : 65535;
     for (int64_t r0 = 0; r0 < nrhs; r0 += chunk_max) {
         int nr = (int)std::min<int64_t>(chunk_max, nrhs - r0);
         double *Bc = B + r0 * ldB;

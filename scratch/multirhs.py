@@ -34,6 +34,8 @@ if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "small"
     if which == "small":
         run(250, 200, [1, 2, 4, 8, 32, 200])
+    elif which == "one":
+        run(1000, 1000, [1], reps=2)
     elif which == "bigprof":
         run(1000, 1000, [64], reps=2)
     elif which == "prof":
