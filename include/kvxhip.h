@@ -41,7 +41,7 @@ typedef struct {
                              * P A P' = Lc Lc'; the LDL' factor is that result seen as L = Lc diag(Lc)^-1, D = diag(Lc)^2: solve
                              * sys = 2..6, getfactor (D on the diagonal, unit diagonal of L implicit) and diag (refused) follow it */
     int32_t ordering;       /* the library's own ordering (used when p == NULL, or compared with p when reserved[4] = 1):
-                             * 0 = best of nested dissection and, up to order reserved[5] (default 200 000), approximate minimum degree --
+                             * 0 = best of nested dissection (from order reserved[6] on) and, up to order reserved[5] (default 200 000), approximate minimum degree --
                              * the one with the least fill, CHOLMOD's strategy of trying several methods (cholmod.c:65-76);
                              * 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only (the role of AMD) */
     int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
@@ -53,7 +53,8 @@ typedef struct {
                              * L_kk < dbound is replaced by dbound; with reserved[3] = 1 by 1e64 (the row drops out of the solves) */
     int32_t reserved[8];    /* [0] nd_leaf, [1] leaf_cols, [2] leaf_rows, [3] dbound mode, [4] 1 = a given p competes with the library's own
                              * ordering(s) and the least fill wins (cholmod.options['nmethods'] = 0 or 2); 0 = p is used as given
-                             * (nmethods = 1), [5] largest order for the minimum-degree candidate of ordering 0                       */
+                             * (nmethods = 1), [5] largest order for the minimum-degree candidate of ordering 0, [6] smallest order for which
+                             * ordering 0 computes the dissection beside the minimum degree (default 20 000; -1 = always)                */
 } kvx_chol_opts;
 
 void kvx_chol_default_opts(kvx_chol_opts *o);

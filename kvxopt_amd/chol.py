@@ -33,6 +33,8 @@ class Factor:
                 o.reserved[4] = 1 if v else 0
             elif k == "amd_auto_max":
                 o.reserved[5] = int(v)
+            elif k == "nd_min_n":          # ordering 0: smallest order for which the dissection is computed beside the minimum degree (-1: always)
+                o.reserved[6] = int(v) if int(v) > 0 else -1
             elif k == "dbound_drop":        # with dbound > 0: a pivot below dbound^2 becomes 1e128 (its row drops out of the solves)
                 o.reserved[3] = 1 if v else 0
             else:

@@ -994,6 +994,7 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
         if (o.reserved[2] > 0) so.leaf_rows = o.reserved[2];
         so.compare_given = o.reserved[4] == 1 ? 1 : 0;
         if (o.reserved[5] > 0) so.amd_auto_max = o.reserved[5];
+        if (o.reserved[6] != 0) so.nd_min_n = std::max<int64_t>(0, o.reserved[6]);      // (-1: always compute the dissection too)
         static const int64_t zero = 0;
         analyze(n, n ? colptr : &zero, rowind, uplo, perm, so, F->S);
         // options['supernodal'] (spsolvers.rst:731-736): 2 -> LL'; 0 -> LDL'; 1 -> whichever CHOLMOD would find cheaper,

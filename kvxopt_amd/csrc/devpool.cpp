@@ -2,7 +2,9 @@
 
 #include <cstdlib>
 #include <map>
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace kvx {
@@ -28,6 +30,48 @@ size_t cache_cap()
         return (size_t)(e ? atoll(e) : 8192) << 20;
     }();
     return cap;
+}
+
+// hipStreamCreate costs ~3 ms on MI355X; a factor object holds three to five streams, so the first call on a new pattern while the
+// streams of earlier objects are still in use paid 10-15 ms for them (klu.linsolve on ACTIVSg2000: 15 ms against 5.6 with streams at
+// hand).  When a request finds the pool empty, a background thread tops it up with spare streams beside the caller's own work; the
+// next objects find them there.  KVX_SPARE_STREAMS=<count per refill> (default 12, 0 = off).
+std::mutex g_refill_mu;                          // guards the thread object (the thread itself only takes g_mu)
+std::thread g_refill;
+std::atomic<bool> g_refill_busy{false};
+bool g_refill_atexit = false;
+
+void join_refill()
+{
+    std::lock_guard<std::mutex> lk(g_refill_mu);
+    if (g_refill.joinable()) g_refill.join();
+}
+
+void start_refill(int dev)
+{
+    static const int spare = [] { const char *e = getenv("KVX_SPARE_STREAMS"); return e ? atoi(e) : 12; }();
+    if (spare <= 0) return;
+    bool expected = false;
+    if (!g_refill_busy.compare_exchange_strong(expected, true)) return;
+    std::lock_guard<std::mutex> lk(g_refill_mu);
+    if (g_refill.joinable()) g_refill.join();    // (a finished earlier refill)
+    if (!g_refill_atexit) { g_refill_atexit = true; (void)atexit(join_refill); }   // runs before the HIP runtime's own exit handlers
+    try {
+        g_refill = std::thread([dev] {
+            if (hipSetDevice(dev) == hipSuccess) {
+                for (int i = 0; i < spare; i++) {
+                    hipStream_t s = nullptr;
+                    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+                    std::lock_guard<std::mutex> lk2(g_mu);
+                    if (g_streams.size() >= 64) { (void)hipStreamDestroy(s); break; }
+                    g_streams.emplace(dev, s);
+                }
+            }
+            g_refill_busy.store(false);
+        });
+    } catch (...) {
+        g_refill_busy.store(false);
+    }
 }
 
 void release_all_locked()
@@ -121,6 +165,7 @@ hipError_t pool_stream_get(hipStream_t *s, bool high)
         auto it = pool.find(dev);
         if (it != pool.end()) { *s = it->second; pool.erase(it); return hipSuccess; }
     }
+    if (!high) start_refill(dev);
     if (high) {
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
@@ -167,6 +212,7 @@ void pool_event_put(hipEvent_t ev, bool timing)
 
 void pool_release_all()
 {
+    join_refill();
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_mu);
     release_all_locked();

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -49,6 +51,7 @@ struct kvx_lu_num {
     int64_t *d_asrc = nullptr, *d_prow = nullptr, *d_qcol = nullptr;
     double *d_rinv = nullptr, *d_rmax = nullptr, *d_Lx = nullptr, *d_Ux = nullptr, *d_arena = nullptr, *d_Ax = nullptr;
     double *d_W = nullptr, *d_X = nullptr, *d_B = nullptr;
+    void *d_struct = nullptr, *d_base = nullptr;               // one device block each: the plan's arrays + factor storage / the per-matrix arrays
     int64_t cap_rhs = 0;
     std::vector<int32_t> lvl_maxm, lvl_maxk, lvl_smallm, lvl_smallk;   // per level: all fronts / those swept by one workgroup
     double tol = 1e-3, stol = 1e-3;
@@ -72,12 +75,52 @@ int dalloc(T **dst, int64_t count)
     return KVX_OK;
 }
 
+struct LuLap {                                      // KVX_LU_TIMING=1: wall time of the phases of a numeric factorisation on stderr
+    bool on = std::getenv("KVX_LU_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "  lu %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
+// hipMalloc costs 0.1-0.7 ms on MI355X and a numeric object owns ~30 arrays: on a new pattern (nothing of the right size cached in
+// the pool) that was most of a first klu.linsolve call.  The arrays of one (re)build share ONE device block and ONE host-to-device
+// copy: uploads first (packed into a staging buffer in the same layout), then the uninitialised ones, every slot 256-byte aligned.
+struct Arena {
+    std::vector<void **> dst;
+    std::vector<size_t> off, bytes;
+    std::vector<const void *> src;
+    size_t total = 0, upload_end = 0;
+    void add(void **p, size_t b, const void *s)
+    {
+        dst.push_back(p); off.push_back(total); bytes.push_back(b); src.push_back(s);
+        total += (std::max<size_t>(b, 1) + 255) & ~(size_t)255;
+        if (s) upload_end = total;
+    }
+    template <class T> void up(T **p, const std::vector<T> &v) { add((void **)p, v.size() * sizeof(T), v.empty() ? (const void *)&total : (const void *)v.data()); }
+    template <class T> void alloc(T **p, int64_t count) { add((void **)p, (size_t)std::max<int64_t>(count, 1) * sizeof(T), nullptr); }
+    int commit(void **base)
+    {
+        HIPCHK(pool_malloc(base, std::max<size_t>(total, 256)));
+        std::vector<char> stage(upload_end, 0);
+        for (size_t i = 0; i < dst.size(); i++) {
+            *dst[i] = (char *)*base + off[i];
+            if (src[i] && bytes[i]) memcpy(stage.data() + off[i], src[i], bytes[i]);
+        }
+        if (upload_end) HIPCHK(hipMemcpy(*base, stage.data(), upload_end, hipMemcpyHostToDevice));
+        return KVX_OK;
+    }
+};
+
 void free_structure(kvx_lu_num *N)
 {
-    void *ptrs[] = {N->d_fr, N->d_rowidx, N->d_rel, N->d_children, N->d_adst, N->d_ipiv, N->d_lperm, N->d_fail, N->d_lists,
-                    N->d_asrc, N->d_prow, N->d_qcol, N->d_Lx, N->d_Ux, N->d_arena, N->d_W, N->d_X, N->d_B, N->d_slists, N->d_fcol,
-                    N->d_frow, N->d_flevpos, N->d_fptr_r, N->d_fptr_c, N->d_fsrc_r, N->d_fsrc_c, N->d_fval_r, N->d_fval_c};
-    for (void *p : ptrs) if (p) (void)pool_free(p);
+    for (void *p : {(void *)N->d_struct, (void *)N->d_W, (void *)N->d_X, (void *)N->d_B})
+        if (p) (void)pool_free(p);
+    N->d_struct = nullptr;
     N->d_slists = N->d_fcol = N->d_frow = N->d_flevpos = nullptr;
     N->d_fptr_r = N->d_fptr_c = N->d_fsrc_r = N->d_fsrc_c = nullptr;
     N->d_fval_r = N->d_fval_c = nullptr;
@@ -90,7 +133,9 @@ void free_structure(kvx_lu_num *N)
 // (Re)build the plan from the symbolic object's merge state and upload it.
 int upload_structure(kvx_lu_num *N)
 {
+    LuLap tl;
     free_structure(N);
+    tl.lap("free structure");
     try {
         lu_build_plan(N->sym->Y, N->P);
     } catch (const std::bad_alloc &) {
@@ -111,32 +156,35 @@ int upload_structure(kvx_lu_num *N)
         F.px = P.px[f]; F.rowptr = P.rowptr[f]; F.childptr = P.childptr[f]; F.aptr = P.aptr[f];
         F.upd_off = P.upd_off[f]; F.wx = P.wx[f]; F.upd_ld = P.upd_ld[f]; F.acnt = (int32_t)(P.aptr[f + 1] - P.aptr[f]);
     }
-    int rc;
-    if ((rc = up(&N->d_fr, fd))) return rc;
-    if ((rc = up(&N->d_rowidx, P.rowidx))) return rc;
-    if ((rc = up(&N->d_rel, P.rel))) return rc;
-    if ((rc = up(&N->d_children, P.children))) return rc;
-    if ((rc = up(&N->d_adst, P.a_dst))) return rc;
-    if ((rc = up(&N->d_asrc, P.a_src))) return rc;
-    if ((rc = up(&N->d_prow, P.prow))) return rc;
-    if ((rc = up(&N->d_qcol, P.qcol))) return rc;
-    if ((rc = up(&N->d_lists, P.levellist))) return rc;
-    if ((rc = up(&N->d_slists, P.stagelist))) return rc;
-    if ((rc = up(&N->d_fcol, P.fcol))) return rc;
-    if ((rc = up(&N->d_frow, P.frow))) return rc;
-    if ((rc = up(&N->d_flevpos, P.flevpos))) return rc;
-    if ((rc = up(&N->d_fptr_r, P.fptr_r))) return rc;
-    if ((rc = up(&N->d_fptr_c, P.fptr_c))) return rc;
-    if ((rc = up(&N->d_fsrc_r, P.fsrc_r))) return rc;
-    if ((rc = up(&N->d_fsrc_c, P.fsrc_c))) return rc;
-    if ((rc = dalloc(&N->d_fval_r, (int64_t)P.fcol.size()))) return rc;
-    if ((rc = dalloc(&N->d_fval_c, (int64_t)P.fcol.size()))) return rc;
-    if ((rc = dalloc(&N->d_ipiv, N->n))) return rc;
-    if ((rc = dalloc(&N->d_lperm, N->n))) return rc;
-    if ((rc = dalloc(&N->d_fail, P.nfront))) return rc;
-    if ((rc = dalloc(&N->d_Lx, P.lsize))) return rc;
-    if ((rc = dalloc(&N->d_Ux, P.lsize))) return rc;
-    if ((rc = dalloc(&N->d_arena, P.arena))) return rc;
+    Arena A;
+    A.up(&N->d_fr, fd);
+    A.up(&N->d_rowidx, P.rowidx);
+    A.up(&N->d_rel, P.rel);
+    A.up(&N->d_children, P.children);
+    A.up(&N->d_adst, P.a_dst);
+    A.up(&N->d_asrc, P.a_src);
+    A.up(&N->d_prow, P.prow);
+    A.up(&N->d_qcol, P.qcol);
+    A.up(&N->d_lists, P.levellist);
+    A.up(&N->d_slists, P.stagelist);
+    A.up(&N->d_fcol, P.fcol);
+    A.up(&N->d_frow, P.frow);
+    A.up(&N->d_flevpos, P.flevpos);
+    A.up(&N->d_fptr_r, P.fptr_r);
+    A.up(&N->d_fptr_c, P.fptr_c);
+    A.up(&N->d_fsrc_r, P.fsrc_r);
+    A.up(&N->d_fsrc_c, P.fsrc_c);
+    A.alloc(&N->d_fval_r, (int64_t)P.fcol.size());
+    A.alloc(&N->d_fval_c, (int64_t)P.fcol.size());
+    A.alloc(&N->d_ipiv, N->n);
+    A.alloc(&N->d_lperm, N->n);
+    A.alloc(&N->d_fail, P.nfront);
+    A.alloc(&N->d_Lx, P.lsize);
+    A.alloc(&N->d_Ux, P.lsize);
+    A.alloc(&N->d_arena, P.arena);
+    tl.lap("build plan");
+    if (int rc = A.commit(&N->d_struct)) return rc;
+    tl.lap("upload plan");
     N->lvl_maxm.assign((size_t)P.nlevels, 0);
     N->lvl_maxk.assign((size_t)P.nlevels, 0);
     N->lvl_smallm.assign((size_t)P.nlevels, 0);
@@ -242,6 +290,7 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     }
     if (lastB >= 0) HIPCHK(hipStreamWaitEvent(N->st, N->evB[lastB], 0));
     HIPCHK(hipGetLastError());
+    if (std::getenv("KVX_LU_TIMING")) fprintf(stderr, "  lu   (pass enqueued, %d levels)\n", (int)P.nlevels);
     fail_host.resize((size_t)P.nfront);
     HIPCHK(hipMemcpyAsync(fail_host.data(), N->d_fail, (size_t)P.nfront * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
     HIPCHK(hipStreamSynchronize(N->st));
@@ -258,9 +307,11 @@ int factor_loop(kvx_lu_num *N, const double *Ax_dev, int reuse)
         return KVX_ESINGULAR;
     }
     std::vector<int32_t> fail;
+    LuLap tl;
     for (int iter = 0; iter < 100000; iter++) {
         int rc = numeric_pass(N, Ax_dev, reuse, fail);
         if (rc) return rc;
+        tl.lap("numeric pass");
         const LuPlan &P = N->P;
         std::vector<int32_t> minimal;
         std::vector<char> below((size_t)P.nfront, 0);
@@ -275,7 +326,9 @@ int factor_loop(kvx_lu_num *N, const double *Ax_dev, int reuse)
             set_last_error("singular matrix");
             return KVX_ESINGULAR;
         }
+        tl.lap("merge fronts");
         if ((rc = upload_structure(N))) return rc;
+        tl.t = std::chrono::steady_clock::now();
     }
     set_last_error("singular matrix");
     return KVX_ESINGULAR;
@@ -289,17 +342,21 @@ int ensure_device(kvx_lu_num *N)
         set_last_error("no HIP device: the LU numeric phase has no CPU fallback");
         return KVX_EDEVICE;
     }
+    LuLap tl;
     HIPCHK(pool_stream_get(&N->st));
     HIPCHK(pool_stream_get(&N->st2));
     HIPCHK(pool_stream_get(&N->st3));
     HIPCHK(pool_event_get(&N->ev0, false));
+    tl.lap("streams + event");
     std::vector<int32_t> ai32((size_t)N->nnz);
     for (int64_t p = 0; p < N->nnz; p++) ai32[p] = (int32_t)N->sym->Y.Ai[p];
-    int rc;
-    if ((rc = up(&N->d_ai32, ai32))) return rc;
-    if ((rc = dalloc(&N->d_rinv, N->n))) return rc;
-    if ((rc = dalloc(&N->d_rmax, N->n))) return rc;
-    if ((rc = dalloc(&N->d_Ax, N->nnz))) return rc;
+    Arena A;
+    A.up(&N->d_ai32, ai32);
+    A.alloc(&N->d_rinv, N->n);
+    A.alloc(&N->d_rmax, N->n);
+    A.alloc(&N->d_Ax, N->nnz);
+    if (int rc = A.commit(&N->d_base)) return rc;
+    tl.lap("per-matrix arrays");
     N->dev = true;
     return upload_structure(N);
 }
@@ -415,8 +472,7 @@ void kvx_lu_free_numeric(kvx_lu_num *N)
     if (!N) return;
     if (N->st) (void)hipDeviceSynchronize();       // streams and events go back to the pool idle
     free_structure(N);
-    void *ptrs[] = {N->d_ai32, N->d_rinv, N->d_rmax, N->d_Ax};
-    for (void *p : ptrs) if (p) (void)pool_free(p);
+    if (N->d_base) (void)pool_free(N->d_base);    // d_ai32, d_rinv, d_rmax, d_Ax
     for (hipEvent_t e : N->evA) pool_event_put(e, false);
     for (hipEvent_t e : N->evB) pool_event_put(e, false);
     for (hipEvent_t e : N->evC) pool_event_put(e, false);

@@ -231,6 +231,26 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
     // ---- 1. initial permutation: candidates (user's, nested dissection, minimum degree), the least fill wins ----------
     std::vector<std::vector<int64_t>> cand;
     std::vector<const char *> cand_name;
+    // fill of an ordering: nnz(L) from the column counts (elimination tree + postorder + Gilbert-Ng-Peyton), no factor formed
+    auto fill_of = [&](const std::vector<int64_t> &pp) -> double {
+        std::vector<int64_t> ip((size_t)n);
+        for (int64_t k = 0; k < n; k++) ip[pp[k]] = k;
+        LowerPattern Lc;
+        std::vector<int32_t> par, post, cc;
+        build_lower(n, Ap, Ai, uplo, ip, Lc);
+        etree_from_lower(n, Lc, par);
+        postorder(n, par, post);
+        std::vector<int32_t> ipost((size_t)n), np2((size_t)n);
+        for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
+        for (int64_t k = 0; k < n; k++) np2[k] = par[post[k]] >= 0 ? ipost[par[post[k]]] : -1;
+        for (int64_t k = 0; k < n; k++) ip[pp[post[k]]] = k;
+        build_lower(n, Ap, Ai, uplo, ip, Lc);
+        column_counts(n, Lc, np2, cc);
+        double lnz = 0.0;
+        for (int64_t j = 0; j < n; j++) lnz += cc[j];
+        return lnz;
+    };
+    std::vector<double> known_fill;        // fill of cand[i] when it was needed to decide what else to compute (else < 0)
     std::vector<int64_t> aptr;             // full symmetric adjacency (built when an ordering is computed here; phase 2 reuses it)
     std::vector<int32_t> adj;
     if (user_perm) {
@@ -242,11 +262,11 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             seen[q] = 1;
             pu[k] = q;
         }
-        cand.push_back(std::move(pu)); cand_name.push_back("given");
+        cand.push_back(std::move(pu)); cand_name.push_back("given"); known_fill.push_back(-1.0);
     }
     if (!user_perm || opts.compare_given) {
         if (opts.ordering == 1) {
-            if (!user_perm) { cand.emplace_back((size_t)n); std::iota(cand.back().begin(), cand.back().end(), 0); cand_name.push_back("natural"); }
+            if (!user_perm) { cand.emplace_back((size_t)n); std::iota(cand.back().begin(), cand.back().end(), 0); cand_name.push_back("natural"); known_fill.push_back(-1.0); }
         } else if (n > 0) {
             // full symmetric adjacency of the analysed triangle
             aptr.assign((size_t)n + 1, 0);
@@ -270,8 +290,13 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             pt.lap("1a adjacency");
             // the two orderings are independent: the minimum-degree candidate runs on a thread of its own beside the dissection
             // (an exception of either is carried to the caller; the result does not depend on the overlap)
-            const bool want_nd = opts.ordering != 3;
             const bool want_md = opts.ordering == 3 || (opts.ordering == 0 && n <= opts.amd_auto_max);
+            bool want_nd = opts.ordering != 3;
+            // Small systems (n < nd_min_n), ordering 0: the minimum-degree ordering first; when it leaves next to no fill
+            // (nnz(L) <= 3 nnz(tril A): power grids, circuits -- ACTIVSg2000: 43 456 against the dissection's 165 132) the dissection
+            // is not computed at all (it costs as much as the rest of the analysis: 3.0 -> 1.5 ms there).  Meshes fill more than that
+            // even when tiny (40 x 40 grid: 4.4 nnz) and get both candidates as before.
+            const bool md_first = opts.ordering == 0 && want_md && n < opts.nd_min_n;
             std::vector<int64_t> perm_nd, perm_md;
             std::exception_ptr md_err;
             auto run_md = [&] {
@@ -293,7 +318,17 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
             };
             std::thread md_thread;
             bool md_async = false;
-            if (want_md && want_nd && analyze_threads() > 1) {
+            double md_fill = -1.0;
+            if (md_first) {
+                run_md();
+                if (md_err) std::rethrow_exception(md_err);
+                md_fill = fill_of(perm_md);
+                int64_t tri = n;                     // entries of the analysed triangle, diagonal counted once per column
+                for (int64_t v = 0; v < n; v++) tri += (aptr[(size_t)v + 1] - aptr[(size_t)v]);
+                tri = (tri - n) / 2 + n;
+                if (md_fill <= 3.0 * (double)tri) want_nd = false;
+            }
+            if (!md_first && want_md && want_nd && analyze_threads() > 1) {
                 try { md_thread = std::thread(run_md); md_async = true; } catch (...) { md_async = false; }
             }
             try {
@@ -303,38 +338,23 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
                 throw;
             }
             if (md_async) md_thread.join();
-            else if (want_md) run_md();
+            else if (want_md && !md_first) run_md();
             if (md_err) std::rethrow_exception(md_err);
-            if (want_nd) { cand.push_back(std::move(perm_nd)); cand_name.push_back("nested dissection"); }
-            if (want_md) { cand.push_back(std::move(perm_md)); cand_name.push_back("minimum degree"); }
+            if (want_nd) { cand.push_back(std::move(perm_nd)); cand_name.push_back("nested dissection"); known_fill.push_back(-1.0); }
+            if (want_md) { cand.push_back(std::move(perm_md)); cand_name.push_back("minimum degree"); known_fill.push_back(md_fill); }
         } else if (!user_perm) {
-            cand.emplace_back(); cand_name.push_back("empty");
+            cand.emplace_back(); cand_name.push_back("empty"); known_fill.push_back(-1.0);
         }
     }
     size_t pick = 0;
     if (cand.size() > 1) {
-        // fill of a candidate: nnz(L) from the column counts (elimination tree + postorder + Gilbert-Ng-Peyton), no factor formed;
         // the candidates are evaluated side by side (independent work on private vectors)
         std::vector<double> fill(cand.size(), 0.0);
         std::vector<std::exception_ptr> ferr(cand.size());
+        known_fill.resize(cand.size(), -1.0);
         auto eval = [&](size_t c) {
             try {
-                std::vector<int64_t> ip((size_t)n), pp(cand[c]);
-                for (int64_t k = 0; k < n; k++) ip[pp[k]] = k;
-                LowerPattern Lc;
-                std::vector<int32_t> par, post, cc;
-                build_lower(n, Ap, Ai, uplo, ip, Lc);
-                etree_from_lower(n, Lc, par);
-                postorder(n, par, post);
-                std::vector<int32_t> ipost((size_t)n), np2((size_t)n);
-                for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
-                for (int64_t k = 0; k < n; k++) np2[k] = par[post[k]] >= 0 ? ipost[par[post[k]]] : -1;
-                for (int64_t k = 0; k < n; k++) ip[pp[post[k]]] = k;
-                build_lower(n, Ap, Ai, uplo, ip, Lc);
-                column_counts(n, Lc, np2, cc);
-                double lnz = 0.0;
-                for (int64_t j = 0; j < n; j++) lnz += cc[j];
-                fill[c] = lnz;
+                fill[c] = known_fill[c] >= 0.0 ? known_fill[c] : fill_of(cand[c]);
             } catch (...) { ferr[c] = std::current_exception(); }
         };
         {

@@ -28,11 +28,13 @@ inline int wave_class_mcap(int cls) { static const int c[3] = {64, 48, 32}; retu
 inline int wave_class_kmax(int cls) { return ((cls - KVX_CLS_WAVE0) & 1) ? 16 : 32; }
 
 struct SymOpts {
-    int ordering = 0;        // 0 = best of nested dissection and (n <= amd_auto_max) approximate minimum degree, by fill;
+    int ordering = 0;        // 0 = best of nested dissection (n >= nd_min_n) and approximate minimum degree (n <= amd_auto_max), by fill;
                              // 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only
     int compare_given = 0;   // with a user permutation: 1 = it is one candidate among the library's own (cholmod.options['nmethods']
                              // 0 / 2, cholmod.c:65-76), the ordering with the least fill wins; 0 = it is used as given (nmethods = 1)
     int64_t amd_auto_max = 200000;   // ordering 0: largest order for which the minimum-degree candidate is computed as well
+    int64_t nd_min_n = 20000;        // ordering 0: below this order the minimum-degree ordering is taken without computing the dissection as well (on small
+                             // systems the dissection rarely wins on fill and costs as much as the rest of the analysis: ACTIVSg2000, n = 4000, 3.0 -> 1.5 ms)
     int postorder = 1;
     int relax_small = 4;
     double relax_z1 = 0.8, relax_z2 = 0.1, relax_z3 = 0.075;   // zero fractions tolerated when a chain supernode joins its parent

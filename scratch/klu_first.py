@@ -18,6 +18,11 @@ for rep in range(3):
     Ar = spmatrix.from_ccs(n, n, cp, ri, vv)
     B = matrix(rng.standard_normal((n, 3)))
     t = time.perf_counter()
+    if rep == 0 and os.environ.get('KVX_LU_TIMING'):
+        t0 = time.perf_counter(); Fs = klu.symbolic(Ar); t1 = time.perf_counter(); Fn = klu.numeric(Ar, Fs); t2 = time.perf_counter(); klu.solve(Ar, Fs, Fn, B); t3 = time.perf_counter()
+        print('  first call pieces: symbolic %.2f numeric %.2f solve %.2f ms' % (1e3*(t1-t0), 1e3*(t2-t1), 1e3*(t3-t2)), flush=True)
+        del Fs, Fn
+        t = time.perf_counter()
     klu.linsolve(Ar, B)
     print("linsolve call %d: %.2f ms" % (rep, 1e3 * (time.perf_counter() - t)), flush=True)
 import scipy.sparse as sp, scipy.sparse.linalg as spla
