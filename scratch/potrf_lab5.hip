@@ -94,13 +94,186 @@ __device__ __forceinline__ void step_v2(double (&acc)[16], double &dg, double *c
     acc[J] = (rr < J) ? 0.0 : ajj * inv;
 }
 
+// ---- V3: V0's arithmetic, software-pipelined by hand: the first update of step J (column J + 1, the next pivot column) is done
+// first, the next step's publish / pivot / rsqrt chain is started at once, and the rest of step J's updates (columns J + 2 ..)
+// are interleaved one by one between the dependent operations of that chain.
+struct Carry { double w; const double *cb; };
+template <int J>
+__device__ __forceinline__ void step_v3(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad, const PivRule pr, Carry &c)
+{
+    // on entry: c.w / c.cb belong to step J - 1 (J > 0); the columns J .. 15 still lack step J - 1's update
+    double *cbn = colbuf + (J & 1) * 80;
+    const double wp = c.w;
+    const double *cbp = c.cb;
+#define UPD(T) do { if (J > 0 && (T) < 16) acc[(T)] = __builtin_fma(-wp, cbp[(T)], acc[(T)]); } while (0)
+    UPD(J);                                         // the pivot column first: everything below waits for it
+    const double aj = acc[J];
+    cbn[wslot] = aj;
+    double d = rl(aj, J);
+    const bool neg = !(d > pr.floor);
+    UPD(J + 1);
+    bad = (neg && bad > J) ? J : bad;
+    d = neg ? pr.sub : d;
+    UPD(J + 2);
+    double inv = __builtin_amdgcn_rsq(d);
+    UPD(J + 3);
+    const double hd = 0.5 * d;
+    UPD(J + 4);
+    double t = hd * inv;
+    UPD(J + 5);
+    double u = __builtin_fma(-t, inv, 1.5);
+    UPD(J + 6);
+    inv = inv * u;
+    UPD(J + 7);
+    t = hd * inv;
+    UPD(J + 8);
+    u = __builtin_fma(-t, inv, 1.5);
+    UPD(J + 9);
+    inv = inv * u;
+    UPD(J + 10);
+    const double lj = aj * inv;
+    UPD(J + 11);
+    const double w = (rr <= J) ? 0.0 : lj * inv;
+    UPD(J + 12);
+    UPD(J + 13);
+    UPD(J + 14);
+    UPD(J + 15);
+#undef UPD
+    acc[J] = (rr < J) ? 0.0 : lj;
+    c.w = w;
+    c.cb = cbn;
+}
+
+// ---- V4: V3 with the published column of the previous step held in REGISTERS: its LDS reads are issued right after the publish of
+// that step (their latency disappears behind that step's rsqrt chain), so the delayed updates interleaved with the next chain
+// wait for nothing.
+struct Carry4 { double w; double cb[16]; };
+template <int J>
+__device__ __forceinline__ void step_v4(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad, const PivRule pr, Carry4 &c)
+{
+    double *cbn = colbuf + (J & 1) * 80;
+    const double wp = c.w;
+#define UPD(T) do { if (J > 0 && (T) < 16) acc[(T)] = __builtin_fma(-wp, c.cb[(T)], acc[(T)]); } while (0)
+    UPD(J);
+    const double aj = acc[J];
+    cbn[wslot] = aj;
+    double d = rl(aj, J);
+    double nb[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) nb[t] = (t > J) ? cbn[t] : 0.0;      // (in order behind the publish: the reads see it)
+    const bool neg = !(d > pr.floor);
+    UPD(J + 1);
+    bad = (neg && bad > J) ? J : bad;
+    d = neg ? pr.sub : d;
+    UPD(J + 2);
+    double inv = __builtin_amdgcn_rsq(d);
+    UPD(J + 3);
+    const double hd = 0.5 * d;
+    UPD(J + 4);
+    double t = hd * inv;
+    UPD(J + 5);
+    double u = __builtin_fma(-t, inv, 1.5);
+    UPD(J + 6);
+    inv = inv * u;
+    UPD(J + 7);
+    t = hd * inv;
+    UPD(J + 8);
+    u = __builtin_fma(-t, inv, 1.5);
+    UPD(J + 9);
+    inv = inv * u;
+    UPD(J + 10);
+    const double lj = aj * inv;
+    UPD(J + 11);
+    const double w = (rr <= J) ? 0.0 : lj * inv;
+    UPD(J + 12);
+    UPD(J + 13);
+    UPD(J + 14);
+    UPD(J + 15);
+#undef UPD
+    acc[J] = (rr < J) ? 0.0 : lj;
+    c.w = w;
+#pragma unroll
+    for (int t = 0; t < 16; t++) c.cb[t] = nb[t];
+}
+
+// ---- V5: V4 with a shorter dependent chain per pivot: (a) the pivot rule is applied AFTER the hardware rsqrt (a select against the
+// constant seed of the substitute pivot; the comparison runs beside the rsqrt), (b) the multiplier uses 1 / d refined on its own
+// from the seed, r0 = s^2, e = 1 - d r0, r = r0 (1 + e + e^2) (third order: the 2^-26 seed gives 2^-75), three dependent operations
+// shorter than two Newton steps of the root followed by two multiplications; (c) 1 / sqrt(d) for the stored column comes from the
+// same e beside the chain: s (1 + e / 2 + 3 e^2 / 8).
+template <int J>
+__device__ __forceinline__ void step_v5(double (&acc)[16], double *colbuf, int wslot, int rr, int &bad, const PivRule pr, Carry4 &c, double sub_seed)
+{
+    double *cbn = colbuf + (J & 1) * 80;
+    const double wp = c.w;
+#define UPD(T) do { if (J > 0 && (T) < 16) acc[(T)] = __builtin_fma(-wp, c.cb[(T)], acc[(T)]); } while (0)
+    UPD(J);
+    const double aj = acc[J];
+    cbn[wslot] = aj;
+    const double draw = rl(aj, J);
+    double nb[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) nb[t] = (t > J) ? cbn[t] : 0.0;
+    const bool neg = !(draw > pr.floor);
+    double s0 = __builtin_amdgcn_rsq(draw);
+    UPD(J + 1);
+    bad = (neg && bad > J) ? J : bad;
+    const double d = neg ? pr.sub : draw;
+    s0 = neg ? sub_seed : s0;
+    UPD(J + 2);
+    const double r0 = s0 * s0;
+    UPD(J + 3);
+    const double e = __builtin_fma(-d, r0, 1.0);
+    UPD(J + 4);
+    const double g = __builtin_fma(e, e, e);
+    UPD(J + 5);
+    const double r = __builtin_fma(r0, g, r0);
+    UPD(J + 6);
+    const double w = (rr <= J) ? 0.0 : aj * r;
+    UPD(J + 7);
+    // beside the chain: the root's reciprocal for the stored column
+    const double q = s0 * e;
+    UPD(J + 8);
+    const double pz = __builtin_fma(0.375, e, 0.5);
+    UPD(J + 9);
+    const double inv = __builtin_fma(q, pz, s0);
+    UPD(J + 10);
+    const double lj = aj * inv;
+    UPD(J + 11);
+    UPD(J + 12);
+    UPD(J + 13);
+    UPD(J + 14);
+    UPD(J + 15);
+#undef UPD
+    acc[J] = (rr < J) ? 0.0 : lj;
+    c.w = w;
+#pragma unroll
+    for (int t = 0; t < 16; t++) c.cb[t] = nb[t];
+}
+
 template <int V, int... Js>
 __device__ __forceinline__ void sweep(double (&acc)[16], double *colbuf, int wslot, int rr, int lr, int &bad, const PivRule pr,
                                       std::integer_sequence<int, Js...>)
 {
     if (V == 0) (step_v0<Js>(acc, colbuf, wslot, rr, bad, pr), ...);
     else if (V == 1) (step_v1<Js>(acc, colbuf, wslot, rr, bad, pr), ...);
-    else {
+    else if (V == 5) {
+        Carry4 c;
+        c.w = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) c.cb[t] = 0.0;
+        const double sub_seed = __builtin_amdgcn_rsq(pr.sub);
+        (step_v5<Js>(acc, colbuf, wslot, rr, bad, pr, c, sub_seed), ...);
+    } else if (V == 4) {
+        Carry4 c;
+        c.w = 0.0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) c.cb[t] = 0.0;
+        (step_v4<Js>(acc, colbuf, wslot, rr, bad, pr, c), ...);
+    } else if (V == 3) {
+        Carry c{0.0, colbuf};
+        (step_v3<Js>(acc, colbuf, wslot, rr, bad, pr, c), ...);
+    } else {
         // dg: the diagonal entry of a factor lane (lane r: acc[r]); the inverse lanes carry nothing useful there
         double dg = 0.0;
 #pragma unroll
@@ -202,6 +375,9 @@ int main()
             if (v == 0) hipLaunchKernelGGL(k_lab<0>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
             if (v == 1) hipLaunchKernelGGL(k_lab<1>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
             if (v == 2) hipLaunchKernelGGL(k_lab<2>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
+            if (v == 5) hipLaunchKernelGGL(k_lab<5>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
+            if (v == 4) hipLaunchKernelGGL(k_lab<4>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
+            if (v == 3) hipLaunchKernelGGL(k_lab<3>, dim3(1), dim3(64), 0, 0, dA, dL, dY, dc, reps);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
@@ -220,6 +396,6 @@ int main()
         printf("V%d: %.1f counter ticks per 16-pivot sweep incl. load/store (%.1f per pivot); %.3f us per sweep by events; max err L %.2e Y %.2e\n", v,
                (double)cyc / reps, (double)cyc / reps / 16, 1e3 * ms / (reps + 2), el, ey);
     };
-    run(0); run(1); run(2);
+    run(0); run(1); run(2); run(3); run(4); run(5);
     return 0;
 }
