@@ -846,7 +846,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     // A block of 64 costs the same whatever it holds, the older kernels grow with every right-hand side: measured break-even
     // (scratch/wide_thresh.py, 2-D grids) at 48 right-hand sides for n = 5e4, ~22 for n = 2.5e5, ~9 for n = 1e6.
     const bool wide_by_size = nrhs >= 48 || (nrhs >= 8 && (double)nrhs * (double)n >= 6e6);
-    bool wide = kind0 >= 0 && !ldl && F->prof_family < 0 && (F->wide_from < 0 ? wide_by_size : (F->wide_from > 0 && nrhs >= F->wide_from));
+    bool wide = kind0 >= 0 && F->prof_family < 0 && (F->wide_from < 0 ? wide_by_size : (F->wide_from > 0 && nrhs >= F->wide_from));
     if (wide) {
         if ((rc = ensure_wide(F))) return rc;
         wide = F->wide_state == 1;
@@ -861,7 +861,10 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
         HIPCHK(hipEventRecord(F->ev[2], st));
         if (wide) {
             const int nchunk = (nr + 63) / 64;
-            launch_wide_gather(st, sys == 0 ? F->d_iperm : nullptr, n, nr, Bc, ldB, F->d_X);
+            // LDL' view: D L' x = b  ->  Lc' x = diag^-1 b;  L' x = b  ->  Lc' x = diag b (on the way in);
+            //            L D x = b   ->  x = diag^-1 Lc^-1 b;  L x = b   ->  x = diag Lc^-1 b (on the way out)
+            const bool sc_in = ldl && (sys == 3 || sys == 5), sc_out = ldl && (sys == 2 || sys == 4);
+            launch_wide_gather(st, sys == 0 ? F->d_iperm : nullptr, n, nr, Bc, ldB, F->d_X, sc_in ? F->d_diag : nullptr, sys == 3 ? 1 : 0);
             auto body = [&]() -> int {
                 if (kind0 == 0 || kind0 == 1) enqueue_fwd_wide(F, F->d_X, nchunk);
                 if (kind0 == 0 || kind0 == 2) enqueue_bwd_wide(F, F->d_X, nchunk);
@@ -879,7 +882,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
             }
             if (exec) HIPCHK(hipGraphLaunch(exec, st));
             else if ((rc = body())) return rc;
-            launch_wide_scatter(st, sys == 0 ? F->d_iperm : nullptr, n, nr, F->d_X, Bc, ldB);
+            launch_wide_scatter(st, sys == 0 ? F->d_iperm : nullptr, n, nr, F->d_X, Bc, ldB, sc_out ? F->d_diag : nullptr, sys == 2 ? 1 : 0);
             HIPCHK(hipEventRecord(F->ev[3], st));
             HIPCHK(hipGetLastError());
             continue;

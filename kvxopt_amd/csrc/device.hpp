@@ -234,8 +234,10 @@ void launch_perm_gather(hipStream_t st, const int32_t *perm, int64_t n, int nrhs
 void launch_perm_scatter(hipStream_t st, const int32_t *perm, int64_t n, int nrhs, const double *in, int64_t ldi,
                          double *out, int64_t ldo);
 // many right-hand sides, rhs-major blocks of 64 (kernels_wide.hip): XT[chunk][row][64]; W*: [chunk][wstride rows][64]
-void launch_wide_gather(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT);
-void launch_wide_scatter(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB);
+void launch_wide_gather(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT,
+                        const double *diag, int mode);   // diag != nullptr: rows scaled on the way (mode 0: times diag, 1: divided by it)
+void launch_wide_scatter(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB,
+                         const double *diag, int mode);
 void launch_wide_fwd_small(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax, int nchunk, const double *Lx,
                            double *XT, int64_t n, const double *Wch, double *Wout, int64_t wstride, const int32_t *inv_ptr,
                            const int32_t *inv_src);

@@ -37,8 +37,11 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) { return __builtin_
 // XT[chunk][iperm[j]][b] = B[j + (64 chunk + b) ldB]: driven by the CALLER's row index j, so the reads of B run down its columns
 // (coalesced) and every write is one whole 512-byte row of XT wherever the permutation sends it.  iperm == nullptr: identity.
 // Right-hand sides past nrhs are zero.
+// diag / mode: optional row scaling on the way (LDL' views: the systems with D are the LL' sweeps with diag(Lc) applied to the
+// right-hand side or the result, indexed by the row's position in the factor): mode 0 multiplies by diag, 1 divides.
 __global__ __launch_bounds__(256) void k_wide_gather(const int32_t *__restrict__ iperm, int64_t n, int nrhs,
-                                                     const double *__restrict__ B, int64_t ldB, double *__restrict__ XT)
+                                                     const double *__restrict__ B, int64_t ldB, double *__restrict__ XT,
+                                                     const double *__restrict__ diag, int mode)
 {
     __shared__ double tile[64][65];
     __shared__ int dst[64];
@@ -57,12 +60,17 @@ __global__ __launch_bounds__(256) void k_wide_gather(const int32_t *__restrict__
     __syncthreads();
     double *out = XT + (int64_t)c * n * 64;
     for (int r = g; r < 64; r += 4)
-        if (row0 + r < n) out[(int64_t)dst[r] * 64 + i] = tile[r][i];
+        if (row0 + r < n) {
+            double v = tile[r][i];
+            if (diag) { const double dg = diag[dst[r]]; v = mode ? v / dg : v * dg; }
+            out[(int64_t)dst[r] * 64 + i] = v;
+        }
 }
 
 // B[j + (64 chunk + b) ldB] = XT[chunk][iperm[j]][b]
 __global__ __launch_bounds__(256) void k_wide_scatter(const int32_t *__restrict__ iperm, int64_t n, int nrhs,
-                                                      const double *__restrict__ XT, double *__restrict__ B, int64_t ldB)
+                                                      const double *__restrict__ XT, double *__restrict__ B, int64_t ldB,
+                                                      const double *__restrict__ diag, int mode)
 {
     __shared__ double tile[64][65];
     __shared__ int src[64];
@@ -74,7 +82,11 @@ __global__ __launch_bounds__(256) void k_wide_scatter(const int32_t *__restrict_
     if (g == 0) src[i] = row < n ? (iperm ? iperm[row] : (int)row) : 0;
     __syncthreads();
     const double *in = XT + (int64_t)c * n * 64;
-    for (int r = g; r < 64; r += 4) tile[r][i] = (row0 + r < n) ? in[(int64_t)src[r] * 64 + i] : 0.0;
+    for (int r = g; r < 64; r += 4) {
+        double v = (row0 + r < n) ? in[(int64_t)src[r] * 64 + i] : 0.0;
+        if (diag && row0 + r < n) { const double dg = diag[src[r]]; v = mode ? v / dg : v * dg; }
+        tile[r][i] = v;
+    }
     __syncthreads();
     if (row >= n) return;
     for (int b = g; b < nv; b += 4) B[row + (int64_t)(64 * c + b) * ldB] = tile[i][b];
@@ -662,15 +674,19 @@ __global__ __launch_bounds__(256) void k_wide_bwd_big_step(DevSym ds, const int3
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------
-void launch_wide_gather(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT)
+void launch_wide_gather(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *B, int64_t ldB, double *XT,
+                        const double *diag, int mode)
 {
     if (n <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_wide_gather, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, B, ldB, XT);
+    hipLaunchKernelGGL(k_wide_gather, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, B, ldB, XT,
+                       diag, mode);
 }
-void launch_wide_scatter(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB)
+void launch_wide_scatter(hipStream_t st, const int32_t *iperm, int64_t n, int nrhs, const double *XT, double *B, int64_t ldB,
+                         const double *diag, int mode)
 {
     if (n <= 0 || nrhs <= 0) return;
-    hipLaunchKernelGGL(k_wide_scatter, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, XT, B, ldB);
+    hipLaunchKernelGGL(k_wide_scatter, dim3((unsigned)((n + 63) / 64), (unsigned)((nrhs + 63) / 64)), dim3(256), 0, st, iperm, n, nrhs, XT, B, ldB,
+                       diag, mode);
 }
 void launch_wide_fwd_small(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax, int nchunk, const double *Lx,
                            double *XT, int64_t n, const double *Wch, double *Wout, int64_t wstride, const int32_t *inv_ptr,

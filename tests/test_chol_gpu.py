@@ -677,8 +677,8 @@ def test_graph_replay_with_the_hip_runtime_of_the_torch_wheel(with_torch):
 def test_rhs_major_blocks_edge_cases():
     """The rhs-major path beyond its plain use: more right-hand sides than one pass of the workspace takes (1024: 1100 go in two
     passes), a natural ordering (a deep, thin tree: hundreds of levels, mostly chains of small fronts), a user permutation,
-    a leading dimension larger than n; in an LDL' view (options['supernodal'] = 0) the systems with D (sys 2, 3, 6) keep the older
-    kernels (bit-identical columns), A x = b and L D L' x = b are the same sweeps as for LL'."""
+    a leading dimension larger than n; an LDL' view (options['supernodal'] = 0): the systems with D are the LL' sweeps with
+    diag(Lc) applied in the layout kernels (sys 2 - 5), D x = b (sys 6) keeps the elementwise kernel."""
     n, cp, ri, v = workloads.laplacian_2d(30, 22)
     rng = np.random.default_rng(3)
     for opts, perm in (({}, None), ({"ordering": 1}, None), ({}, rng.permutation(n))):
@@ -706,13 +706,13 @@ def test_rhs_major_blocks_edge_cases():
     Fl = Factor(n, cp, ri, opts={"supernodal": 0})
     Fl.factorize(v)
     B = rng.standard_normal((n, 66))
-    for sys in (0, 1, 2, 3, 6):
+    for sys in (0, 1, 2, 3, 4, 5, 6):
         X = np.asfortranarray(B.copy())
         Fl.solve(X, sys=sys)
-        for j in (0, 65):
+        for j in (0, 33, 65):
             xj = B[:, j].copy()
             Fl.solve(xj, sys=sys)
-            if sys >= 2:
+            if sys == 6:
                 assert np.array_equal(xj, X[:, j]), (sys, j)
             else:
                 assert np.abs(xj - X[:, j]).max() <= 1e-12 * np.abs(xj).max(), (sys, j)
