@@ -164,16 +164,19 @@ int build_subtrees(kvx_chol *F)
     if (lsw.empty()) lsw.push_back(0);
     std::vector<SubDesc> subs;
     F->nsub32 = 0;
-    for (int pass = 0; pass < 2; pass++)
+    F->nsub48 = 0;
+    for (int pass = 0; pass < 3; pass++)           // three size groups: largest front of the subtree <= 32, <= 48, larger
         for (const SubDesc &d : F->subs_host) {
             int mm = 0;
             for (int q = d.lo; q <= d.hi; q++) mm = std::max(mm, S.sn_m[q]);
-            if ((mm <= 32) == (pass == 0)) subs.push_back(d);
-            if (pass == 0 && mm <= 32) F->nsub32++;
+            const int grp = mm <= 32 ? 0 : (mm <= 48 ? 1 : 2);
+            if (grp == pass) subs.push_back(d);
+            if (grp == pass && pass == 0) F->nsub32++;
+            if (grp == pass && pass <= 1) F->nsub48++;
         }
     F->nsub = enabled ? (int)subs.size() : 0;
     F->solve_merged = enabled;
-    if (!enabled) F->nsub32 = 0;
+    if (!enabled) { F->nsub32 = 0; F->nsub48 = 0; }
     if (subs.empty()) subs.push_back(SubDesc{0, -1, 0, 0});
     // edge records of the subtree walk: (update rows, offset of the relative indices, LDS stack offset) per tree edge
     std::vector<int32_t> cd_woff(3 * std::max<size_t>(S.children.size(), 1), 0);
@@ -708,8 +711,28 @@ void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int l
         ls.join();
     }
     if (lto == S.nlevels - 1 && F->nsub > 0) {        // the leaf subtrees last: every ancestor is solved
-        ProfScope ps(F, FAM_BWD);
-        launch_bwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->nsub32, F->d_Lx, X, ldx, nrhs);
+        if (nrhs == 1 && F->prof_family < 0) {
+            // one right-hand side: the three size groups (registers for 32 / 48 / 64 rows of a column) side by side on three streams --
+            // the walks of the largest group alone fit the GPU in one round instead of two to three for all of them in its kernel
+            const int cnt[3] = {F->nsub32, F->nsub48 - F->nsub32, F->nsub - F->nsub48};
+            const int off[3] = {0, F->nsub32, F->nsub48};
+            const int cap[3] = {32, 48, 64};
+            hipStream_t ss[3] = {F->stream, F->side[0], F->side[1]};
+            const bool fork = (cnt[0] > 0) + (cnt[1] > 0) + (cnt[2] > 0) > 1;
+            if (fork) {
+                (void)hipEventRecord(F->ev_fork, F->stream);
+                for (int g = 1; g < 3; g++)
+                    if (cnt[g] > 0) (void)hipStreamWaitEvent(ss[g], F->ev_fork, 0);
+            }
+            for (int g = 2; g >= 0; g--)               // (the longest walks first)
+                launch_bwd_subtree_group(fork ? ss[g] : F->stream, cap[g], F->ds, F->d_subs + off[g], cnt[g], F->d_Lx, X, ldx);
+            if (fork)
+                for (int g = 1; g < 3; g++)
+                    if (cnt[g] > 0) { (void)hipEventRecord(F->ev_join[g - 1], ss[g]); (void)hipStreamWaitEvent(F->stream, F->ev_join[g - 1], 0); }
+        } else {
+            ProfScope ps(F, FAM_BWD);
+            launch_bwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->nsub32, F->d_Lx, X, ldx, nrhs);
+        }
     }
 }
 

@@ -100,7 +100,7 @@ struct kvx_chol {
     int nsubf[3] = {0, 0, 0};
     bool factor_subtrees = false;              // opt-in KVX_FACTOR_SUBTREES=1: the subtrees are factored by one wavefront each before the level loop (measured slower)
     int32_t *d_cd_woff = nullptr, *d_depth = nullptr, *d_lists_sw = nullptr;
-    int nsub = 0, nsub32 = 0;                  // subtrees; the first nsub32 hold only fronts of order <= 32
+    int nsub = 0, nsub32 = 0, nsub48 = 0;      // subtrees; the first nsub32 hold only fronts of order <= 32, the next nsub48 - nsub32 of order <= 48
     bool use_subtrees = true;
     std::vector<SubDesc> subs_host;
     std::vector<int32_t> cd_woff_host;

@@ -217,6 +217,8 @@ void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, i
                         const int32_t *depth);
 void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, int nsub32, const double *Lx, double *X,
                         int64_t ldx, int nrhs);
+void launch_bwd_subtree_group(hipStream_t st, int mcap, const DevSym &ds, const SubDesc *subs, int count, const double *Lx, double *X,
+                              int64_t ldx);   // single rhs: one size group (32 / 48 / 64 rows) of the subtree table
 // LDS classes (m <= 128, k <= 64): two wavefronts per front (kernels_wave.hip)
 void launch_fwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int kmax,
                     const double *Lx, double *X, int64_t ldx, int nrhs, const double *Wchild, double *Wout, int64_t wstride);

@@ -865,6 +865,17 @@ void launch_fwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, i
                        W0, W1, wstride, depth);
 }
 
+// one size group of the subtree table (every front of its subtrees has order <= mcap, 32 / 48 / 64: registers for a column of that
+// height only, so more walks are resident at once) on a stream of its own: enqueue_bwd runs the three groups side by side
+void launch_bwd_subtree_group(hipStream_t st, int mcap, const DevSym &ds, const SubDesc *subs, int count, const double *Lx, double *X,
+                              int64_t ldx)
+{
+    if (count <= 0) return;
+    if (mcap <= 32) hipLaunchKernelGGL(k_bwd_subtree<32>, dim3((unsigned)count, 1u), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+    else if (mcap <= 48) hipLaunchKernelGGL(k_bwd_subtree<48>, dim3((unsigned)count, 1u), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+    else hipLaunchKernelGGL(k_bwd_subtree<64>, dim3((unsigned)count, 1u), dim3(64), 0, st, ds, subs, Lx, X, ldx);
+}
+
 // the subtree table holds the subtrees whose fronts all have order <= 32 first (nsub32 of them): half the registers
 void launch_bwd_subtree(hipStream_t st, const DevSym &ds, const SubDesc *subs, int nsub, int nsub32, const double *Lx, double *X,
                         int64_t ldx, int nrhs)
