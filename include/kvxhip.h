@@ -338,6 +338,10 @@ int kvx_dense_from_ccs_dev(int64_t m, int64_t n, const int64_t *Ap_dev, const in
                            double *D_dev, int64_t ld);
 /* out := lower triangle of the dense p x p matrix K, column by column (the value array of a dense lower CCS pattern) */
 int kvx_pack_lower_dev(int64_t p, const double *K_dev, int64_t ld, double *out_dev);
+/* y := alpha A x + beta y, A dense column-major m x n (ld = lda), nrhs columns of x (ldx) and y (ldy): with X = S^-1 A' at hand,
+ * S^-1 (b - A' uy) = S^-1 b - X uy is a product instead of a second solve with S (the role of misc.py:1545-1553) */
+int kvx_dense_gemv_dev(int64_t m, int64_t n, int64_t nrhs, double alpha, const double *A_dev, int64_t lda, const double *x_dev, int64_t ldx,
+                       double beta, double *y_dev, int64_t ldy);
 
 /* ---- device memory plumbing for hosts without their own allocator ------------------------ */
 int kvx_dev_malloc(void **p, int64_t bytes);

@@ -110,6 +110,7 @@ _SIGS = {
                                                 ctypes.POINTER(vp), f64p]),
     "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),
     "kvx_vec_axpy_dev": (ctypes.c_int, [i64, f64, vp, vp]),
+    "kvx_dense_gemv_dev": (ctypes.c_int, [i64, i64, i64, f64, vp, i64, vp, i64, f64, vp, i64]),
     "kvx_vec_lincomb_dev": (ctypes.c_int, [i64, f64, vp, f64, vp, vp]),
     "kvx_vec_scal_dev": (ctypes.c_int, [i64, f64, vp]),
     "kvx_vec_addc_dev": (ctypes.c_int, [i64, f64, vp]),

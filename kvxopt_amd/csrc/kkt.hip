@@ -162,6 +162,33 @@ __global__ void k_fill(int64_t n, double c, double *__restrict__ x) { GS_LOOP(i,
 // z := a * (x .* y) + b * z
 __global__ void k_xmy(int64_t n, double a, const double *__restrict__ x, const double *__restrict__ y, double b, double *__restrict__ z)
 { GS_LOOP(i, n) z[i] = a * (x[i] * y[i]) + (b == 0.0 ? 0.0 : b * z[i]); }
+// y := alpha * A x + beta * y for a dense column-major m x n matrix (ld = lda), one thread per row: the reads of a column are
+// coalesced across the threads, x is read by every thread (cached).  nrhs columns of x / y (ldx, ldy) in grid.y.
+__global__ __launch_bounds__(256) void k_dense_gemv(int64_t m, int64_t n, double alpha, const double *__restrict__ A, int64_t lda,
+                                                    const double *__restrict__ x, int64_t ldx, double beta, double *__restrict__ y,
+                                                    int64_t ldy)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double *xc = x + (int64_t)blockIdx.y * ldx;
+    double *yc = y + (int64_t)blockIdx.y * ldy;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t j = 0;
+    for (; j + 4 <= n; j += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = __builtin_fma(A[i + (j + q) * lda], xc[j + q], acc[q]);
+    }
+    for (; j < n; j++) acc[0] = __builtin_fma(A[i + j * lda], xc[j], acc[0]);
+    const double r = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    yc[i] = (beta == 0.0) ? alpha * r : __builtin_fma(alpha, r, beta * yc[i]);
+}
+void launch_dense_gemv(hipStream_t st, int64_t m, int64_t n, int64_t nrhs, double alpha, const double *A, int64_t lda, const double *x,
+                       int64_t ldx, double beta, double *y, int64_t ldy)
+{
+    if (m <= 0 || nrhs <= 0) return;
+    hipLaunchKernelGGL(k_dense_gemv, dim3((unsigned)((m + 255) / 256), (unsigned)nrhs), dim3(256), 0, st, m, n, alpha, A, lda, x, ldx, beta, y, ldy);
+}
+
 // z := a * x + b * y (b == 0: z := a * x, y is not read); z may be x or y
 __global__ void k_lincomb(int64_t n, double a, const double *x, double b, const double *y, double *z)
 { GS_LOOP(i, n) z[i] = (b == 0.0) ? a * x[i] : __builtin_fma(b, y[i], a * x[i]); }

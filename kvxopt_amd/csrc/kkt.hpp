@@ -12,6 +12,8 @@ struct MultiRed {
     const double *x[32];
     const double *y[32];
 };
+void launch_dense_gemv(hipStream_t st, int64_t m, int64_t n, int64_t nrhs, double alpha, const double *A, int64_t lda, const double *x,
+                       int64_t ldx, double beta, double *y, int64_t ldy);
 void launch_lincomb(hipStream_t st, int64_t n, double a, const double *x, double b, const double *y, double *z);
 void launch_reduce_multi(hipStream_t st, const MultiRed &mr, double *part, double *out);
 void launch_compute_scaling(hipStream_t st, int64_t n, const double *s, const double *z, double *d, double *di, double *lm);

@@ -355,6 +355,14 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
 // ---- BLAS-1 glue of the interior-point loop on device vectors (blas.axpy/scal/copy/dot calls of coneprog.py) ----
 int kvx_vec_axpy_dev(int64_t n, double alpha, const double *x, double *y)
 { launch_axpy(nullptr, n, alpha, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
+int kvx_dense_gemv_dev(int64_t m, int64_t n, int64_t nrhs, double alpha, const double *A, int64_t lda, const double *x, int64_t ldx,
+                       double beta, double *y, int64_t ldy)
+{
+    if (m < 0 || n < 0 || nrhs < 0 || lda < std::max<int64_t>(m, 1)) { kvx::set_last_error("kvx_dense_gemv_dev: bad dimensions"); return KVX_EINVAL; }
+    launch_dense_gemv(nullptr, m, n, nrhs, alpha, A, lda, x, ldx, beta, y, ldy);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
 int kvx_vec_lincomb_dev(int64_t n, double a, const double *x, double b, const double *y, double *z)
 { launch_lincomb(nullptr, n, a, x, b, y, z); HIPCHK(hipGetLastError()); return KVX_OK; }
 int kvx_vec_scal_dev(int64_t n, double alpha, double *x)

@@ -412,6 +412,7 @@ class KKTGenEqDev:
         np.cumsum(ATp, out=ATp)
         self.AT = SpMatDev(n, p, ATp, cols[order], Ax[order])
         self.X = DVec(max(n * self.cols, 1))
+        self.x_whole = p <= self.cols and os.environ.get("KVX_KKT_NO_X") != "1"     # X = S^-1 A' of the last factorisation is held as a whole
         self.Kd = DVec(max(p * p, 1))
         self.Kx = DVec(max(p * (p + 1) // 2, 1))
         Kp = np.zeros(p + 1, dtype=np.int64)
@@ -476,23 +477,50 @@ class KKTGenEqDev:
 
     def solve(self, x, y, z):
         """Overwrites (x, y, z) = (bx, by, bz) with (ux, uy, uz)."""
-        di, n, p = self.di, self.n, self.p
-        z.mul(di)
-        self.t.xmy(1.0, di, z)
-        self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)        # x := bx + G' W^-1 W^-T bz
-        self.u.copy_from(x)
-        self.S.fac.solve_dev(self.u.ptr, 0, 1, max(1, n), sync=not self._async)       # u := S^-1 x
-        self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)       # y := A u - by
-        self.fac.solve_dev(y.ptr, 0, 1, max(1, p), sync=not self._async)
-        y.scal(self.kscale)                                           # uy = K^-1 (A u - by)
-        self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)            # x := x - A' uy
-        self.S.fac.solve_dev(x.ptr, 0, 1, max(1, n), sync=not self._async)            # ux = S^-1 (...)
-        self.G.gemv(x, self.t, trans="N")
-        z.xmy(1.0, di, self.t, -1.0)                                  # uz = W^-T (G ux - bz)
+        self._solve_cols(((x, y, z),))
 
     def solve2(self, xa, ya, za, xb, yb, zb):
-        self.solve(xa, ya, za)
-        self.solve(xb, yb, zb)
+        """Two KKT systems: their solves with S and with K are two-column solves (see KKTChol2Dev.solve2)."""
+        self._solve_cols(((xa, ya, za), (xb, yb, zb)))
+
+    def _solve_cols(self, systems):
+        # u = S^-1 (bx + G' W^-1 W^-T bz), uy = K^-1 (A u - by), ux = u - X uy with X = S^-1 A' of the last factorisation when the
+        # whole of it is at hand (p columns fit one block): S^-1 (b - A' uy) = S^-1 b - X uy, a dense product (80 MB at n = 50 000,
+        # p = 200: 20 us) instead of a second sweep through the factor of S (0.5 ms).  Otherwise the second solve as in misc.py:1545-1553.
+        di, n, p = self.di, self.n, self.p
+        nc = len(systems)
+        if getattr(self, "_u2", None) is None:
+            self._u2 = DVec(2 * max(n, 1))
+            self._y2 = DVec(2 * max(p, 1))
+        U, Y = self._u2, self._y2
+        for c, (x, y, z) in enumerate(systems):
+            z.mul(di)
+            self.t.xmy(1.0, di, z)
+            self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)    # x := bx + G' W^-1 W^-T bz
+            raise_for(lib().kvx_vec_copy_dev(n, x.ptr, U.ptr + 8 * n * c))
+        self.S.fac.solve_dev(U.ptr, 0, nc, max(1, n), sync=not self._async)           # u := S^-1 x
+        for c, (x, y, z) in enumerate(systems):
+            raise_for(lib().kvx_vec_copy_dev(n, U.ptr + 8 * n * c, self.u.ptr))
+            self.A.gemv(self.u, y, trans="N", alpha=1.0, beta=-1.0)   # y := A u - by
+            raise_for(lib().kvx_vec_copy_dev(p, y.ptr, Y.ptr + 8 * p * c))
+        self.fac.solve_dev(Y.ptr, 0, nc, max(1, p), sync=not self._async)
+        for c, (x, y, z) in enumerate(systems):
+            raise_for(lib().kvx_vec_copy_dev(p, Y.ptr + 8 * p * c, y.ptr))
+            y.scal(self.kscale)                                       # uy = K^-1 (A u - by)
+        if self.x_whole:
+            for c, (x, y, z) in enumerate(systems):
+                raise_for(lib().kvx_vec_copy_dev(n, U.ptr + 8 * n * c, x.ptr))
+                raise_for(lib().kvx_dense_gemv_dev(n, p, 1, -1.0, self.X.ptr, n, y.ptr, p, 1.0, x.ptr, n))   # ux = u - X uy
+        else:
+            for c, (x, y, z) in enumerate(systems):
+                self.A.gemv(y, x, trans="T", alpha=-1.0, beta=1.0)    # x := x - A' uy
+                raise_for(lib().kvx_vec_copy_dev(n, x.ptr, U.ptr + 8 * n * c))
+            self.S.fac.solve_dev(U.ptr, 0, nc, max(1, n), sync=not self._async)       # ux = S^-1 (...)
+            for c, (x, y, z) in enumerate(systems):
+                raise_for(lib().kvx_vec_copy_dev(n, U.ptr + 8 * n * c, x.ptr))
+        for c, (x, y, z) in enumerate(systems):
+            self.G.gemv(x, self.t, trans="N")
+            z.xmy(1.0, di, self.t, -1.0)                              # uz = W^-T (G ux - bz)
 
 
 # The KKT objects of the last few constraint structures are kept: a sequence of cone programs on the same patterns of G, A (and

@@ -1030,3 +1030,45 @@ def test_conelp_reuses_kkt_objects_of_a_known_structure(monkeypatch):
             assert np.array_equal(np.asarray(warm[key]), np.asarray(cold[key])), key
     lp.clear_cache()
     assert len(lp._KKT_CACHE) == 0
+
+
+@pytest.mark.gpu
+def test_general_equality_kkt_solves_through_the_kept_solution_block(monkeypatch):
+    """lp.KKTGenEqDev: with X = S^-1 A' of the last factorisation at hand (p columns fit one block), S^-1 (b - A' uy) is taken as
+    S^-1 b - X uy -- one sweep through the factor of S per KKT system instead of two -- and the two systems of an iteration share
+    their sweeps (two-column solves).  Same iterates as the two-sweep form (KVX_KKT_NO_X=1) to rounding: same iteration count,
+    solution to 1e-8; the KKT residual of one solve is checked against the definition."""
+    P = workloads.lp_grid_eq(40, 30, 24)
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], P["Gx"])
+    A = spmatrix.from_ccs(P["p"], P["n"], P["Ap"], P["Ai"], P["Ax"])
+    sols = {}
+    for no_x in ("0", "1"):
+        monkeypatch.setenv("KVX_KKT_NO_X", no_x)
+        lp.clear_cache()
+        sols[no_x] = lp.conelp(P["c"], G, P["h"], A=A, b=P["b"])
+    monkeypatch.delenv("KVX_KKT_NO_X")
+    lp.clear_cache()
+    a, b = sols["0"], sols["1"]
+    assert a["status"] == b["status"] == "optimal" and a["iterations"] == b["iterations"]
+    for key in ("x", "y", "s", "z"):
+        assert np.abs(np.asarray(a[key]) - np.asarray(b[key])).max() <= 1e-8 * max(1.0, np.abs(np.asarray(b[key])).max()), key
+    # one KKT solve against the dense definition  [0 A' G'; A 0 0; G 0 -W'W] (ux, uy, uz') = (bx, by, bz),  W = diag(1 / di)
+    ml, n, p = P["ml"], P["n"], P["p"]
+    kkt = lp.KKTGenEqDev(ml, n, P["Gp"], P["Gi"], P["Gx"], p, P["Ap"], P["Ai"], P["Ax"])
+    assert kkt.x_whole
+    rng = np.random.default_rng(4)
+    di = rng.uniform(0.5, 2.0, ml)
+    bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(ml)
+    dv = lp.DVec(ml, di)
+    kkt.factor(dv, sync=True)
+    x, y, z = lp.DVec(n, bx), lp.DVec(p, by), lp.DVec(ml, bz)
+    kkt.solve(x, y, z)
+    ux, uy, wz = x.get(), y.get(), z.get()                      # z holds W uz
+    uz = wz * di
+    import scipy.sparse as sp
+    Gs = sp.csc_matrix((P["Gx"], P["Gi"], P["Gp"]), shape=(ml, n)); As = sp.csc_matrix((P["Ax"], P["Ai"], P["Ap"]), shape=(p, n))
+    r1 = As.T @ uy + Gs.T @ uz - bx
+    r2 = As @ ux - by
+    r3 = Gs @ ux - uz / di ** 2 - bz
+    scale = max(np.abs(bx).max(), np.abs(by).max(), np.abs(bz).max())
+    assert max(np.abs(r1).max(), np.abs(r2).max(), np.abs(r3).max()) < 1e-9 * scale * max(1.0, np.abs(uz).max())
