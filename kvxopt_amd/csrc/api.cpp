@@ -278,7 +278,9 @@ int ensure_device(kvx_chol *F)
         HIPCHK(pool_malloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
     HIPCHK(pool_malloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
     HIPCHK(pool_malloc((void **)&F->d_status, sizeof(int)));
-    HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&F->h_status, sizeof(int), hipHostMallocMapped));
+    *F->h_status = 0x7f7f7f7f;
+    if (hipHostGetDevicePointer((void **)&F->h_status_dev, F->h_status, 0) != hipSuccess) { (void)hipGetLastError(); F->h_status_dev = nullptr; }
     std::vector<int64_t> &loff_host = F->linv_off_host;
     {
         // inverted diagonal blocks of the big fronts: ceil(k/NB) blocks of NB x NB each
@@ -548,7 +550,10 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         for (int i = 0; i < 3; i++)
             if (side_used[i]) { HIPCHK(hipEventRecord(F->ev_join[i], F->side[i])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[i], 0)); }
     }
-    if (epilogue) HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (epilogue) {
+        if (F->h_status_dev && !getenv("KVX_DBG_MEMSET_NODES")) launch_publish_status(st, F->d_status, F->h_status_dev);
+        else HIPCHK(hipMemcpyAsync(F->h_status, F->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }

@@ -75,6 +75,7 @@ struct kvx_chol {
     int64_t x_cap = 0;        // right-hand sides the solve workspace holds
     int *d_status = nullptr;
     int *h_status = nullptr;  // pinned
+    int *h_status_dev = nullptr;   // the device's address of h_status (hipHostGetDevicePointer); null: copied by a memcpy instead
     DevSym ds{};
     // sharded mode (kvx_chol_dist_*, dist_api.cpp): the level lists hold only the fronts this rank takes part in; the
     // factorisation additionally leaves out the block-cyclic fronts (factored by dist_api.cpp's panel loop): fplan / d_flists

@@ -50,6 +50,20 @@ void launch_clear_factor(hipStream_t st, double *Lx, int64_t n, int *status)
     hipLaunchKernelGGL(k_clear_factor, dim3((unsigned)blocks), dim3(256), 0, st, (double2 *)Lx, n2, Lx, n, status);
 }
 
+// the status word of a factorisation into pinned host memory (device-visible mapping): the last node of the captured factorisation
+// is a kernel too, not a device-to-host memcpy node
+__global__ void k_publish_status(const int *__restrict__ d_status, int *host_status)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *host_status = *d_status;
+        __threadfence_system();
+    }
+}
+void launch_publish_status(hipStream_t st, const int *d_status, int *host_status_dev)
+{
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, st, d_status, host_status_dev);
+}
+
 // dst := src (n doubles, both 16-byte aligned): a kernel instead of a memcpy node inside the captured solve sweeps
 __global__ __launch_bounds__(256) void k_copy_d(double2 *__restrict__ dst2, const double2 *__restrict__ src2, int64_t n2,
                                                 double *__restrict__ dst, const double *__restrict__ src, int64_t n)

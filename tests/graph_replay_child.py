@@ -25,8 +25,20 @@ FK = Factor(p, kcp, rows.astype(np.int64))
 dK = DeviceBuffer.from_array(np.ascontiguousarray(kv))
 b = rng.standard_normal(p)
 ref = np.linalg.solve(K, b)
+kv_bad = kv.copy()
+kv_bad[0] = -1.0                                   # K[0, 0] < 0: not positive definite
+dKbad = DeviceBuffer.from_array(np.ascontiguousarray(kv_bad))
 bad = 0
 for it in range(16):
+    if it % 5 == 4:                                # a replay that must FAIL, and be reported: the status word travels through the graph too
+        FK.factorize_dev(dKbad.ptr, sync=False)
+        raise_for(lib().kvx_dev_sync())
+        try:
+            FK.status()
+            bad += 1
+            print("iteration", it, "an indefinite matrix went unnoticed", flush=True)
+        except ArithmeticError:
+            pass
     FS.factorize_dev(dS.ptr, sync=False)
     B = DeviceBuffer.from_array(np.asfortranarray(rng.standard_normal((n, 8))).reshape(-1, order="F"))
     FS.solve_dev(B.ptr, sys=0, nrhs=8, ldB=n, sync=False)
