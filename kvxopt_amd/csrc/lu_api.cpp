@@ -62,13 +62,6 @@ struct kvx_lu_num {
 namespace {
 
 template <class T>
-int up(T **dst, const std::vector<T> &src)
-{
-    HIPCHK(pool_malloc((void **)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
-    if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-    return KVX_OK;
-}
-template <class T>
 int dalloc(T **dst, int64_t count)
 {
     HIPCHK(pool_malloc((void **)dst, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
