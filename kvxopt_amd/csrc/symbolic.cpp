@@ -4,6 +4,7 @@
 #include "par.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -546,53 +547,114 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
 
     pt.lap("4 supernodes");
     // ---- 5. front row structures (supernodal symbolic factorisation) -------------------------
+    // The order of every front is known from the amalgamation (a merged front = its pivots + the rows of the supernode it was
+    // merged into), so the row lists have their final places before they are computed: independent subtrees of the supernodal tree
+    // are filled in by different threads (each front needs its own columns and its children's lists only), the top of the tree
+    // after them on the calling thread.  A front whose list does not come out at the predicted length (it cannot) sends the
+    // whole phase back to the plain serial pass.
     S.rowptr.assign((size_t)ns + 1, 0);
     S.sn_m.resize((size_t)ns);
-    S.rowidx.clear();
-    S.rowidx.reserve((size_t)(4 * n));
     {
-        std::vector<int32_t> mark((size_t)n, -1);
-        std::vector<int32_t> tail;
-        for (int64_t s = 0; s < ns; s++) {
-            int64_t f = S.super[s], e = S.super[s + 1];
+        for (int64_t s0 = 0; s0 < ns0; s0++)
+            if (!dead[s0]) S.sn_m[(size_t)old2new[s0]] = (int32_t)nrow[s0];
+        for (int64_t s = 0; s < ns; s++) S.rowptr[s + 1] = S.rowptr[s] + S.sn_m[s];
+        S.rowidx.assign((size_t)S.rowptr[ns], 0);
+        std::atomic<bool> mismatch{false};
+        auto fill = [&](int64_t s, std::vector<int32_t> &mark, std::vector<int32_t> &tail) {
+            const int64_t f = S.super[s], e = S.super[s + 1];
             tail.clear();
-            for (int64_t j = f; j < e; j++) {
+            for (int64_t j = f; j < e; j++)
                 for (int64_t p = Lo.ptr[j]; p < Lo.ptr[j + 1]; p++) {
-                    int32_t i = Lo.idx[p];
+                    const int32_t i = Lo.idx[p];
                     if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
                 }
-            }
             for (int64_t c = S.childptr[s]; c < S.childptr[s + 1]; c++) {
-                int32_t ch = S.children[c];
+                const int32_t ch = S.children[c];
                 for (int64_t p = S.rowptr[ch] + S.sn_k[ch]; p < S.rowptr[ch + 1]; p++) {
-                    int32_t i = S.rowidx[p];
+                    const int32_t i = S.rowidx[p];
                     if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
                 }
             }
+            if ((int64_t)tail.size() + (e - f) != S.sn_m[s]) { mismatch.store(true); return; }
             std::sort(tail.begin(), tail.end());
-            for (int64_t j = f; j < e; j++) S.rowidx.push_back((int32_t)j);
-            S.rowidx.insert(S.rowidx.end(), tail.begin(), tail.end());
-            S.rowptr[s + 1] = (int64_t)S.rowidx.size();
-            S.sn_m[s] = (int32_t)(e - f + (int64_t)tail.size());
+            int32_t *dst = S.rowidx.data() + S.rowptr[s];
+            for (int64_t j = f; j < e; j++) *dst++ = (int32_t)j;
+            std::copy(tail.begin(), tail.end(), dst);
+        };
+        // tasks: maximal subtrees of at most `thr` columns (a subtree is a contiguous range of the postordered numbering)
+        const int T = analyze_threads();
+        std::vector<int64_t> scols((size_t)ns), scnt((size_t)ns, 1);
+        for (int64_t s = 0; s < ns; s++) scols[s] = S.sn_k[s];
+        for (int64_t s = 0; s < ns; s++)
+            if (S.sparent[s] >= 0) { scols[S.sparent[s]] += scols[s]; scnt[S.sparent[s]] += scnt[s]; }
+        const int64_t thr = std::max<int64_t>(n / (8 * (int64_t)std::max(T, 1)), 2048);
+        std::vector<int64_t> task_lo, task_hi;
+        std::vector<char> in_task((size_t)ns, 0);
+        if (T > 1 && n >= 8 * thr)
+            for (int64_t s = 0; s < ns; s++)
+                if (scols[s] <= thr && (S.sparent[s] < 0 || scols[S.sparent[s]] > thr)) {
+                    task_lo.push_back(s - scnt[s] + 1);
+                    task_hi.push_back(s);
+                }
+        for (size_t t = 0; t < task_lo.size(); t++)
+            for (int64_t s = task_lo[t]; s <= task_hi[t]; s++) in_task[s] = 1;
+        parallel_for((int64_t)task_lo.size(), T, 1, [&](int64_t a, int64_t b) {
+            std::vector<int32_t> mark((size_t)n, -1), tail;
+            for (int64_t t = a; t < b && !mismatch.load(); t++)
+                for (int64_t s = task_lo[t]; s <= task_hi[t]; s++) fill(s, mark, tail);
+        });
+        {
+            std::vector<int32_t> mark((size_t)n, -1), tail;
+            for (int64_t s = 0; s < ns && !mismatch.load(); s++)
+                if (!in_task[s]) fill(s, mark, tail);
+        }
+        if (mismatch.load()) {                     // (never observed: the plain pass, lists appended as they are found)
+            if (pt.on) fprintf(stderr, "  analyze 5: predicted front orders did not hold -- serial pass\n");
+            S.rowidx.clear();
+            S.rowidx.reserve((size_t)(4 * n));
+            std::vector<int32_t> mark((size_t)n, -1), tail;
+            for (int64_t s = 0; s < ns; s++) {
+                const int64_t f = S.super[s], e = S.super[s + 1];
+                tail.clear();
+                for (int64_t j = f; j < e; j++)
+                    for (int64_t p = Lo.ptr[j]; p < Lo.ptr[j + 1]; p++) {
+                        const int32_t i = Lo.idx[p];
+                        if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
+                    }
+                for (int64_t c = S.childptr[s]; c < S.childptr[s + 1]; c++) {
+                    const int32_t ch = S.children[c];
+                    for (int64_t p = S.rowptr[ch] + S.sn_k[ch]; p < S.rowptr[ch + 1]; p++) {
+                        const int32_t i = S.rowidx[p];
+                        if (i >= e && mark[i] != s) { mark[i] = (int32_t)s; tail.push_back(i); }
+                    }
+                }
+                std::sort(tail.begin(), tail.end());
+                for (int64_t j = f; j < e; j++) S.rowidx.push_back((int32_t)j);
+                S.rowidx.insert(S.rowidx.end(), tail.begin(), tail.end());
+                S.rowptr[s + 1] = (int64_t)S.rowidx.size();
+                S.sn_m[s] = (int32_t)(e - f + (int64_t)tail.size());
+            }
         }
     }
     pt.lap("5 front rows");
     // ---- 6. relative indices child -> parent --------------------------------------------------
     S.rel.assign(S.rowidx.size(), -1);
-    for (int64_t s = 0; s < ns; s++) {
-        int32_t p = S.sparent[s];
-        if (p < 0) {
-            if (S.sn_m[s] != S.sn_k[s]) throw std::runtime_error("internal: root front has update rows");
-            continue;
+    parallel_for(ns, analyze_threads(), 1 << 12, [&](int64_t lo, int64_t hi) {     // (disjoint slices of rel; exceptions travel to the caller)
+        for (int64_t s = lo; s < hi; s++) {
+            int32_t p = S.sparent[s];
+            if (p < 0) {
+                if (S.sn_m[s] != S.sn_k[s]) throw std::runtime_error("internal: root front has update rows");
+                continue;
+            }
+            int64_t a = S.rowptr[s] + S.sn_k[s], ae = S.rowptr[s + 1];
+            int64_t b = S.rowptr[p], be = S.rowptr[p + 1];
+            for (; a < ae; a++) {
+                while (b < be && S.rowidx[b] < S.rowidx[a]) b++;
+                if (b >= be || S.rowidx[b] != S.rowidx[a]) throw std::runtime_error("internal: child row missing in parent front");
+                S.rel[a] = (int32_t)(b - S.rowptr[p]);
+            }
         }
-        int64_t a = S.rowptr[s] + S.sn_k[s], ae = S.rowptr[s + 1];
-        int64_t b = S.rowptr[p], be = S.rowptr[p + 1];
-        for (; a < ae; a++) {
-            while (b < be && S.rowidx[b] < S.rowidx[a]) b++;
-            if (b >= be || S.rowidx[b] != S.rowidx[a]) throw std::runtime_error("internal: child row missing in parent front");
-            S.rel[a] = (int32_t)(b - S.rowptr[p]);
-        }
-    }
+    });
     pt.lap("6 relative indices");
     // ---- 7. storage offsets, levels ---------------------------------------------------------------
     S.px.assign((size_t)ns + 1, 0);
