@@ -10,7 +10,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -42,8 +44,8 @@ struct RelaxedI32 {
 struct NDState {
     Graph g;
     std::vector<int32_t> verts;      // task ranges are contiguous slices; slice position = final position
-    std::vector<RelaxedI32> region;  // region id of every vertex (-1 = already numbered)
-    std::vector<RelaxedI32> level;   // BFS levels (-1 = not visited)
+    struct RL { RelaxedI32 region, level; };   // region id (-1 = already numbered) and BFS level (-1 = not visited) of a vertex, side by
+    std::vector<RL> rl;                        // side: a breadth-first pass looks at both for every neighbour (one cache line, not two)
     std::vector<int32_t> queue;      // BFS scratch: a task uses the slice of its own vertex range
     std::atomic<int32_t> next_region{1};
 };
@@ -54,15 +56,15 @@ int64_t bfs(NDState &st, int32_t *queue, int32_t rid, int32_t root, int32_t &nle
 {
     int64_t head = 0, tail = 0;
     queue[tail++] = root;
-    st.level[root] = 0;
+    st.rl[root].level = 0;
     nlev = 1;
     while (head < tail) {
         int32_t v = queue[head++];
-        int32_t lv = st.level[v];
+        int32_t lv = st.rl[v].level;
         for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1]; p++) {
             int32_t u = st.g.adj[p];
-            if (st.region[u] != rid || st.level[u] >= 0) continue;
-            st.level[u] = lv + 1;
+            if (st.rl[u].region != rid || st.rl[u].level >= 0) continue;
+            st.rl[u].level = lv + 1;
             if (lv + 2 > nlev) nlev = lv + 2;
             queue[tail++] = u;
         }
@@ -72,7 +74,7 @@ int64_t bfs(NDState &st, int32_t *queue, int32_t rid, int32_t root, int32_t &nle
 
 void reset_levels(NDState &st, const int32_t *queue, int64_t cnt)
 {
-    for (int64_t i = 0; i < cnt; i++) st.level[queue[i]] = -1;
+    for (int64_t i = 0; i < cnt; i++) st.rl[queue[i]].level = -1;
 }
 
 // Halo-aware exact minimum degree on a small vertex set (bitset elimination graph).
@@ -103,18 +105,23 @@ void leaf_min_degree(NDState &st, int64_t lo, int64_t hi, std::vector<int32_t> &
             row(u)[i >> 6] |= 1ull << (i & 63);
         }
     }
+    // degrees are kept up to date instead of recounted: an elimination changes the rows of the eliminated vertex's neighbours
+    // only, and only the rows of the leaf's own vertices are ever read (a halo vertex is never eliminated and its row never
+    // consulted), so those are the only ones touched.  Same choices as recounting everything at every step.
     std::vector<char> done((size_t)s, 0);
-    std::vector<int32_t> order;
+    std::vector<int32_t> order, deg((size_t)s);
     order.reserve((size_t)s);
+    for (int64_t i = 0; i < s; i++) {
+        int32_t d = 0;
+        const uint64_t *r = row(i);
+        for (int64_t w = 0; w < W; w++) d += (int32_t)__builtin_popcountll(r[w]);
+        deg[(size_t)i] = d;
+    }
     for (int64_t step = 0; step < s; step++) {
-        int64_t best = -1, bestdeg = INT64_MAX;
-        for (int64_t i = 0; i < s; i++) {
-            if (done[i]) continue;
-            int64_t d = 0;
-            const uint64_t *r = row(i);
-            for (int64_t w = 0; w < W; w++) d += __builtin_popcountll(r[w]);
-            if (d < bestdeg) { bestdeg = d; best = i; }
-        }
+        int64_t best = -1;
+        int32_t bestdeg = INT32_MAX;
+        for (int64_t i = 0; i < s; i++)
+            if (!done[i] && deg[(size_t)i] < bestdeg) { bestdeg = deg[(size_t)i]; best = i; }
         done[best] = 1;
         order.push_back(nodes[best]);
         const uint64_t *rb = row(best);
@@ -122,12 +129,16 @@ void leaf_min_degree(NDState &st, int64_t lo, int64_t hi, std::vector<int32_t> &
         for (int64_t w = 0; w < W; w++) {
             uint64_t m = rb[w];
             while (m) {
-                int64_t u = w * 64 + __builtin_ctzll(m);
+                const int64_t u = w * 64 + __builtin_ctzll(m);
                 m &= m - 1;
+                if (u >= s) continue;
                 uint64_t *ru = row(u);
+                int32_t d = 0;
                 for (int64_t x = 0; x < W; x++) ru[x] |= rb[x];
                 ru[u >> 6] &= ~(1ull << (u & 63));
                 ru[best >> 6] &= ~(1ull << (best & 63));
+                for (int64_t x = 0; x < W; x++) d += (int32_t)__builtin_popcountll(ru[x]);
+                deg[(size_t)u] = d;
             }
         }
     }
@@ -136,6 +147,17 @@ void leaf_min_degree(NDState &st, int64_t lo, int64_t hi, std::vector<int32_t> &
 }
 
 struct NDTask { int64_t lo, hi; int32_t rid; };
+
+// KVX_ANALYZE_TIMING=1: where the dissection spends its time (summed over the host threads, and along the chain of the largest region)
+struct NDProf {
+    bool on = getenv("KVX_ANALYZE_TIMING") != nullptr;
+    std::atomic<int64_t> bfs_ns{0}, pass_ns{0}, leaf_ns{0}, chain_ns{0};
+};
+static NDProf *g_ndprof = nullptr;
+static inline int64_t nd_now()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct NDWorker {
     std::vector<int32_t> local_id;   // leaf_min_degree scratch, indexed by vertex (halo vertices are shared between leaves)
@@ -149,12 +171,16 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
     if (sz <= 0) return;
     if (sz <= leaf) {
         if (wk.local_id.empty()) wk.local_id.assign((size_t)st.g.n, -1);
+        const int64_t t0 = g_ndprof && g_ndprof->on ? nd_now() : 0;
         leaf_min_degree(st, t.lo, t.hi, wk.local_id);
-        for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
+        if (g_ndprof && g_ndprof->on) g_ndprof->leaf_ns += nd_now() - t0;
+        for (int64_t i = t.lo; i < t.hi; i++) st.rl[st.verts[i]].region = -1;
         return;
     }
     int32_t *queue = st.queue.data() + t.lo;       // a connected component of the slice has at most sz vertices
     // pseudo-peripheral root: repeat BFS from a min-degree vertex of the last level
+    const bool prof = g_ndprof && g_ndprof->on;
+    const int64_t tb0 = prof ? nd_now() : 0;
     int32_t root = st.verts[t.lo];
     int32_t nlev = 0;
     int64_t cnt = bfs(st, queue, t.rid, root, nlev);
@@ -162,7 +188,7 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
         // (the level structure of `root` is in place here: a deeper candidate of the previous round is not swept again)
         int32_t cand = -1;
         int64_t cdeg = INT64_MAX;
-        for (int64_t i = cnt - 1; i >= 0 && st.level[queue[i]] == nlev - 1; i--) {
+        for (int64_t i = cnt - 1; i >= 0 && st.rl[queue[i]].level == nlev - 1; i--) {
             int32_t v = queue[i];
             int64_t d = st.g.ptr[v + 1] - st.g.ptr[v];
             if (d < cdeg) { cdeg = d; cand = v; }
@@ -178,6 +204,8 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
             break;
         }
     }
+    const int64_t tb1 = prof ? nd_now() : 0;
+    if (prof) { g_ndprof->bfs_ns += tb1 - tb0; if (sz * 2 >= st.g.n || t.lo == 0) g_ndprof->chain_ns += tb1 - tb0; }
     // queue[0..cnt) holds one connected component in BFS order with levels set
     if (cnt < sz) {
         // disconnected: every connected component of the slice becomes a task of its own, no separator.  One sweep labels them
@@ -189,21 +217,21 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
         std::vector<int32_t> rid_of;                 // region id of component c
         std::vector<int64_t> csize;
         for (int32_t v0 : tmp) {
-            if (st.region[v0] != t.rid) continue;    // already in a component
+            if (st.rl[v0].region != t.rid) continue;    // already in a component
             const int32_t rc = st.next_region.fetch_add(1, std::memory_order_relaxed);
             const int32_t ci = (int32_t)rid_of.size();
             rid_of.push_back(rc);
             int64_t head = 0, tail = 0;
             queue[tail++] = v0;
-            st.region[v0] = rc;
-            st.level[v0] = ci;                       // (component index, cleared below)
+            st.rl[v0].region = rc;
+            st.rl[v0].level = ci;                       // (component index, cleared below)
             while (head < tail) {
                 const int32_t v = queue[head++];
                 for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1]; p++) {
                     const int32_t u = st.g.adj[p];
-                    if (st.region[u] != t.rid) continue;
-                    st.region[u] = rc;
-                    st.level[u] = ci;
+                    if (st.rl[u].region != t.rid) continue;
+                    st.rl[u].region = rc;
+                    st.rl[u].level = ci;
                     queue[tail++] = u;
                 }
             }
@@ -214,8 +242,8 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
         {
             std::vector<int64_t> cur(pos.begin(), pos.end() - 1);
             for (int32_t v : tmp) {
-                st.verts[(size_t)cur[(size_t)(int32_t)st.level[v]]++] = v;
-                st.level[v] = -1;
+                st.verts[(size_t)cur[(size_t)(int32_t)st.rl[v].level]++] = v;
+                st.rl[v].level = -1;
             }
         }
         for (size_t c = csize.size(); c-- > 0;) out.push_back(NDTask{pos[c], pos[c + 1], rid_of[c]});   // (LIFO: the first component is taken first)
@@ -228,12 +256,12 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
             int64_t da = st.g.ptr[a + 1] - st.g.ptr[a], db = st.g.ptr[b + 1] - st.g.ptr[b];
             return da != db ? da < db : a < b;
         });
-        for (int64_t i = t.lo; i < t.hi; i++) st.region[st.verts[i]] = -1;
+        for (int64_t i = t.lo; i < t.hi; i++) st.rl[st.verts[i]].region = -1;
         return;
     }
     std::vector<int64_t> &levcnt = wk.levcnt;
     levcnt.assign((size_t)nlev, 0);
-    for (int64_t i = 0; i < cnt; i++) levcnt[st.level[queue[i]]]++;
+    for (int64_t i = 0; i < cnt; i++) levcnt[st.rl[queue[i]].level]++;
     // pick the separator level: smallest level among those leaving >= 30% on each side,
     // else the level where the cumulative count crosses one half
     int32_t best = -1;
@@ -254,29 +282,30 @@ void nd_step(NDState &st, NDWorker &wk, const NDTask &t, int leaf, std::vector<N
     int64_t nA = 0, nB = 0, nS = 0;
     for (int64_t i = 0; i < cnt; i++) {
         int32_t v = queue[i];
-        int32_t lv = st.level[v];
-        if (lv < best) { st.region[v] = ra; nA++; }
-        else if (lv > best) { st.region[v] = rb; nB++; }
+        int32_t lv = st.rl[v].level;
+        if (lv < best) { st.rl[v].region = ra; nA++; }
+        else if (lv > best) { st.rl[v].region = rb; nB++; }
         else {
             bool touches = false;
             for (int64_t p = st.g.ptr[v]; p < st.g.ptr[v + 1] && !touches; p++) {
                 int32_t u = st.g.adj[p];
-                const int32_t ru = st.region[u];
-                touches = (ru == t.rid || ru == rb) && (st.level[u] == best + 1);
+                const int32_t ru = st.rl[u].region;
+                touches = (ru == t.rid || ru == rb) && (st.rl[u].level == best + 1);
             }
-            if (touches) { st.region[v] = -1; nS++; }
-            else { st.region[v] = ra; nA++; }
+            if (touches) { st.rl[v].region = -1; nS++; }
+            else { st.rl[v].region = ra; nA++; }
         }
     }
     // lay out verts[lo,hi) as [A | B | S], each in BFS order
     int64_t a = t.lo, b = t.lo + nA, s = t.lo + nA + nB;
     for (int64_t i = 0; i < cnt; i++) {
         int32_t v = queue[i];
-        if (st.region[v] == ra) st.verts[a++] = v;
-        else if (st.region[v] == rb) st.verts[b++] = v;
+        if (st.rl[v].region == ra) st.verts[a++] = v;
+        else if (st.rl[v].region == rb) st.verts[b++] = v;
         else st.verts[s++] = v;
     }
     reset_levels(st, queue, cnt);
+    if (prof) g_ndprof->pass_ns += nd_now() - tb1;
     out.push_back(NDTask{t.lo + nA, t.lo + nA + nB, rb});
     out.push_back(NDTask{t.lo, t.lo + nA, ra});
 }
@@ -299,13 +328,14 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
 {
     perm.resize((size_t)n);
     if (n == 0) return;
+    NDProf prof_obj;
+    g_ndprof = prof_obj.on ? &prof_obj : nullptr;
     NDState st;
     st.g = Graph{n, adjptr.data(), adj.data()};
     st.verts.resize((size_t)n);
     std::iota(st.verts.begin(), st.verts.end(), 0);
-    st.region = std::vector<RelaxedI32>((size_t)n);            // region 0
-    st.level = std::vector<RelaxedI32>((size_t)n);
-    for (int64_t i = 0; i < n; i++) st.level[(size_t)i] = -1;
+    st.rl = std::vector<NDState::RL>((size_t)n);                // region 0
+    for (int64_t i = 0; i < n; i++) st.rl[(size_t)i].level = -1;
     st.queue.resize((size_t)n);
     if (leaf < 4) leaf = 4;
 
@@ -372,6 +402,10 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
         if (failure) std::rethrow_exception(failure);   // -> KVX_ENOMEM / KVX_EINVAL at the C ABI (abi_guard.hpp, kvx_chol_analyze)
     }
     for (int64_t i = 0; i < n; i++) perm[(size_t)i] = st.verts[(size_t)i];
+    if (prof_obj.on && n >= 100000)
+        fprintf(stderr, "  dissection: breadth-first passes %.1f ms, separator passes %.1f ms, leaf orderings %.1f ms (summed over threads); first-region chain %.1f ms\n",
+                prof_obj.bfs_ns / 1e6, prof_obj.pass_ns / 1e6, prof_obj.leaf_ns / 1e6, prof_obj.chain_ns / 1e6);
+    g_ndprof = nullptr;
 }
 
 }  // namespace kvx
