@@ -397,6 +397,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         etree_from_lower(n, Lo, parent);
         lower_built = true;
     }
+    pt.lap("2a etree");
     S.perm = perm0;
     S.iperm = iperm0;
     // Supernodes need contiguous subtrees, so the postorder is always applied (CHOLMOD's
@@ -404,12 +405,15 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
     {
         std::vector<int32_t> post;
         postorder(n, parent, post);
+        pt.lap("2b postorder");
         bool identity = true;
         for (int64_t k = 0; k < n && identity; k++) identity = (post[k] == k);
         if (!identity) {
             for (int64_t k = 0; k < n; k++) S.perm[k] = perm0[post[k]];
             for (int64_t k = 0; k < n; k++) S.iperm[S.perm[k]] = k;
+            pt.lap("2c compose");
             build_lower(n, Ap, Ai, uplo, S.iperm, Lo);
+            pt.lap("2d permuted pattern");
             // the elimination tree of the relabelled matrix is the relabelled tree: no second pass of Liu's algorithm
             std::vector<int32_t> ipost((size_t)n), np((size_t)n);
             for (int64_t k = 0; k < n; k++) ipost[post[k]] = (int32_t)k;
