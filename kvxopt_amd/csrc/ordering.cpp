@@ -19,6 +19,7 @@
 #include <numeric>
 #include <exception>
 #include <thread>
+#include <utility>
 
 namespace kvx {
 namespace {
@@ -324,8 +325,9 @@ void nd_run_local(NDState &st, NDWorker &wk, NDTask t0, int leaf)
 }  // namespace
 
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
-              int leaf, std::vector<int64_t> &perm)
+              int leaf, std::vector<int64_t> &perm, std::vector<std::pair<int64_t, int64_t>> *closed)
 {
+    if (closed) closed->clear();
     perm.resize((size_t)n);
     if (n == 0) return;
     NDProf prof_obj;
@@ -372,7 +374,10 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
                     }
                     try {
                         out.clear();
-                        if (t.hi - t.lo < cutoff) nd_run_local(st, wk, t, leaf);
+                        if (t.hi - t.lo < cutoff) {
+                            nd_run_local(st, wk, t, leaf);
+                            if (closed) { std::lock_guard<std::mutex> lk(mu); closed->emplace_back(t.lo, t.hi); }
+                        }
                         else nd_step(st, wk, t, leaf, out);
                         std::lock_guard<std::mutex> lk(mu);
                         for (const NDTask &c : out) pool.push_back(c);
@@ -402,6 +407,7 @@ void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<i
         if (failure) std::rethrow_exception(failure);   // -> KVX_ENOMEM / KVX_EINVAL at the C ABI (abi_guard.hpp, kvx_chol_analyze)
     }
     for (int64_t i = 0; i < n; i++) perm[(size_t)i] = st.verts[(size_t)i];
+    if (closed) std::sort(closed->begin(), closed->end());     // (which subdomains were handed over whole does not depend on the threads; their order of completion does)
     if (prof_obj.on && n >= 100000)
         fprintf(stderr, "  dissection: breadth-first passes %.1f ms, separator passes %.1f ms, leaf orderings %.1f ms (summed over threads); first-region chain %.1f ms\n",
                 prof_obj.bfs_ns / 1e6, prof_obj.pass_ns / 1e6, prof_obj.leaf_ns / 1e6, prof_obj.chain_ns / 1e6);

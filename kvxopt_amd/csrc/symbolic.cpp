@@ -4,6 +4,7 @@
 #include "par.hpp"
 
 #include <algorithm>
+#include <string>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -89,23 +90,44 @@ void etree_from_lower(int64_t n, const LowerPattern &Lo, std::vector<int32_t> &p
 }
 
 // The same tree from the full symmetric adjacency (original labels) and the permutation: no permuted pattern is formed.
+// closed (optional): disjoint position ranges whose vertices have no earlier neighbour outside their range (the subdomains a
+// nested dissection finished as a whole).  Liu's algorithm on the rows of such a range touches the range only, so the ranges
+// run on different threads; the rows outside them (the separators) follow on the calling thread in ascending order -- each of
+// them finds every smaller row done, which is all the algorithm asks for.
 void etree_from_adjacency(int64_t n, const std::vector<int64_t> &aptr, const std::vector<int32_t> &adj,
-                          const std::vector<int64_t> &perm, const std::vector<int64_t> &iperm, std::vector<int32_t> &parent)
+                          const std::vector<int64_t> &perm, const std::vector<int64_t> &iperm, std::vector<int32_t> &parent,
+                          const std::vector<std::pair<int64_t, int64_t>> *closed = nullptr)
 {
     parent.assign((size_t)n, -1);
     std::vector<int32_t> anc((size_t)n, -1), ip32((size_t)n);
     for (int64_t v = 0; v < n; v++) ip32[(size_t)v] = (int32_t)iperm[(size_t)v];
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t v = perm[(size_t)k];
-        for (int64_t p = aptr[(size_t)v]; p < aptr[(size_t)v + 1]; p++) {
-            int32_t i = ip32[(size_t)adj[(size_t)p]];
-            while (i != -1 && i < k) {
-                const int32_t nxt = anc[i];
-                anc[i] = (int32_t)k;
-                if (nxt == -1) parent[i] = (int32_t)k;
-                i = nxt;
+    auto rows = [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; k++) {
+            const int64_t v = perm[(size_t)k];
+            for (int64_t p = aptr[(size_t)v]; p < aptr[(size_t)v + 1]; p++) {
+                int32_t i = ip32[(size_t)adj[(size_t)p]];
+                while (i != -1 && i < k) {
+                    const int32_t nxt = anc[i];
+                    anc[i] = (int32_t)k;
+                    if (nxt == -1) parent[i] = (int32_t)k;
+                    i = nxt;
+                }
             }
         }
+    };
+    const int T = analyze_threads();
+    if (!closed || closed->size() < 2 || T <= 1) { rows(0, n); return; }
+    const std::vector<std::pair<int64_t, int64_t>> &R = *closed;
+    for (size_t r = 0; r < R.size(); r++)          // (sorted, disjoint, inside [0, n): anything else and the plain pass runs)
+        if (R[r].first < 0 || R[r].second > n || R[r].first >= R[r].second || (r > 0 && R[r].first < R[r - 1].second)) { rows(0, n); return; }
+    parallel_for((int64_t)R.size(), T, 1, [&](int64_t a, int64_t b) {
+        for (int64_t r = a; r < b; r++) rows(R[(size_t)r].first, R[(size_t)r].second);
+    });
+    int64_t k = 0;
+    for (size_t r = 0; r <= R.size(); r++) {
+        const int64_t stop = r < R.size() ? R[r].first : n;
+        rows(k, stop);
+        if (r < R.size()) k = R[r].second;
     }
 }
 
@@ -252,6 +274,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
         return lnz;
     };
     std::vector<double> known_fill;        // fill of cand[i] when it was needed to decide what else to compute (else < 0)
+    std::vector<std::pair<int64_t, int64_t>> nd_closed;   // closed subdomains of the dissection candidate (order_nd)
     std::vector<int64_t> aptr;             // full symmetric adjacency (built when an ordering is computed here; phase 2 reuses it)
     std::vector<int32_t> adj;
     if (user_perm) {
@@ -333,7 +356,7 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
                 try { md_thread = std::thread(run_md); md_async = true; } catch (...) { md_async = false; }
             }
             try {
-                if (want_nd) order_nd(n, aptr, adj, opts.nd_leaf, perm_nd);
+                if (want_nd) order_nd(n, aptr, adj, opts.nd_leaf, perm_nd, &nd_closed);
             } catch (...) {
                 if (md_async) md_thread.join();
                 throw;
@@ -391,7 +414,8 @@ void analyze(int64_t n, const int64_t *Ap, const int64_t *Ai, int uplo, const in
     if (!adj.empty() || (n > 0 && !aptr.empty() && aptr[n] == 0)) {
         // the adjacency of the ordering phase is at hand: Liu's algorithm straight from it (row k of the permuted matrix = the
         // neighbours of perm0[k] that come earlier), no permuted pattern and no row lists for this pass
-        etree_from_adjacency(n, aptr, adj, perm0, iperm0, parent);
+        const bool nd_picked = !cand.empty() && pick < cand_name.size() && std::string(cand_name[pick]) == "nested dissection";
+        etree_from_adjacency(n, aptr, adj, perm0, iperm0, parent, nd_picked ? &nd_closed : nullptr);
     } else {
         build_lower(n, Ap, Ai, uplo, iperm0, Lo);
         etree_from_lower(n, Lo, parent);

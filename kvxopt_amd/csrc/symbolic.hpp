@@ -7,6 +7,7 @@
 // the elimination-tree level schedule.  Own design; no SuiteSparse code.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <vector>
 #include <string>
 
@@ -89,8 +90,10 @@ void analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, int uplo,
 
 // Fill-reducing ordering of a symmetric graph given as full adjacency without
 // diagonal (adjptr[n+1], adj[]).  Returns perm (new -> old).
+// closed (optional): the subdomains the dissection finished as a whole, as position ranges [lo, hi) of the ordering -- a vertex of
+// such a range has no neighbour at an earlier position outside the range (its other neighbours are separators, numbered later)
 void order_nd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj,
-              int leaf, std::vector<int64_t> &perm);
+              int leaf, std::vector<int64_t> &perm, std::vector<std::pair<int64_t, int64_t>> *closed = nullptr);
 
 // Approximate minimum degree on the quotient graph (amd_order.cpp); same graph format as order_nd.
 void order_amd(int64_t n, const std::vector<int64_t> &adjptr, const std::vector<int32_t> &adj, std::vector<int64_t> &perm);
