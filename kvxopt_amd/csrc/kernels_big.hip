@@ -26,6 +26,19 @@
 namespace kvx {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// -DKVX_PHASE_TIMING (scratch/phase_timing.sh builds such a library next to the product one): cycle stamps along the path of the
+// workgroup that updates tile (0, 0) and factors the next diagonal block, summed in g_phase[] and read back by kvx_dbg_phase_read:
+// [0] launches counted, [1] operands + MFMA update, [2] read-modify-write of the tile, [3] tile into LDS, [4] potrf_lds as a whole,
+// [5] store of factor + inverse, [6] / [7] / [8] phases A (pivot sweep) / B / C inside potrf_lds.
+#ifdef KVX_PHASE_TIMING
+__device__ unsigned long long g_phase[16];
+#define KVX_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define KVX_PHASE_ADD(slot, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_phase[slot], (unsigned long long)((b) - (a))); } while (0)
+#else
+#define KVX_STAMP(var) do { } while (0)
+#define KVX_PHASE_ADD(slot, a, b) do { } while (0)
+#endif
 constexpr int NB = KVX_NB;
 
 // ------------------------------------------------------------------------------------------
@@ -200,6 +213,7 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
     for (int s = 0; s < nblk; s++) {
         double *Sd = lds.S + blk_slot(s, s) * SBS;
         double *Yd = lds.Yl + blk_slot(s, s) * YBS;
+        KVX_STAMP(pa);
         // ---- A: diagonal block and its inverse (wave 0)
         if (wv == 0) {
             const bool fac = i < 16;
@@ -221,6 +235,8 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
             }
         }
         __syncthreads();
+        KVX_STAMP(pb);
+        KVX_PHASE_ADD(6, pa, pb);
         // ---- B: tiles below (X = A Dinv') and block row s of the inverse; task t -> wave t
         {
             const int ntr = nblk - 1 - s;
@@ -264,6 +280,8 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
             }
         }
         __syncthreads();
+        KVX_STAMP(pc);
+        KVX_PHASE_ADD(7, pb, pc);
         // ---- C: trailing update of the tiles (ti, tj), s < tj <= ti < nblk; task t -> wave t & 3
         {
             int t = 0;
@@ -287,6 +305,8 @@ __device__ __forceinline__ void potrf_lds(PotrfLds &lds, int nbk, int tid, int *
                 }
         }
         __syncthreads();
+        KVX_STAMP(pd);
+        KVX_PHASE_ADD(8, pc, pd);
     }
 }
 
@@ -437,6 +457,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 {
     const int ti = blockIdx.x, tj = blockIdx.y;
     if (tj > ti) return;
+    KVX_STAMP(q0);
     const FrontDesc fd = ds.fd[list[blockIdx.z]];
     const int k = fd.k, m = fd.m, u = m - k;
     if (jb >= k) return;
@@ -458,6 +479,10 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
     for (int t = 0; t < 4; t++) cin[t] = (c0 + 16 * t + lr) < m;
     // Operand loads of 4 k-steps (20 loads per lane, branch-free) are issued before their 16 MFMAs.
+#ifdef KVX_PHASE_TIMING
+    unsigned long long qr[5];
+    qr[0] = __builtin_readcyclecounter();
+#endif
 #pragma unroll
     for (int kg = 0; kg < NB; kg += 16) {
         if (kg < nbk) {                             // wave-uniform
@@ -476,9 +501,14 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
 #pragma unroll
                 for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
         }
+#ifdef KVX_PHASE_TIMING
+        asm volatile("s_nop 0" ::: "memory");
+        qr[kg / 16 + 1] = __builtin_readcyclecounter();
+#endif
     }
     // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row.
     // Branch-free read-modify-write: all 16 loads go out (clamped addresses), then 16 predicated stores.
+    KVX_STAMP(q1);
     const int rs = min(rr, m - 1);
     double *ptr[4][4];
     double old[4][4];
@@ -499,6 +529,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
         for (int q = 0; q < 4; q++)
             if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
     if (ti == 0 && tj == 0 && t0 < cend && t0 < k) {   // workgroup-uniform
+        KVX_STAMP(q2);
         __shared__ PotrfLds lds;
         const int nb2 = min(NB, k - t0);
         const int i = 16 * w + lr;
@@ -510,10 +541,33 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
                 if (t <= w) lds.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? old[t][q] - acc[t][q] : (cc == i ? 1.0 : 0.0);
             }
         __syncthreads();
+        KVX_STAMP(q3);
         potrf_lds(lds, nb2, threadIdx.x, status, fd.first + t0, make_piv_rule(ds));
+        KVX_STAMP(q4);
         potrf_store(lds, nb2, threadIdx.x, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
+#ifdef KVX_PHASE_TIMING
+        __threadfence();
+#endif
+        KVX_STAMP(q5);
+#ifdef KVX_PHASE_TIMING
+        if (threadIdx.x == 0) atomicAdd(&g_phase[0], 1ull);
+#endif
+#ifdef KVX_PHASE_TIMING
+        KVX_PHASE_ADD(9, q0, qr[0]);
+        for (int g = 0; g < 4; g++) KVX_PHASE_ADD(10 + g, qr[g], qr[g + 1]);
+#endif
+        KVX_PHASE_ADD(1, q0, q1); KVX_PHASE_ADD(2, q1, q2); KVX_PHASE_ADD(3, q2, q3); KVX_PHASE_ADD(4, q3, q4); KVX_PHASE_ADD(5, q4, q5);
     }
 }
+
+#ifdef KVX_PHASE_TIMING
+extern "C" int kvx_dbg_phase_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Mid-size fronts (big class, order <= KVX_MID_M): the whole front in ONE workgroup and ONE launch per level -- extend-add,
