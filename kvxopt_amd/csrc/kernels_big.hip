@@ -451,6 +451,9 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 // workgroups per CU, what the plain update (116 VGPRs) had.
 // col_lim: two-level blocking (launch_panel_updates): only the columns < min(col_lim, k) -- the rest of the
 // current 256-column outer block -- are updated per panel; INT_MAX = the whole trailing matrix.
+// DEEP (opt-in, KVX_SYRK_DEEP_TILES = largest tile count of a launch that takes it): all 80 operand loads of a lane go out before
+// the first MFMA -- one memory round trip instead of four, 139 registers (two workgroups per CU instead of three).
+template <bool DEEP>
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo,
                                                        double *__restrict__ Linv, int *status, int col_lim)
@@ -481,8 +484,24 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     // Operand loads of 4 k-steps (20 loads per lane, branch-free) are issued before their 16 MFMAs.
 #ifdef KVX_PHASE_TIMING
     unsigned long long qr[5];
-    qr[0] = __builtin_readcyclecounter();
+    qr[0] = qr[1] = qr[2] = qr[3] = qr[4] = __builtin_readcyclecounter();
 #endif
+    if (DEEP) {
+        double bq[16], aq[16][4];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int kc = 4 * q + lk;
+            const bool kin = kc < nbk;
+            const int64_t coff = (int64_t)(jb + kc) * m;
+            bq[q] = kvx_ld0(P, rr + coff, kin && rin);
+#pragma unroll
+            for (int t = 0; t < 4; t++) aq[q][t] = kvx_ld0(P, (c0 + 16 * t + lr) + coff, kin && cin[t]);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int kg = 0; kg < NB; kg += 16) {
         if (kg < nbk) {                             // wave-uniform
@@ -505,6 +524,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
         asm volatile("s_nop 0" ::: "memory");
         qr[kg / 16 + 1] = __builtin_readcyclecounter();
 #endif
+    }
     }
     // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row.
     // Branch-free read-modify-write: all 16 loads go out (clamped addresses), then 16 predicated stores.
@@ -878,7 +898,11 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     if (T * (T + 1) / 2 * count >= big_limit) {
         hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
     } else {                                          // latency regime: more, smaller workgroups
-        hipLaunchKernelGGL(k_syrk_trailing, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
+        static const int64_t deep_tiles = [] { const char *d = getenv("KVX_SYRK_DEEP_TILES"); return d ? atoll(d) : (int64_t)0; }();
+        if (T * (T + 1) / 2 * count <= deep_tiles)
+            hipLaunchKernelGGL(k_syrk_trailing<true>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
+        else
+            hipLaunchKernelGGL(k_syrk_trailing<false>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
 }
 
@@ -895,7 +919,7 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (rows <= 0) return;
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     const unsigned TC = (unsigned)std::min<int>((int)T, (ob_end - jb - NB + KVX_TILE - 1) / KVX_TILE);
-    hipLaunchKernelGGL(k_syrk_trailing, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
+    hipLaunchKernelGGL(k_syrk_trailing<false>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
 }
 
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
