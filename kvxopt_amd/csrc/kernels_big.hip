@@ -543,12 +543,16 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
             ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
             old[t][q] = *ptr[t][q];
         }
+    // the workgroup that goes on to factor the next diagonal block does not write that block back first: nobody reads it before
+    // potrf_store puts the factor there, and the barrier below would wait for those stores
+    const bool fused = ti == 0 && tj == 0 && t0 < cend && t0 < k;   // workgroup-uniform
+    const int dend = fused ? t0 + min(NB, k - t0) : 0;              // rows below dend (a partial last block) are written as always
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
-    if (ti == 0 && tj == 0 && t0 < cend && t0 < k) {   // workgroup-uniform
+            if (ok[t][q] && rr >= dend) *ptr[t][q] = old[t][q] - acc[t][q];
+    if (fused) {
         KVX_STAMP(q2);
         __shared__ PotrfLds lds;
         const int nb2 = min(NB, k - t0);
