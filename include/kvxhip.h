@@ -62,6 +62,9 @@ void kvx_chol_default_opts(kvx_chol_opts *o);
 /* Library / device probes (host layer uses these to fail loudly when there is no GPU). */
 const char *kvx_version(void);
 int  kvx_device_count(void);            /* number of visible HIP devices (0 on a CPU-only box) */
+int  kvx_current_device(void);          /* the calling thread's current HIP device, -1 without one: device objects (factors, plans,
+                                         * KKT objects) live on the device that was current when they were built; the host layer's
+                                         * caches key on it                                    */
 const char *kvx_last_error(void);       /* text of the last error on this thread               */
 
 /* ---- sparse Cholesky: replaces kvxopt.cholmod ------------------------------------------ */

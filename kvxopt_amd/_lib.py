@@ -44,6 +44,7 @@ class CholInfo(ctypes.Structure):
 _SIGS = {
     "kvx_version": (ctypes.c_char_p, []),
     "kvx_device_count": (ctypes.c_int, []),
+    "kvx_current_device": (ctypes.c_int, []),
     "kvx_last_error": (ctypes.c_char_p, []),
     "kvx_chol_default_opts": (None, [ctypes.POINTER(CholOpts)]),
     "kvx_chol_analyze": (ctypes.c_int, [i64, i64p, i64p, ctypes.c_int, i64p, ctypes.POINTER(CholOpts), ctypes.POINTER(vp)]),
@@ -193,6 +194,39 @@ def as_f64(a):
 def require_device():
     if lib().kvx_device_count() <= 0:
         raise RuntimeError("kvxopt_amd: no HIP device visible; the numeric path has no CPU fallback")
+
+
+def current_device():
+    """The calling thread's current HIP device (-1 without one): part of every cache key of the host layer -- a factor, a plan
+    or a KKT object lives on the device that was current when it was built."""
+    return int(lib().kvx_current_device())
+
+
+_CACHE_CLEARERS = []
+
+
+def register_cache(clear_fn):
+    """The host layer's object caches (lp._KKT_CACHE, cholmod._SYMBOLIC_CACHE, klu._LINSOLVE_CACHE) register here so that
+    release_cached() -- and the retry after a MemoryError -- can give their device memory back."""
+    _CACHE_CLEARERS.append(clear_fn)
+
+
+def release_cached():
+    """Drop every cached device object of the host layer, then hand the pool's cached blocks back to the driver."""
+    for f in _CACHE_CLEARERS:
+        f()
+    import gc
+    gc.collect()
+    lib().kvx_dev_trim()
+
+
+def retry_after_release(fn):
+    """fn(); on MemoryError release the caches and the pool once and try again."""
+    try:
+        return fn()
+    except MemoryError:
+        release_cached()
+        return fn()
 
 
 def raise_for(rc, what=""):

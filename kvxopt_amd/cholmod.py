@@ -29,7 +29,7 @@ import os
 
 import numpy as np
 
-from . import base
+from . import _lib, base
 from .base import matrix, spmatrix
 from .chol import Factor
 
@@ -309,15 +309,23 @@ _SYMBOLIC_CACHE = collections.OrderedDict()
 _SYMBOLIC_CACHE_MAX = int(os.environ.get("KVX_LINSOLVE_CACHE", "4"))      # 0 turns the cache off (every kept factor holds device memory)
 
 
+def clear_cache():
+    """Release the symbolic factors kept for linsolve / splinsolve (device memory, launch graphs)."""
+    _SYMBOLIC_CACHE.clear()
+
+
+_lib.register_cache(clear_cache)
+
+
 def _cached_symbolic(A, p, uplo, n, cp, ri, v):
     q = _perm(p, n)
     key = (n, uplo, v.dtype.kind, None if q is None else q.tobytes(), cp.tobytes(), ri.tobytes(),
-           tuple(sorted((k, repr(val)) for k, val in options.items())))
+           tuple(sorted((k, repr(val)) for k, val in options.items())), _lib.current_device())   # a factor lives on ONE device
     if _SYMBOLIC_CACHE_MAX <= 0:
         return symbolic(A, p, uplo)
     F = _SYMBOLIC_CACHE.pop(key, None)
     if F is None:
-        F = symbolic(A, p, uplo)
+        F = _lib.retry_after_release(lambda: symbolic(A, p, uplo))
     _SYMBOLIC_CACHE[key] = F
     while len(_SYMBOLIC_CACHE) > _SYMBOLIC_CACHE_MAX:
         _SYMBOLIC_CACHE.popitem(last=False)

@@ -986,6 +986,14 @@ int kvx_device_count(void)
     return n;
 }
 
+int kvx_current_device(void)
+{
+    int n = 0, d = -1;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return -1; }
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return d;
+}
+
 void kvx_chol_default_opts(kvx_chol_opts *o)
 {
     memset(o, 0, sizeof(*o));

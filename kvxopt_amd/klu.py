@@ -23,7 +23,7 @@ import os
 
 import numpy as np
 
-from . import base
+from . import _lib, base
 from .base import matrix, spmatrix
 from .lu import LuSymbolic, LuNumeric
 
@@ -166,12 +166,20 @@ _LINSOLVE_CACHE = collections.OrderedDict()
 _LINSOLVE_CACHE_MAX = int(os.environ.get("KVX_LINSOLVE_CACHE", "8"))      # 0 turns the cache off (every kept factor holds device memory)
 
 
+def clear_cache():
+    """Release the factors kept for linsolve (device memory)."""
+    _LINSOLVE_CACHE.clear()
+
+
+_lib.register_cache(clear_cache)
+
+
 def linsolve(A, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
     n, cp, ri, v = _sp(A)
     buf, nrhs_, ldB_ = _rhs_args(n, B, trans, nrhs, ldB, offsetB, "z" if v.dtype.kind == "c" else "d")
     if nrhs_ == 0:
         return 0 if n == 0 or nrhs == 0 else None
-    key = (n, v.dtype.kind, cp.tobytes(), ri.tobytes())
+    key = (n, v.dtype.kind, cp.tobytes(), ri.tobytes(), _lib.current_device())     # the factors live on ONE device
     hit = _LINSOLVE_CACHE.pop(key, None) if _LINSOLVE_CACHE_MAX > 0 else None
     if hit is not None:
         Fs, Fn = hit

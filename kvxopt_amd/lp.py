@@ -16,7 +16,6 @@ pattern) and KKTGenEqDev (general S, dense K in HBM, any p).  `kvxopt_amd.misc.k
 import collections
 import ctypes
 import hashlib
-import json
 import math
 import os
 import time
@@ -536,6 +535,14 @@ def clear_cache():
     _KKT_CACHE.clear()
 
 
+_lib.register_cache(clear_cache)
+
+
+def _opts_key(chol_opts):
+    """Hashable key of an options dict whatever the value types (numpy integers, bools, floats): sorted (name, repr) pairs."""
+    return tuple(sorted((str(k), repr(v.item() if hasattr(v, "item") else v)) for k, v in (chol_opts or {}).items()))
+
+
 def _pattern_key(*arrays):
     h = hashlib.blake2b(digest_size=16)
     for a in arrays:
@@ -549,10 +556,11 @@ def _kkt_for(kind, dims_key, patterns, chol_opts, build, refresh):
     """The cached KKT object of this structure with its values refreshed, or a new one (build())."""
     if os.environ.get("KVX_LP_NO_CACHE") == "1":
         return build()
-    key = (kind, dims_key, _pattern_key(*patterns), json.dumps(chol_opts or {}, sort_keys=True))
+    # the device is part of the key: the buffers, streams and launch graphs of a KKT object live on the device it was built on
+    key = (kind, dims_key, _pattern_key(*patterns), _opts_key(chol_opts), _lib.current_device())
     kkt = _KKT_CACHE.pop(key, None)
     if kkt is None:
-        kkt = build()
+        kkt = _lib.retry_after_release(build)
     else:
         refresh(kkt)
     _KKT_CACHE[key] = kkt

@@ -134,3 +134,42 @@ def test_golden_nonlinear_block_is_the_kkt_solution(golden_dir, tag, p):
     assert np.allclose(u[:n], g[tag + "_x"], rtol=1e-9, atol=1e-11)
     assert np.allclose(u[n:n + p], g[tag + "_y"], rtol=1e-9, atol=1e-11)
     assert np.allclose(w * u[n + p:], g[tag + "_z"], rtol=1e-9, atol=1e-11)
+
+
+def test_object_caches_key_on_the_device_and_take_numpy_options(monkeypatch):
+    """the KKT / symbolic / linsolve caches hold device objects, so the current HIP device is part of every key (a
+    hit after a device switch would hand out buffers, streams and graphs of the other device), and option values of any scalar
+    type (numpy integers) make a key."""
+    import numpy as np
+    from kvxopt_amd import _lib, lp
+    lp.clear_cache()
+    built = []
+
+    def build():
+        built.append(object())
+        return built[-1]
+    pat = [np.array([0, 1, 2]), np.array([0, 1])]
+    opts = {"nd_leaf": np.int64(96), "postorder": True, "dbound": np.float64(1e-9)}
+    monkeypatch.setattr(_lib, "current_device", lambda: 0)
+    a = lp._kkt_for("t", (2, 2), pat, opts, build, lambda k: None)
+    assert lp._kkt_for("t", (2, 2), pat, dict(opts), build, lambda k: None) is a and len(built) == 1     # same device: a hit
+    monkeypatch.setattr(_lib, "current_device", lambda: 1)
+    b = lp._kkt_for("t", (2, 2), pat, opts, build, lambda k: None)
+    assert b is not a and len(built) == 2                                                                  # other device: a new object
+    # the release hook empties all three caches (the out-of-memory retry and release_cached() go through it)
+    from kvxopt_amd import cholmod, klu
+    cholmod._SYMBOLIC_CACHE["x"] = 1
+    klu._LINSOLVE_CACHE["x"] = 1
+    for f in _lib._CACHE_CLEARERS:
+        f()
+    assert not lp._KKT_CACHE and not cholmod._SYMBOLIC_CACHE and not klu._LINSOLVE_CACHE
+    # a MemoryError from a build releases the caches and retries once
+    calls = []
+
+    def flaky():
+        calls.append(1)
+        if len(calls) == 1:
+            raise MemoryError("pool exhausted")
+        return "ok"
+    monkeypatch.setattr(_lib, "release_cached", lambda: calls.append("released"))
+    assert _lib.retry_after_release(flaky) == "ok" and calls == [1, "released", 1]
