@@ -11,13 +11,22 @@ usage of misc.kkt_chol2 (numeric refactor with the symbolic analysis reused, mis
 metric = (sum_j c_j^2 + 4 nnz(L) nrhs) / time  [GF/s], c_j from the library's own symbolic
 analysis for the permutation it uses.
 
-One JSON line on stdout (rank 0).  N > 1 ranks: every rank factors its own system (the
-systems are independent; no data-path collective) -> "scaling": "weak".  `--dist subtree`
-shards ONE system over the ranks instead (kvxopt_amd/dist.py) -> "scaling": "strong";
-`--workload lap3d --grid 200` is BASELINE configs[4].  The line carries `roofline` (dominant
-kernel family, timed live with HIP events on the stream it runs on) and `cpu_baseline` (host
-supernodal restatement on all cores, SciPy SuperLU and the simplicial oracle beside it) in
-both modes, and `ipm` (IPM iterations/s with its own roofline and CPU baseline).
+One JSON line on stdout (rank 0).
+
+Ranks.  `python bench.py --gpus N` with no torchrun environment starts the N ranks itself: the parent process -- before it
+imports torch or touches HIP -- starts N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, lets
+rank 0's line through and exits non-zero when any child does.  Under `python -m torch.distributed.run ... bench.py --gpus N`
+the environment is already there and is used as it is.  N > 1 shards ONE system -- the SAME workload as N = 1 -- over the ranks
+(`--dist subtree`, kvxopt_amd/dist.py: subtrees of the elimination tree by proportional mapping, block-cyclic top fronts with
+panel broadcasts over RCCL) -> "scaling": "strong"; `--dist replicas` (every rank its own system, no data-path collective,
+"weak") stays available.  `--workload lap3d --grid 200` is BASELINE configs[4].
+
+The line carries `roofline` (dominant kernel family, timed live with HIP events on the stream it runs on), `cpu_baseline` (host
+supernodal restatement on the host cores that go with one GPU and on 32 threads, SciPy SuperLU and the simplicial oracle
+beside it), `ipm` (IPM iterations/s with its own roofline and CPU baseline), `extra` (the north-star systems measured in the
+same run: 21-point stencil 1000^2 and the 7-point Laplacian 100^3, each with its own roofline and CPU baseline), `one_shot`
+(time to first solution of cholmod.linsolve on a new pattern with host buffers, next to SciPy's splu) and `ranks` (backend,
+world size, device bytes per rank).
 """
 import argparse
 import ctypes
@@ -37,27 +46,64 @@ FP64_MFMA_PEAK_TF = 78.6     # MI355X FP64 matrix = vector peak; 2
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs; without a torchrun environment this process starts them itself")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--grid", type=int, default=0, help="grid side (default: 1000 for the 5-pt Laplacian of config 2, 100 for --workload lap3d)")
-    ap.add_argument("--workload", default="lap2d", choices=["lap2d", "lap3d"],
-                    help="lap2d = BASELINE configs[1] (5-pt Laplacian, the headline); lap3d = 7-pt Laplacian on a cube (configs[4] is --grid 200)")
+    ap.add_argument("--workload", default="lap2d", choices=["lap2d", "lap3d", "stencil21"],
+                    help="lap2d = BASELINE configs[1] (5-pt Laplacian, the headline); lap3d = 7-pt Laplacian on a cube (configs[4] is --grid 200); "
+                         "stencil21 = the ~20 nnz/row system of north_star")
     ap.add_argument("--dist-ob", type=int, default=0, help="--dist subtree: column-block width of the block-cyclic fronts (0 = library default)")
     ap.add_argument("--dist-min-m", type=int, default=0, help="--dist subtree: smallest order of a block-cyclic front (0 = library default)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the host supernodal baseline (0 = all cores)")
-    ap.add_argument("--no-splu", action="store_true", help="skip the SciPy SuperLU line of the CPU baseline (it takes ~10 s on config 2)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the host supernodal baseline (0 = the cores that go with one GPU, and 32)")
+    ap.add_argument("--no-splu", action="store_true", help="skip the SciPy SuperLU line of the CPU baseline (it takes ~2 s on config 2)")
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` systems (21-point stencil, 100^3 cube)")
+    ap.add_argument("--no-one-shot", action="store_true", help="skip the time-to-first-solution leg")
     ap.add_argument("--roofline-family", default="auto")
     ap.add_argument("--chol-opts", default="", help="JSON dict of analysis options (nd_leaf, leaf_cols, leaf_rows, relax_*) for experiments")
-    ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop and the CPU baseline (experiments)")
-    ap.add_argument("--dist", default="replicas", choices=["replicas", "subtree"],
-                    help="N > 1 ranks: 'replicas' = every rank factors its own system (weak scaling, no data-path collective; default); "
-                         "'subtree' = ONE system sharded over the ranks (kvxopt_amd.dist.DistFactor: subtrees by proportional mapping, "
-                         "block-cyclic top fronts with panel broadcasts; strong scaling)")
+    ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop, the CPU baselines and the secondary legs (experiments)")
+    ap.add_argument("--dist", default=None, choices=["replicas", "subtree"],
+                    help="N > 1 ranks: 'subtree' (default) = ONE system -- the N = 1 workload -- sharded over the ranks (kvxopt_amd.dist.DistFactor: "
+                         "subtrees by proportional mapping, block-cyclic top fronts with panel broadcasts; strong scaling); "
+                         "'replicas' = every rank factors its own system (weak scaling, no data-path collective)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks from THIS process, which has not imported torch and has
+    made no HIP call (a process that has initialised the GPU must never be replaced or forked into ranks).  Children inherit
+    stdout / stderr -- only rank 0 prints the JSON line.  Returns the exit code: 0 when every rank ended with 0."""
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL between processes needs it on this host driver)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for other in alive:                                 # one rank failed: the others would wait in a collective for ever
+                    other.terminate()
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with code %d\n" % rc)
+    return rc
 
 
 def front_stats(F):
@@ -94,49 +140,63 @@ def front_stats(F):
             "n_small": int(small.sum()), "n_big": int((~small).sum())}
 
 
-def host_threads(args):
-    """Threads of the host baselines: the cores this process may run on (affinity mask), at most 32 -- the OpenBLAS inside scipy is
-    built for 64 threads and its buffer table overflows when more OpenMP threads than that call it at once."""
-    if args.cpu_threads:
-        return max(1, min(int(args.cpu_threads), 32))
+def host_cores():
     try:
-        c = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except Exception:
-        c = os.cpu_count() or 1
-    return max(1, min(c, 16))                     # 16 = the CPU share that goes with one GPU of this node
+        return os.cpu_count() or 1
 
 
-def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu):
+def host_threads(args):
+    """Thread counts of the host supernodal baseline: the cores that go with ONE GPU of this node (16 of 256 on an 8-GPU box;
+    fewer when the process may run on fewer) and 32 -- the most the OpenBLAS inside scipy takes (it is built for 64 threads and
+    its buffer table overflows when more OpenMP threads than that call it at once).  --cpu-threads T: that count only."""
+    avail = host_cores()
+    if args.cpu_threads:
+        return [max(1, min(int(args.cpu_threads), 32, avail))]
+    out = [max(1, min(avail, 16))]
+    if avail >= 32:
+        out.append(32)
+    return out
+
+
+def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu, lite=False):
     """The reference's CPU path is SuiteSparse CHOLMOD (third-party, absent from this image: probed below).  Timed instead, on
-    the same matrix, permutation and flop count: (1) the host supernodal multifrontal restatement on all cores (OpenMP
-    subtrees + OpenBLAS BLAS-3 in the fronts, oracle/kvx_supernodal.c) -- the strongest CPU number and the headline baseline;
-    (2) SciPy SuperLU on P A P' with the natural column order, 1 thread (the calibration of BASELINE.md section 2);
-    (3) the simplicial up-looking oracle, 1 core (the parity checker)."""
+    the same matrix, permutation and flop count: (1) the host supernodal multifrontal restatement (OpenMP subtrees + OpenBLAS
+    BLAS-3 in the fronts, oracle/kvx_supernodal.c) on the cores that go with one GPU AND on 32 threads -- the better of the two
+    is the headline baseline, `cores` says which it was and `cores_available` what the box has; (2) SciPy SuperLU on P A P' with
+    the natural column order, 1 thread (the calibration of BASELINE.md section 2); (3) the simplicial up-looking oracle, 1 core
+    (the parity checker).  lite: (1) only, one repetition per thread count (the `extra` systems)."""
     import ctypes.util
     B = np.asfortranarray(b_host.reshape(n, nrhs, order="F").copy())
-    cores = host_threads(args)
-    out = {"cholmod_found": bool(ctypes.util.find_library("cholmod")), "os_cpu_count": os.cpu_count(), "affinity_cores": (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None),
+    out = {"cholmod_found": bool(ctypes.util.find_library("cholmod")), "os_cpu_count": os.cpu_count(), "cores_available": host_cores(),
            "env_threads": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS") if os.environ.get(k)}}
     others = {}
+    runs = []
     try:
         from oracle.kvx_oracle import OracleSupernodal
-        S = OracleSupernodal.from_factor(n, colptr, rowind, F, threads=cores)
-        best = None
-        for _ in range(3):                              # first pass pays page faults and thread start-up: best of three
-            xb = B.copy(order="F")
-            t0 = time.perf_counter(); S.factorize(values); t1 = time.perf_counter(); S.solve(xb); t2 = time.perf_counter()
-            if best is None or t2 - t0 < best[0]:
-                best = (t2 - t0, t1 - t0, t2 - t1)
-        diff = float(np.abs(xb.reshape(-1, order="F") - x_gpu).max() / np.abs(xb).max())
-        out.update({"value": work / best[0] / 1e9, "unit": "GF/s", "cores": cores, "kind": "port",
+        for cores in host_threads(args):
+            S = OracleSupernodal.from_factor(n, colptr, rowind, F, threads=cores)
+            best = None
+            for _ in range(1 if lite else 3):               # first pass pays page faults and thread start-up: best of three
+                xb = B.copy(order="F")
+                t0 = time.perf_counter(); S.factorize(values); t1 = time.perf_counter(); S.solve(xb); t2 = time.perf_counter()
+                if best is None or t2 - t0 < best[0]:
+                    best = (t2 - t0, t1 - t0, t2 - t1)
+            diff = float(np.abs(xb.reshape(-1, order="F") - x_gpu).max() / np.abs(xb).max())
+            runs.append({"cores": cores, "value": work / best[0] / 1e9, "factor_s": best[1], "solve_s": best[2], "max_rel_diff_vs_gpu": diff})
+            del S
+        top = max(runs, key=lambda r: r["value"])
+        out.update({"value": top["value"], "unit": "GF/s", "cores": top["cores"], "kind": "port",
                     "library": "host supernodal multifrontal restatement (oracle/kvx_supernodal.c): OpenMP over elimination-tree subtrees, "
                                "OpenBLAS dpotrf/dtrsm/dsyrk inside the fronts (the OpenBLAS that ships in scipy)",
-                    "sample": "same system, permutation and supernodes as the GPU run: numeric factorisation %.3f s + solve %.3f s, best of 3"
-                              % (best[1], best[2]),
-                    "max_rel_diff_vs_gpu": diff})
-        del S
+                    "sample": "same system, permutation and supernodes as the GPU run: numeric factorisation %.3f s + solve %.3f s on %d threads, best of %d"
+                              % (top["factor_s"], top["solve_s"], top["cores"], 1 if lite else 3),
+                    "max_rel_diff_vs_gpu": top["max_rel_diff_vs_gpu"], "by_threads": runs})
     except Exception as e:
         out["supernodal_error"] = repr(e)
+    if lite:
+        return out
     if not args.no_splu and n <= 1200000:
         try:
             import scipy.sparse as sp
@@ -251,7 +311,7 @@ def ipm_leg(args, torch):
             Fs = Factor(nl, Sp, Si)
             sup, nrows, parent, level = Fs.supernodes()
             rp, ri = Fs.front_rows()
-            cores = host_threads(args)
+            cores = host_threads(args)[0]
             sc = lp_oracle.conelp_l(Pl["c"], ml, nl, Pl["Gp"], Pl["Gi"], Pl["Gx"], Pl["h"], structure=(Fs.perm(), sup, rp, ri, parent, Sp, Si),
                                     threads=cores)
             ipm["cpu_baseline"] = {"value": sc["iterations"] / sc["loop seconds"], "unit": "iterations/s", "cores": cores, "kind": "port",
@@ -267,53 +327,50 @@ def ipm_leg(args, torch):
     return ipm
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
-    backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+def source_fingerprint():
+    """sha256 over the library sources (csrc/*): a committed PMC profile names the sources it was taken on, and the line says
+    when the kernels have changed since (`traffic_stale`)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "kvxopt_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kvxopt_amd", "csrc", "*.[ch]pp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
+
+PMC_FILE = "r03_pmc_fetch_write_per_kernel.json"
+
+
+def build_workload(name, g):
+    from kvxopt_amd import workloads
+    if name == "lap2d":
+        return workloads.laplacian_2d(g) + ("5-pt Laplacian %dx%d" % (g, g),)
+    if name == "lap3d":
+        return workloads.laplacian_3d(g) + ("7-pt Laplacian %dx%dx%d" % (g, g, g),)
+    return workloads.stencil21_2d(g) + ("21-pt stencil %dx%d (radius-2 box+cross, ~20 nnz/row, seed 20)" % (g, g),)
+
+
+def measure_system(args, torch, dist, rank, world, dev, wl, nrhs, steps, warmup, mode, family="auto", cpu="full", pmc_key=None):
+    """Factor + solve of one system, timed as the contract says (barrier + synchronize on both sides, MAX over the ranks),
+    with the roofline of the dominant kernel family (HIP events on the factor's own streams) and the CPU baselines beside it.
+    mode: 'single' (this rank alone), 'replicas' (every rank its own copy), 'subtree' (ONE system over the ranks).
+    Returns the result dict on every rank (CPU legs on rank 0 only)."""
     from kvxopt_amd import workloads
     from kvxopt_amd.chol import Factor
-
-    g = args.grid or (1000 if args.workload == "lap2d" else 100)
-    if args.workload == "lap2d":
-        n, colptr, rowind, values = workloads.laplacian_2d(g)
-        wname = "5-pt Laplacian %dx%d" % (g, g)
-    else:
-        n, colptr, rowind, values = workloads.laplacian_3d(g)
-        wname = "7-pt Laplacian %dx%dx%d" % (g, g, g)
+    n, colptr, rowind, values, wname = wl
     chol_opts = json.loads(args.chol_opts) if args.chol_opts else None
     DF = None
     t0 = time.time()
-    if args.dist == "subtree":
+    if mode == "subtree":
         from kvxopt_amd.dist import DistFactor
-        DF = DistFactor(n, colptr, rowind, "L", None, chol_opts, device=torch.device("cuda", local_rank), ob=args.dist_ob, min_m=args.dist_min_m)
+        DF = DistFactor(n, colptr, rowind, "L", None, chol_opts, device=dev, ob=args.dist_ob, min_m=args.dist_min_m)
         F = DF.F
     else:
         F = Factor(n, colptr, rowind, "L", None, chol_opts)
     t_analyze = time.time() - t0
     info = F.info()
-    nrhs = args.nrhs
     work = info["flops"] + 4.0 * info["lnz"] * nrhs          # SURVEY 8(d) flop measure per step
-
-    dev = torch.device("cuda", local_rank)
     vals_d = torch.from_numpy(values).to(dev)
     b_host = np.random.default_rng(2).standard_normal((n, nrhs)).reshape(n * nrhs, order="F") if nrhs > 1 \
         else np.random.default_rng(2).standard_normal(n)
@@ -332,38 +389,52 @@ def main():
         torch.cuda.current_stream().synchronize()          # x_d ready before the factor's own stream reads it
         F.solve_dev(x_d.data_ptr(), 0, nrhs, n)              # synchronises the factor's stream
 
+    collective = dist is not None and mode != "single"
+
     def barrier():
-        if dist is not None:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     # --- timed region ------------------------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
+    if collective:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_factor, ms_solve = F.timing()
-    steps_run = args.warmup + args.steps
-    if DF is not None:
-        steps_run_marker = (DF.collectives, DF.bytes_moved)   # (counted up to here: warm-up + timed steps)
+    steps_run = warmup + steps
+    coll = (DF.collectives, DF.bytes_moved) if DF is not None else (0, 0)   # (counted up to here: warm-up + timed steps)
 
     # residual of the last solve (parity bar: <= 1e-10 relative)
     x = x_d.cpu().numpy()
     r = workloads.sym_matvec(n, colptr, rowind, values, x.reshape(n, nrhs, order="F")) - b_host.reshape(n, nrhs, order="F")
     relres = float(np.linalg.norm(r) / np.linalg.norm(b_host))
+    nsys = world if mode == "replicas" else 1
+    res = {"workload": wname, "n": int(n), "nrhs": nrhs, "value": work * steps * nsys / dt / 1e9, "unit": "GF/s", "ms_per_step": dt / steps * 1e3,
+           "ms_factor": ms_factor, "ms_solve": ms_solve, "rel_residual": relres, "steps": steps, "warmup": warmup,
+           "nnz_lower": int(len(values)), "lnz": int(info["lnz"]), "flops_sum_cj2": info["flops"], "nsuper": int(info["nsuper"]),
+           "nlevels": int(info["nlevels"]), "max_front": int(info["max_front"]), "lsize": int(info["lsize"]), "analyze_s": round(t_analyze, 3),
+           "dev_bytes_rank0": int(F.info()["dev_bytes"]), "_work": work, "_dt": dt, "_x": x, "_F": F, "_DF": DF}
+    if DF is not None:
+        res["sharding"] = {"shared_fronts_rank0": DF.nshared, "block_cyclic_rank0": DF.ncyclic, "block_columns": DF.ob,
+                           "collectives_per_step_rank0": coll[0] // max(steps_run, 1), "mb_moved_per_step_rank0": coll[1] / max(steps_run, 1) / 1e6,
+                           "panel_doubles_rank0": DF.lsize_local, "panel_doubles_total": DF.lsize_total}
+    if args.quick:
+        return res
 
-    # --- roofline leg: dominant kernel family timed live with HIP events on the factor's stream
+    # --- roofline leg: dominant kernel family timed live with HIP events on the factor's stream (hipGraph replay is off for
+    # these passes: the events go around the individual launches) -----------------------------------------------------------
     st = front_stats(F)
     fam_times = {}
-    for fam in (Factor.FAMILIES if not args.quick else ()):
+    for fam in Factor.FAMILIES:
         samples = []
         for _ in range(3):                         # median of three single-step readings: one hiccup must not pick the family
             F.prof_select(fam)
@@ -372,20 +443,17 @@ def main():
         samples.sort(key=lambda t: t[0])
         fam_times[fam] = (samples[1][0], samples[1][1])
     F.prof_select(None)
-    if args.quick:
-        if rank == 0:
-            print(json.dumps({"value": work * args.steps * world / dt / 1e9, "ms_per_step": dt / args.steps * 1e3, "ms_factor": ms_factor,
-                              "ms_solve": ms_solve, "rel_residual": relres, "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]),
-                              "lsize": int(info["lsize"]), "opts": args.chol_opts}))
-        return
-    dom = max(fam_times, key=lambda f: fam_times[f][0]) if args.roofline_family == "auto" else args.roofline_family
+    pick = args.roofline_family if family == "auto" else family
+    dom = max(fam_times, key=lambda f: fam_times[f][0]) if pick == "auto" else pick
     dom_ms, dom_launches = fam_times[dom]
     if DF is not None and world > 1:
         # rank 0 times its own launches: scale the family's work by the share of the flops rank 0 executes (host-side map)
         from kvxopt_amd.dist import partition
-        mp = partition(F, world, DF.ob, DF.min_m)
+        mp = partition(F, world, DF.ob, DF.min_m)              # (the map reads the tree and the front sizes only: the per-rank layout does not change it)
         share0 = float(mp["rank_flops"][0] / mp["flops"])
+        res["sharding"]["flop_share_by_rank"] = [round(float(v / mp["flops"]), 4) for v in mp["rank_flops"]]
         st = {k: (v * share0 if isinstance(v, float) else v) for k, v in st.items()}
+    alg_bytes = None
     if dom in ("syrk_trailing", "front_mid"):
         achieved = st["flops_syrk" if dom == "syrk_trailing" else "flops_mid"] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -402,56 +470,193 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None}
-    # HBM traffic of the dominant family from the committed PMC passes (profiles/, separate
-    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); null when no profile matches.
+    roofline["timing_mode"] = "HIP events around every launch of the family on the stream it runs on, hipGraph replay off for these passes (the timed step replays graphs)"
+    # HBM traffic of the dominant family from the committed PMC passes (profiles/, separate rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE runs of this same command; not measured in this run); null when no profile matches this workload,
+    # `traffic_stale` when the library sources have changed since the profile was taken.
     try:
-        pmc_file = "r02_pmc_fetch_write_per_kernel.json"
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-        if args.workload == "lap2d" and g == 1000 and nrhs == 1 and DF is None and dom in pmc.get("family_bytes_per_step", {}):
-            roofline["traffic"] = pmc["family_bytes_per_step"][dom] / max(dom_launches, 1)
-            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE+WRITE_SIZE, raw; profiles/%s)" % pmc_file
-            roofline["algorithmic_bytes_per_launch"] = (alg_bytes / max(dom_launches, 1)) if roofline["bound"] == "hbm" else None
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        fam_b = pmc.get(pmc_key or "", {}).get("family_bytes_per_step", {}) if pmc_key else {}
+        if DF is None and dom in fam_b:
+            roofline["traffic"] = fam_b[dom] / max(dom_launches, 1)
+            roofline["traffic_unit"] = "bytes per launch, FETCH_SIZE x fetch_scale + WRITE_SIZE, from the committed profile profiles/%s (fetch_scale %s: %s)" % (
+                PMC_FILE, pmc.get("fetch_scale"), pmc.get("fetch_scale_note", ""))
+            roofline["traffic_stale"] = pmc.get("source_fingerprint") != source_fingerprint()
+            roofline["algorithmic_bytes_per_launch"] = (alg_bytes / max(dom_launches, 1)) if alg_bytes is not None else None
     except Exception:
         pass
     roofline["ms_per_step"] = dom_ms
     roofline["launches_per_step"] = dom_launches
     roofline["family_ms_per_step"] = {f: round(v[0], 4) for f, v in fam_times.items()}
+    roofline["also"] = {"flops_syrk_per_step": st["flops_syrk"], "mfma_frac_syrk_trailing": (st["flops_syrk"] / (fam_times["syrk_trailing"][0] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TF) if fam_times["syrk_trailing"][0] > 0 else None,
+                        "bytes_small_per_step": st["bytes_small"], "hbm_frac_front_small": (st["bytes_small"] / (fam_times["front_small"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if fam_times["front_small"][0] > 0 else None}
+    res["roofline"] = roofline
 
     # --- CPU baselines on the same system and permutation (rank 0, host cores of this box) -------
-    cpu = None
-    if rank == 0 and (world == 1 or DF is not None) and not args.no_cpu_baseline:   # (replicas: rank 0 at N = 1 only; one sharded system: beside every N)
-        cpu = cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x)
+    res["cpu_baseline"] = None
+    if rank == 0 and cpu != "none" and not args.no_cpu_baseline and (world == 1 or mode != "replicas"):
+        res["cpu_baseline"] = cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x, lite=(cpu == "lite"))
+    return res
+
+
+def public(res):
+    return {k: v for k, v in res.items() if not k.startswith("_")}
+
+
+def one_shot_leg(args, wl):
+    """Time to first solution on a NEW pattern with HOST buffers -- what one cholmod.linsolve call costs (cholmod.c:618-753:
+    analysis + upload + numeric factorisation + solve + download) -- next to SciPy's splu (ordering + factorisation + solve) on
+    this box's host.  The object cache is emptied first; the library itself (code objects, pools) is warm."""
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import matrix, spmatrix
+    n, colptr, rowind, values, wname = wl
+    A = spmatrix.from_ccs(n, n, colptr, rowind, values)
+    b = np.random.default_rng(2).standard_normal(n)
+    cholmod.clear_cache()
+    B = matrix(b.copy())
+    t0 = time.perf_counter()
+    cholmod.linsolve(A, B)
+    t_first = time.perf_counter() - t0
+    x = np.asarray(B._a).reshape(-1).copy()
+    B2 = matrix(b.copy())
+    t0 = time.perf_counter()
+    cholmod.linsolve(A, B2)                                  # the same pattern again: refactorisation + solve on the kept analysis
+    t_again = time.perf_counter() - t0
+    cholmod.clear_cache()
+    out = {"workload": wname + ", cholmod.linsolve(A, b) with host buffers", "gpu_first_call_s": t_first, "gpu_known_pattern_s": t_again,
+           "measured": "wall time of the call: host analysis (ordering, symbolic), upload, numeric factorisation, solve, download"}
+    if not args.no_splu:
+        try:
+            import scipy.sparse as sp
+            from scipy.sparse.linalg import splu
+            Al = sp.csc_matrix((values, rowind, colptr), shape=(n, n))
+            Af = (Al + sp.tril(Al, -1).T).tocsc()
+            t0 = time.perf_counter()
+            lu = splu(Af, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options={"SymmetricMode": True})
+            xs = lu.solve(b)
+            t_cpu = time.perf_counter() - t0
+            out["scipy_splu_s"] = t_cpu
+            out["scipy_splu"] = "splu(A, permc_spec='MMD_AT_PLUS_A', SymmetricMode) + solve, 1 thread (the calibration set-up of BASELINE.md section 2)"
+            out["speedup_first_call"] = t_cpu / t_first
+            out["max_rel_diff_vs_splu"] = float(np.abs(xs - x).max() / np.abs(xs).max())
+        except Exception as e:
+            out["scipy_splu_error"] = repr(e)
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))                          # (nothing above has imported torch or touched HIP)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
+    backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    if backend != "nccl":
+        local_rank = local_rank % ndev
+    elif world > ndev:
+        raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    mode = "single" if world == 1 else (args.dist or "subtree")
+
+    g = args.grid or (100 if args.workload == "lap3d" else 1000)
+    wl = build_workload(args.workload, g)
+    headline_cfg2 = args.workload == "lap2d" and g == 1000 and args.nrhs == 1
+    res = measure_system(args, torch, dist, rank, world, dev, wl, args.nrhs, args.steps, args.warmup, mode,
+                         pmc_key=("config2" if headline_cfg2 and mode == "single" else None))
+    if args.quick:
+        if rank == 0:
+            print(json.dumps(dict(public(res), opts=args.chol_opts, n_gpus=world)))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # per-rank device memory: the factor's own large buffers (library count) and what the device reports in use
+    free_b, total_b = torch.cuda.mem_get_info()
+    mine = torch.tensor([float(res["_F"].info()["dev_bytes"]), float(total_b - free_b)], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)]
+    if dist is not None:
+        dist.all_gather(per_rank, mine)
+    ranks = {"backend": (dist.get_backend() if dist is not None else "none"), "world_size": (dist.get_world_size() if dist is not None else 1),
+             "factor_bytes_by_rank": [int(t[0].item()) for t in per_rank], "device_bytes_in_use_by_rank": [int(t[1].item()) for t in per_rank]}
+
+    # --- the north-star systems in the same run (every N; CPU baselines at N = 1): ~20 nnz/row at n = 1e6, and the flop-bound cube
+    extra = []
+    if not args.no_extra and headline_cfg2:
+        for name, gg, st_, wu in (("stencil21", 1000, 5, 2), ("lap3d", 100, 3, 1)):
+            try:
+                del res["_F"], res["_DF"]                   # (one factor resident at a time)
+            except KeyError:
+                pass
+            try:
+                w2 = build_workload(name, gg)
+                r2 = measure_system(args, torch, dist, rank, world, dev, w2, 1, st_, wu, mode, family="syrk_trailing",
+                                    cpu=("lite" if world == 1 else "none"), pmc_key=None)
+                if r2.get("cpu_baseline") and r2["cpu_baseline"].get("value"):
+                    r2["vs_cpu_baseline"] = r2["value"] / r2["cpu_baseline"]["value"]
+                extra.append(public(r2))
+                del r2
+            except Exception as e:                          # the headline line must not depend on these legs
+                extra.append({"workload": name, "error": repr(e)})
 
     # --- the other half of BASELINE.json's metric: IPM iterations/s of the device-resident conelp on configs[3]
     # (inequality form, SURVEY 8(d) config 4b), rank 0 only, a few hundred ms; never part of `value`
     ipm = None
-    if rank == 0 and world == 1 and not args.no_ipm:
-        try:
-            ipm = ipm_leg(args, torch)
-        except Exception as e:                      # the headline line must not depend on this leg
-            ipm = {"error": repr(e)}
+    one_shot = None
+    if rank == 0 and world == 1:
+        if not args.no_ipm:
+            try:
+                ipm = ipm_leg(args, torch)
+            except Exception as e:                      # the headline line must not depend on this leg
+                ipm = {"error": repr(e)}
+        if not args.no_one_shot and headline_cfg2:
+            try:
+                one_shot = one_shot_leg(args, wl)
+            except Exception as e:
+                one_shot = {"error": repr(e)}
 
     if rank == 0:
-        total = work * args.steps * (1 if DF is not None else world)
+        cpu = res.get("cpu_baseline")
+        n = res["n"]
+        par = "1 GPU" if world == 1 else (("replicas x%d: every rank its own system, no data-path collective" % world) if mode == "replicas" else
+                                         ("ONE system sharded x%d over %s: subtrees by proportional mapping, %d shared fronts on rank 0 (%d block-cyclic, "
+                                          "%d-column blocks), %d collectives / %.1f MB per step on rank 0"
+                                          % (world, ranks["backend"], res["sharding"]["shared_fronts_rank0"], res["sharding"]["block_cyclic_rank0"],
+                                             res["sharding"]["block_columns"], res["sharding"]["collectives_per_step_rank0"],
+                                             res["sharding"]["mb_moved_per_step_rank0"])))
         out = {
-            "metric": "sparse Cholesky factor+solve GF/s", "value": total / dt / 1e9, "unit": "GF/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if DF is not None else "weak",
+            "metric": "sparse Cholesky factor+solve GF/s", "value": res["value"], "unit": "GF/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak" if mode == "replicas" else "strong",
             "vs_baseline": None,                    # BASELINE.md holds no published number for this metric
-            "vs_cpu_baseline": (total / dt / 1e9 / cpu["value"]) if (cpu and cpu.get("value")) else None,
+            "vs_cpu_baseline": (res["value"] / cpu["value"]) if (cpu and cpu.get("value")) else None,
+            "vs_cpu_baseline_note": "GPU / the restated CPU path (host supernodal port, `cpu_baseline.cores` of `cpu_baseline.cores_available` cores); "
+                                    "the reference's own CPU library (SuiteSparse CHOLMOD) is not on this box",
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (wname, n, nrhs),
-                       "nnz_lower": int(len(values)), "lnz": int(info["lnz"]), "flops_sum_cj2": info["flops"],
-                       "nsuper": int(info["nsuper"]), "nlevels": int(info["nlevels"]), "max_front": int(info["max_front"]),
-                       "analyze_s": round(t_analyze, 3),
-                       "parallelism": ("replicas x%d" % world) if DF is None else
-                                      ("one system sharded x%d: proportional mapping, %d shared fronts on rank 0 (%d block-cyclic, %d-column blocks), "
-                                       "%d collectives / %.1f MB per step on rank 0" % (world, DF.nshared, DF.ncyclic, DF.ob,
-                                                                                        steps_run_marker[0] // max(steps_run, 1), steps_run_marker[1] / max(steps_run, 1) / 1e6))},
-            "ms_factor": ms_factor, "ms_solve": ms_solve, "rel_residual": relres,
-            "roofline": roofline, "cpu_baseline": cpu, "ipm": ipm,
+            "config": {"workload": "%s, n=%d, lower CCS int64, nrhs=%d, factor+solve per step" % (res["workload"], n, args.nrhs),
+                       "nnz_lower": res["nnz_lower"], "lnz": res["lnz"], "flops_sum_cj2": res["flops_sum_cj2"],
+                       "nsuper": res["nsuper"], "nlevels": res["nlevels"], "max_front": res["max_front"],
+                       "analyze_s": res["analyze_s"], "parallelism": par},
+            "ms_factor": res["ms_factor"], "ms_solve": res["ms_solve"], "rel_residual": res["rel_residual"],
+            "roofline": res["roofline"], "cpu_baseline": cpu, "ranks": ranks, "sharding": res.get("sharding"),
+            "extra": extra, "ipm": ipm, "one_shot": one_shot,
         }
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()                  # rank 0 has extra legs (CPU baseline, IPM): leave together
         dist.destroy_process_group()

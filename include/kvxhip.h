@@ -128,7 +128,10 @@ typedef struct {
     int64_t minor;
     int64_t solve_rowidx;    /* sum_s m_s: index entries read per triangular sweep           */
     int64_t is_ll;           /* 1: LL' factor, 0: LDL' (options['supernodal'] = 0, or 1 on a sparse factor) */
-    int64_t reserved[4];
+    int64_t dev_bytes;       /* bytes of the large device buffers of this handle (panels, inverted diagonal blocks, update
+                              * matrices, values); 0 before the first device use.  Sharded mode: THIS rank's share          */
+    int64_t lsize_local;     /* panel doubles resident on this rank (= lsize except in sharded mode: own + shared fronts)   */
+    int64_t reserved[2];
 } kvx_chol_info;
 int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info);
 int kvx_chol_get_perm(kvx_chol *F, int64_t *perm);     /* final permutation (ordering o postorder) */

@@ -38,7 +38,7 @@ DIST_COMM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(Di
 class CholInfo(ctypes.Structure):
     _fields_ = [("n", i64), ("nnz_a", i64), ("lnz", i64), ("flops", f64), ("nsuper", i64), ("lsize", i64),
                 ("nlevels", i64), ("max_front", i64), ("upd_size", i64), ("is_numeric", i64), ("minor", i64),
-                ("solve_rowidx", i64), ("is_ll", i64), ("reserved", i64 * 4)]
+                ("solve_rowidx", i64), ("is_ll", i64), ("dev_bytes", i64), ("lsize_local", i64), ("reserved", i64 * 2)]
 
 
 _SIGS = {

@@ -288,9 +288,10 @@ int ensure_device(kvx_chol *F)
         loff.assign((size_t)S.nsuper, -1);
         int64_t tot = 0;
         for (int64_t s = 0; s < S.nsuper; s++)
-            if (front_class(S.sn_m[s], S.sn_k[s]) == KVX_CLS_BIG) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
+            if (front_class(S.sn_m[s], S.sn_k[s]) == KVX_CLS_BIG && (F->part.empty() || F->part[s])) { loff[s] = tot; tot += (int64_t)((S.sn_k[s] + KVX_NB - 1) / KVX_NB) * KVX_NB * KVX_NB; }
         if ((rc = upload(&F->d_linv_off, loff))) return rc;
         HIPCHK(pool_malloc((void **)&F->d_Linv, std::max<int64_t>(tot, 1) * sizeof(double)));
+        F->dev_bytes = (S.lsize + S.upd_size[0] + S.upd_size[1] + S.nnzA + tot) * (int64_t)sizeof(double);
     }
     {
         std::vector<FrontDesc> fd((size_t)S.nsuper);
@@ -1385,6 +1386,7 @@ int kvx_chol_spsolve(kvx_chol *F, int sys, int64_t ncol, const int64_t *Bp, cons
 int kvx_chol_diag(kvx_chol *F, double *d)
 {
     if (!F || !d) return KVX_EINVAL;
+    if (!F->part.empty()) { set_err("diag: this rank holds only its own fronts of a sharded factor"); return KVX_EINVAL; }
     if (!F->dev_ready || !F->is_ll) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESYMBOLIC; }
     int rc = finish_factor(F, nullptr);
     if (rc == KVX_ENOTPOSDEF) { set_err("F must be a nonsingular supernodal Cholesky factor"); return KVX_ESINGULAR; }
@@ -1403,6 +1405,7 @@ int kvx_chol_diag(kvx_chol *F, double *d)
 static int kvx_chol_get_factor_impl(kvx_chol *F, int64_t *lnz, int64_t *Lp, int64_t *Li, double *Lx)
 {
     if (!F) return KVX_EINVAL;
+    if (!F->part.empty()) { set_err("getfactor: this rank holds only its own fronts of a sharded factor"); return KVX_EINVAL; }
     Symbolic &S = F->S;
     // structural entries of the supernodal factor: lower trapezoid of every panel
     int64_t cnt = 0;
@@ -1454,7 +1457,9 @@ int kvx_chol_get_info(kvx_chol *F, kvx_chol_info *info)
     info->lnz = S.lnz;
     info->flops = S.flops;
     info->nsuper = S.nsuper;
-    info->lsize = S.lsize;
+    info->lsize = F->lsize_total >= 0 ? F->lsize_total : S.lsize;
+    info->dev_bytes = F->dev_bytes;                   // bytes of the large device buffers this handle holds (0 before the first device use)
+    info->lsize_local = S.lsize;                      // panel doubles resident on THIS rank (= lsize unless the sharded layout was trimmed)
     info->nlevels = S.nlevels;
     info->max_front = S.max_m;
     info->upd_size = S.upd_size[0] + S.upd_size[1];

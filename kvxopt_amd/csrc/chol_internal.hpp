@@ -80,6 +80,9 @@ struct kvx_chol {
     // sharded mode (kvx_chol_dist_*, dist_api.cpp): the level lists hold only the fronts this rank takes part in; the
     // factorisation additionally leaves out the block-cyclic fronts (factored by dist_api.cpp's panel loop): fplan / d_flists
     int dist_rank = 0, dist_nranks = 1;
+    std::vector<uint8_t> part;                 // sharded mode with a per-rank layout (dist_api.cpp trim_to_rank): 1 = this rank holds the front; empty = all fronts
+    int64_t lsize_total = -1;                  // panel doubles of the WHOLE factor when S.lsize was trimmed to this rank's fronts (-1: S.lsize is the whole)
+    int64_t dev_bytes = 0;                     // bytes of the factor's large device buffers (panels, inverted blocks, update matrices, values)
     kvx::DistState *dist = nullptr;
     bool fplan_on = false;
     std::vector<LevelPlan> fplan;

@@ -329,20 +329,62 @@ int dist_solve_impl(kvx_chol *F, double *B, int64_t nrhs, int64_t ldB, kvx_dist_
     return KVX_OK;
 }
 
+// Per-rank layout (before anything is allocated): a rank holds the panels (and inverted diagonal blocks) of the fronts whose
+// rank range includes it -- its own subtrees plus the shared fronts above them, whose complete panels reach it through the
+// broadcasts -- and an update-matrix slot for those fronts and for the children of its shared fronts (received from their
+// owners before the parent assembles).  Everything else of the factor never exists on this rank: S.px / S.ux / S.amap are
+// rewritten to the compact layout, S.lsize / S.upd_size shrink, F->lsize_total keeps the size of the whole factor.
+void trim_to_rank(kvx_chol *F, const DistMap &M, int rank)
+{
+    Symbolic &S = F->S;
+    const int64_t ns = S.nsuper;
+    F->part.assign((size_t)ns, 0);
+    for (int64_t s = 0; s < ns; s++) F->part[s] = (rank >= M.glo[s] && rank < M.ghi[s]) ? 1 : 0;
+    std::vector<int64_t> npx((size_t)ns + 1, 0);
+    for (int64_t s = 0; s < ns; s++) npx[s + 1] = npx[s] + (F->part[s] ? (int64_t)S.sn_m[s] * S.sn_k[s] : 0);
+    for (size_t e = 0; e < S.amap.size(); e++) {
+        const int64_t a = S.amap[e];
+        if (a < 0) continue;
+        const int64_t s = (int64_t)(std::upper_bound(S.px.begin(), S.px.end(), a) - S.px.begin()) - 1;
+        S.amap[e] = F->part[s] ? npx[s] + (a - S.px[s]) : -1;
+    }
+    F->lsize_total = S.lsize;
+    S.px = npx;
+    S.lsize = npx[ns];
+    S.upd_size[0] = S.upd_size[1] = 0;
+    for (int32_t l = 0; l < S.nlevels; l++) {
+        int64_t off = 0;
+        for (int64_t q = S.levelptr[l]; q < S.levelptr[l + 1]; q++) {
+            const int32_t s = S.levellist[q];
+            const int32_t p = S.sparent[s];
+            if (!(F->part[s] || (p >= 0 && F->part[p]))) { S.ux[s] = 0; continue; }
+            const int64_t u = S.sn_m[s] - S.sn_k[s];
+            S.ux[s] = off;
+            off += u * u;
+        }
+        S.upd_size[l & 1] = std::max(S.upd_size[l & 1], off);
+    }
+}
+
 int dist_setup_impl(kvx_chol *F, int rank, int nranks, int ob, int min_m, int64_t info[8])
 {
     if (!F || nranks < 1 || rank < 0 || rank >= nranks || !info) return KVX_EINVAL;
+    Symbolic &S = F->S;
+    if (const char *e = getenv("KVX_DIST_OB")) ob = atoi(e);
+    if (const char *e = getenv("KVX_DIST_MIN_M")) min_m = atoi(e);
+    DistMap M0;
+    dist_map(S, nranks, ob > 0 ? ob : 512, min_m > 0 ? min_m : 6144, M0);
+    // the device objects are created HERE when the handle has none yet: panels, inverted diagonal blocks and update matrices
+    // are then laid out for the fronts this rank takes part in only (KVX_DIST_NO_TRIM=1: the whole factor on every rank)
+    if (!F->dev_ready && nranks > 1 && !(getenv("KVX_DIST_NO_TRIM") && getenv("KVX_DIST_NO_TRIM")[0] == '1')) trim_to_rank(F, M0, rank);
     int rc = ensure_device(F);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(F->stream));
-    Symbolic &S = F->S;
     dist_release(F);
     F->dist = new DistState();
     DistState &D = *F->dist;
     D.rank = rank; D.nranks = nranks;
-    if (const char *e = getenv("KVX_DIST_OB")) ob = atoi(e);
-    if (const char *e = getenv("KVX_DIST_MIN_M")) min_m = atoi(e);
-    dist_map(S, nranks, ob > 0 ? ob : 512, min_m > 0 ? min_m : 6144, D.M);
+    D.M = std::move(M0);
     const DistMap &M = D.M;
     // level lists: the fronts this rank takes part in (solves); without the block-cyclic ones (factorisation)
     std::vector<int32_t> flists;

@@ -125,7 +125,15 @@ class DistFactor:
         self._xchg = torch.zeros(cnt, dtype=torch.float64, device=self.device)
         raise_for(lib().kvx_chol_dist_set_xchg(self.F._h, self._xchg.data_ptr(), cnt))
         self._base = self._xchg.data_ptr()
-        self._host_staged = self._dist is not None and self._dist.get_backend(group) != "nccl"
+        # RCCL collectives are enqueued in stream order (torch puts them behind the current = null stream, which do_comm has put
+        # behind the factor's stream): no host synchronisation.  gloo stages through the host: settle the producers first.
+        # KVX_DIST_STREAM_ORDERED=1 rehearses the stream-ordered branch over gloo (torch's gloo backend orders its staging
+        # copies against the current stream itself), so the event ordering around the callback runs on a one-GPU box too.
+        self.backend = self._dist.get_backend(group) if self._dist is not None else "none"
+        self._host_staged = self._dist is not None and self.backend != "nccl" and os.environ.get("KVX_DIST_STREAM_ORDERED") != "1"
+        inf = self.F.info()
+        self.dev_bytes = int(inf["dev_bytes"])                  # this rank's large device buffers (panels, inverted blocks, update matrices, values)
+        self.lsize_local, self.lsize_total = int(inf["lsize_local"]), int(inf["lsize"])
         self.collectives = 0
         self.bytes_moved = 0
         self._err = None

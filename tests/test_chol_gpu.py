@@ -334,6 +334,36 @@ def test_config5_workload_properties_on_one_gpu():
     assert e.value.args[0] == n - 1
 
 
+def test_config5_full_size_on_one_gpu():
+    """BASELINE.json configs[4] AT ITS SIZE -- the 7-point Laplacian on the 200^3 grid, n = 8e6, 73 GB of factor -- on the one
+    GPU of the box, by properties that need no oracle run (the CPU oracle would take an hour): residual <= 1e-10, linearity of
+    the solve, permutation round trip, positive bounded diagonal, bitwise reproducible refactorisation and solve."""
+    n, cp, ri, vx = workloads.laplacian_3d(200)
+    assert n == 8000000
+    F = Factor(n, cp, ri)
+    inf = F.info()
+    assert inf["max_front"] >= 40000 and inf["lsize"] * 8 > 50e9      # the root separator of the cube; tens of GB of panels
+    F.factorize(vx)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n)
+    x = b.copy(); F.solve(x)
+    assert np.linalg.norm(workloads.sym_matvec(n, cp, ri, vx, x) - b) / np.linalg.norm(b) < 1e-10
+    c = rng.standard_normal(n)
+    X = np.asfortranarray(np.stack([c, 2.0 * b - 3.0 * c], axis=1))
+    F.solve(X)
+    assert rel(2.0 * x - 3.0 * X[:, 0], X[:, 1]) < 1e-9
+    y = b.copy(); F.solve(y, sys=7); F.solve(y, sys=8)
+    assert np.array_equal(y, b)
+    d1 = F.diag()
+    assert np.all(d1 > 0) and np.all(d1 <= np.sqrt(6.0) + 1e-12)
+    F.factorize(vx)
+    assert np.array_equal(d1, F.diag())
+    x2 = b.copy(); F.solve(x2)
+    assert np.array_equal(x, x2)
+    del F
+    _lib.lib().kvx_dev_trim()                                          # hand the 100 GB back before the next test
+
+
 def test_dbound_replaces_small_pivots():
     """cholmod.options['dbound'] (cholmod.c:116-117; CHOLMOD: diagonal entries of L below dbound are replaced by dbound),
     in every kernel class (wave, LDS, blocked), and the drop-the-row form used by the interior-point driver."""

@@ -63,6 +63,7 @@ def _worker(rank, world, port, q, big):
         R = workloads.sym_matvec(n, cp, ri, vx, X) - B
         res.append((name, DF.nshared, DF.ncyclic, DF.collectives, float(np.abs(X - X1).max() / np.abs(X1).max()),
                     float(np.abs(X - Xo).max() / np.abs(Xo).max()), float(np.linalg.norm(R) / np.linalg.norm(B))))
+        res.append(("layout", name, DF.lsize_local, DF.lsize_total, DF.dev_bytes))
         if big:
             continue
         # a non-positive pivot inside ONE rank's subtree is reported by every rank, with the single-process column
@@ -122,6 +123,9 @@ def test_sharded_factor_solve_matches_single_process(world):
                 assert item[1] is not None and item[1] == item[2], (rank, item)
             elif item[0] == "again":
                 assert item[1] == 0.0, (rank, item)                        # bitwise repeatable on the same handle
+            elif item[0] == "layout":
+                # per-rank layout: a rank allocates the panels of its own and shared fronts only, never the whole factor
+                assert 0 < item[2] < item[3] and item[4] > 0, (rank, item)
             else:
                 name, nshared, ncyclic, ncoll, dx, dxo, rr = item
                 assert nshared >= 1 and ncoll >= 2, (rank, item)
@@ -135,6 +139,24 @@ def test_sharded_3d_grid_40_four_ranks():
     """Config 5's workload shape at 1/125 of its size: 7-point Laplacian 40^3 (n = 64 000) over 4 ranks with 256-column
     blocks; equal to the single-process path and the oracle to 1e-11."""
     out = _run(4, big=True)
+    loc = []
     for rank, res in out:
         name, nshared, ncyclic, ncoll, dx, dxo, rr = res[0]
         assert ncyclic >= 1 and dx < 1e-11 and dxo < 1e-11 and rr < 1e-11, (rank, res[0])
+        loc.append(res[1][2] / res[1][3])
+    assert max(loc) < 0.75, loc              # four ranks: the most loaded rank holds well under the whole factor
+
+
+def test_sharded_stream_ordered_collectives(monkeypatch):
+    """The branch a real node takes (RCCL: collectives ordered by streams and events, no host synchronisation around the
+    callback) rehearsed over gloo on the one GPU: same solutions as the host-staged runs."""
+    monkeypatch.setenv("KVX_DIST_STREAM_ORDERED", "1")
+    out = _run(2)
+    for rank, res in out:
+        for item in res:
+            if item[0] in ("minor",):
+                assert item[1] is not None and item[1] == item[2], (rank, item)
+            elif item[0] == "again":
+                assert item[1] == 0.0, (rank, item)
+            elif item[0] != "layout":
+                assert item[4] < 1e-11 and item[5] < 1e-11 and item[6] < 1e-11, (rank, item)
