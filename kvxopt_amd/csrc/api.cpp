@@ -437,20 +437,20 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         // the least loaded stream) instead of queueing up: two side streams beside a big chain, main +
         // two side streams on the levels without big fronts.  Joined at level end.
         const bool have_big = P.cnt[KVX_CLS_BIG] > 0;
-        struct Item { int c; int cnt; int64_t off; double est; int stream; };
+        struct Item { int c; int cnt; int64_t off; double est; int stream; int mcap; int kmax; };
         Item items[5];
         int nitems = 0;
         for (int c = KVX_CLS_LDS128; c < KVX_CLS_WAVE0; c++)
             if (P.cnt[c] > 0) {
                 const double slots = c == KVX_CLS_LDS128 ? 512.0 : 1024.0;         // packed LDS image: two / four fronts per CU
-                items[nitems++] = Item{c, P.cnt[c], P.off[c], (P.maxk[c] > 32 ? 80.0 : 45.0) * std::max(1.0, P.cnt[c] / slots), 0};
+                items[nitems++] = Item{c, P.cnt[c], P.off[c], (P.maxk[c] > 32 ? 80.0 : 45.0) * std::max(1.0, P.cnt[c] / slots), 0, 0, 0};
             }
         for (int c = KVX_CLS_WAVE0; c < KVX_NCLS; c += 2) {
             const int cnt = P.cnt[c] + P.cnt[c + 1];
             if (cnt == 0) continue;
             const int mcap = wave_class_mcap(c);
             const double base = mcap == 64 ? 35.0 : (mcap == 48 ? 28.0 : 18.0), slots = mcap == 64 ? 2048.0 : (mcap == 48 ? 4096.0 : 8192.0);
-            items[nitems++] = Item{c, cnt, P.cnt[c] > 0 ? P.off[c] : P.off[c + 1], base * std::max(1.0, cnt / slots), 0};
+            items[nitems++] = Item{c, cnt, P.cnt[c] > 0 ? P.off[c] : P.off[c + 1], base * std::max(1.0, cnt / slots), 0, mcap, P.cnt[c] > 0 ? 32 : 16};
         }
         std::sort(items, items + nitems, [](const Item &x, const Item &y) { return x.est > y.est; });
         double load[3] = {have_big ? 1e30 : 0.0, 0.0, 0.0};                          // main, side[0], side[1]
@@ -477,7 +477,7 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             if (it.c < KVX_CLS_WAVE0)
                 launch_front_small(sl, it.c == KVX_CLS_LDS128 ? 128 : 96, P.maxk[it.c] <= 32 ? 32 : 64, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
             else    // the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
-                launch_front_wave(sl, wave_class_mcap(it.c), P.cnt[it.c] > 0 ? 32 : 16, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
+                launch_front_wave(sl, it.mcap, it.kmax, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
         // big class: its tail of fronts of order <= mid_m goes to ONE launch of the one-workgroup-per-front kernel (its own
         // stream beside the chain); the larger ones run the batched multi-workgroup panel chain on the main stream
@@ -541,10 +541,27 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 }
                 if (bulk_pending) HIPCHK(hipStreamWaitEvent(st, F->ev_la[1], 0));
             } else {
-                for (int jb = 0; jb < P.chain_maxk; jb += KVX_NB) {
+                // Pair schedule where a launch holds many tiles (the levels bound by the read-modify-write of the trailing matrices): panel
+                // jb updates only the columns of panel jb + 64 (one tile column), panel jb + 64 is solved, and ONE pass over everything
+                // right of both applies the two panels together -- half the passes over the trailing matrices, the same number of
+                // launches.  Where a launch is a handful of tiles (the pivot chain at the top of the tree) the pass over C is not what the
+                // step waits for and the eight operand rounds of a K = 128 tile would lengthen the chain: one panel per launch there.
+                // KVX_PAIR_TILES = tile count (upper estimate: largest front x fronts in the launch) from which on pairs are used.
+                static const int64_t pair_tiles = [] { const char *e = getenv("KVX_PAIR_TILES"); return e ? atoll(e) : (int64_t)3000; }();
+                for (int jb = 0; jb < P.chain_maxk;) {
+                    const int64_t T = (bigm - jb - 1 + KVX_TILE - 1) / KVX_TILE;
+                    const bool pair = jb + KVX_NB < P.chain_maxk && T * (T + 1) / 2 * nbig >= pair_tiles;
                     // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
                     { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
-                    { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                    if (!pair) {
+                        { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                        jb += KVX_NB;
+                        continue;
+                    }
+                    { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, jb + 2 * KVX_NB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                    { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb + KVX_NB, F->d_Lx, F->d_Linv); }
+                    { ProfScope ps(F, FAM_SYRK); launch_syrk_pair(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
+                    jb += 2 * KVX_NB;
                 }
             }
         }
@@ -679,7 +696,7 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int l
         if (P.scnt[0] > 0) {
             ProfScope ps(F, FAM_FWD);
             launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
-                           X, F->d_X0, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride);
+                           X, F->d_X0, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride, P.scnt[0]);
         }
         ls.join();
     }
@@ -1293,7 +1310,7 @@ static int spsolve_forward_reach(kvx_chol *F, int sys, int64_t ncol, const int64
                                    n, nc, Wch, Wout, wstride);
                 if (v.nbig > 0)
                     launch_fwd_big(st, F->ds, d_l + v.big, v.nbig, P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv, F->d_X, F->d_X0, n, nc,
-                                   F->d_WK, S.n, Wch, Wout, wstride);
+                                   F->d_WK, S.n, Wch, Wout, wstride, P.scnt[0]);
             }
             if (!F->is_ll) {                                      // LDL' view: L D x = b -> diag^-1 Lc^-1 b;  L x = b -> diag Lc^-1 b
                 if (!F->diag_valid) {

@@ -192,6 +192,10 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
                        double *Lx, double *Uout, double *Linv, int *status);
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
                        double *Lx, double *Uout, double *Linv, int *status);
+// pair schedule: the panels jb and jb + 64 in ONE pass over everything right of them (64-tile kernel, K = 128; tile (0, 0) factors
+// the diagonal block at jb + 128); launch_syrk_inner(jb, jb + 128) goes in front of the second panel's solve
+void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                      double *Lx, double *Uout, double *Linv, int *status);
 
 // look-ahead: the rank-ob_len update of the columns [c_from, c_to) only; fuse = 1: tile (0, 0) factors the next diagonal block
 void launch_syrk_outer_cols(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
@@ -228,7 +232,7 @@ void launch_bwd_lds(hipStream_t st, const DevSym &ds, const int32_t *list, int c
 // big fronts (m > KVX_SMALL_MAX): multi-workgroup solves using the inverted diagonal blocks
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, const double *X0, int64_t ldx, int nrhs,
-                    double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride);
+                    double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride, int level_count = 0);
 void launch_bwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, int64_t ldx, int nrhs, double *WK, int64_t ldw);
 // out[k + r*ldo] = in[perm[k] + r*ldi]  (gather)   /   out[perm[k] + r*ldo] = in[k + r*ldi]  (scatter)

@@ -449,11 +449,13 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 // streams was measured and lost: a cross-queue dependency costs ~10 us inside a graph replay.)
 // The factor code costs the kernel nothing in occupancy: 126 VGPRs and 50 KB of LDS keep three
 // workgroups per CU, what the plain update (116 VGPRs) had.
-// col_lim: two-level blocking (launch_panel_updates): only the columns < min(col_lim, k) -- the rest of the
-// current 256-column outer block -- are updated per panel; INT_MAX = the whole trailing matrix.
-// DEEP (opt-in, KVX_SYRK_DEEP_TILES = largest tile count of a launch that takes it): all 80 operand loads of a lane go out before
-// the first MFMA -- one memory round trip instead of four, 139 registers (two workgroups per CU instead of three).
-template <bool DEEP>
+// col_lim: only the columns < min(col_lim, k) are updated (the pair schedule's narrow launch, the inner launches of the two-level
+// blocking); INT_MAX = the whole trailing matrix.
+// KW = 64: the K range is ONE 64-column panel [jb, jb + 64).  KW = 128: TWO panels [jb, jb + 128) in one pass over C (the pair
+// schedule of launch_panel_chain): a rank-64 update moves 16 bytes of C per 128 flops and the big levels of the ~20-nnz/row
+// systems are bound by exactly that traffic (rocprofv3: 30 GB per factorisation of the 21-point system, 1000 x 1000 grid) --
+// with two panels per pass it is halved.
+template <int KW>
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo,
                                                        double *__restrict__ Linv, int *status, int col_lim)
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     const FrontDesc fd = ds.fd[list[blockIdx.z]];
     const int k = fd.k, m = fd.m, u = m - k;
     if (jb >= k) return;
-    const int nbk = min(NB, k - jb);
+    const int nbk = min(KW, k - jb);
     const int t0 = jb + nbk;
     const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
     if (r0 >= m) return;
@@ -486,24 +488,8 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
     unsigned long long qr[5];
     qr[0] = qr[1] = qr[2] = qr[3] = qr[4] = __builtin_readcyclecounter();
 #endif
-    if (DEEP) {
-        double bq[16], aq[16][4];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int kc = 4 * q + lk;
-            const bool kin = kc < nbk;
-            const int64_t coff = (int64_t)(jb + kc) * m;
-            bq[q] = kvx_ld0(P, rr + coff, kin && rin);
-#pragma unroll
-            for (int t = 0; t < 4; t++) aq[q][t] = kvx_ld0(P, (c0 + 16 * t + lr) + coff, kin && cin[t]);
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-#pragma unroll
-            for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
-    } else {
-#pragma unroll
-    for (int kg = 0; kg < NB; kg += 16) {
+    for (int kg = 0; kg < KW; kg += 16) {
         if (kg < nbk) {                             // wave-uniform
             double bq[4], aq[4][4];
 #pragma unroll
@@ -521,10 +507,11 @@ __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t 
                 for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
         }
 #ifdef KVX_PHASE_TIMING
-        asm volatile("s_nop 0" ::: "memory");
-        qr[kg / 16 + 1] = __builtin_readcyclecounter();
+        if (kg < 64) {
+            asm volatile("s_nop 0" ::: "memory");
+            qr[kg / 16 + 1] = __builtin_readcyclecounter();
+        }
 #endif
-    }
     }
     // lane holds D[i = (l>>4) + 4q][j = l&15] with i <-> tile column, j <-> tile row.
     // Branch-free read-modify-write: all 16 loads go out (clamped addresses), then 16 predicated stores.
@@ -902,12 +889,20 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     if (T * (T + 1) / 2 * count >= big_limit) {
         hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
     } else {                                          // latency regime: more, smaller workgroups
-        static const int64_t deep_tiles = [] { const char *d = getenv("KVX_SYRK_DEEP_TILES"); return d ? atoll(d) : (int64_t)0; }();
-        if (T * (T + 1) / 2 * count <= deep_tiles)
-            hipLaunchKernelGGL(k_syrk_trailing<true>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
-        else
-            hipLaunchKernelGGL(k_syrk_trailing<false>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
+        hipLaunchKernelGGL(k_syrk_trailing<64>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
     }
+}
+
+// Pair schedule, second launch: the panels [jb, jb + 64) and [jb + 64, jb + 128) applied together to everything right of them
+// (the first launch -- launch_syrk_inner(jb, jb + 128) -- has brought the second panel's own columns up to date with the first).
+void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
+                      double *Lx, double *Uout, double *Linv, int *status)
+{
+    if (count <= 0) return;
+    int rows = max_m - jb - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
+    if (rows <= 0) return;
+    const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
+    hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(T, T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
 }
 
 // Two-level blocking for the fronts that are flop-bound (level with a front of order >= KVX_TWO_LEVEL_M): the pivot
@@ -923,7 +918,7 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (rows <= 0) return;
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     const unsigned TC = (unsigned)std::min<int>((int)T, (ob_end - jb - NB + KVX_TILE - 1) / KVX_TILE);
-    hipLaunchKernelGGL(k_syrk_trailing<false>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
+    hipLaunchKernelGGL(k_syrk_trailing<64>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
 }
 
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
@@ -979,7 +974,12 @@ __device__ __forceinline__ constexpr int sblk(int ib, int s) { return ib * (ib -
 // every workgroup gathers, for the diagonal rows (redundantly) and for its own 256 rows below, the
 // entries of x (pivot rows) and the children's update vectors (parent-pull, children in sequence) in
 // LDS -- no separate initialisation launch in front of the dependent chain.
-template <bool FIRST>
+// ROWS = rows below the super-block per workgroup, 256 or 64.  One CU streams a panel at ~25 GB/s: the 256 x 256 doubles of a
+// 256-row workgroup are 512 KB = 20 us of one CU's time, four dependent rounds of 16 loads per lane.  Where a launch holds few fronts
+// (the top of the tree, where the solves are a chain of these steps) 64 rows per workgroup spread the same bytes over four times
+// as many CUs and every lane needs ONE round of at most 16 loads; where a level holds hundreds of fronts the wide form repeats the
+// diagonal chain less often (launch_fwd_big chooses).  The partial sums of a row meet in LDS in a fixed order in both forms.
+template <bool FIRST, int ROWS>
 __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int32_t *__restrict__ list, int jb0,
                                                            const double *__restrict__ Lx, const double *__restrict__ Linv,
                                                            double *__restrict__ X, const double *__restrict__ X0, int64_t ldx,
@@ -990,14 +990,14 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
     unsigned bx, by, rh;
     kvx_part_front_rhs(bx, by, rh);
     __shared__ double red[3 * 16 * NB];
-    __shared__ double own[FIRST ? 256 : 1];
+    __shared__ double own[FIRST ? ROWS : 1];
     __shared__ double wsh[SB];
     __shared__ double ysh[SB];
     const FrontDesc fd = ds.fd[list[by]];
     const int k = fd.k, m = fd.m, f = fd.first, tid = threadIdx.x;
     if (jb0 >= k) return;
     const int nb = min(SB, k - jb0);
-    const int rbase = jb0 + nb + bx * 256;
+    const int rbase = jb0 + nb + bx * ROWS;
     if (bx > 0 && rbase >= m) return;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
         const double *x0 = X0 + (int64_t)rh * ldx + f;     // rhs as it was before the sweep (x gets y meanwhile)
         wsh[tid] = kvx_ld0(FIRST ? x0 : wk, jb0 + tid, tid < nb);
         ysh[tid] = 0.0;
-        if (FIRST) own[tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
+        if (FIRST && tid < ROWS) own[tid] = kvx_ld0(x0, rbase + tid, rbase + tid < k);
     }
     __syncthreads();
     if (FIRST && fd.nchild > 0) {
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
                 const int t = rl[i];
                 const double v = src[i];
                 if (t < nb) wsh[t] += v;
-                else if (t >= rbase && t < rbase + 256) own[t - rbase] += v;
+                else if (t >= rbase && t < rbase + ROWS) own[t - rbase] += v;
             }
             __syncthreads();
             cd = nx;
@@ -1086,11 +1086,12 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
     }
     if (bx == 0 && tid < nb) x[jb0 + tid] = ysh[tid];
     // rows below the super-block: thread = (row, quarter of the nb columns), partial sums meet in LDS
-    const int rr = tid & 255;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+    constexpr int NQ = SOLVE_NT / ROWS;            // column groups: 4 quarters (ROWS = 256) or 16 groups (ROWS = 64)
+    const int rr = tid % ROWS;
+    const int q = __builtin_amdgcn_readfirstlane(tid / ROWS);
     const int r = rbase + rr;
     double acc = 0.0;
-    const int cq = ((nb + 63) >> 6) << 4;          // columns per quarter, a multiple of 16 (16 .. 64)
+    const int cq = ROWS == 256 ? (((nb + 63) >> 6) << 4) : ((nb + 15) >> 4);   // columns per group: a multiple of 16 (16 .. 64) / 1 .. 16
     if (q * cq < nb && rbase < m) {
         const bool okr = r < m;
         const double *Pr = P + (okr ? r : 0) + (int64_t)(jb0 + q * cq) * m;
@@ -1105,10 +1106,17 @@ __global__ __launch_bounds__(SOLVE_NT) void k_fwd_big_step(DevSym ds, const int3
             for (int j = 0; j < 16; j++) acc = __builtin_fma(v[j], yq[j0 + j], acc);
         }
     }
-    red[q * 256 + rr] = acc;
+    red[q * ROWS + rr] = acc;
     __syncthreads();
-    if (tid < 256 && r < m) {
-        const double t = (red[rr] + red[256 + rr]) + (red[512 + rr] + red[768 + rr]);
+    if (tid < ROWS && r < m) {
+        double t;
+        if (NQ == 4) {
+            t = (red[rr] + red[ROWS + rr]) + (red[2 * ROWS + rr] + red[3 * ROWS + rr]);
+        } else {
+            t = 0.0;
+#pragma unroll
+            for (int g = 0; g < NQ; g++) t += red[g * ROWS + rr];
+        }
         if (FIRST) {
             if (r < k) wk[r] = own[rr] - t;
             else wo[r - k] = own[rr] - t;
@@ -1253,7 +1261,7 @@ __global__ __launch_bounds__(SOLVE_NT) void k_bwd_big_step(DevSym ds, const int3
 // The same three kernels for a BLOCK of RB right-hand sides per workgroup (used from KVX_BIG_MR_FROM right-hand sides on).  With the
 // right-hand sides spread over the grid every workgroup fetches the diagonal inverses, the sub-diagonal blocks, the panel rows
 // and the children's relative indices again; here they are fetched once per block and the right-hand sides of the block follow
-// each other through the dependent part.  Same operations in the same order per right-hand side: every column is bit-identical
+// each other through the dependent part.  Same operations in the same order per right-hand side as the 256-row form of the single-rhs step: every column is bit-identical
 // to its single-rhs solve.  Right-hand sides past nrhs (ragged last block) are skipped.
 // MODE 1: the diagonal solve only (grid x = 1; writes y into X).  MODE 2: the rows below only (reads y back from X) -- with the GPU
 // saturated by right-hand sides, every row block repeating the diagonal solve (as the single-rhs kernel does to save a launch)
@@ -1568,7 +1576,7 @@ constexpr int KVX_BIG_MR_FROM = 64;    // used from this many right-hand sides o
 
 void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int max_k,
                     const double *Lx, const double *Linv, double *X, const double *X0, int64_t ldx, int nrhs,
-                    double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride)
+                    double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride, int level_count)
 {
     if (count <= 0 || nrhs <= 0) return;
     if (nrhs >= KVX_BIG_MR_FROM) {
@@ -1588,13 +1596,22 @@ void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
         }
         return;
     }
+    // 64-row workgroups while the launch stays within ~two workgroups per CU (KVX_FWD_NARROW_WGS, 0 = never), 256-row ones beyond
+    static const int narrow_wgs = [] { const char *e = getenv("KVX_FWD_NARROW_WGS"); return e ? atoi(e) : 512; }();
     for (int jb = 0; jb < max_k; jb += SB) {
         int rows = max_m - jb - 1;
-        dim3 grid((unsigned)std::max(1, (rows + 255) / 256), (unsigned)count, (unsigned)nrhs);
-        if (jb == 0)
-            hipLaunchKernelGGL(k_fwd_big_step<true>, grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
-        else
-            hipLaunchKernelGGL(k_fwd_big_step<false>, grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+        // (a function of the LEVEL -- its big fronts, all of them -- not of this launch: a sweep over a part of the level (spsolve's
+        // reach) and a sweep with more right-hand sides must sum every row in the same order as the full single-rhs sweep)
+        const int64_t wg64 = (int64_t)std::max(1, (rows + 63) / 64) * std::max(level_count, count);
+        const bool narrow = wg64 <= narrow_wgs;
+        dim3 grid((unsigned)std::max(1, narrow ? (rows + 63) / 64 : (rows + 255) / 256), (unsigned)count, (unsigned)nrhs);
+        if (jb == 0) {
+            if (narrow) hipLaunchKernelGGL((k_fwd_big_step<true, 64>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+            else hipLaunchKernelGGL((k_fwd_big_step<true, 256>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+        } else {
+            if (narrow) hipLaunchKernelGGL((k_fwd_big_step<false, 64>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+            else hipLaunchKernelGGL((k_fwd_big_step<false, 256>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+        }
     }
 }
 

@@ -462,8 +462,10 @@ def test_many_right_hand_sides_blocked_kernels(g, h, nrhs):
     """From 16 right-hand sides on the leaf-subtree walks take blocks of four right-hand sides per wavefront
     (k_fwd_subtree_mr / k_bwd_subtree_mr) and, from 64 on, the big-front steps blocks of eight per workgroup (k_fwd_big_step_mr,
     k_bwd_big_init_mr, k_bwd_big_step_mr; the 300 x 280 grid has fronts with more than 256 pivot columns: several super-steps);
-    18, 37 and 67 leave ragged last blocks.  Every column must equal the single-rhs solve of the same column bit for bit
-    (same operations in the same order), and match the oracle."""
+    18, 37 and 67 leave ragged last blocks.  Below 64 right-hand sides every column must equal the single-rhs solve of the same
+    column bit for bit (same kernels, same operations in the same order); the blocks of eight sum the rows below a super-block
+    in four column groups where the single-rhs step of a launch with few fronts uses sixteen (64-row workgroups): equal to
+    1e-13 there.  All match the oracle."""
     n, cp, ri, v = workloads.laplacian_2d(g, h)
     os.environ["KVX_WIDE_FROM"] = "0"            # (read at the device set-up of the factor: keeps the 67-rhs case on these kernels)
     try:
@@ -483,7 +485,10 @@ def test_many_right_hand_sides_blocked_kernels(g, h, nrhs):
         for j in (0, nrhs // 2, nrhs - 1):
             xj = B[:, j].copy()
             F.solve(xj, sys=sys)
-            assert np.array_equal(xj, X[:, j]), (sys, j)
+            if nrhs < 64:
+                assert np.array_equal(xj, X[:, j]), (sys, j)
+            else:
+                assert np.abs(xj - X[:, j]).max() <= 1e-13 * np.abs(xj).max(), (sys, j)
 
 
 @pytest.mark.parametrize("name,nrhs", [("grid61x47", 64), ("grid61x47", 70), ("grid300x280", 67), ("grid300x280", 130),
@@ -604,7 +609,7 @@ def test_spsolve_forward_systems_sweep_only_the_reach(g, h, supernodal, monkeypa
     """spsolve with sys = 4 (L x = b) and 2 (L D x = b) on sparse right-hand sides (cholmod.c:524-587; what misc.kkt_chol2 uses to
     form L^-1 P A', misc.py:1483-1487) sweeps only the fronts that hold a nonzero row of a column block and their ancestors.
     The result must be what the dense column-block path gives (KVX_SPSOLVE_DENSE=1: every front swept) -- the same kernels on
-    the same data, so bit for bit, pattern included -- for 150 columns (three blocks, one ragged), empty columns, a duplicate
+    the same data: the same pattern bit for bit, the same values to rounding -- for 150 columns (three blocks, one ragged), empty columns, a duplicate
     entry and columns that reach the root through different subtrees; the 160 x 150 grid has big-class fronts."""
     n, cp, ri, v = workloads.laplacian_2d(g, h)
     monkeypatch.setenv("KVX_WIDE_FROM", "0")     # (the dense reference path would otherwise take the rhs-major kernels: same values to rounding, not the same bits)
@@ -627,8 +632,11 @@ def test_spsolve_forward_systems_sweep_only_the_reach(g, h, supernodal, monkeypa
         got = F.spsolve(ncol, Bp, Bi, Bx, sys=sys)
         monkeypatch.setenv("KVX_SPSOLVE_DENSE", "1")
         ref = F.spsolve(ncol, Bp, Bi, Bx, sys=sys)
-        for a, b in zip(got, ref):
-            assert np.array_equal(a, b), sys
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), sys     # the patterns, bit for bit
+        # values: the same kernels on the same data, except that the big-front forward step sums the rows below a super-block in
+        # sixteen column groups (64-row workgroups, launches with few fronts, fewer than 64 right-hand sides) or in four (the
+        # blocks of eight right-hand sides of the dense path): equal to rounding
+        assert np.abs(got[2] - ref[2]).max() <= 1e-13 * np.abs(ref[2]).max(), sys
         assert got[0][-1] < 0.5 * n * ncol                       # L^-1 b is sparse here: the reach, not the whole vector
     # and against the definition, through a dense solve of one block
     monkeypatch.delenv("KVX_SPSOLVE_DENSE", raising=False)
@@ -641,7 +649,8 @@ def test_spsolve_forward_systems_sweep_only_the_reach(g, h, supernodal, monkeypa
     for j in range(8):
         col = np.zeros(n)
         col[Xi[Xp[j]:Xp[j + 1]]] = Xx[Xp[j]:Xp[j + 1]]
-        assert np.array_equal(col, Y[:, j])
+        assert np.array_equal(col != 0, Y[:, j] != 0)                          # the same pattern ...
+        assert np.abs(col - Y[:, j]).max() <= 1e-13 * np.abs(Y[:, j]).max()    # ... the same values to rounding (blocks of eight vs single columns)
 
 
 @pytest.mark.gpu
