@@ -289,7 +289,7 @@ def ipm_leg(args, torch):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     alg = 12.0 * len(Pl["Gx"]) + 8.0 * ml + 8.0 * snz.value
-    ipm["roofline"] = {"kernel": "k_atda (S = G' diag(w) G on the fixed pattern)", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
+    ipm["roofline"] = {"kernel": "k_atda_scale + k_atda (S = G' diag(w) G on the fixed pattern: two launches)", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": reps,
                        "note": "back-to-back launches: time per launch includes the launch gap; the loop itself is bound by the factor/solve latency chains"}

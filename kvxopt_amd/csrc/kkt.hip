@@ -8,6 +8,7 @@
 // All of it is HBM/latency-bound streaming work: coalesced grid-stride loops, wavefront (64-lane)
 // shuffles for the reductions, no MFMA.
 #include "kkt.hpp"
+#include <cstdlib>
 #include <algorithm>
 
 namespace kvx {
@@ -325,28 +326,50 @@ void launch_reduce_multi(hipStream_t st, const MultiRed &mr, double *part, doubl
 int reduce_scratch_doubles() { return 32 * RED_BLOCKS + 1; }
 
 // ---- S = G' diag(w) G (+ P) on a fixed pattern ----------------------------------------------------
-// One thread per stored S entry e: sum over its product list [pp[e], pp[e+1]) of
-// w[Gi[pa]] * Gx[pa] * Gx[pb].  Lists are short (sum_r nnz_r(nnz_r+1)/2 products in total).
-__global__ void k_atda(int64_t snz, const int64_t *__restrict__ pp, const int32_t *__restrict__ pa,
-                       const int32_t *__restrict__ pb, const int32_t *__restrict__ gi, const double *__restrict__ gx,
-                       const double *__restrict__ w, double *__restrict__ sx)
+// Two launches.  (1) k_atda_scale streams G once: wg[a] = w[row(a)] * G[a] (coalesced reads of the CCS arrays, the weights
+// gathered along a column's ascending rows).  (2) k_atda: FOUR lanes per stored S entry e walk its product list
+// [pp[e], pp[e + 1]) with stride four -- acc += wg[pa[q]] * G[pb[q]] -- and meet by two shuffles in a fixed order (bitwise
+// reproducible).  A product costs ONE scattered 8-byte gather (wg[pa]: the partner entry of the row sits in another column);
+// G[pb] runs along the entry's own column.  The form this replaces -- one lane per entry, three dependent gathers
+// w[gi[pa]] * G[pa] * G[pb] per product, a grid capped at 2048 workgroups -- took 80 us on the random-pattern calibration of
+// BASELINE.md (ml = 2e5, 4 entries per row, nnz(S) = 1.25e6: entries with 16 products serialised 16 dependent round trips).
+__global__ void k_atda_scale(int64_t gnz, const int32_t *__restrict__ gi, const double *__restrict__ gx, const double *__restrict__ w,
+                             double *__restrict__ wg)
 {
-    GS_LOOP(e, snz) {
-        double acc = 0.0;
-        for (int64_t q = pp[e]; q < pp[e + 1]; q++) {
-            const int32_t a = pa[q];
-            acc += (w[gi[a]] * gx[a]) * gx[pb[q]];
-        }
-        sx[e] = acc;
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < gnz) wg[a] = w[gi[a]] * gx[a];
+}
+template <int LPE>                                   // lanes per entry: 1, 2 or 4
+__global__ __launch_bounds__(256) void k_atda(int64_t snz, const int64_t *__restrict__ pp, const int32_t *__restrict__ pa,
+                                              const int32_t *__restrict__ pb, const double *__restrict__ wg, const double *__restrict__ gx,
+                                              double *__restrict__ sx)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = t / LPE;
+    const int sub = (int)(t % LPE);
+    double acc = 0.0;
+    if (e < snz) {
+        const int64_t q1 = pp[e + 1];
+        for (int64_t q = pp[e] + sub; q < q1; q += LPE) acc += wg[pa[q]] * gx[pb[q]];
     }
+    if (LPE >= 2) acc += __shfl_xor(acc, 1);
+    if (LPE >= 4) acc += __shfl_xor(acc, 2);
+    if (sub == 0 && e < snz) sx[e] = acc;
 }
 __global__ void k_add_at(int64_t pnz, const int64_t *__restrict__ slot, const double *__restrict__ px, double *__restrict__ sx)
 {
     GS_LOOP(q, pnz) sx[slot[q]] += px[q];
 }
-void launch_atda(hipStream_t st, int64_t snz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
-                 const int32_t *gi, const double *gx, const double *w, double *sx)
-{ if (snz > 0) hipLaunchKernelGGL(k_atda, dim3(grid_for(snz)), dim3(256), 0, st, snz, pp, pa, pb, gi, gx, w, sx); }
+void launch_atda(hipStream_t st, int64_t snz, int64_t gnz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
+                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx)
+{
+    if (snz <= 0) return;
+    if (gnz > 0) hipLaunchKernelGGL(k_atda_scale, dim3((unsigned)((gnz + 255) / 256)), dim3(256), 0, st, gnz, gi, gx, w, wg);
+    static const int lpe = [] { const char *e = getenv("KVX_ATDA_LPE"); return e ? atoi(e) : 4; }();
+    if (lpe >= 4) hipLaunchKernelGGL(k_atda<4>, dim3((unsigned)((4 * snz + 255) / 256)), dim3(256), 0, st, snz, pp, pa, pb, wg, gx, sx);
+    else if (lpe == 2) hipLaunchKernelGGL(k_atda<2>, dim3((unsigned)((2 * snz + 255) / 256)), dim3(256), 0, st, snz, pp, pa, pb, wg, gx, sx);
+    else hipLaunchKernelGGL(k_atda<1>, dim3((unsigned)((snz + 255) / 256)), dim3(256), 0, st, snz, pp, pa, pb, wg, gx, sx);
+}
 void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx)
 { if (pnz > 0) hipLaunchKernelGGL(k_add_at, dim3(grid_for(pnz)), dim3(256), 0, st, pnz, slot, px, sx); }
 

@@ -38,8 +38,8 @@ void launch_xmy(hipStream_t st, int64_t n, double a, const double *x, const doub
 void launch_dot(hipStream_t st, int64_t n, const double *x, const double *y, double *part, double *out);
 void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, double *out);
 int reduce_scratch_doubles();
-void launch_atda(hipStream_t st, int64_t snz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
-                 const int32_t *gi, const double *gx, const double *w, double *sx);
+void launch_atda(hipStream_t st, int64_t snz, int64_t gnz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
+                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx);
 void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx);
 void launch_spmm_t(hipStream_t st, int64_t n, int64_t ncols, const int64_t *Ap, const int64_t *Ai, const double *Ax, const double *X,
                    int64_t ldx, double *Y, int64_t ldy);

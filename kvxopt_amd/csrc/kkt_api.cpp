@@ -33,6 +33,7 @@ struct kvx_atda {
     int32_t *d_pa = nullptr, *d_pb = nullptr, *d_gi = nullptr;
     std::vector<int32_t> gi32;
     double *d_gx = nullptr, *d_w = nullptr, *d_px = nullptr, *d_sx = nullptr;   // staging for the host variant
+    double *d_wg = nullptr;         // w[row] * G, refreshed by every assembly (gnz doubles)
 };
 
 namespace {
@@ -76,6 +77,7 @@ int atda_device(kvx_atda *T)
     if ((rc = up(&T->d_pb, T->pb))) return rc;
     if ((rc = up(&T->d_gi, T->gi32))) return rc;
     if ((rc = up(&T->d_pslot, T->pslot))) return rc;
+    HIPCHK(pool_malloc((void **)&T->d_wg, std::max<int64_t>(T->gnz, 1) * sizeof(double)));
     T->dev = true;
     return KVX_OK;
 }
@@ -204,7 +206,7 @@ int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx, const double *w, const 
     if (!T) return KVX_EINVAL;
     int rc = atda_device(T);
     if (rc) return rc;
-    launch_atda(nullptr, T->snz, T->d_pp, T->d_pa, T->d_pb, T->d_gi, Gx, w, Sx);
+    launch_atda(nullptr, T->snz, T->gnz, T->d_pp, T->d_pa, T->d_pb, T->d_gi, Gx, w, T->d_wg, Sx);
     if (Px && T->pnz > 0) launch_add_at(nullptr, T->pnz, T->d_pslot, Px, Sx);
     HIPCHK(hipGetLastError());
     return KVX_OK;
@@ -242,7 +244,7 @@ int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const doub
 void kvx_atda_free(kvx_atda *T)
 {
     if (!T) return;
-    void *ptrs[] = {T->d_pp, T->d_pslot, T->d_pa, T->d_pb, T->d_gi, T->d_gx, T->d_w, T->d_px, T->d_sx};
+    void *ptrs[] = {T->d_pp, T->d_pslot, T->d_pa, T->d_pb, T->d_gi, T->d_gx, T->d_w, T->d_px, T->d_sx, T->d_wg};
     for (void *p : ptrs)
         if (p) (void)pool_free(p);
     delete T;

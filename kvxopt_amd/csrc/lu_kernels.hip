@@ -887,9 +887,16 @@ __global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *_
     }
 }
 
+// A22 -= L21 U12 on 64 x 64 tiles, rank LU_NB, on the FP64 matrix pipe (v_mfma_f64_16x16x4_f64): both operand tiles are staged in
+// LDS (rows padded to 80 doubles: the four k-lanes of an operand read land on disjoint banks), wave w owns rows 16 w .. 16 w + 15 of
+// the tile and all four column tiles -- 8 k-steps x 4 MFMAs.  Operand roles as in the Cholesky kernels (A operand <- the tile's
+// columns, B operand <- its rows): the 16 lanes that share an accumulator register hold consecutive ROWS of one column of the
+// column-major front, so the read-modify-write of A22 is coalesced.
+constexpr int LU_GLD = 80;
+typedef double lu_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs)
 {
-    __shared__ double Ls[LU_NB * 64], Us[LU_NB * 64];
+    __shared__ double Ls[LU_NB * LU_GLD], Us[LU_NB * LU_GLD];
     const int tid = threadIdx.x;
     const LuFrontD F = d.fr[list[blockIdx.z]];
     const int m = F.m, k = F.k;
@@ -900,33 +907,33 @@ __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
     for (int idx = tid; idx < LU_NB * 64; idx += 256) {
         const int i = idx & 63, t = idx >> 6;                 // L21 tile: rows r0.., block column t
-        Ls[idx] = (t < nbk && r0 + i < m) ? Fm[(r0 + i) + (int64_t)(jb + t) * m] : 0.0;
+        Ls[t * LU_GLD + i] = (t < nbk && r0 + i < m) ? Fm[(r0 + i) + (int64_t)(jb + t) * m] : 0.0;
     }
     for (int idx = tid; idx < LU_NB * 64; idx += 256) {
         const int t = idx % LU_NB, c = idx / LU_NB;           // U12 tile: block row t, columns c0..
-        Us[t * 64 + c] = (t < nbk && c0 + c < m) ? Fm[(jb + t) + (int64_t)(c0 + c) * m] : 0.0;
+        Us[t * LU_GLD + c] = (t < nbk && c0 + c < m) ? Fm[(jb + t) + (int64_t)(c0 + c) * m] : 0.0;
     }
     __syncthreads();
-    const int tx = tid & 15, ty = tid >> 4;
-    double acc[4][4] = {};
-    for (int t = 0; t < nbk; t++) {
-        double a[4], b[4];
+    const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+    lu_d4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { a[q] = Ls[t * 64 + tx + 16 * q]; b[q] = Us[t * 64 + ty + 16 * q]; }
+    for (int t = 0; t < 4; t++) acc[t] = (lu_d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+    for (int ks = 0; ks < LU_NB; ks += 4) {
+        const double bv = Ls[(ks + lk) * LU_GLD + 16 * w + lr];
 #pragma unroll
-            for (int p = 0; p < 4; p++) acc[q][p] += a[q] * b[p];
+        for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[(ks + lk) * LU_GLD + 16 * t + lr], bv, acc[t], 0, 0, 0);
     }
+    // lane holds (L21 U12)[row 16 w + lr][column 16 t + lk + 4 q]
+    const int i = r0 + 16 * w + lr;
+    if (i < m) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int c = c0 + ty + 16 * p;
-        if (c >= m) continue;
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int i = r0 + tx + 16 * q;
-            if (i < m) Fm[i + (int64_t)c * m] -= acc[q][p];
-        }
+            for (int q = 0; q < 4; q++) {
+                const int c = c0 + 16 * t + lk + 4 * q;
+                if (c < m) Fm[i + (int64_t)c * m] -= acc[t][q];
+            }
     }
 }
 
