@@ -133,10 +133,7 @@ def front_stats(F):
             jb += 64
     lsize = float(np.sum(m * k))
     sum_m = float(np.sum(m))
-    mid = ~small & (m <= int(os.environ.get("KVX_MID_M", "0")))   # big-class fronts factored by one workgroup each (opt-in experiment)
-    S2 = lambda v: v * (v + 1.0) * (2.0 * v + 1.0) / 6.0
-    flops_mid = float(np.sum((S2(m.astype(float)) - S2((m - k).astype(float)))[mid]))
-    return {"bytes_small": bytes_small, "flops_syrk": flops_syrk, "flops_mid": flops_mid, "lsize": lsize, "sum_m": sum_m,
+    return {"bytes_small": bytes_small, "flops_syrk": flops_syrk, "lsize": lsize, "sum_m": sum_m,
             "n_small": int(small.sum()), "n_big": int((~small).sum())}
 
 
@@ -454,8 +451,8 @@ def measure_system(args, torch, dist, rank, world, dev, wl, nrhs, steps, warmup,
         res["sharding"]["flop_share_by_rank"] = [round(float(v / mp["flops"]), 4) for v in mp["rank_flops"]]
         st = {k: (v * share0 if isinstance(v, float) else v) for k, v in st.items()}
     alg_bytes = None
-    if dom in ("syrk_trailing", "front_mid"):
-        achieved = st["flops_syrk" if dom == "syrk_trailing" else "flops_mid"] / (dom_ms * 1e-3) / 1e12
+    if dom == "syrk_trailing":
+        achieved = st["flops_syrk"] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TF, "traffic": None}
     else:

@@ -147,8 +147,7 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);
 /* Per-kernel-family timing for the roofline leg of bench.py: HIP events are recorded around
  * every launch of ONE family on the factor's own stream while it is selected.
  * family: -1 off, 0 scatter_a, 1 front_small (LDS fronts), 2 assemble_big, 3 potrf_diag,
- * 4 trsm_panel, 5 syrk_trailing (FP64 MFMA), 6 fwd_level, 7 bwd_level, 8 front_mid (big-class fronts of order <= 256:
- * one workgroup per front).
+ * 4 trsm_panel, 5 syrk_trailing (FP64 MFMA), 6 fwd_level, 7 bwd_level.
  * prof_read returns the summed kernel time and launch count since the last select. */
 int kvx_chol_prof_select(kvx_chol *F, int family);
 int kvx_chol_prof_read(kvx_chol *F, double *total_ms, int64_t *launches);

@@ -94,7 +94,7 @@ class Factor:
         return a.value, b.value
 
     FAMILIES = ("scatter_a", "front_small", "assemble_big", "potrf_diag", "trsm_panel", "syrk_trailing",
-                "fwd_level", "bwd_level", "front_mid")
+                "fwd_level", "bwd_level")
 
     def prof_select(self, family):
         fam = -1 if family is None else (self.FAMILIES.index(family) if isinstance(family, str) else int(family))

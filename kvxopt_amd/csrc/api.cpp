@@ -22,7 +22,7 @@ namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // 
 namespace kvx {
 
 // per-level launch plan of the level lists (lists / lptr: fronts grouped by level, each level sorted by kernel class)
-void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan, int mid_m)
+void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan)
 {
     plan.assign((size_t)S.nlevels, LevelPlan());
     for (int l = 0; l < S.nlevels; l++) {
@@ -39,8 +39,7 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
             P.maxk[c] = std::max(P.maxk[c], k);
             if (c == KVX_CLS_BIG) {
                 P.big_maxk = std::max(P.big_maxk, k);
-                if (m <= mid_m) P.nmid++;                  // (the class is sorted by decreasing order: these are its tail)
-                else P.chain_maxk = std::max(P.chain_maxk, k);
+                P.chain_maxk = std::max(P.chain_maxk, k);
                 P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
             }
             int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
@@ -52,7 +51,7 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
 }
 
 // from F->lists_host / F->lptr_host (the level lists already uploaded to d_lists)
-void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host, F->plan, F->mid_m); }
+void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host, F->plan); }
 
 void destroy_graphs(kvx_chol *F)
 {
@@ -223,7 +222,7 @@ int build_subtrees(kvx_chol *F)
         }
         if (F->d_flists) { (void)pool_free(F->d_flists); F->d_flists = nullptr; }
         if ((rc = upload(&F->d_flists, fl))) return rc;
-        build_plan_from(S, fl, flp, F->fplan, F->mid_m);
+        build_plan_from(S, fl, flp, F->fplan);
         F->fplan_on = true;
     }
     std::vector<int32_t> dep(S.depth.begin(), S.depth.end());
@@ -242,8 +241,7 @@ int ensure_device(kvx_chol *F)
     }
     Symbolic &S = F->S;
     analyze_subtrees(F);
-    { const char *e = getenv("KVX_CHAIN_PRIO"); F->prio_stream = e && e[0] == '1'; }
-    HIPCHK(pool_stream_get(&F->stream, F->prio_stream));
+    HIPCHK(pool_stream_get(&F->stream));
     for (int i = 0; i < 4; i++) HIPCHK(pool_event_get(&F->ev[i], true));
     for (int i = 0; i < 4; i++) {
         HIPCHK(pool_stream_get(&F->side[i]));
@@ -251,7 +249,6 @@ int ensure_device(kvx_chol *F)
     }
     HIPCHK(pool_event_get(&F->ev_fork, false));
     HIPCHK(pool_event_get(&F->ev_fork2, false));
-    for (int i = 0; i < 2; i++) HIPCHK(pool_event_get(&F->ev_la[i], false));
     HIPCHK(pool_event_get(&F->ev_in, false));
     HIPCHK(pool_event_get(&F->ev_out, false));
     int rc;
@@ -337,7 +334,6 @@ int ensure_device(kvx_chol *F)
     }
     F->lists_host = S.levellist;
     F->lptr_host = S.levelptr;
-    { const char *e = getenv("KVX_MID_M"); if (e) F->mid_m = std::max(0, std::min(atoi(e), 512)); }
     build_plan(F);
     { const char *e = getenv("KVX_NO_SUBTREES"); F->use_subtrees = !(e && e[0] == '1'); }
     if ((rc = build_subtrees(F))) return rc;
@@ -345,7 +341,6 @@ int ensure_device(kvx_chol *F)
     { const char *e = getenv("KVX_WIDE_FROM"); if (e) F->wide_from = std::max(0, atoi(e)); }
     { const char *e = getenv("KVX_SIDE_SPREAD"); if (e) F->side_spread = atoi(e); }
     { const char *e = getenv("KVX_TWO_LEVEL_M"); if (e) F->two_level_m = atoi(e); }
-    { const char *e = getenv("KVX_LOOKAHEAD"); F->lookahead = e && e[0] == '1'; }
     { const char *e = getenv("KVX_OUTER_BLOCK"); if (e && atoi(e) >= 64) F->outer_block = atoi(e) / 64 * 64; }
     F->dev_ready = true;
     return KVX_OK;
@@ -465,7 +460,7 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             items[i].stream = best;
             if (best > 0) side_used[best - 1] = true;
         }
-        if (side_used[0] || side_used[1]) {        // (side_used[2], the mid-front launch, forks with an event of its own below)
+        if (side_used[0] || side_used[1]) {
             HIPCHK(hipEventRecord(F->ev_fork, st));
             for (int i = 0; i < 2; i++)
                 if (side_used[i]) HIPCHK(hipStreamWaitEvent(F->side[i], F->ev_fork, 0));
@@ -479,23 +474,10 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             else    // the k <= 32 and k <= 16 lists of one row capacity are adjacent -> one launch
                 launch_front_wave(sl, it.mcap, it.kmax, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
-        // big class: its tail of fronts of order <= mid_m goes to ONE launch of the one-workgroup-per-front kernel (its own
-        // stream beside the chain); the larger ones run the batched multi-workgroup panel chain on the main stream
-        const int nchain = P.cnt[KVX_CLS_BIG] - P.nmid;
+        const int nchain = P.cnt[KVX_CLS_BIG];
         if (have_big) {                                     // extend-add of every big front of the level, one launch
             ProfScope ps(F, FAM_ASSEMBLE);
             launch_assemble_big(st, F->ds, lbase + P.off[KVX_CLS_BIG], P.cnt[KVX_CLS_BIG], P.maxm[KVX_CLS_BIG], F->d_Lx, Uch, Uout);
-        }
-        if (P.nmid > 0) {
-            hipStream_t sm = st;
-            if (nchain > 0) {
-                HIPCHK(hipEventRecord(F->ev_fork2, st));
-                HIPCHK(hipStreamWaitEvent(F->side[2], F->ev_fork2, 0));
-                sm = F->side[2];
-                side_used[2] = true;
-            }
-            ProfScope ps(F, FAM_MID, sm);
-            launch_front_mid(sm, F->ds, lbase + P.off[KVX_CLS_BIG] + nchain, P.nmid, F->d_Lx, Uch, Uout, F->d_Linv, F->d_status);
         }
         if (nchain > 0) {
             const int nbig = nchain, bigm = P.maxm[KVX_CLS_BIG];
@@ -506,40 +488,16 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 // on a dense trailing matrix; rocBLAS dgemm at K = 256 reaches 48-59).  Measured on MI355X against the
                 // single-level path: dense n = 10240 14.8 vs 16.7 ms, 3-D 80^3 49.6 vs 51.0 ms, but 21-point 1000^2
                 // (fronts <= 5007, many per level) 29.1 vs 24.3 ms -- the outer update is an extra serial launch per
-                // block, so it is used for very large fronts only; look-ahead (outer update of block b beside the panel
-                // chain of block b + 1) is the missing piece
+                // block, so it is used for very large fronts only (look-ahead -- the outer update of block b beside the panel chain
+                // of block b + 1 on a second stream -- was measured slower, docs/lab.md)
                 const int OB = F->outer_block;
-                // Look-ahead (opt-in, KVX_LOOKAHEAD=1): the outer update of block ob is split -- the strip of the next outer block (with the
-                // next diagonal block factored in its (0, 0) tile) stays on the chain's stream, everything right of it runs on side[3]
-                // beside the panel chain of block ob + OB, which only touches that strip; the next strip update waits for it.
-                // Measured on MI355X (100^3 Laplacian, factor 116.6 ms): 128 ms with the strip first, 125 ms with both parts started
-                // together (then they share the CUs and finish together) -- the panel chain of a front this wide is itself a few
-                // hundred workgroups per launch and waits for CU slots behind the bulk update (a high-priority chain stream: 129 ms).
-                // Off by default.
-                const bool la = F->lookahead && F->prof_family < 0;
-                bool bulk_pending = false;
                 for (int ob = 0; ob < P.chain_maxk; ob += OB) {
                     for (int jb = ob; jb < std::min(ob + OB, P.chain_maxk); jb += KVX_NB) {
                         { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
                         { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, ob + OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
                     }
-                    if (!la) {
-                        ProfScope ps(F, FAM_SYRK);
-                        launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status);
-                        continue;
-                    }
-                    // the strip of the next block first (behind the previous bulk update, which wrote these columns too) ...
-                    if (bulk_pending) HIPCHK(hipStreamWaitEvent(st, F->ev_la[1], 0));
-                    launch_syrk_outer_cols(st, F->ds, list, nbig, bigm, ob, OB, 0, ob + 2 * OB, 1, F->d_Lx, Uout, F->d_Linv, F->d_status);   // (from column 0: a front whose pivots end inside this block starts its update matrix left of ob + OB)
-                    // ... then the bulk update on the side stream, beside the panel chain of the next block (started together, the two
-                    // launches share the CUs and the strip finishes with the bulk: measured)
-                    HIPCHK(hipEventRecord(F->ev_la[0], st));
-                    HIPCHK(hipStreamWaitEvent(F->side[3], F->ev_la[0], 0));
-                    launch_syrk_outer_cols(F->side[3], F->ds, list, nbig, bigm, ob, OB, ob + 2 * OB, INT_MAX, 0, F->d_Lx, Uout, F->d_Linv, F->d_status);
-                    HIPCHK(hipEventRecord(F->ev_la[1], F->side[3]));
-                    bulk_pending = true;
+                    { ProfScope ps(F, FAM_SYRK); launch_syrk_outer(st, F->ds, list, nbig, bigm, ob, OB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
                 }
-                if (bulk_pending) HIPCHK(hipStreamWaitEvent(st, F->ev_la[1], 0));
             } else {
                 // Pair schedule where a launch holds many tiles (the levels bound by the read-modify-write of the trailing matrices): panel
                 // jb updates only the columns of panel jb + 64 (one tile column), panel jb + 64 is solved, and ONE pass over everything
@@ -1590,11 +1548,9 @@ void kvx_chol_free(kvx_chol *F)
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
         if (F->ev_fork2) pool_event_put(F->ev_fork2, false);
-        for (int i = 0; i < 2; i++)
-            if (F->ev_la[i]) pool_event_put(F->ev_la[i], false);
         if (F->ev_in) pool_event_put(F->ev_in, false);
         if (F->ev_out) pool_event_put(F->ev_out, false);
-        if (F->stream) pool_stream_put(F->stream, F->prio_stream);
+        if (F->stream) pool_stream_put(F->stream);
         lap("streams");
     }
     delete F;

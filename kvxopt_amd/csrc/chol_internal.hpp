@@ -30,8 +30,7 @@ struct LevelPlan {
     int maxm[KVX_NCLS];
     int maxk[KVX_NCLS];
     int big_maxk = 0;          // largest pivot count among the big fronts (solves)
-    int chain_maxk = 0;        // ... among those factored by the batched multi-workgroup chain (the big fronts that are not `mid`)
-    int nmid = 0;              // trailing part of the big list: fronts of order <= mid_m, one workgroup each (k_front_mid)
+    int chain_maxk = 0;        // ... among those factored by the batched multi-workgroup chain (all of them)
     int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
     // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
     int64_t soff[3];
@@ -50,9 +49,6 @@ struct kvx_chol {
     bool diag_valid = false;
     int64_t minor = 0;
     hipStream_t stream = nullptr;
-    bool prio_stream = false;  // KVX_CHAIN_PRIO=1: the main stream (the pivot chain) gets the highest stream priority.  OFF by default: nothing on
-                               // config 2 (4.31 vs 4.26 ms) and -22 % on the interior-point loop (313 vs 400 iterations/s: the loop hops between
-                               // the null stream and the factor's stream through events, which a high-priority queue serves more slowly)
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: trailing updates beside the pivot chain   // independent kernel classes of one level run concurrently
     hipEvent_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
@@ -92,11 +88,6 @@ struct kvx_chol {
     std::vector<int32_t> lists_host;           // level lists in use (filtered in sharded mode)
     std::vector<int64_t> lptr_host;
     int outer_block = 1024;    // columns per outer block of the two-level update (KVX_OUTER_BLOCK; a multiple of 64): config 5 runs at 33.3 / 37.5 / 38.6 / 37.4 TF/s with 256 / 512 / 1024 / 2048
-    int mid_m = 0;             // big-class fronts up to this order: one workgroup per front (k_front_mid).  OFF by default: measured on
-                               // config 2, factor 4.37 ms -> 4.55 (256) / 4.42 (192) / 5.49 (384): a lone workgroup needs ~100 us per front
-                               // (dependent L2 round trips tile after tile), the batched chain amortises them.  KVX_MID_M=<order> turns it on
-    bool lookahead = false;    // two-level blocking: the update right of the NEXT outer block runs on side[3] beside that block's panel chain (KVX_LOOKAHEAD=1; measured slower)
-    hipEvent_t ev_la[2] = {nullptr, nullptr};
     int two_level_m = 6144;    // levels whose largest front is at least this order use the two-level blocked update (KVX_TWO_LEVEL_M)
     // leaf subtrees walked by one wavefront each in the solves (build_subtrees)
     SubDesc *d_subs = nullptr;
@@ -167,7 +158,7 @@ struct ProfScope {
         if (on) (void)hipEventRecord(F->prof_ev[F->prof_used++], st);
     }
 };
-enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7, FAM_MID = 8 };
+enum { FAM_SCATTER = 0, FAM_SMALL = 1, FAM_ASSEMBLE = 2, FAM_POTRF = 3, FAM_TRSM = 4, FAM_SYRK = 5, FAM_FWD = 6, FAM_BWD = 7 };
 
 inline void prof_collect(kvx_chol *F)
 {
@@ -180,7 +171,7 @@ inline void prof_collect(kvx_chol *F)
 
 
 // api.cpp
-void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan, int mid_m);
+void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan);
 void build_plan(kvx_chol *F);
 int build_subtrees(kvx_chol *F);
 int ensure_device(kvx_chol *F);

@@ -174,9 +174,6 @@ void launch_factor_subtree(hipStream_t st, int mcap, const DevSym &ds, const Sub
                            double *Lx, double *U0, double *U1, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
-// one workgroup per front, one launch: extend-add + the whole panel loop (big-class fronts of order <= KVX_MID_M)
-void launch_front_mid(hipStream_t st, const DevSym &ds, const int32_t *list, int count, double *Lx, const double *Uchild,
-                      double *Uout, double *Linv, int *status);
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
                       double *Lx, double *Linv, int *status);
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
@@ -197,9 +194,6 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
 void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
                       double *Lx, double *Uout, double *Linv, int *status);
 
-// look-ahead: the rank-ob_len update of the columns [c_from, c_to) only; fuse = 1: tile (0, 0) factors the next diagonal block
-void launch_syrk_outer_cols(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
-                            int c_from, int c_to, int fuse, double *Lx, double *Uout, double *Linv, int *status);
 // sharded mode: rank-ob_len update with the panel [ob, ob + ob_len) of the columns in [c_from, c_to) that rank own_r owns
 void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,
                             int own_ob, int own_g, int own_r, int c_from, int c_to, double *Lx, double *Uout);

@@ -416,7 +416,7 @@ int dist_setup_impl(kvx_chol *F, int rank, int nranks, int ob, int min_m, int64_
     if ((rc = upload(&F->d_flists, flists))) return rc;
     if ((rc = upload(&D.d_dist_ids, dist_ids))) return rc;
     build_plan(F);
-    build_plan_from(S, flists, flptr, F->fplan, F->mid_m);
+    build_plan_from(S, flists, flptr, F->fplan);
     F->fplan_on = true;
     F->dist_rank = rank; F->dist_nranks = nranks;        // (with more than one rank the leaf subtrees of the solves stay in the level lists)
     if ((rc = build_subtrees(F))) return rc;

@@ -49,8 +49,7 @@ constexpr int NB = KVX_NB;
 // table (ChildDesc::tile).  The kernel is a chain of indirect accesses, i.e. latency-bound, so each
 // wave works on its (up to) four child columns at once -- 16 independent row updates per lane in
 // flight -- and the next child's descriptor is fetched while the current child is added.
-// (device function: the multi-workgroup kernel calls it once per workgroup, the one-workgroup-per-front kernel k_front_mid
-// loops over the column tiles; 256 threads, contains barriers: every thread of the workgroup must call it)
+// (256 threads, contains barriers: every thread of the workgroup must call it)
 __device__ __forceinline__ void assemble_cols(const DevSym &ds, const FrontDesc &fd, const int ct, double *__restrict__ Lx,
                                               const double *__restrict__ Uc, double *__restrict__ Uo)
 {
@@ -581,109 +580,6 @@ extern "C" int kvx_dbg_phase_read(unsigned long long *out, int reset)
 #endif
 
 // ------------------------------------------------------------------------------------------
-// Mid-size fronts (big class, order <= KVX_MID_M): the whole front in ONE workgroup and ONE launch per level -- extend-add,
-// then per 64-column panel: diagonal block (potrf_lds), panel solve, trailing update, tile after tile.  On config 2 three
-// quarters of the "big" fronts of the middle levels have 129..256 rows; going through the batched multi-workgroup chain they
-// cost those levels an extend-add + 3 launches per 64 columns whose grids are sized for the largest front of the level.
-// Here a front costs its own time only, the fronts of a level run side by side on the CUs (50 KB of LDS: three per CU), and
-// the chain of the few larger fronts runs beside them on the main stream.  Same arithmetic, same order of operations per
-// entry as the multi-workgroup kernels (bitwise identical factors).
-__device__ __forceinline__ void syrk_tile(const FrontDesc &fd, int jb, int ti, int tj, double *__restrict__ P, double *__restrict__ U,
-                                          const int lt)
-{
-    const int k = fd.k, m = fd.m, u = m - k;
-    const int nbk = min(NB, k - jb);
-    const int t0 = jb + nbk;
-    const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
-    const int w = lt >> 6, l = lt & 63, lr = l & 15, lk = l >> 4;
-    d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-    const int rr = r0 + 16 * w + lr;
-    const bool rin = rr < m;
-    bool cin[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++) cin[t] = (c0 + 16 * t + lr) < m;
-#pragma unroll
-    for (int kg = 0; kg < NB; kg += 16) {
-        if (kg < nbk) {                             // wave-uniform
-            double bq[4], aq[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int kc = kg + 4 * q + lk;
-                const bool kin = kc < nbk;
-                const int64_t coff = (int64_t)(jb + kc) * m;
-                bq[q] = kvx_ld0(P, rr + coff, kin && rin);
-#pragma unroll
-                for (int t = 0; t < 4; t++) aq[q][t] = kvx_ld0(P, (c0 + 16 * t + lr) + coff, kin && cin[t]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[q][t], bq[q], acc[t], 0, 0, 0);
-        }
-    }
-    const int rs = min(rr, m - 1);
-    double *ptr[4][4];
-    double old[4][4];
-    bool ok[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c0 + 16 * t + lk + 4 * q;
-            ok[t][q] = rin && c <= rr;
-            const int cs = min(c, rs);
-            ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
-            old[t][q] = *ptr[t][q];
-        }
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (ok[t][q]) *ptr[t][q] = old[t][q] - acc[t][q];
-}
-
-constexpr int MID_NT = 512;                         // eight waves: two teams of four, one tile / row block per team at a time (sixteen waves spill: 128 VGPRs each)
-__global__ __launch_bounds__(MID_NT) void k_front_mid(DevSym ds, const int32_t *__restrict__ list, double *__restrict__ Lx,
-                                                      const double *__restrict__ Uc, double *__restrict__ Uo,
-                                                      double *__restrict__ Linv, int *status)
-{
-    __shared__ PotrfLds lds;
-    const FrontDesc fd = ds.fd[list[blockIdx.x]];
-    const int k = fd.k, m = fd.m;
-    double *P = Lx + fd.px;
-    double *U = Uo + fd.ux;
-    const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8), lt = threadIdx.x & 255;
-    // (the extend-add stays with the multi-workgroup kernel, all big fronts of the level in one launch: done by ONE
-    // workgroup it is a chain of dependent index loads per 16-column tile, 130 us for a front of order 256)
-    (void)Uc;
-    // right-looking over the 64-column panels
-    for (int jb = 0; jb < k; jb += NB) {
-        potrf_block(ds, fd, jb, Lx, Linv, status, lds);
-        __syncthreads();
-        const int nbk = min(NB, k - jb);
-        const int rows = m - jb - nbk;
-        if (rows <= 0) break;
-        const int T = (rows + KVX_TILE - 1) / KVX_TILE;
-        for (int rb = team; rb < T; rb += MID_NT / 256) trsm_rows(fd, jb, rb, Lx, Linv, lt);
-        __syncthreads();
-        int t = 0;
-        for (int ti = 0; ti < T; ti++)
-            for (int tj = 0; tj <= ti; tj++, t++)
-                if ((t & (MID_NT / 256 - 1)) == team) syrk_tile(fd, jb, ti, tj, P, U, lt);
-        __syncthreads();
-    }
-}
-
-void launch_front_mid(hipStream_t st, const DevSym &ds, const int32_t *list, int count, double *Lx, const double *Uchild,
-                      double *Uout, double *Linv, int *status)
-{
-    if (count <= 0) return;
-    hipLaunchKernelGGL(k_front_mid, dim3((unsigned)count), dim3(MID_NT), 0, st, ds, list, Lx, Uchild, Uout, Linv, status);
-}
-
-// ------------------------------------------------------------------------------------------
 // The same update on 128 x 128 tiles (opt-in, see launch_syrk_trailing for the measurement): the
 // two operand strips X[rows, :] and X[cols, :] staged through LDS in chunks of 16 panel columns
 // (k-major, double-buffered, global loads of chunk c + 1 in flight under the MFMAs of chunk c).
@@ -928,19 +824,6 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
     int rows = max_m - ob - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
     hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
-}
-
-// look-ahead (two-level blocking on one GPU): the same rank-ob_len update restricted to the columns [c_from, c_to) of the
-// fronts.  The strip of the NEXT outer block goes first on the pivot chain's stream (fuse = 1: its (0, 0) tile factors the next
-// diagonal block), the rest beside the next block's panel chain on another stream.
-void launch_syrk_outer_cols(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,
-                            int c_from, int c_to, int fuse, double *Lx, double *Uout, double *Linv, int *status)
-{
-    if (count <= 0 || c_from >= c_to) return;
-    int rows = max_m - ob - 1;
-    if (rows <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trailing128<true>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, ob, ob_len, Lx, Uout, Linv, status,
-                       ColOwner{1, 1, 0, c_from, c_to, fuse});
 }
 
 // sharded mode: the rank-ob_len update of the columns this rank owns (block-cyclic, see ColOwner); no fused factorisation
