@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` systems (21-point stencil, 100^3 cube)")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the time-to-first-solution leg")
+    ap.add_argument("--separate-calls", action="store_true", help="the step as two calls (factorize, then solve) instead of the one-enqueue "
+                    "form whose forward sweep is pipelined behind the factorisation")
     ap.add_argument("--roofline-family", default="auto")
     ap.add_argument("--chol-opts", default="", help="JSON dict of analysis options (nd_leaf, leaf_cols, leaf_rows, relax_*) for experiments")
     ap.add_argument("--quick", action="store_true", help="skip the per-family roofline loop, the CPU baselines and the secondary legs (experiments)")
@@ -238,7 +240,7 @@ def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu,
     return out
 
 
-def ipm_leg(args, torch):
+def ipm_leg(args, pl):
     """IPM iterations/s of the device-resident conelp on BASELINE configs[3] (inequality form), with the roofline of the
     normal-equations assembly kernel (k_atda, HBM-bound: 12 nnz(G) + 8 ml + 8 nnz(S) bytes per launch) timed
     live with events on the stream it runs on (the null stream), and a CPU run of the same loop beside it."""
@@ -272,19 +274,17 @@ def ipm_leg(args, torch):
     _lib.raise_for(L.kvx_atda_plan(ml, nl, _lib.pi(Pl["Gp"]), _lib.pi(Pl["Gi"]), None, None, ctypes.byref(h)))
     snz = ctypes.c_int64()
     _lib.raise_for(L.kvx_atda_pattern(h, ctypes.byref(snz), None, None))
-    gx = torch.from_numpy(Pl["Gx"]).cuda(); w = torch.rand(ml, dtype=torch.float64, device="cuda") + 0.5
-    sx = torch.zeros(max(snz.value, 1), dtype=torch.float64, device="cuda")
+    gx = pl.to_dev(Pl["Gx"]); w = pl.to_dev(np.random.default_rng(0).uniform(0.5, 1.5, ml))
+    sx = pl.empty(max(snz.value, 1))
     reps = 50
     for _ in range(5):
-        _lib.raise_for(L.kvx_atda_assemble_dev(h, gx.data_ptr(), w.data_ptr(), None, sx.data_ptr()))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
+        _lib.raise_for(L.kvx_atda_assemble_dev(h, pl.ptr(gx), pl.ptr(w), None, pl.ptr(sx)))
+    pl.sync()
+    t0 = time.perf_counter()                      # back-to-back launches on the null stream between two device synchronisations
     for _ in range(reps):
-        _lib.raise_for(L.kvx_atda_assemble_dev(h, gx.data_ptr(), w.data_ptr(), None, sx.data_ptr()))
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+        _lib.raise_for(L.kvx_atda_assemble_dev(h, pl.ptr(gx), pl.ptr(w), None, pl.ptr(sx)))
+    pl.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / reps
     alg = 12.0 * len(Pl["Gx"]) + 8.0 * ml + 8.0 * snz.value
     ipm["roofline"] = {"kernel": "k_atda_scale + k_atda (S = G' diag(w) G on the fixed pattern: two launches)", "bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -348,7 +348,60 @@ def build_workload(name, g):
     return workloads.stencil21_2d(g) + ("21-pt stencil %dx%d (radius-2 box+cross, ~20 nnz/row, seed 20)" % (g, g),)
 
 
-def measure_system(args, torch, dist, rank, world, dev, wl, nrhs, steps, warmup, mode, family="auto", cpu="full", pmc_key=None):
+class Plumbing:
+    """Device memory, copies and synchronisation of one rank.  A run with ranks needs torch.distributed, so there the buffers are
+    torch tensors (torch's default stream IS the null stream the library orders itself against).  A single-GPU run does not
+    import torch at all: buffers come from the library's own allocator (kvx_dev_malloc) and the process runs on the system's HIP
+    runtime (ROCm 7.2) instead of the 7.0.51831 bundled with the PyTorch wheel -- under which the one-enqueue step falls back to
+    its two separate graphs (include/kvxhip.h, kvx_chol_factorize_solve_dev)."""
+
+    def __init__(self, torch=None, dev=None):
+        self.torch, self.dev = torch, dev
+
+    def to_dev(self, a):
+        a = np.ascontiguousarray(a)
+        if self.torch is not None:
+            return self.torch.from_numpy(a).to(self.dev)
+        from kvxopt_amd import _lib
+        return _lib.DeviceBuffer.from_array(a)
+
+    def empty(self, ndoubles):
+        if self.torch is not None:
+            return self.torch.empty(ndoubles, dtype=self.torch.float64, device=self.dev)
+        from kvxopt_amd import _lib
+        return _lib.DeviceBuffer(8 * ndoubles)
+
+    def ptr(self, h):
+        return h.data_ptr() if self.torch is not None else h.ptr
+
+    def copy(self, dst, src, ndoubles):                      # on the null stream
+        if self.torch is not None:
+            dst.copy_(src)
+        else:
+            from kvxopt_amd import _lib
+            _lib.raise_for(_lib.lib().kvx_vec_copy_dev(ndoubles, src.ptr, dst.ptr))
+
+    def to_host(self, h, ndoubles):
+        return h.cpu().numpy() if self.torch is not None else h.download(np.float64, ndoubles)
+
+    def sync(self):
+        if self.torch is not None:
+            self.torch.cuda.synchronize()
+        else:
+            from kvxopt_amd import _lib
+            _lib.raise_for(_lib.lib().kvx_dev_sync())
+
+    def mem_info(self):
+        from kvxopt_amd import _lib
+        f, t = ctypes.c_int64(), ctypes.c_int64()
+        _lib.raise_for(_lib.lib().kvx_dev_mem_info(ctypes.byref(f), ctypes.byref(t)))
+        return f.value, t.value
+
+    def runtime(self):
+        return ("HIP runtime of the PyTorch wheel %s" % self.torch.version.hip) if self.torch is not None else "system HIP runtime (/opt/rocm), torch not imported"
+
+
+def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mode, family="auto", cpu="full", pmc_key=None):
     """Factor + solve of one system, timed as the contract says (barrier + synchronize on both sides, MAX over the ranks),
     with the roofline of the dominant kernel family (HIP events on the factor's own streams) and the CPU baselines beside it.
     mode: 'single' (this rank alone), 'replicas' (every rank its own copy), 'subtree' (ONE system over the ranks).
@@ -368,30 +421,36 @@ def measure_system(args, torch, dist, rank, world, dev, wl, nrhs, steps, warmup,
     t_analyze = time.time() - t0
     info = F.info()
     work = info["flops"] + 4.0 * info["lnz"] * nrhs          # SURVEY 8(d) flop measure per step
-    vals_d = torch.from_numpy(values).to(dev)
+    torch = pl.torch
+    vals_d = pl.to_dev(values)
     b_host = np.random.default_rng(2).standard_normal((n, nrhs)).reshape(n * nrhs, order="F") if nrhs > 1 \
         else np.random.default_rng(2).standard_normal(n)
-    b_d = torch.from_numpy(np.ascontiguousarray(b_host)).to(dev)
-    x_d = torch.empty_like(b_d)
-    torch.cuda.synchronize()
+    b_d = pl.to_dev(b_host)
+    x_d = pl.empty(n * nrhs)
+    pl.sync()
 
     def step():
         if DF is not None:                                   # one system over all ranks
             DF.factorize(vals_d)
-            x_d.copy_(b_d)
+            pl.copy(x_d, b_d, n * nrhs)
             DF.solve(x_d, nrhs)
             return
-        F.factorize_dev(vals_d.data_ptr(), sync=False)
-        x_d.copy_(b_d)
-        torch.cuda.current_stream().synchronize()          # x_d ready before the factor's own stream reads it
-        F.solve_dev(x_d.data_ptr(), 0, nrhs, n)              # synchronises the factor's stream
+        if args.separate_calls:                              # numeric() then solve(): two entry points, the sweep waits for the whole factor
+            F.factorize_dev(pl.ptr(vals_d), sync=False)
+            pl.copy(x_d, b_d, n * nrhs)
+            F.solve_dev(pl.ptr(x_d), 0, nrhs, n)             # ordered behind the copy (null stream) by an event; synchronises the factor's stream
+            return
+        # numeric() + solve() as ONE enqueue (kvx_chol_factorize_solve_dev): the forward sweep follows the factorisation level by
+        # level on its own streams -- same kernels, same order per front, bitwise the same factor and solution as the two calls
+        pl.copy(x_d, b_d, n * nrhs)
+        F.factorize_solve_dev(pl.ptr(vals_d), pl.ptr(x_d), nrhs, n)   # ordered behind the copy by an event; synchronises
 
     collective = dist is not None and mode != "single"
 
     def barrier():
         if collective:
             dist.barrier()
-        torch.cuda.synchronize()
+        pl.sync()
 
     for _ in range(warmup):
         step()
@@ -407,16 +466,30 @@ def measure_system(args, torch, dist, rank, world, dev, wl, nrhs, steps, warmup,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_factor, ms_solve = F.timing()
+    ms_sep = None
+    if DF is None and not args.separate_calls:
+        # the one-enqueue step cannot tell its two parts apart: a few steps as two calls (factorize, then solve) for the split
+        acc = [0.0, 0.0]
+        for _ in range(5):
+            F.factorize_dev(pl.ptr(vals_d), sync=False)
+            pl.copy(x_d, b_d, n * nrhs)
+            F.solve_dev(pl.ptr(x_d), 0, nrhs, n)
+            a, b_ = F.timing()
+            acc[0] += a / 5; acc[1] += b_ / 5
+        ms_sep = {"ms_factor": acc[0], "ms_solve": acc[1], "note": "the same work as two calls (factorize, then solve), 5 steps outside the timed region"}
     steps_run = warmup + steps
     coll = (DF.collectives, DF.bytes_moved) if DF is not None else (0, 0)   # (counted up to here: warm-up + timed steps)
 
     # residual of the last solve (parity bar: <= 1e-10 relative)
-    x = x_d.cpu().numpy()
+    x = pl.to_host(x_d, n * nrhs)
     r = workloads.sym_matvec(n, colptr, rowind, values, x.reshape(n, nrhs, order="F")) - b_host.reshape(n, nrhs, order="F")
     relres = float(np.linalg.norm(r) / np.linalg.norm(b_host))
     nsys = world if mode == "replicas" else 1
     res = {"workload": wname, "n": int(n), "nrhs": nrhs, "value": work * steps * nsys / dt / 1e9, "unit": "GF/s", "ms_per_step": dt / steps * 1e3,
-           "ms_factor": ms_factor, "ms_solve": ms_solve, "rel_residual": relres, "steps": steps, "warmup": warmup,
+           "ms_factor": ms_factor, "ms_solve": ms_solve, "as_two_calls": ms_sep, "rel_residual": relres, "steps": steps, "warmup": warmup,
+           "step_form": ("two calls: factorize, then solve" if (args.separate_calls or DF is not None) else
+                         "one enqueue (kvx_chol_factorize_solve_dev): the forward sweep runs beside the factorisation of the top of the tree; "
+                         "ms_factor is the whole call and ms_solve 0 -- the two parts are not separable (see as_two_calls)"),
            "nnz_lower": int(len(values)), "lnz": int(info["lnz"]), "flops_sum_cj2": info["flops"], "nsuper": int(info["nsuper"]),
            "nlevels": int(info["nlevels"]), "max_front": int(info["max_front"]), "lsize": int(info["lsize"]), "analyze_s": round(t_analyze, 3),
            "dev_bytes_rank0": int(F.info()["dev_bytes"]), "_work": work, "_dt": dt, "_x": x, "_F": F, "_DF": DF}
@@ -548,20 +621,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
-    backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
-    if backend != "nccl":
-        local_rank = local_rank % ndev
-    elif world > ndev:
-        raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    from kvxopt_amd import _lib as _kvx_lib
     dist = None
-    if world > 1:
+    if world == 1:
+        # one GPU: no torch in the process at all (Plumbing): the library's own allocator and the system's HIP runtime
+        try:
+            _kvx_lib.require_device()
+        except Exception:
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        pl = Plumbing()
+        dev = None
+    else:
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+        # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
+        backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend != "nccl":
+            local_rank = local_rank % ndev
+        elif world > ndev:
+            raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        pl = Plumbing(torch, dev)
         import torch.distributed as dist_
         dist = dist_
         if backend == "nccl":
@@ -573,7 +656,7 @@ def main():
     g = args.grid or (100 if args.workload == "lap3d" else 1000)
     wl = build_workload(args.workload, g)
     headline_cfg2 = args.workload == "lap2d" and g == 1000 and args.nrhs == 1
-    res = measure_system(args, torch, dist, rank, world, dev, wl, args.nrhs, args.steps, args.warmup, mode,
+    res = measure_system(args, pl, dist, rank, world, dev, wl, args.nrhs, args.steps, args.warmup, mode,
                          pmc_key=("config2" if headline_cfg2 and mode == "single" else None))
     if args.quick:
         if rank == 0:
@@ -583,13 +666,17 @@ def main():
             dist.destroy_process_group()
         return
     # per-rank device memory: the factor's own large buffers (library count) and what the device reports in use
-    free_b, total_b = torch.cuda.mem_get_info()
-    mine = torch.tensor([float(res["_F"].info()["dev_bytes"]), float(total_b - free_b)], dtype=torch.float64, device=dev)
-    per_rank = [mine.clone() for _ in range(world)]
+    free_b, total_b = pl.mem_info()
+    mine_l = [float(res["_F"].info()["dev_bytes"]), float(total_b - free_b)]
+    per_rank = [mine_l]
     if dist is not None:
-        dist.all_gather(per_rank, mine)
+        mine = pl.torch.tensor(mine_l, dtype=pl.torch.float64, device=dev)
+        gathered = [mine.clone() for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [[float(t[0].item()), float(t[1].item())] for t in gathered]
     ranks = {"backend": (dist.get_backend() if dist is not None else "none"), "world_size": (dist.get_world_size() if dist is not None else 1),
-             "factor_bytes_by_rank": [int(t[0].item()) for t in per_rank], "device_bytes_in_use_by_rank": [int(t[1].item()) for t in per_rank]}
+             "factor_bytes_by_rank": [int(t[0]) for t in per_rank], "device_bytes_in_use_by_rank": [int(t[1]) for t in per_rank],
+             "hip_runtime": pl.runtime()}
 
     # --- the north-star systems in the same run (every N; CPU baselines at N = 1): ~20 nnz/row at n = 1e6, and the flop-bound cube
     extra = []
@@ -601,7 +688,7 @@ def main():
                 pass
             try:
                 w2 = build_workload(name, gg)
-                r2 = measure_system(args, torch, dist, rank, world, dev, w2, 1, st_, wu, mode, family="syrk_trailing",
+                r2 = measure_system(args, pl, dist, rank, world, dev, w2, 1, st_, wu, mode, family="syrk_trailing",
                                     cpu=("lite" if world == 1 else "none"), pmc_key=None)
                 if r2.get("cpu_baseline") and r2["cpu_baseline"].get("value"):
                     r2["vs_cpu_baseline"] = r2["value"] / r2["cpu_baseline"]["value"]
@@ -617,7 +704,7 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_ipm:
             try:
-                ipm = ipm_leg(args, torch)
+                ipm = ipm_leg(args, pl)
             except Exception as e:                      # the headline line must not depend on this leg
                 ipm = {"error": repr(e)}
         if not args.no_one_shot and headline_cfg2:
@@ -648,7 +735,8 @@ def main():
                        "nnz_lower": res["nnz_lower"], "lnz": res["lnz"], "flops_sum_cj2": res["flops_sum_cj2"],
                        "nsuper": res["nsuper"], "nlevels": res["nlevels"], "max_front": res["max_front"],
                        "analyze_s": res["analyze_s"], "parallelism": par},
-            "ms_factor": res["ms_factor"], "ms_solve": res["ms_solve"], "rel_residual": res["rel_residual"],
+            "ms_factor": res["ms_factor"], "ms_solve": res["ms_solve"], "as_two_calls": res.get("as_two_calls"), "step_form": res["step_form"],
+            "rel_residual": res["rel_residual"],
             "roofline": res["roofline"], "cpu_baseline": cpu, "ranks": ranks, "sharding": res.get("sharding"),
             "extra": extra, "ipm": ipm, "one_shot": one_shot,
         }

@@ -97,6 +97,12 @@ int kvx_chol_solve_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_
 /* Enqueue only: no host synchronisation; work the caller submits to the null stream afterwards is ordered behind the
  * solve.  Errors of a factorisation still in flight are reported by the next synchronising call (kvx_chol_status). */
 int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB);
+/* numeric(A, F) followed by solve(F, B) with sys = 0 (cholmod.c:322-398 then :429-499; what linsolve does after its analysis,
+ * cholmod.c:618-753) as ONE enqueue on device buffers: the forward sweep follows the factorisation level by level on streams of
+ * its own, so only the backward sweep and the root's forward step are left when the last front is factored.  Same kernels, same
+ * order per front: the factor and X are bitwise those of kvx_chol_factorize_dev + kvx_chol_solve_dev.  Synchronises; returns
+ * KVX_ENOTPOSDEF with *minor = failing column (B_dev then holds garbage).  The factor stays usable for further solves. */
+int kvx_chol_factorize_solve_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB, int64_t *minor);
 
 /* spsolve(F, B, sys) -- cholmod.c:524-587.  B is n x ncol CCS; the result is returned as a
  * newly malloc'ed CCS triple the caller frees with kvx_free() (entries that are exactly zero are dropped, as
@@ -358,6 +364,7 @@ int kvx_dev_sync(void);
  * and handed out again; kvx_dev_trim() gives everything cached back to the driver (e.g. before another framework needs the
  * memory).  No reference counterpart. */
 int kvx_dev_trim(void);
+int kvx_dev_mem_info(int64_t *free_bytes, int64_t *total_bytes);   /* hipMemGetInfo of the current device */
 
 /* ---------------------------------------------------------------------------------------------------------
  * Sparse LU (the kvxopt.klu API, src/C/klu.c; SURVEY 8(f)1, BASELINE configs[2]).  Real 'd' matrices, square,

@@ -128,6 +128,15 @@ class Factor:
             rc = lib().kvx_chol_factorize_async_dev(self._h, values_ptr)
         raise_for(rc, "factorization failed")
 
+    def factorize_solve_dev(self, values_ptr, B_ptr, nrhs=1, ldB=None):
+        """Numeric factorisation + solve of A X = B in one enqueue on device buffers (the forward sweep pipelined behind the
+        factorisation level by level); synchronises.  ArithmeticError(minor) when the matrix is not positive definite."""
+        minor = ctypes.c_int64()
+        rc = lib().kvx_chol_factorize_solve_dev(self._h, values_ptr, B_ptr, int(nrhs), int(ldB or max(1, self.n)), ctypes.byref(minor))
+        if rc == _lib.KVX_ENOTPOSDEF:
+            raise ArithmeticError(int(minor.value))
+        raise_for(rc, "factorization failed")
+
     def status(self):
         minor = ctypes.c_int64()
         rc = lib().kvx_chol_status(self._h, ctypes.byref(minor))

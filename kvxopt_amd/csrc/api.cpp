@@ -59,6 +59,9 @@ void destroy_graphs(kvx_chol *F)
     for (auto &g : F->g_solve)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     F->g_solve.clear();
+    for (auto &g : F->g_fused)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    F->g_fused.clear();
 }
 
 // Leaf subtrees for the solves: maximal subtrees made of wave-class fronts only, small enough for one wavefront
@@ -525,6 +528,18 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         }
         for (int i = 0; i < 3; i++)
             if (side_used[i]) { HIPCHK(hipEventRecord(F->ev_join[i], F->side[i])); HIPCHK(hipStreamWaitEvent(st, F->ev_join[i], 0)); }
+        if (F->pipe_on) {
+            // kvx_chol_factorize_solve_dev: level l is complete -- its forward sweep goes onto the sweep's own streams right here, so
+            // that its launches sit between the factorisation's in submission order too (enqueued after the whole factorisation they
+            // were submitted -- eagerly and from a replayed graph alike -- only when the last front had been)
+            HIPCHK(hipEventRecord(F->ev_lvl[(size_t)l], st));
+            const SweepStreams ss2{F->side[2], F->side[3], F->side[3], F->ev_pipe[1], F->ev_pipe[2], F->ev_pipe[3]};
+            // Below pipe_from the levels hold thousands of small fronts that fill the CUs: a sweep beside them only takes their
+            // wavefront slots (measured: the factorisation lost what the sweep gained).  From pipe_from up the factorisation is a chain
+            // of small launches on an idle machine: the sweep of everything below starts there in one go, then follows level by level.
+            if (l == F->pipe_from) enqueue_fwd(F, F->d_X, S.n, F->pipe_nr, S.nlevels - 1, l, &ss2, true, true);
+            else if (l < F->pipe_from) enqueue_fwd(F, F->d_X, S.n, F->pipe_nr, l, l, &ss2, true);
+        }
     }
     if (epilogue) {
         if (F->h_status_dev && !getenv("KVX_DBG_MEMSET_NODES")) launch_publish_status(st, F->d_status, F->h_status_dev);
@@ -595,36 +610,44 @@ int finish_factor(kvx_chol *F, int64_t *minor)
 
 // Fork the independent kernel groups of one level onto the side streams; join at level end.
 struct LevelStreams {
-    kvx_chol *F;
+    SweepStreams S;
     hipStream_t lds, wave;
     bool fork_lds, fork_wave;
-    LevelStreams(kvx_chol *F_, bool have_big, bool have_lds, bool have_wave) : F(F_)
+    static SweepStreams own(kvx_chol *F) { return SweepStreams{F->stream, F->side[0], F->side[1], F->ev_fork, F->ev_join[0], F->ev_join[1]}; }
+    LevelStreams(kvx_chol *F, bool have_big, bool have_lds, bool have_wave, const SweepStreams *ss = nullptr) : S(ss ? *ss : own(F))
     {
         fork_lds = have_lds && (have_big || have_wave);
         fork_wave = have_wave && have_big;
-        lds = fork_lds ? F->side[0] : F->stream;
-        wave = fork_wave ? F->side[1] : F->stream;
+        lds = fork_lds ? S.lds : S.main;
+        wave = fork_wave ? S.wave : S.main;
         if (fork_lds || fork_wave) {
-            (void)hipEventRecord(F->ev_fork, F->stream);
-            if (fork_lds) (void)hipStreamWaitEvent(F->side[0], F->ev_fork, 0);
-            if (fork_wave) (void)hipStreamWaitEvent(F->side[1], F->ev_fork, 0);
+            (void)hipEventRecord(S.fork, S.main);
+            if (fork_lds) (void)hipStreamWaitEvent(S.lds, S.fork, 0);
+            if (fork_wave) (void)hipStreamWaitEvent(S.wave, S.fork, 0);
         }
     }
     void join()
     {
-        if (fork_lds) { (void)hipEventRecord(F->ev_join[0], F->side[0]); (void)hipStreamWaitEvent(F->stream, F->ev_join[0], 0); }
-        if (fork_wave) { (void)hipEventRecord(F->ev_join[1], F->side[1]); (void)hipStreamWaitEvent(F->stream, F->ev_join[1], 0); }
+        if (fork_lds) { (void)hipEventRecord(S.join0, S.lds); (void)hipStreamWaitEvent(S.main, S.join0, 0); }
+        if (fork_wave) { (void)hipEventRecord(S.join1, S.wave); (void)hipStreamWaitEvent(S.main, S.join1, 0); }
     }
 };
 
-void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int lto)
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int lto, const SweepStreams *ss, bool wait_levels, bool sub_tail)
 {
     Symbolic &S = F->S;
     const int64_t wstride = std::max(S.wrk_size[0], S.wrk_size[1]);
+    hipStream_t sm = ss ? ss->main : F->stream;
     if (lfrom < 0) lfrom = S.nlevels - 1;
-    if (lfrom == S.nlevels - 1 && F->nsub > 0) {       // the leaf subtrees: one wavefront each, before any level
-        ProfScope ps(F, FAM_FWD);
-        launch_fwd_subtree(F->stream, F->ds, F->d_subs, F->nsub, F->d_cd_woff, F->d_Lx, X, ldx, nrhs, F->d_W[0], F->d_W[1], wstride, F->d_depth);
+    if (lfrom == S.nlevels - 1 && F->nsub > 0 && !wait_levels) {       // the leaf subtrees: one wavefront each, before any level
+        ProfScope ps(F, FAM_FWD, sm);
+        launch_fwd_subtree(sm, F->ds, F->d_subs, F->nsub, F->d_cd_woff, F->d_Lx, X, ldx, nrhs, F->d_W[0], F->d_W[1], wstride, F->d_depth);
+    }
+    if (wait_levels && sub_tail && F->nsub > 0) {
+        // the part of the tree at level lto and below is factored: its subtrees (the groups are stored by ascending level) in one launch
+        (void)hipStreamWaitEvent(sm, F->ev_lvl[(size_t)lto], 0);
+        const int off = F->sub_lvl_off[(size_t)lto];
+        launch_fwd_subtree(sm, F->ds, F->d_subs_lvl + off, F->nsub - off, F->d_cd_woff, F->d_Lx, X, ldx, nrhs, F->d_W[0], F->d_W[1], wstride, F->d_depth);
     }
     for (int l = lfrom; l >= lto; l--) {
         const LevelPlan &P = F->plan[l];
@@ -633,10 +656,16 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int l
         const int64_t woff = F->sw_off[l];
         const int wcnt = F->sw_cnt[l];
         const int nlds = F->solve_merged ? 0 : P.scnt[1];
+        const int nsubl = (wait_levels && !sub_tail && F->nsub > 0) ? F->sub_lvl_cnt[(size_t)l] : 0;
+        if (wcnt == 0 && P.scnt[0] == 0 && nlds == 0 && nsubl == 0) continue;
+        if (wait_levels) (void)hipStreamWaitEvent(sm, F->ev_lvl[(size_t)l], 0);         // level l (and every deeper one) is factored
+        if (nsubl > 0)      // behind a factorisation in flight: the subtrees ROOTED at this level (their fronts are at this depth or deeper)
+            launch_fwd_subtree(sm, F->ds, F->d_subs_lvl + F->sub_lvl_off[(size_t)l], nsubl, F->d_cd_woff, F->d_Lx, X, ldx, nrhs, F->d_W[0], F->d_W[1],
+                               wstride, F->d_depth);
         if (wcnt == 0 && P.scnt[0] == 0 && nlds == 0) continue;
         // with subtrees: every small front of the level that is outside them goes into ONE launch of the LDS kernel;
         // without (sharded mode): the wave classes keep their own kernel and stream
-        LevelStreams ls(F, P.scnt[0] > 0, F->solve_merged ? wcnt > 0 : nlds > 0, F->solve_merged ? false : wcnt > 0);
+        LevelStreams ls(F, P.scnt[0] > 0, F->solve_merged ? wcnt > 0 : nlds > 0, F->solve_merged ? false : wcnt > 0, ss);
         if (wcnt > 0) {
             if (F->solve_merged) {
                 ProfScope ps(F, FAM_FWD, ls.lds);
@@ -652,8 +681,8 @@ void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom, int l
                            F->d_Lx, X, ldx, nrhs, Wch, Wout, wstride);
         }
         if (P.scnt[0] > 0) {
-            ProfScope ps(F, FAM_FWD);
-            launch_fwd_big(F->stream, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
+            ProfScope ps(F, FAM_FWD, sm);
+            launch_fwd_big(sm, F->ds, F->d_lists + P.soff[0], P.scnt[0], P.smaxm[0], P.big_maxk, F->d_Lx, F->d_Linv,
                            X, F->d_X0, ldx, nrhs, F->d_WK, S.n, Wch, Wout, wstride, P.scnt[0]);
         }
         ls.join();
@@ -949,6 +978,123 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
     return KVX_OK;
 }
 
+// Numeric factorisation AND the solve of A X = B (sys 0) as ONE enqueue: the right-hand sides are known before the factorisation
+// starts, so the forward sweep does not have to wait for all of it -- level l of the sweep needs the fronts of level l and below
+// only.  The sweep runs on two streams of its own (side[2], side[3]) behind one event per level of the factorisation: by the
+// time the root front is factored the sweep has reached the top of the tree, and what is left of it is the root's own step
+// (config 2: 0.65 ms of forward sweep hidden under the pivot chain of the top levels).  Same kernels on the same data in the
+// same order per front as kvx_chol_factorize_dev + kvx_chol_solve_dev: bitwise the same factor and solution.  The whole
+// sequence replays from a captured graph from the second call with the same (nrhs, B, ldB) on.
+int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t nrhs, int64_t ldB)
+{
+    int rc = ensure_device(F);
+    if (rc) return rc;
+    Symbolic &S = F->S;
+    const int64_t n = S.n;
+    if (nrhs < 0) { set_err("nrhs out of range"); return KVX_EINVAL; }
+    if (n > 0 && nrhs > 0 && ldB < n) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
+    // outside the pipelined form: sharded factors, LDL' views, the rhs-major path of many right-hand sides, family timing
+    // ... and HIP runtimes before 7.2: under 7.0.51831 (the one inside the PyTorch wheel, which a process gets when it imports torch
+    // before this library) hipGraphLaunch of the captured five-stream sequence crashes inside the runtime (the three-stream graphs
+    // of the separate calls replay correctly there); without a graph the pipelined form is slower than the two replayed graphs
+    static const bool old_runtime = [] {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return true; }
+        const char *e = getenv("KVX_FUSED_ANY_RUNTIME");
+        return v < 70200000 && !(e && e[0] == '1');
+    }();
+    const bool plain = F->dist_nranks != 1 || !F->is_ll || nrhs == 0 || nrhs > 16 || n == 0 || F->prof_family >= 0 || F->factor_subtrees ||
+                       old_runtime || !F->use_graph;
+    if ((rc = wait_for_caller(F))) return rc;
+    if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
+    if (plain) {
+        if ((rc = enqueue_factor(F))) return rc;
+        return solve_dev(F, 0, B, nrhs, ldB);
+    }
+    const int nr = (int)nrhs;
+    if ((rc = ensure_solve_ws(F, nr))) return rc;
+    if (F->ev_lvl.empty()) {
+        F->ev_lvl.assign((size_t)S.nlevels, nullptr);
+        for (auto &e : F->ev_lvl) HIPCHK(pool_event_get(&e, false));
+        for (int i = 0; i < 4; i++) HIPCHK(pool_event_get(&F->ev_pipe[i], false));
+        if (F->nsub > 0) {
+            std::vector<std::vector<SubDesc>> by((size_t)S.nlevels);
+            for (const SubDesc &d : F->subs_host) by[(size_t)S.depth[(size_t)d.hi]].push_back(d);      // (fronts of a subtree are numbered in postorder: hi is the root)
+            std::vector<SubDesc> flat;
+            F->sub_lvl_off.assign((size_t)S.nlevels, 0);
+            F->sub_lvl_cnt.assign((size_t)S.nlevels, 0);
+            for (int l = 0; l < S.nlevels; l++) {
+                F->sub_lvl_off[(size_t)l] = (int)flat.size();
+                F->sub_lvl_cnt[(size_t)l] = (int)by[(size_t)l].size();
+                flat.insert(flat.end(), by[(size_t)l].begin(), by[(size_t)l].end());
+            }
+            if (F->d_subs_lvl) { (void)pool_free(F->d_subs_lvl); F->d_subs_lvl = nullptr; }
+            if ((rc = upload(&F->d_subs_lvl, flat))) return rc;
+        }
+        // the level the sweep starts at: the deepest one from which up no level holds more than KVX_PIPE_FRONTS fronts.  Default 4 --
+        // on the 2-D systems the sweep then starts when the children of the root are factored and runs beside the root's own pivot
+        // chain, a handful of workgroups per launch (config 2: step 5.15 -> 4.66 ms; started two levels earlier, beside launches of
+        // thousands of tiles, 4.83; five levels earlier 5.2: the sweep's workgroups then delay the factorisation by what they gain)
+        int lim = 4;
+        if (const char *e = getenv("KVX_PIPE_FRONTS")) lim = atoi(e);
+        F->pipe_from = 0;
+        for (int l = 0; l < S.nlevels; l++) {
+            if (S.levelptr[(size_t)l + 1] - S.levelptr[(size_t)l] > lim) break;
+            F->pipe_from = l;
+        }
+    }
+    hipStream_t st = F->stream, s2 = F->side[2];
+    auto body = [&]() -> int {
+        // the sweep's stream joins behind the values (and, in a capture, the capture): right-hand sides into the work vector first
+        HIPCHK(hipEventRecord(F->ev_pipe[0], st));
+        HIPCHK(hipStreamWaitEvent(s2, F->ev_pipe[0], 0));
+        launch_perm_gather(s2, F->d_perm, n, nr, B, ldB, F->d_X, n);
+        launch_copy_d(s2, F->d_X0, F->d_X, n * (int64_t)nr);
+        F->pipe_on = true;
+        F->pipe_nr = nr;
+        const int rb = enqueue_factor_body(F);                     // (with the forward sweep of every level right behind that level)
+        F->pipe_on = false;
+        if (rb) return rb;
+        HIPCHK(hipEventRecord(F->ev_pipe[0], s2));
+        HIPCHK(hipStreamWaitEvent(st, F->ev_pipe[0], 0));
+        enqueue_bwd(F, F->d_X, n, nr);
+        launch_perm_scatter(st, F->d_perm, n, nr, F->d_X, n, B, ldB);
+        return hipGetLastError() == hipSuccess ? KVX_OK : KVX_EDEVICE;
+    };
+    HIPCHK(hipEventRecord(F->ev[0], st));
+    F->factor_calls++;
+    F->diag_valid = false;
+    hipGraphExec_t exec = nullptr;
+    if (F->use_graph && !getenv("KVX_DBG_NO_FACTOR_GRAPH") && !getenv("KVX_FUSED_EAGER")) {
+        kvx_chol::FusedGraph *slot = nullptr;
+        for (auto &g : F->g_fused)
+            if (g.nrhs == nr && g.B == B && g.ldB == ldB) slot = &g;
+        if (!slot) {
+            if (F->g_fused.size() >= 4) {                           // (right-hand sides at changing addresses: no pile of graphs)
+                for (auto &g : F->g_fused)
+                    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+                F->g_fused.clear();
+            }
+            F->g_fused.push_back({nr, B, ldB, 0, nullptr});
+            slot = &F->g_fused.back();
+        }
+        slot->calls++;
+        if (!slot->exec && slot->calls >= 2) slot->exec = capture_graph(F, body);
+        exec = slot->exec;
+    }
+    if (exec) HIPCHK(hipGraphLaunch(exec, st));
+    else if ((rc = body())) return rc;
+    HIPCHK(hipEventRecord(F->ev[1], st));                           // (the two parts are not separable here: last_timing reports the whole
+    HIPCHK(hipGetLastError());                                      //  call as the factorisation and 0 for the solve)
+    F->pending = true;
+    F->have_ftime = false;
+    HIPCHK(hipStreamSynchronize(st));
+    rc = finish_factor(F, nullptr);
+    F->ms_solve = 0.0; F->have_stime = true;
+    if (rc == KVX_ENOTPOSDEF) { set_err("singular matrix"); return KVX_ENOTPOSDEF; }
+    return rc;
+}
+
 }  // namespace kvx
 
 extern "C" {
@@ -1101,6 +1247,16 @@ static int kvx_chol_solve_async_dev_impl(kvx_chol *F, int sys, double *B_dev, in
 int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     return guarded([&] { return kvx_chol_solve_async_dev_impl(F, sys, B_dev, nrhs, ldB); });
+}
+
+int kvx_chol_factorize_solve_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB, int64_t *minor)
+{
+    return guarded([&] {
+        if (!F) return (int)KVX_EINVAL;
+        int rc = factor_solve_dev(F, values_dev, B_dev, nrhs, ldB);
+        if (minor) *minor = F->minor;
+        return rc;
+    });
 }
 
 static int kvx_chol_solve_impl(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
@@ -1544,10 +1700,14 @@ void kvx_chol_free(kvx_chol *F)
         if (F->d_keep) (void)pool_free(F->d_keep);
         if (F->d_flists) (void)pool_free(F->d_flists);
         dist_release(F);
-        for (void *p : {(void *)F->d_subs, (void *)F->d_subs_f, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
+        for (void *p : {(void *)F->d_subs, (void *)F->d_subs_f, (void *)F->d_subs_lvl, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
         if (F->ev_fork2) pool_event_put(F->ev_fork2, false);
+        for (hipEvent_t e : F->ev_lvl)
+            if (e) pool_event_put(e, false);
+        for (int i = 0; i < 4; i++)
+            if (F->ev_pipe[i]) pool_event_put(F->ev_pipe[i], false);
         if (F->ev_in) pool_event_put(F->ev_in, false);
         if (F->ev_out) pool_event_put(F->ev_out, false);
         if (F->stream) pool_stream_put(F->stream);
@@ -1565,5 +1725,13 @@ int kvx_dev_upload(void *dst, const void *src, int64_t bytes) { if (bytes > 0) H
 int kvx_dev_download(void *dst, const void *src, int64_t bytes) { if (bytes > 0) HIPCHK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return KVX_OK; }
 int kvx_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return KVX_OK; }
 int kvx_dev_trim(void) { pool_release_all(); return KVX_OK; }
+int kvx_dev_mem_info(int64_t *free_bytes, int64_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return KVX_OK;
+}
 
 }  // extern "C"

@@ -54,6 +54,17 @@ struct kvx_chol {
     hipEvent_t ev_out = nullptr;                // orders the caller's (null-stream) work after an asynchronous solve
     hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // factor + solve in one call (kvx_chol_factorize_solve_dev): the forward sweep follows the factorisation level by level on
+    // streams of its own (side[2], side[3]) -- a level's fronts are swept while the levels above it are still being factored
+    std::vector<hipEvent_t> ev_lvl;             // [nlevels]: recorded on the factor's stream when a level is complete (while pipe_on)
+    bool pipe_on = false;
+    int pipe_nr = 0;                            // right-hand sides of the sweep that follows the factorisation in flight
+    int pipe_from = 0;                          // the sweep starts when this level is factored (everything below it in one go), then follows level by level
+    hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join of the forward sweep's streams
+    SubDesc *d_subs_lvl = nullptr;              // the leaf subtrees once more, grouped by the level of their ROOT front: the pipelined sweep
+    std::vector<int> sub_lvl_off, sub_lvl_cnt;  // walks the subtrees rooted at level l when level l is factored ([nlevels] offsets / counts)
+    struct FusedGraph { int nrhs; double *B; int64_t ldB; int calls; hipGraphExec_t exec; };
+    std::vector<FusedGraph> g_fused;
     bool have_ftime = false, have_stime = false;
     double ms_factor = 0, ms_solve = 0;
 
@@ -179,7 +190,13 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs);
 int wait_for_caller(kvx_chol *F);
 int enqueue_factor_body(kvx_chol *F, int lfrom = -1, int lto = 0, bool prologue = true, bool epilogue = true);
 int finish_factor(kvx_chol *F, int64_t *minor);
-void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0);
+// the streams and events a triangular sweep forks its kernel classes over (default: the factor's own main / side[0] / side[1])
+struct SweepStreams { hipStream_t main, lds, wave; hipEvent_t fork, join0, join1; };
+// wait_levels: the sweep follows a factorisation in flight -- each level waits for that level's completion event (ev_lvl)
+// sub_tail (with wait_levels): the subtrees rooted at level lto or deeper are walked by ONE launch in front of the levels (instead of
+// one launch per level for the subtrees rooted there)
+void enqueue_fwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = -1, int lto = 0, const SweepStreams *ss = nullptr, bool wait_levels = false,
+                 bool sub_tail = false);
 void enqueue_bwd(kvx_chol *F, double *X, int64_t ldx, int nrhs, int lfrom = 0, int lto = -1);
 void destroy_graphs(kvx_chol *F);
 // dist_api.cpp

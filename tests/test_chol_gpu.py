@@ -755,3 +755,48 @@ def test_rhs_major_blocks_edge_cases():
                 assert np.array_equal(xj, X[:, j]), (sys, j)
             else:
                 assert np.abs(xj - X[:, j]).max() <= 1e-12 * np.abs(xj).max(), (sys, j)
+
+
+@pytest.mark.parametrize("g,h,nrhs", [(90, 90, 1), (300, 280, 3), (33, 71, 2)])
+def test_factor_and_solve_in_one_enqueue(g, h, nrhs):
+    """kvx_chol_factorize_solve_dev: numeric factorisation + solve A X = B with the forward sweep pipelined behind the
+    factorisation level by level (its own streams, one event per level).  Same kernels in the same order per front as
+    factorize + solve: the solution must be bitwise that of the two separate calls -- eagerly (first call), from the captured
+    graph (later calls), after a change of values, and the failing column of an indefinite matrix must come back."""
+    n, cp, ri, v = workloads.laplacian_2d(g, h)
+    F = Factor(n, cp, ri)
+    B = np.asfortranarray(np.random.default_rng(g + nrhs).standard_normal((n, nrhs)))
+    Xref = B.copy(order="F")
+    F.factorize(v)
+    F.solve(Xref)
+    vd = _lib.DeviceBuffer.from_array(v)
+    bd = _lib.DeviceBuffer(8 * n * nrhs)
+    for rep in range(4):                                        # eager, capture, replay, replay
+        bd.upload(B.reshape(-1, order="F"))
+        F.factorize_solve_dev(vd.ptr, bd.ptr, nrhs, n)
+        X = bd.download(np.float64, n * nrhs).reshape(n, nrhs, order="F")
+        assert np.array_equal(X, Xref), rep
+    # the factor stays usable: a plain solve with it
+    Y = B.copy(order="F"); F.solve(Y)
+    assert np.array_equal(Y, Xref)
+    # new values through the replayed graph
+    v2 = v * 1.5
+    vd.upload(v2)
+    bd.upload(B.reshape(-1, order="F"))
+    F.factorize_solve_dev(vd.ptr, bd.ptr, nrhs, n)
+    X2 = bd.download(np.float64, n * nrhs).reshape(n, nrhs, order="F")
+    assert np.abs(X2 - Xref / 1.5).max() <= 1e-12 * np.abs(Xref).max()
+    # an indefinite matrix: the failing column, and the handle recovers
+    bad = v.copy(); p = F.perm(); bad[cp[int(p[n // 2])]] = -1.0
+    F2 = Factor(n, cp, ri)
+    with pytest.raises(ArithmeticError) as e1:
+        F2.factorize(bad)
+    vd.upload(bad)
+    bd.upload(B.reshape(-1, order="F"))
+    with pytest.raises(ArithmeticError) as e2:
+        F.factorize_solve_dev(vd.ptr, bd.ptr, nrhs, n)
+    assert e1.value.args[0] == e2.value.args[0]
+    vd.upload(v)
+    bd.upload(B.reshape(-1, order="F"))
+    F.factorize_solve_dev(vd.ptr, bd.ptr, nrhs, n)
+    assert np.array_equal(bd.download(np.float64, n * nrhs).reshape(n, nrhs, order="F"), Xref)
