@@ -55,12 +55,10 @@ void build_plan(kvx_chol *F) { build_plan_from(F->S, F->lists_host, F->lptr_host
 
 void destroy_graphs(kvx_chol *F)
 {
-    if (F->g_factor) { (void)hipGraphExecDestroy(F->g_factor); F->g_factor = nullptr; }
-    for (auto &g : F->g_solve)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    F->g_factor.drop();
+    for (auto &g : F->g_solve) g.exec.drop();
     F->g_solve.clear();
-    for (auto &g : F->g_fused)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto &g : F->g_fused) g.exec.drop();
     F->g_fused.clear();
 }
 
@@ -353,9 +351,10 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
 {
     if (nrhs <= F->x_cap) return KVX_OK;
     Symbolic &S = F->S;
-    for (auto &g : F->g_solve)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto &g : F->g_solve) g.exec.drop();
     F->g_solve.clear();                          // the captured sweeps point into the old workspace
+    for (auto &g : F->g_fused) g.exec.drop();
+    F->g_fused.clear();
     if (F->d_X) { (void)pool_free(F->d_X); F->d_X = nullptr; }
     if (F->d_X0) { (void)pool_free(F->d_X0); F->d_X0 = nullptr; }
     if (F->d_WK) { (void)pool_free(F->d_WK); F->d_WK = nullptr; }
@@ -552,17 +551,15 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
 // Capture `body` (which enqueues on F->stream and, through events, on the side streams) into an
 // executable graph.  Returns nullptr (and leaves the stream usable) if capture is not possible.
 template <class Body>
-hipGraphExec_t capture_graph(kvx_chol *F, Body body)
+void capture_graph(kvx_chol *F, Body body, LazyExec &out)
 {
+    out.tried = true;
     hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    if (hipStreamBeginCapture(F->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipStreamBeginCapture(F->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return; }
     int rc = body();
     hipError_t e = hipStreamEndCapture(F->stream, &graph);
-    if (rc != KVX_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return nullptr; }
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); exec = nullptr; }
-    (void)hipGraphDestroy(graph);
-    return exec;
+    if (rc != KVX_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return; }
+    out.start(graph);                              // instantiation on a thread of its own; the graph is destroyed there
 }
 
 int enqueue_factor(kvx_chol *F)
@@ -574,11 +571,13 @@ int enqueue_factor(kvx_chol *F)
     const bool graph_ok = F->use_graph && F->prof_family < 0 && !(dbg_ng && (atoll(dbg_ng) == 1 || atoll(dbg_ng) == F->S.n));
     F->factor_calls++;
     F->diag_valid = false;
-    if (graph_ok && !F->g_factor && F->factor_calls >= 2)
-        F->g_factor = capture_graph(F, [&] { return enqueue_factor_body(F); });   // (sharded mode drives the body itself)
-    if (graph_ok && F->g_factor) {
+    // (a capture records the launches without running them: the call that takes it still runs its own launches below)
+    if (graph_ok && !F->g_factor.tried && F->factor_calls >= 2)
+        capture_graph(F, [&] { return enqueue_factor_body(F); }, F->g_factor);   // (sharded mode drives the body itself)
+    hipGraphExec_t fexec = graph_ok ? F->g_factor.ready() : nullptr;
+    if (fexec) {
         if (const char *e = getenv("KVX_DBG_GRAPH_SYNC")) { if (atoi(e) & 1) HIPCHK(hipStreamSynchronize(st)); }
-        HIPCHK(hipGraphLaunch(F->g_factor, st));
+        HIPCHK(hipGraphLaunch(fexec, st));
         if (const char *e = getenv("KVX_DBG_GRAPH_SYNC")) { if (atoi(e) & 2) HIPCHK(hipStreamSynchronize(st)); }
     } else {
         int rc = enqueue_factor_body(F);
@@ -908,10 +907,10 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
                 kvx_chol::SolveGraph *slot = nullptr;
                 for (auto &g : F->g_solve)
                     if (g.kind == kind0 + 8 && g.nrhs == nchunk) slot = &g;
-                if (!slot) { F->g_solve.push_back({kind0 + 8, nchunk, 0, nullptr}); slot = &F->g_solve.back(); }
+                if (!slot) { F->g_solve.push_back({kind0 + 8, nchunk, 0, LazyExec{}}); slot = &F->g_solve.back(); }
                 slot->calls++;
-                if (!slot->exec && slot->calls >= 2 && F->g_solve.size() <= 16) slot->exec = capture_graph(F, body);
-                exec = slot->exec;
+                if (!slot->exec.tried && slot->calls >= 2 && F->g_solve.size() <= 16) capture_graph(F, body, slot->exec);
+                exec = slot->exec.ready();
             }
             if (exec) HIPCHK(hipGraphLaunch(exec, st));
             else if ((rc = body())) return rc;
@@ -944,10 +943,10 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
                 kvx_chol::SolveGraph *slot = nullptr;
                 for (auto &g : F->g_solve)
                     if (g.kind == kind && g.nrhs == nr) slot = &g;
-                if (!slot) { F->g_solve.push_back({kind, nr, 0, nullptr}); slot = &F->g_solve.back(); }
+                if (!slot) { F->g_solve.push_back({kind, nr, 0, LazyExec{}}); slot = &F->g_solve.back(); }
                 slot->calls++;
-                if (!slot->exec && slot->calls >= 2 && F->g_solve.size() <= 16) slot->exec = capture_graph(F, body);
-                exec = slot->exec;
+                if (!slot->exec.tried && slot->calls >= 2 && F->g_solve.size() <= 16) capture_graph(F, body, slot->exec);
+                exec = slot->exec.ready();
             }
             if (exec) HIPCHK(hipGraphLaunch(exec, st));
             else if ((rc = body())) return rc;
@@ -1071,16 +1070,15 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
             if (g.nrhs == nr && g.B == B && g.ldB == ldB) slot = &g;
         if (!slot) {
             if (F->g_fused.size() >= 4) {                           // (right-hand sides at changing addresses: no pile of graphs)
-                for (auto &g : F->g_fused)
-                    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+                for (auto &g : F->g_fused) g.exec.drop();
                 F->g_fused.clear();
             }
-            F->g_fused.push_back({nr, B, ldB, 0, nullptr});
+            F->g_fused.push_back({nr, B, ldB, 0, LazyExec{}});
             slot = &F->g_fused.back();
         }
         slot->calls++;
-        if (!slot->exec && slot->calls >= 2) slot->exec = capture_graph(F, body);
-        exec = slot->exec;
+        if (!slot->exec.tried && slot->calls >= 2) capture_graph(F, body, slot->exec);
+        exec = slot->exec.ready();
     }
     if (exec) HIPCHK(hipGraphLaunch(exec, st));
     else if ((rc = body())) return rc;
@@ -1684,9 +1682,9 @@ void kvx_chol_free(kvx_chol *F)
         lap("hostfree");
         for (int i = 0; i < 4; i++)
             if (F->ev[i]) pool_event_put(F->ev[i], true);
-        if (F->g_factor) (void)hipGraphExecDestroy(F->g_factor);
-        for (auto &g : F->g_solve)
-            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        F->g_factor.drop();
+        for (auto &g : F->g_solve) g.exec.drop();
+        for (auto &g : F->g_fused) g.exec.drop();
         lap("graphs");
         for (hipEvent_t e : F->prof_ev)
             if (e) pool_event_put(e, true);

@@ -6,7 +6,10 @@
 #include "device.hpp"
 #include "symbolic.hpp"
 
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -22,6 +25,46 @@ using namespace kvx;
             return KVX_EDEVICE;                                                          \
         }                                                                                \
     } while (0)
+
+// An executable graph whose INSTANTIATION runs on a host thread of its own: hipGraphInstantiate of a ~300-node capture takes 10-12 ms
+// under ROCm 7.2's runtime (1-2 ms under 7.0.51831) -- as much as a dozen replays save -- while the capture itself is ~1 ms.  The
+// calls that arrive before the executable is ready run their launches eagerly, as the first call does; results do not depend on
+// which way a call ran.  KVX_GRAPH_SYNC_INSTANTIATE=1: instantiate in the calling thread (as before).
+struct LazyExec {
+    hipGraphExec_t exec = nullptr;
+    std::shared_future<hipGraphExec_t> fut;
+    bool pending = false;
+    bool tried = false;                          // a capture was taken (or failed): no second attempt
+    hipGraphExec_t ready()
+    {
+        if (pending && fut.wait_for(std::chrono::seconds(0)) == std::future_status::ready) { exec = fut.get(); pending = false; }
+        return pending ? nullptr : exec;
+    }
+    void start(hipGraph_t graph)
+    {
+        tried = true;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        auto work = [graph, dev]() -> hipGraphExec_t {
+            (void)hipSetDevice(dev);
+            hipGraphExec_t e = nullptr;
+            if (hipGraphInstantiate(&e, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+            (void)hipGraphDestroy(graph);
+            return e;
+        };
+        const char *sy = getenv("KVX_GRAPH_SYNC_INSTANTIATE");
+        if (sy && sy[0] == '1') { exec = work(); return; }
+        fut = std::async(std::launch::async, work).share();
+        pending = true;
+    }
+    void drop()
+    {
+        if (pending) { exec = fut.get(); pending = false; }
+        if (exec) (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
+        tried = false;
+    }
+};
 
 struct LevelPlan {
     // fronts of the level grouped by kernel class (symbolic.hpp front_class), big first
@@ -63,7 +106,7 @@ struct kvx_chol {
     hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join of the forward sweep's streams
     SubDesc *d_subs_lvl = nullptr;              // the leaf subtrees once more, grouped by the level of their ROOT front: the pipelined sweep
     std::vector<int> sub_lvl_off, sub_lvl_cnt;  // walks the subtrees rooted at level l when level l is factored ([nlevels] offsets / counts)
-    struct FusedGraph { int nrhs; double *B; int64_t ldB; int calls; hipGraphExec_t exec; };
+    struct FusedGraph { int nrhs; double *B; int64_t ldB; int calls; LazyExec exec; };
     std::vector<FusedGraph> g_fused;
     bool have_ftime = false, have_stime = false;
     double ms_factor = 0, ms_solve = 0;
@@ -126,8 +169,8 @@ struct kvx_chol {
     // Disabled while a kernel family is being event-timed and by KVX_NO_GRAPH=1.
     bool use_graph = true;
     int factor_calls = 0;
-    hipGraphExec_t g_factor = nullptr;
-    struct SolveGraph { int kind; int nrhs; int calls; hipGraphExec_t exec; };
+    LazyExec g_factor;
+    struct SolveGraph { int kind; int nrhs; int calls; LazyExec exec; };
     std::vector<SolveGraph> g_solve;
     // optional per-kernel-family timing (bench.py roofline leg): HIP events around every launch
     // of ONE selected family on the factor's stream
