@@ -128,6 +128,10 @@ class Factor:
             rc = lib().kvx_chol_factorize_async_dev(self._h, values_ptr)
         raise_for(rc, "factorization failed")
 
+    def factorize_solve_async_dev(self, values_ptr, B_ptr, nrhs=1, ldB=None):
+        """The same, enqueued only: later null-stream work is ordered behind it; status() reports the factorisation afterwards."""
+        raise_for(lib().kvx_chol_factorize_solve_async_dev(self._h, values_ptr, B_ptr, int(nrhs), int(ldB or max(1, self.n))), "factorization failed")
+
     def factorize_solve_dev(self, values_ptr, B_ptr, nrhs=1, ldB=None):
         """Numeric factorisation + solve of A X = B in one enqueue on device buffers (the forward sweep pipelined behind the
         factorisation level by level); synchronises.  ArithmeticError(minor) when the matrix is not positive definite."""

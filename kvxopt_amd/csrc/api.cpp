@@ -984,7 +984,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
 // (config 2: 0.65 ms of forward sweep hidden under the pivot chain of the top levels).  Same kernels on the same data in the
 // same order per front as kvx_chol_factorize_dev + kvx_chol_solve_dev: bitwise the same factor and solution.  The whole
 // sequence replays from a captured graph from the second call with the same (nrhs, B, ldB) on.
-int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t nrhs, int64_t ldB)
+int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t nrhs, int64_t ldB, bool async = false)
 {
     int rc = ensure_device(F);
     if (rc) return rc;
@@ -1008,7 +1008,7 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
     if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
     if (plain) {
         if ((rc = enqueue_factor(F))) return rc;
-        return solve_dev(F, 0, B, nrhs, ldB);
+        return solve_dev(F, 0, B, nrhs, ldB, async);
     }
     const int nr = (int)nrhs;
     if ((rc = ensure_solve_ws(F, nr))) return rc;
@@ -1086,6 +1086,13 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
     HIPCHK(hipGetLastError());                                      //  call as the factorisation and 0 for the solve)
     F->pending = true;
     F->have_ftime = false;
+    if (async) {
+        // no host synchronisation: the caller's (null-stream) work is ordered behind the call by an event; the status of the
+        // factorisation is examined at the next synchronising call (kvx_chol_status)
+        HIPCHK(hipEventRecord(F->ev_out, st));
+        HIPCHK(hipStreamWaitEvent(nullptr, F->ev_out, 0));
+        return KVX_OK;
+    }
     HIPCHK(hipStreamSynchronize(st));
     rc = finish_factor(F, nullptr);
     F->ms_solve = 0.0; F->have_stime = true;
@@ -1245,6 +1252,14 @@ static int kvx_chol_solve_async_dev_impl(kvx_chol *F, int sys, double *B_dev, in
 int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     return guarded([&] { return kvx_chol_solve_async_dev_impl(F, sys, B_dev, nrhs, ldB); });
+}
+
+int kvx_chol_factorize_solve_async_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    return guarded([&] {
+        if (!F) return (int)KVX_EINVAL;
+        return factor_solve_dev(F, values_dev, B_dev, nrhs, ldB, true);
+    });
 }
 
 int kvx_chol_factorize_solve_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB, int64_t *minor)

@@ -224,6 +224,30 @@ class KKTChol2Dev:
         self.di = di
         self.nfactor += 1
 
+    def factor_solve2(self, di, xa, za, xb, zb):
+        """factor(di) and solve2(xa, za, xb, zb) as ONE enqueue (kvx_chol_factorize_solve_async_dev): the two right-hand sides
+        do not depend on the factor, so they are formed first and the forward sweep runs beside the factorisation of the top of
+        the tree.  Same kernels, same order: bitwise what factor() followed by solve2() gives.  Enqueue only -- check() after
+        the next host synchronisation."""
+        n = self.n
+        if getattr(self, "_x2", None) is None:
+            self._x2 = DVec(2 * max(n, 1))
+        self.w.sqr_of(di)
+        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
+                                              None if self.Px is None else self.Px.ptr, self.Sx.ptr))
+        self.di = di
+        self.nfactor += 1
+        for k, (x, z) in enumerate(((xa, za), (xb, zb))):
+            z.mul(di)
+            self.t.xmy(1.0, di, z)
+            self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)
+            raise_for(lib().kvx_vec_copy_dev(n, x.ptr, self._x2.ptr + 8 * n * k))
+        self.fac.factorize_solve_async_dev(self.Sx.ptr, self._x2.ptr, 2, max(1, n))
+        for k, (x, z) in enumerate(((xa, za), (xb, zb))):
+            raise_for(lib().kvx_vec_copy_dev(n, self._x2.ptr + 8 * n * k, x.ptr))
+            self.G.gemv(x, self.t, trans="N")
+            z.xmy(1.0, di, self.t, -1.0)
+
     def check(self):
         """Raise ArithmeticError if the last (asynchronous) factorisation failed; synchronises the factor's stream."""
         self.fac.status()
@@ -618,6 +642,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         y, dy, y1, ry, hry = (DVec(p) for _ in range(5))
         ksolve = kkt.solve
         ksolve2 = kkt.solve2
+        kfactor_solve2 = None
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
     else:
@@ -628,6 +653,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             kkt.solve(xx, zz)
         def ksolve2(xa, ya, za, xb, yb, zb):
             kkt.solve2(xa, za, xb, zb)
+        def kfactor_solve2(dd, xa, ya, za, xb, yb, zb):
+            kkt.factor_solve2(dd, xa, za, xb, zb)
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             if trans == "T" and beta == 0.0:
                 v.fill(0.0)                                          # A' y with p = 0: the zero vector
@@ -794,13 +821,21 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         # factor + the two solves that do not depend on each other (coneprog.py:1066-1077 and the predictor's f3):
         # one two-column triangular solve with the new factor
         try:
-            kkt.factor(di, sync=False)                   # a failed factorisation surfaces in the solve right below
-            x1.lincomb(-1.0, cv)
-            y1.copy_from(bv)
-            z1.copy_from(hv)
-            newton_rhs(0)
             kkt.async_solves = True                      # enqueue only: the host runs ahead of the GPU up to the next scalar
-            ksolve2(x1, y1, z1, dx, dy, dz)
+            if kfactor_solve2 is not None:
+                # the factorisation and the two solves in one enqueue: their right-hand sides do not depend on the factor
+                x1.lincomb(-1.0, cv)
+                y1.copy_from(bv)
+                z1.copy_from(hv)
+                newton_rhs(0)
+                kfactor_solve2(di, x1, y1, z1, dx, dy, dz)
+            else:
+                kkt.factor(di, sync=False)               # a failed factorisation surfaces in the solve right below
+                x1.lincomb(-1.0, cv)
+                y1.copy_from(bv)
+                z1.copy_from(hv)
+                newton_rhs(0)
+                ksolve2(x1, y1, z1, dx, dy, dz)
             x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
             th.copy_from(hv).mul(di)                     # th = W^{-T} h      (coneprog.py:1126-1128)
         except ArithmeticError:
