@@ -690,7 +690,7 @@ def main():
             try:
                 w2 = build_workload(name, gg)
                 r2 = measure_system(args, pl, dist, rank, world, dev, w2, 1, st_, wu, mode, family="syrk_trailing",
-                                    cpu=("lite" if world == 1 else "none"), pmc_key=None)
+                                    cpu=("lite" if world == 1 else "none"), pmc_key=("stencil21" if (name == "stencil21" and mode == "single") else None))
                 if r2.get("cpu_baseline") and r2["cpu_baseline"].get("value"):
                     r2["vs_cpu_baseline"] = r2["value"] / r2["cpu_baseline"]["value"]
                 extra.append(public(r2))

@@ -2,7 +2,7 @@
 # Profile artefacts of the sparse-LU (kvxopt.klu) path, run through gpurun from the repo root:
 #   bash profiles/collect_klu.sh r01c
 # 1. bench_extra.py JSON lines (klu3 = BASELINE configs[2], lu2d = unsymmetric 600 x 600 grid), 2. rocprofv3 kernel
-# stats of ten refactor+solve steps on ACTIVSg2000 (scratch/lu_prof.py).
+# stats of ten refactor+solve steps on ACTIVSg2000 (tools/lu_prof.py).
 set -e -o pipefail
 TAG=${1:-r01c}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,5 +10,5 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 timeout -k 10 600 python3 bench_extra.py --cases klu3,lu2d > $OUT/${TAG}_lu.jsonl 2> $OUT/${TAG}_lu.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_lustats -o s --output-format csv -- python3 scratch/lu_prof.py > $OUT/${TAG}_lustats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_lustats -o s --output-format csv -- python3 tools/lu_prof.py > $OUT/${TAG}_lustats.log 2>&1
 ls $OUT | grep $TAG

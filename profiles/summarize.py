@@ -2,44 +2,61 @@
 """Condense the rocprofv3 outputs of profiles/collect.sh into the small, committed files under profiles/:
    <tag>_bench.json               the bench.py line of the same build
    <tag>_kernel_stats.csv         rocprofv3 --kernel-trace --stats summary (per kernel: calls, total, average)
-   <tag>_pmc_fetch_write_per_kernel.json   FETCH_SIZE / WRITE_SIZE (KB, raw counter values) per kernel and per step,
-                                  plus per bench.py kernel family (bench.py reads "family_bytes_per_step")."""
-import csv, glob, json, os, re, shutil, sys
+   <tag>_pmc_fetch_write_per_kernel.json   FETCH_SIZE / WRITE_SIZE per kernel and per factor+solve step for the headline system
+                                  ("config2") and the 21-point system ("stencil21"), the calibration of the two counters on a kernel
+                                  of known byte count in the library's access pattern (8 bytes per lane), the per-family bytes
+                                  bench.py reads ("family_bytes_per_step", already scaled by the calibration) and the fingerprint of
+                                  the library sources the profile was taken on."""
+import csv, glob, hashlib, json, os, re, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
 
 
+def clean(name):
+    return re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "").replace("kvx::", "")
+
+
 def short(name):
-    n = re.sub(r"\(.*", "", name).replace("void ", "").replace("kvx::", "")
-    return re.sub(r"<.*", "", n)
+    return re.sub(r"<.*", "", clean(name))
+
+
+def source_fingerprint():
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "kvxopt_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "kvxopt_amd", "csrc", "*.[ch]pp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 FAMILY = {"k_scatter_a": "scatter_a", "k_front_wave": "front_small", "k_front_lds": "front_small", "k_assemble_big": "assemble_big",
-          "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing",
-          "k_fwd_wave": "fwd_level", "k_fwd_subtree": "fwd_level", "k_bwd_subtree": "bwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_init": "fwd_level", "k_fwd_big_step": "fwd_level",
+          "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing", "k_syrk_trailing128": "syrk_trailing",
+          "k_fwd_wave": "fwd_level", "k_fwd_subtree": "fwd_level", "k_bwd_subtree": "bwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_step": "fwd_level",
           "k_bwd_wave": "bwd_level", "k_bwd_lds": "bwd_level", "k_bwd_big_init": "bwd_level", "k_bwd_big_step": "bwd_level"}
 
 # bench line
 b = os.path.join(out, tag + "_bench.json")
 if os.path.exists(b):
-    line = [l for l in open(b) if l.startswith("{")][-1]
-    json.dump(json.loads(line), open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
+    lines = [l for l in open(b) if l.startswith("{")]
+    if lines:
+        json.dump(json.loads(lines[-1]), open(os.path.join(prof, tag + "_bench.json"), "w"), indent=1)
 
 # kernel stats
 st = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
+    nfac = sum(int(r["Calls"]) for r in rows if clean(r["Name"]).startswith("k_clear_factor"))
     with open(os.path.join(prof, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline  (12 factor+solve steps + 27 in the per-family timing loop)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ipm --no-extra --no-one-shot\n")
+        f.write("# %d numeric factorisations in the process: 12 one-enqueue steps (factor + solve, forward sweep beside the top of the tree), 8 steps as two calls, "
+                "24 in the per-family timing loop (graphs off)\n" % nfac)
         f.write("kernel,calls,total_us,avg_us,pct\n")
         for r in rows:
-            f.write("%s,%s,%.1f,%.2f,%s\n" % (re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("kvx::", "").replace(",", ";"),
-                                              r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+            f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
 
-# PMC passes
+
 def pmc(dirname, counter):
     f = glob.glob(os.path.join(out, dirname, "**", "*counter_collection.csv"), recursive=True)
     acc, cnt = {}, {}
@@ -53,10 +70,33 @@ def pmc(dirname, counter):
         cnt[k] = cnt.get(k, 0) + 1
     return acc, cnt
 
-fa, fc = pmc(tag + "_pmc_fetch", "FETCH_SIZE")
-wa, wc = pmc(tag + "_pmc_write", "WRITE_SIZE")
-if fa or wa:
-    steps = 1 + 2 + 3 * 9          # warmup + timed + the per-family event-timing loop of bench.py (3 steps x 9 families)
+
+# calibration: k_scal, 2^26 doubles, 5 launches: 512 MiB read and written per launch, 8 bytes per lane
+cf, cfc = pmc(tag + "_cal_fetch", "FETCH_SIZE")
+cw, cwc = pmc(tag + "_cal_write", "WRITE_SIZE")
+known = 8.0 * (1 << 26)
+cal = {}
+if cf.get("k_scal") and cw.get("k_scal"):
+    cal = {"kernel": "k_scal (x := a x), 2^26 doubles, 8 bytes per lane", "known_bytes_read_per_launch": known, "known_bytes_written_per_launch": known,
+           "FETCH_SIZE_per_launch_raw": cf["k_scal"] / cfc["k_scal"], "WRITE_SIZE_per_launch_raw": cw["k_scal"] / cwc["k_scal"]}
+    # rocprofv3 reports both counters in KiB on this stack
+    cal["fetch_scale"] = known / (cal["FETCH_SIZE_per_launch_raw"] * 1024.0)
+    cal["write_scale"] = known / (cal["WRITE_SIZE_per_launch_raw"] * 1024.0)
+fscale = cal.get("fetch_scale", 1.0)
+wscale = cal.get("write_scale", 1.0)
+
+res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 1 --quick [--workload W]`. "
+                "Counter values are KiB; per_step = raw KiB per factor+solve step (steps counted from the k_clear_factor launches of the run); "
+                "family_bytes_per_step = (FETCH_SIZE x fetch_scale + WRITE_SIZE x write_scale) x 1024 per step, the scales from the calibration kernel "
+                "(known byte count, the library's 8-byte-per-lane pattern) as MI355X_MICROARCH.md prescribes for access widths other than 16 bytes per lane.",
+       "source_fingerprint": source_fingerprint(), "calibration": cal, "fetch_scale": round(fscale, 4), "write_scale": round(wscale, 4),
+       "fetch_scale_note": "known bytes / counter on k_scal (8 B per lane streaming read)"}
+for key, W in (("config2", "lap2d"), ("stencil21", "stencil21")):
+    fa, fc = pmc("%s_pmc_fetch_%s" % (tag, W), "FETCH_SIZE")
+    wa, wc = pmc("%s_pmc_write_%s" % (tag, W), "WRITE_SIZE")
+    if not (fa or wa):
+        continue
+    steps = max(fc.get("k_clear_factor", wc.get("k_clear_factor", 1)), 1)
     per = {}
     for k in sorted(set(fa) | set(wa)):
         per[k] = {"dispatches": round(fc.get(k, wc.get(k, 0)) / steps, 1), "FETCH_SIZE_KB": round(fa.get(k, 0.0) / steps, 1),
@@ -64,13 +104,8 @@ if fa or wa:
     fam = {}
     for k, v in per.items():
         if k in FAMILY:
-            fam[FAMILY[k]] = fam.get(FAMILY[k], 0.0) + (v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
-    json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 1 "
-                        "--no-cpu-baseline` (%d factor+solve steps in the process). KB per step, raw counter values: "
-                        "MI355X_MICROARCH.md says FETCH_SIZE under-reports 16-B-per-lane streaming reads by 2x on gfx950 and other "
-                        "widths are uncalibrated; these kernels issue 8-B-per-lane loads, so no correction is applied and the numbers "
-                        "are read as a check against re-reads (traffic >> algorithmic bytes), not as absolutes. The syrk_trailing "
-                        "family includes the fused next-diagonal-block factorisation." % steps,
-               "steps_in_run": steps, "per_step": per, "family_bytes_per_step": fam},
-              open(os.path.join(prof, tag + "_pmc_fetch_write_per_kernel.json"), "w"), indent=1)
-print("summarised", tag)
+            fam[FAMILY[k]] = fam.get(FAMILY[k], 0.0) + (v["FETCH_SIZE_KB"] * fscale + v["WRITE_SIZE_KB"] * wscale) * 1024.0
+    res[key] = {"steps_in_run": steps, "per_step": per, "family_bytes_per_step": fam}
+if "config2" in res or "stencil21" in res:
+    json.dump(res, open(os.path.join(prof, tag + "_pmc_fetch_write_per_kernel.json"), "w"), indent=1)
+print("summarised", tag, "calibration:", {k: cal.get(k) for k in ("fetch_scale", "write_scale")})
