@@ -36,6 +36,8 @@ size_t cache_cap()
 // streams of earlier objects are still in use paid 10-15 ms for them (klu.linsolve on ACTIVSg2000: 15 ms against 5.6 with streams at
 // hand).  When a request finds the pool empty, a background thread tops it up with spare streams beside the caller's own work; the
 // next objects find them there.  KVX_SPARE_STREAMS=<count per refill> (default 12, 0 = off).
+// fork() after the first device use is not supported (as for the HIP runtime itself): the child would inherit the pool's lock in
+// whatever state the refill thread left it.
 std::mutex g_refill_mu;                          // guards the thread object (the thread itself only takes g_mu)
 std::thread g_refill;
 std::atomic<bool> g_refill_busy{false};
@@ -63,7 +65,7 @@ void start_refill(int dev)
                     hipStream_t s = nullptr;
                     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
                     std::lock_guard<std::mutex> lk2(g_mu);
-                    if (g_streams.size() >= 64) { (void)hipStreamDestroy(s); break; }
+                    if (g_streams.count(dev) >= 64) { (void)hipStreamDestroy(s); break; }   // (per device: one device's spares do not block another's)
                     g_streams.emplace(dev, s);
                 }
             }

@@ -361,3 +361,46 @@ def test_complex_matrices_as_the_reference_tests_build_them(golden_dir, name):
         klu.linsolve(Az, matrix(np.ones(n)))                           # real B with a complex A (klu.c:121-122)
     with pytest.raises(TypeError):
         klu.numeric(A, Fs)                                             # real A with the symbolic factor of a complex one
+
+
+def test_linsolve_cache_hit_with_very_different_values(monkeypatch):
+    """klu.linsolve keeps the analysis (value-aware matching, block triangular form, pivot sequence) of the last
+    matrices by PATTERN.  A second matrix on the same pattern whose large entries sit elsewhere -- tiny diagonal, a dominant
+    cyclic shift, explicit zeros where the first matching was -- must come out as accurately as from a cold call
+    (KVX_LINSOLVE_CACHE=0 semantics: fresh analysis + factorisation)."""
+    import scipy.sparse as sp
+    from kvxopt_amd import klu
+    from kvxopt_amd.base import matrix, spmatrix
+    n = 400
+    rng = np.random.default_rng(11)
+    M = sp.random(n, n, 0.01, random_state=5, format="csc")
+    shift = sp.csc_matrix((np.ones(n), (np.arange(n), (np.arange(n) + 1) % n)), shape=(n, n))
+    P = ((M != 0) + sp.eye(n, format="csc") + shift).astype(float).tocsc(); P.sort_indices()      # the common pattern
+    def with_values(diag, sh):
+        V = P.copy()
+        V.data = rng.uniform(-0.3, 0.3, V.nnz)
+        V = V.tolil()
+        for i in range(n):
+            V[i, i] = diag[i]
+            V[i, (i + 1) % n] = sh[i]
+        V = V.tocsc(); V.sort_indices()
+        return V
+    A1 = with_values(np.full(n, 10.0), np.full(n, 0.1))                                     # diagonally dominant: matching = the diagonal
+    A2 = with_values(np.where(np.arange(n) % 3 == 0, 0.0, 1e-9), np.full(n, 10.0))        # the shift dominates; zeros / dust on the old matching
+    b = rng.standard_normal(n)
+    def solve(V):
+        # the values of V on the COMMON pattern P (explicit zeros stay stored: the cache keys on the pattern)
+        Vc = sp.csc_matrix((np.asarray(V[P.nonzero()]).ravel(), P.nonzero()), shape=(n, n)); Vc.sort_indices()
+        Vc = sp.csc_matrix((Vc.data, Vc.indices, Vc.indptr), shape=(n, n))                # explicit zeros stay stored
+        A = spmatrix.from_ccs(n, n, Vc.indptr.astype(np.int64), Vc.indices.astype(np.int64), Vc.data.copy())
+        x = matrix(b.copy())
+        klu.linsolve(A, x)
+        xv = np.asarray(x._a).reshape(-1)
+        return float(np.abs(V @ xv - b).max() / (np.abs(V).sum(axis=1).max() * np.abs(xv).max() + np.abs(b).max()))
+    klu.clear_cache()
+    r1 = solve(A1)
+    r2_hit = solve(A2)                       # cache hit on the pattern analysed with A1's values
+    klu.clear_cache()
+    r2_cold = solve(A2)
+    assert r1 < 1e-13 and r2_cold < 1e-13
+    assert r2_hit < 1e-12 and r2_hit <= 100 * max(r2_cold, 1e-16), (r2_hit, r2_cold)
