@@ -532,7 +532,14 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             // that its launches sit between the factorisation's in submission order too (enqueued after the whole factorisation they
             // were submitted -- eagerly and from a replayed graph alike -- only when the last front had been)
             HIPCHK(hipEventRecord(F->ev_lvl[(size_t)l], st));
-            const SweepStreams ss2{F->side[2], F->side[3], F->side[3], F->ev_pipe[1], F->ev_pipe[2], F->ev_pipe[3]};
+            // The sweep goes onto side[0] -- the stream of the factorisation's small-front launches, which has nothing left to do at the
+            // top of the tree -- not onto a stream of its own: a replayed graph runs its parallel branches on streams the executable
+            // creates for itself, as many as the capture is wide, and a process gets four hardware queues; with a fourth / fifth
+            // branch two of them share a queue and the step was 4.65 or 4.9 ms from one process to the next, depending on whether the
+            // pivot chain's queue was the shared one.  KVX_PIPE_OWN_STREAM=1: side[2] (the old form, for comparison).
+            static const bool own = [] { const char *e = getenv("KVX_PIPE_OWN_STREAM"); return e && e[0] == '1'; }();
+            hipStream_t sw = own ? F->side[2] : F->side[0];
+            const SweepStreams ss2{sw, sw, sw, F->ev_pipe[1], F->ev_pipe[2], F->ev_pipe[3]};
             // Below pipe_from the levels hold thousands of small fronts that fill the CUs: a sweep beside them only takes their
             // wavefront slots (measured: the factorisation lost what the sweep gained).  From pipe_from up the factorisation is a chain
             // of small launches on an idle machine: the sweep of everything below starts there in one go, then follows level by level.
@@ -615,8 +622,8 @@ struct LevelStreams {
     static SweepStreams own(kvx_chol *F) { return SweepStreams{F->stream, F->side[0], F->side[1], F->ev_fork, F->ev_join[0], F->ev_join[1]}; }
     LevelStreams(kvx_chol *F, bool have_big, bool have_lds, bool have_wave, const SweepStreams *ss = nullptr) : S(ss ? *ss : own(F))
     {
-        fork_lds = have_lds && (have_big || have_wave);
-        fork_wave = have_wave && have_big;
+        fork_lds = have_lds && (have_big || have_wave) && S.lds != S.main;
+        fork_wave = have_wave && have_big && S.wave != S.main;
         lds = fork_lds ? S.lds : S.main;
         wave = fork_wave ? S.wave : S.main;
         if (fork_lds || fork_wave) {
@@ -1042,7 +1049,8 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
             F->pipe_from = l;
         }
     }
-    hipStream_t st = F->stream, s2 = F->side[2];
+    static const bool own_stream = [] { const char *e = getenv("KVX_PIPE_OWN_STREAM"); return e && e[0] == '1'; }();
+    hipStream_t st = F->stream, s2 = own_stream ? F->side[2] : F->side[0];
     auto body = [&]() -> int {
         // the sweep's stream joins behind the values (and, in a capture, the capture): right-hand sides into the work vector first
         HIPCHK(hipEventRecord(F->ev_pipe[0], st));
