@@ -566,6 +566,11 @@ void capture_graph(kvx_chol *F, Body body, LazyExec &out)
     int rc = body();
     hipError_t e = hipStreamEndCapture(F->stream, &graph);
     if (rc != KVX_OK || e != hipSuccess || !graph) { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); return; }
+    if (const char *dot = getenv("KVX_DBG_GRAPH_DOT")) {           // debugging: the captured graph (nodes and edges) as a .dot file
+        static int serial = 0;
+        const std::string path = std::string(dot) + "." + std::to_string(serial++) + ".dot";
+        if (hipGraphDebugDotPrint(graph, path.c_str(), 0) != hipSuccess) (void)hipGetLastError();
+    }
     out.start(graph);                              // instantiation on a thread of its own; the graph is destroyed there
 }
 
