@@ -103,6 +103,8 @@ int kvx_chol_solve_async_dev(kvx_chol *F, int sys, double *B_dev, int64_t nrhs, 
  * order per front: the factor and X are bitwise those of kvx_chol_factorize_dev + kvx_chol_solve_dev.  Synchronises; returns
  * KVX_ENOTPOSDEF with *minor = failing column (B_dev then holds garbage).  The factor stays usable for further solves. */
 int kvx_chol_factorize_solve_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB, int64_t *minor);
+/* ... with host buffers: the numeric + solve part of linsolve(A, B) (cholmod.c:663-753) in one call. */
+int kvx_chol_factorize_solve(kvx_chol *F, const double *values, double *B, int64_t nrhs, int64_t ldB, int64_t *minor);
 /* ... enqueue only: the caller's later null-stream work is ordered behind it; kvx_chol_status reports the factorisation afterwards
  * (the form misc.kkt_chol2's factor + first solves take inside the interior-point loop). */
 int kvx_chol_factorize_solve_async_dev(kvx_chol *F, const double *values_dev, double *B_dev, int64_t nrhs, int64_t ldB);

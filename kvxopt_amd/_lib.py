@@ -56,6 +56,7 @@ _SIGS = {
     "kvx_chol_solve_dev": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
     "kvx_chol_solve_async_dev": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
     "kvx_chol_factorize_solve_dev": (ctypes.c_int, [vp, vp, vp, i64, i64, i64p]),
+    "kvx_chol_factorize_solve": (ctypes.c_int, [vp, f64p, f64p, i64, i64, i64p]),
     "kvx_chol_factorize_solve_async_dev": (ctypes.c_int, [vp, vp, vp, i64, i64]),
     "kvx_chol_spsolve": (ctypes.c_int, [vp, ctypes.c_int, i64, i64p, i64p, f64p,
                                         ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p)]),

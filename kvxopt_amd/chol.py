@@ -128,6 +128,22 @@ class Factor:
             rc = lib().kvx_chol_factorize_async_dev(self._h, values_ptr)
         raise_for(rc, "factorization failed")
 
+    def factorize_solve(self, values, B, nrhs=None, ldB=None, offset=0):
+        """Numeric factorisation + solve A X = B with host buffers in one call (kvx_chol_factorize_solve): B overwritten."""
+        v = as_f64(values)
+        if v.size != (self.colptr[-1] if self.n else 0):
+            raise TypeError("values do not match the analysed pattern")
+        flat = B.reshape(-1, order="F") if B.ndim > 1 else B
+        if nrhs is None:
+            nrhs = 1 if B.ndim == 1 else B.shape[1]
+        ptr = ctypes.cast(flat.ctypes.data + 8 * offset, _lib.f64p)
+        minor = ctypes.c_int64()
+        rc = lib().kvx_chol_factorize_solve(self._h, pd(v), ptr, int(nrhs), int(ldB or max(1, self.n)), ctypes.byref(minor))
+        if rc == _lib.KVX_ENOTPOSDEF:
+            raise ArithmeticError(int(minor.value))
+        raise_for(rc, "factorization failed")
+        return B
+
     def factorize_solve_async_dev(self, values_ptr, B_ptr, nrhs=1, ldB=None):
         """The same, enqueued only: later null-stream work is ordered behind it; status() reports the factorisation afterwards."""
         raise_for(lib().kvx_chol_factorize_solve_async_dev(self._h, values_ptr, B_ptr, int(nrhs), int(ldB or max(1, self.n))), "factorization failed")

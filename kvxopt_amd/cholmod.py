@@ -197,6 +197,11 @@ def numeric(A, F):
             raise ValueError("factorization failed: A does not have the sparsity pattern of the symbolic factorization")
         F.fac.factorize(F.evals(v))
         return
+    F.fac.factorize(_triangle_values(F, n, cp, ri, v))    # ArithmeticError(minor) if not positive definite
+
+
+def _triangle_values(F, n, cp, ri, v):
+    """The values of A's `uplo` triangle in the order of the analysed pattern (what numeric hands to the factorisation)."""
     if n != F.fac.n:
         raise ValueError("factorization failed")
     # only the `uplo` triangle counts (cholmod.c:137-157): same full pattern as analysed -> reuse its mask; otherwise the
@@ -209,7 +214,7 @@ def numeric(A, F):
         if tri.size != F.tri[1].size or not np.array_equal(tcp, F.tri[0]) or not np.array_equal(tri, F.tri[1]):
             raise ValueError("factorization failed: A does not have the sparsity pattern of the symbolic factorization")
         vt = v if keep is None else v[keep]
-    F.fac.factorize(vt)                                  # ArithmeticError(minor) if not positive definite
+    return vt
 
 
 def _solve_args(F, B, sys, nrhs, ldB, offsetB):
@@ -343,6 +348,13 @@ def linsolve(A, B, p=None, uplo="L", nrhs=-1, ldB=0, offsetB=0):
     if n == 0 or nrhs == 0:
         return
     F = _cached_symbolic(A, p, uplo, n, cp, ri, v)
+    # numeric + solve as ONE call into the library (kvx_chol_factorize_solve: the forward sweep runs beside the factorisation of
+    # the top of the tree) for the plain case -- a real LL' factor, a handful of right-hand sides, B checked as solve() checks it
+    if v.dtype.kind != "c" and 0 < nrhs <= 16 and F.fac.info()["is_ll"]:
+        ld = ldB if ldB else max(1, size[0])
+        if ld >= max(1, n) and offsetB >= 0 and offsetB + (nrhs - 1) * ld + n <= buf.size:
+            F.fac.factorize_solve(_triangle_values(F, n, cp, ri, v), buf, nrhs=nrhs, ldB=ld, offset=offsetB)
+            return
     numeric(A, F)
     solve(F, B, 0, nrhs, ldB, offsetB)
 

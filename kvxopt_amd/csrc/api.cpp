@@ -1314,6 +1314,40 @@ int kvx_chol_solve(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB)
     return guarded([&] { return kvx_chol_solve_impl(F, sys, B, nrhs, ldB); });
 }
 
+// numeric + solve (sys 0) with HOST buffers: what cholmod.linsolve does after its analysis (cholmod.c:663-753), as the one-enqueue
+// form.  The staging block of B keeps its address from call to call (the captured graph reads and writes it).
+static int kvx_chol_factorize_solve_impl(kvx_chol *F, const double *values, double *B, int64_t nrhs, int64_t ldB, int64_t *minor)
+{
+    if (!F) return KVX_EINVAL;
+    int rc = ensure_device(F);
+    if (rc) return rc;
+    const int64_t n = F->S.n;
+    if (nrhs < 0) { set_err("nrhs out of range"); return KVX_EINVAL; }
+    if (n > 0 && nrhs > 0 && ldB < n) { set_err("ldB must be >= max(1,n)"); return KVX_EINVAL; }
+    double *d_vals = nullptr, *d_B = nullptr;
+    HIPCHK(pool_malloc((void **)&d_vals, std::max<int64_t>(F->S.nnzA, 1) * sizeof(double)));
+    if (pool_malloc((void **)&d_B, std::max<int64_t>(n * nrhs, 1) * sizeof(double)) != hipSuccess) { (void)pool_free(d_vals); set_err("out of device memory"); return KVX_ENOMEM; }
+    hipError_t e = hipSuccess;
+    if (F->S.nnzA > 0) e = hipMemcpy(d_vals, values, F->S.nnzA * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n > 0 && nrhs > 0)
+        e = hipMemcpy2D(d_B, n * sizeof(double), B, ldB * sizeof(double), n * sizeof(double), nrhs, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = factor_solve_dev(F, d_vals, d_B, nrhs, n);
+        if (minor) *minor = F->minor;
+        if (rc == KVX_OK && n > 0 && nrhs > 0)
+            e = hipMemcpy2D(B, ldB * sizeof(double), d_B, n * sizeof(double), n * sizeof(double), nrhs, hipMemcpyDeviceToHost);
+    }
+    (void)pool_free(d_vals);
+    (void)pool_free(d_B);
+    if (e != hipSuccess) { set_err(hipGetErrorString(e)); return KVX_EDEVICE; }
+    return rc;
+}
+
+int kvx_chol_factorize_solve(kvx_chol *F, const double *values, double *B, int64_t nrhs, int64_t ldB, int64_t *minor)
+{
+    return guarded([&] { return kvx_chol_factorize_solve_impl(F, values, B, nrhs, ldB, minor); });
+}
+
 // Sparse right-hand sides, forward systems (L x = b, L D x = b): only the REACH of a block of columns is swept -- the fronts
 // that hold a nonzero row of the block and their ancestors in the supernodal elimination tree (the supernodal form of
 // CHOLMOD's sparse-rhs solve, cholmod.c:524-587; misc.kkt_chol2 forms L^-1 P A' this way, misc.py:1483-1487).  Everything

@@ -800,3 +800,40 @@ def test_factor_and_solve_in_one_enqueue(g, h, nrhs):
     bd.upload(B.reshape(-1, order="F"))
     F.factorize_solve_dev(vd.ptr, bd.ptr, nrhs, n)
     assert np.array_equal(bd.download(np.float64, n * nrhs).reshape(n, nrhs, order="F"), Xref)
+
+
+@pytest.mark.gpu
+def test_factorize_solve_with_host_buffers_and_linsolve():
+    """kvx_chol_factorize_solve (host buffers: what cholmod.linsolve calls for a real LL' factor): the same answer as
+    kvx_chol_factorize + kvx_chol_solve bit for bit, with ldB > n and an offset, repeated (cached symbolic factor, replayed graph)
+    and with an indefinite matrix reported by its column; and linsolve against the CPU oracle."""
+    from kvxopt_amd import cholmod
+    from kvxopt_amd.base import matrix, spmatrix
+    n, cp, ri, v = workloads.laplacian_2d(37, 29)
+    F = Factor(n, cp, ri)
+    rng = np.random.default_rng(5)
+    ld, off, nrhs = n + 3, 2, 3
+    buf = rng.standard_normal(off + ld * nrhs)
+    ref = buf.copy()
+    F.factorize(v)
+    F.solve(ref, 0, nrhs, ld, off)
+    for rep in range(3):
+        out = buf.copy()
+        F.factorize_solve(v, out, nrhs=nrhs, ldB=ld, offset=off)
+        assert np.array_equal(out, ref), rep                    # the gaps between the columns untouched as well
+    bad = v.copy(); bad[cp[int(F.perm()[n // 3])]] = -2.0
+    with pytest.raises(ArithmeticError) as e1:
+        Factor(n, cp, ri).factorize(bad)
+    with pytest.raises(ArithmeticError) as e2:
+        F.factorize_solve(bad, buf.copy(), nrhs=nrhs, ldB=ld, offset=off)
+    assert e1.value.args[0] == e2.value.args[0]
+    # through the reference-facing call
+    A = spmatrix.from_ccs(n, n, cp, ri, v)
+    cholmod.clear_cache()
+    for rep in range(3):                                         # analysis + eager, capture, replay
+        B = matrix(buf[off:off + ld * nrhs].reshape(ld, nrhs, order="F").copy(order="F"))
+        cholmod.linsolve(A, B, nrhs=nrhs, ldB=ld)
+        got = np.array(B.a).reshape(ld, nrhs, order="F")
+        assert np.array_equal(got, ref[off:].reshape(ld, nrhs, order="F")), rep
+    with pytest.raises(ArithmeticError):
+        cholmod.linsolve(spmatrix.from_ccs(n, n, cp, ri, bad), matrix(buf[:n].copy()))
