@@ -220,6 +220,9 @@ int kvx_atda_pattern(kvx_atda *T, int64_t *snz, int64_t *Sp, int64_t *Si);
 int kvx_atda_assemble(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx);
 int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx_dev, const double *w_dev,
                           const double *Px_dev, double *Sx_dev);
+/* the same with the square roots of the weights: S = G' diag(di)^2 G (+ P), what misc.kkt_chol2 forms (misc.py:1418-1426: W^-1
+ * applied to G, then syrk) -- the square is taken while G is scaled, same roundings as ssqr followed by assemble */
+int kvx_atda_assemble_sq_dev(kvx_atda *T, const double *Gx_dev, const double *di_dev, const double *Px_dev, double *Sx_dev);
 void kvx_atda_free(kvx_atda *T);
 
 /* ---- Nesterov-Todd scaling, orthant ('l') cone: replaces kvxopt.misc / misc_solvers ------ */
@@ -253,6 +256,28 @@ int kvx_lp_newton_rhs_dev(int64_t ml, const double *lmbdasq, const double *ws3, 
                           const double *lmbda, const double *d, double *ds, double *dz);
 int kvx_lp_step_post_dev(int64_t ml, double dtau, const double *z1, const double *lmbda, double *ds, double *dz, double *ws3);
 int kvx_lp_update_dev(int64_t ml, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s, double *z);
+/* (newton_rhs: lmbdasq may be NULL -- lmbda o lmbda is then formed in the kernel, rounded as misc.ssqr rounds it.)
+ * The remaining short launches of an iteration, fused (round 3; a launch of a few microseconds costs 4-5 us on its stream, ~85 of them
+ * were a fifth of an iteration).  Same arithmetic per element, same roundings: an interior-point run is bit for bit the unfused one.
+ *   update_x  : kvx_lp_update_dev and x += step*dx (coneprog.py:1339) in one launch;
+ *   residuals : hrx := -G'z, rx := hrx - tau*c, hrz := G*x + s, rz := hrz - tau*h (coneprog.py:861-896, p = 0) in one launch; G by its
+ *               CCS arrays and by those of its transpose (device pointers, int64 indices, as for kvx_spmv_dev);
+ *   kkt_solve_pre / _post: misc.kkt_chol2's solve (misc.py:1489-1563, p = 0) around the triangular solves, for one or two right-hand
+ *               sides:  x2(:,k) := xscale*xin + G'(di.*(zin.*di))   [z := W^-1 z, x += Gs'z]   and, after S^-1 on x2,
+ *               xout := xoscale*x2(:,k),  zout := zoscale*(di.*(G*x2(:,k)) - zin.*di)           [z := Gs*x - z]. */
+typedef struct kvx_kkt_side {
+    const double *xin;  double xscale;  const double *zin;     /* pre */
+    double *xout;       double xoscale; double *zout; double zoscale;   /* post (zin is read again) */
+} kvx_kkt_side;
+int kvx_lp_update_x_dev(int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s,
+                        double *z, const double *dx, double *x);
+int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *GTp,
+                         const int64_t *GTi, const double *GTx, const double *x, const double *z, const double *s, const double *c,
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz);
+int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
+                          const kvx_kkt_side *sides, double *x2, int64_t ldx2);
+int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int64_t *GTi, const double *GTx, const double *di, int nrhs,
+                           const kvx_kkt_side *sides, const double *x2, int64_t ldx2);
 /* count <= 32 reductions with one host synchronisation: kind[i] = 0 sdot(x_i, y_i), 1 max_step(x_i) -- bitwise the
  * values of the single calls (the per-iteration residual norms / objectives of coneprog.py:861-896 in one go). */
 /* second half of f6_no_ir + step bounds (coneprog.py:1162-1195, 1303-1321) in one host round trip: dtau is formed on the

@@ -35,6 +35,11 @@ class DistOp(ctypes.Structure):
 DIST_COMM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(DistOp))
 
 
+class KktSide(ctypes.Structure):
+    """kvx_kkt_side of include/kvxhip.h: one right-hand side of kvx_kkt_solve_pre_dev / _post_dev."""
+    _fields_ = [("xin", vp), ("xscale", f64), ("zin", vp), ("xout", vp), ("xoscale", f64), ("zout", vp), ("zoscale", f64)]
+
+
 class CholInfo(ctypes.Structure):
     _fields_ = [("n", i64), ("nnz_a", i64), ("lnz", i64), ("flops", f64), ("nsuper", i64), ("lsize", i64),
                 ("nlevels", i64), ("max_front", i64), ("upd_size", i64), ("is_numeric", i64), ("minor", i64),
@@ -82,6 +87,7 @@ _SIGS = {
     "kvx_atda_pattern": (ctypes.c_int, [vp, i64p, i64p, i64p]),
     "kvx_atda_assemble": (ctypes.c_int, [vp, f64p, f64p, f64p, f64p]),
     "kvx_atda_assemble_dev": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+    "kvx_atda_assemble_sq_dev": (ctypes.c_int, [vp, vp, vp, vp, vp]),
     "kvx_atda_free": (None, [vp]),
     "kvx_nt_compute_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
     "kvx_nt_update_scaling_dev": (ctypes.c_int, [i64, vp, vp, vp, vp, vp]),
@@ -109,6 +115,10 @@ _SIGS = {
     "kvx_lp_newton_rhs_dev": (ctypes.c_int, [i64, vp, vp, f64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_step_post_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_update_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp, vp, vp]),
+    "kvx_lp_update_x_dev": (ctypes.c_int, [i64, i64, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "kvx_lp_residuals_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp]),
+    "kvx_kkt_solve_pre_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, ctypes.c_int, vp, vp, i64]),
+    "kvx_kkt_solve_post_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, ctypes.c_int, vp, vp, i64]),
     "kvx_lp_second_half_dev": (ctypes.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64p]),
     "kvx_nt_reduce_multi_dev": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), i64p, ctypes.POINTER(vp),
                                                 ctypes.POINTER(vp), f64p]),

@@ -21,6 +21,13 @@ static inline unsigned grid_for(int64_t n, int bs = 256)
     return (unsigned)b;
 }
 
+// a product that stays a product (never contracted into a following addition)
+__device__ __forceinline__ double kvx_mul_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+
 #define GS_LOOP(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
@@ -58,7 +65,9 @@ __global__ void k_lp_newton_rhs(int64_t n, const double *__restrict__ lsq, const
                                 const double *__restrict__ d, double *__restrict__ ds, double *__restrict__ dz)
 {
     GS_LOOP(i, n) {
-        double v = lsq[i];
+        double v;
+        if (lsq) v = lsq[i];
+        else { const double l0 = lm[i]; v = kvx_mul_rn(l0, l0); }             // lmbda o lmbda, rounded as misc.ssqr's product
         if (ws3) v = (v + ws3[i]) - shift;
         v = -(v / lm[i]);
         ds[i] = v;
@@ -81,23 +90,27 @@ __global__ void k_lp_step_post(int64_t n, double dtau, const double *__restrict_
 }
 // (3) end of the iteration (coneprog.py:1343-1432, 'l' block): ds := (step ds + 1) .* lmbda, same for dz, then
 //     update_scaling (misc.py:444-464) and the unscaled iterates s = W' lmbda, z = W^-1 lmbda
+__device__ __forceinline__ void lp_update_elem(int64_t i, double step, double *__restrict__ ds, double *__restrict__ dz,
+                                               double *__restrict__ d, double *__restrict__ di, double *__restrict__ lm,
+                                               double *__restrict__ s, double *__restrict__ z)
+{
+    const double l = lm[i];
+    const double ss = sqrt((step * ds[i] + 1.0) * l), zz = sqrt((step * dz[i] + 1.0) * l);
+    ds[i] = ss;
+    dz[i] = zz;
+    const double dd = (d[i] * ss) / zz;
+    d[i] = dd;
+    const double dinv = 1.0 / dd;
+    di[i] = dinv;
+    const double ln = ss * zz;
+    lm[i] = ln;
+    s[i] = ln * dd;
+    z[i] = ln * dinv;
+}
 __global__ void k_lp_update(int64_t n, double step, double *__restrict__ ds, double *__restrict__ dz, double *__restrict__ d,
                             double *__restrict__ di, double *__restrict__ lm, double *__restrict__ s, double *__restrict__ z)
 {
-    GS_LOOP(i, n) {
-        const double l = lm[i];
-        const double ss = sqrt((step * ds[i] + 1.0) * l), zz = sqrt((step * dz[i] + 1.0) * l);
-        ds[i] = ss;
-        dz[i] = zz;
-        const double dd = (d[i] * ss) / zz;
-        d[i] = dd;
-        const double dinv = 1.0 / dd;
-        di[i] = dinv;
-        const double ln = ss * zz;
-        lm[i] = ln;
-        s[i] = ln * dd;
-        z[i] = ln * dinv;
-    }
+    GS_LOOP(i, n) lp_update_elem(i, step, ds, dz, d, di, lm, s, z);
 }
 
 // ---- second half of f6_no_ir with dtau kept on the device (coneprog.py:1162-1195, 1303-1316): the host used to fetch the
@@ -333,11 +346,16 @@ int reduce_scratch_doubles() { return 32 * RED_BLOCKS + 1; }
 // G[pb] runs along the entry's own column.  The form this replaces -- one lane per entry, three dependent gathers
 // w[gi[pa]] * G[pa] * G[pb] per product, a grid capped at 2048 workgroups -- took 80 us on the random-pattern calibration of
 // BASELINE.md (ml = 2e5, 4 entries per row, nnz(S) = 1.25e6: entries with 16 products serialised 16 dependent round trips).
+template <bool SQ>                                    // SQ: w holds di, the weight is its square (misc.py:1420: W^-1 applied twice)
 __global__ void k_atda_scale(int64_t gnz, const int32_t *__restrict__ gi, const double *__restrict__ gx, const double *__restrict__ w,
                              double *__restrict__ wg)
 {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < gnz) wg[a] = w[gi[a]] * gx[a];
+    if (a < gnz) {
+        const double v = w[gi[a]];
+        const double wv = SQ ? v * v : v;
+        wg[a] = wv * gx[a];
+    }
 }
 template <int LPE>                                   // lanes per entry: 1, 2 or 4
 __global__ __launch_bounds__(256) void k_atda(int64_t snz, const int64_t *__restrict__ pp, const int32_t *__restrict__ pa,
@@ -361,10 +379,11 @@ __global__ void k_add_at(int64_t pnz, const int64_t *__restrict__ slot, const do
     GS_LOOP(q, pnz) sx[slot[q]] += px[q];
 }
 void launch_atda(hipStream_t st, int64_t snz, int64_t gnz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
-                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx)
+                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx, bool w_is_di)
 {
     if (snz <= 0) return;
-    if (gnz > 0) hipLaunchKernelGGL(k_atda_scale, dim3((unsigned)((gnz + 255) / 256)), dim3(256), 0, st, gnz, gi, gx, w, wg);
+    if (gnz > 0 && w_is_di) hipLaunchKernelGGL(k_atda_scale<true>, dim3((unsigned)((gnz + 255) / 256)), dim3(256), 0, st, gnz, gi, gx, w, wg);
+    else if (gnz > 0) hipLaunchKernelGGL(k_atda_scale<false>, dim3((unsigned)((gnz + 255) / 256)), dim3(256), 0, st, gnz, gi, gx, w, wg);
     static const int lpe = [] { const char *e = getenv("KVX_ATDA_LPE"); return e ? atoi(e) : 4; }();
     if (lpe >= 4) hipLaunchKernelGGL(k_atda<4>, dim3((unsigned)((4 * snz + 255) / 256)), dim3(256), 0, st, snz, pp, pa, pb, wg, gx, sx);
     else if (lpe == 2) hipLaunchKernelGGL(k_atda<2>, dim3((unsigned)((2 * snz + 255) / 256)), dim3(256), 0, st, snz, pp, pa, pb, wg, gx, sx);
@@ -464,6 +483,275 @@ void launch_dense_from_ccs(hipStream_t st, int64_t n, const int64_t *Ap, const i
 void launch_pack_lower(hipStream_t st, int64_t p, const double *K, int64_t ld, double *out)
 {
     if (p > 0) hipLaunchKernelGGL(k_pack_lower, dim3((unsigned)std::min<int64_t>((p + 255) / 256, 64), (unsigned)p), dim3(256), 0, st, p, K, ld, out);
+}
+
+// ---- round 3: the interior-point iteration in a fifth of the launches --------------------------------------------------------
+// A kernel of a few microseconds costs its launch and the drain before the next dependent one (4-5 us each on one stream): the
+// ~85 BLAS-1-sized launches of an iteration were a fifth of its time.  The kernels below do the same arithmetic, element for
+// element in the same order and with the same roundings as the sequences they replace (products that the separate kernels
+// rounded before an addition are rounded here too: `fp contract(off)` and explicit fma where the old code had one), so an
+// interior-point run is bit for bit the one of the unfused calls (tests/test_kkt_gpu.py::test_fused_iteration_is_bitwise).
+// Reductions are ONE launch: the second stage of the fixed tree (256 partial results per reduction) is run by the consumer -- the
+// host after the copy it makes anyway, or every workgroup of the next kernel for itself -- with the same association as k_reduce2.
+// (A "last workgroup finishes" form with a ticket was measured first: its device-scope release/acquire fences write back and
+// invalidate the L2 of every XCD, 25-48 us per launch against 5 for a second launch.)
+
+// second stage of the fixed tree for one reduction, by one wavefront (the arithmetic of k_reduce2)
+template <bool MAXNEG>
+__device__ __forceinline__ double reduce2_wave(const double *__restrict__ part, int lane)
+{
+    double acc = MAXNEG ? -1.7976931348623157e308 : 0.0;
+    for (int i = lane; i < RED_BLOCKS; i += 64) acc = MAXNEG ? fmax(acc, part[i]) : acc + part[i];
+    return wave_red<MAXNEG>(acc);
+}
+// first stage only (k_reduce1 / k_reduce1_multi): the caller fetches the RED_BLOCKS partial results per reduction and runs the
+// second stage on the host with the same association (kkt_api.cpp, host_reduce2) -- one launch per reduction call instead of two
+void launch_reduce_multi_stage1(hipStream_t st, const MultiRed &mr, double *part)
+{
+    if (mr.count <= 0) return;
+    hipLaunchKernelGGL(k_reduce1_multi, dim3(RED_BLOCKS, (unsigned)mr.count), dim3(256), 0, st, mr, part);
+}
+int reduce_blocks() { return RED_BLOCKS; }
+
+// ---- KKT solve with misc.kkt_chol2's factor (misc.py:1489-1563, p = 0), the parts around the triangular solves:
+//   pre :  x2_k := xs_k xin_k + G' (di .* (zin_k .* di))                                     [z := W^-1 z ; x += Gs' z]
+//   post:  xout_k := xos_k x2_k ;  zout_k := zos_k (di .* (G x2_k) - zin_k .* di)            [z := Gs x - z]
+// for one or two right-hand sides (grid.y), one launch each: mul + xmy + spmv + copy, copy + spmv + xmy (+ two scal) before.
+__global__ __launch_bounds__(256) void k_kkt_pre(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
+                                                 const double *__restrict__ Ax, const double *__restrict__ di, KktSides r,
+                                                 double *__restrict__ x2, int64_t ld)
+{
+#pragma clang fp contract(off)
+    const KktSide sd = r.s[blockIdx.y];
+    const double *__restrict__ z = sd.zin;
+    double *__restrict__ out = x2 + (int64_t)blockIdx.y * ld;
+    const int sub = threadIdx.x & 15;
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (; j < n; j += stride) {
+        double acc = 0.0;
+        for (int64_t p = Ap[j] + sub; p < Ap[j + 1]; p += 16) {
+            const int64_t i = Ai[p];
+            const double dd = di[i];
+            const double zs = z[i] * dd;                      // z := W^-1 z
+            const double t = dd * zs;                         // t := di .* z
+            acc = __builtin_fma(Ax[p], t, acc);
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) {
+            const double x0 = sd.xs * sd.xin[j];
+            out[j] = x0 + acc;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_kkt_post(int64_t ml, int64_t n, unsigned nb_rows, const int64_t *__restrict__ Ap,
+                                                  const int64_t *__restrict__ Ai, const double *__restrict__ Ax,
+                                                  const double *__restrict__ di, KktSides r, const double *__restrict__ x2, int64_t ld)
+{
+#pragma clang fp contract(off)
+    const KktSide sd = r.s[blockIdx.y];
+    const double *__restrict__ xk = x2 + (int64_t)blockIdx.y * ld;
+    if (blockIdx.x >= nb_rows) {                                                 // the x part
+        const int64_t stride = (int64_t)(gridDim.x - nb_rows) * 256;
+        for (int64_t j = (int64_t)(blockIdx.x - nb_rows) * 256 + threadIdx.x; j < n; j += stride) sd.xout[j] = xk[j] * sd.xos;
+        return;
+    }
+    const int sub = threadIdx.x & 15;
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)nb_rows * 256) >> 4;
+    for (; i < ml; i += stride) {
+        double acc = 0.0;
+        for (int64_t p = Ap[i] + sub; p < Ap[i + 1]; p += 16) acc = __builtin_fma(Ax[p], xk[Ai[p]], acc);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (sub == 0) {
+            const double t = 0.0 + acc;                       // t := G x  (beta = 0, alpha = 1 of the mat-vec)
+            const double dd = di[i];
+            const double zs = sd.zin[i] * dd;
+            const double pr = dd * t;
+            const double v = pr - zs;
+            sd.zout[i] = v * sd.zos;
+        }
+    }
+}
+static inline unsigned groups16(int64_t rows) { return (unsigned)std::min<int64_t>(std::max<int64_t>((rows * 16 + 255) / 256, 1), 16384); }
+void launch_kkt_pre(hipStream_t st, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
+                    const KktSides &r, double *x2, int64_t ld)
+{
+    if (n > 0 && nrhs > 0) hipLaunchKernelGGL(k_kkt_pre, dim3(groups16(n), (unsigned)nrhs), dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
+}
+void launch_kkt_post(hipStream_t st, int64_t ml, int64_t n, const int64_t *tGp, const int64_t *tGi, const double *tGx, const double *di,
+                     int nrhs, const KktSides &r, const double *x2, int64_t ld)
+{
+    if (nrhs <= 0 || (ml <= 0 && n <= 0)) return;
+    const unsigned nbr = ml > 0 ? groups16(ml) : 0, nbx = n > 0 ? (unsigned)std::min<int64_t>((n + 255) / 256, 4096) : 0;
+    hipLaunchKernelGGL(k_kkt_post, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+}
+
+// ---- residuals of an iteration (coneprog.py:861-896, p = 0): hrx := -G'z ; rx := hrx - tau c ; hrz := G x + s ; rz := hrz - tau h
+// in one launch (fill + two mat-vecs + axpy + two lincomb before): workgroups [0, nb_c) take the columns of G, the rest its rows.
+__global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, unsigned nb_c, const int64_t *__restrict__ Gp,
+                                                      const int64_t *__restrict__ Gi, const double *__restrict__ Gx,
+                                                      const int64_t *__restrict__ Tp, const int64_t *__restrict__ Ti,
+                                                      const double *__restrict__ Tx, const double *__restrict__ x,
+                                                      const double *__restrict__ z, const double *__restrict__ s,
+                                                      const double *__restrict__ c, const double *__restrict__ h, double tau,
+                                                      double *__restrict__ hrx, double *__restrict__ rx, double *__restrict__ hrz,
+                                                      double *__restrict__ rz)
+{
+#pragma clang fp contract(off)
+    const int sub = threadIdx.x & 15;
+    if (blockIdx.x < nb_c) {
+        int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+        const int64_t stride = ((int64_t)nb_c * 256) >> 4;
+        for (; j < n; j += stride) {
+            double acc = 0.0;
+            for (int64_t p = Gp[j] + sub; p < Gp[j + 1]; p += 16) acc = __builtin_fma(Gx[p], z[Gi[p]], acc);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (sub == 0) {
+                const double v = __builtin_fma(-1.0, acc, 0.0);                 // hrx := 0 ; hrx := -G'z + hrx
+                hrx[j] = v;
+                rx[j] = __builtin_fma(-tau, c[j], v);                           // rx := hrx - tau c
+            }
+        }
+    } else {
+        int64_t i = ((int64_t)(blockIdx.x - nb_c) * 256 + threadIdx.x) >> 4;
+        const int64_t stride = ((int64_t)(gridDim.x - nb_c) * 256) >> 4;
+        for (; i < ml; i += stride) {
+            double acc = 0.0;
+            for (int64_t p = Tp[i] + sub; p < Tp[i + 1]; p += 16) acc = __builtin_fma(Tx[p], x[Ti[p]], acc);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (sub == 0) {
+                const double t = __builtin_fma(1.0, acc, 0.0);                  // hrz := G x
+                const double v = __builtin_fma(1.0, s[i], t);                   // hrz += s
+                hrz[i] = v;
+                rz[i] = __builtin_fma(-tau, h[i], v);                           // rz := hrz - tau h
+            }
+        }
+    }
+}
+void launch_lp_residuals(hipStream_t st, int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *Tp,
+                         const int64_t *Ti, const double *Tx, const double *x, const double *z, const double *s, const double *c,
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
+{
+    const unsigned nbc = n > 0 ? groups16(n) : 0, nbr = ml > 0 ? groups16(ml) : 0;
+    if (nbc + nbr == 0) return;
+    hipLaunchKernelGGL(k_lp_residuals, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx,
+                       hrz, rz);
+}
+
+// ---- second half of f6_no_ir in two launches (sixteen before; kvx_lp_second_half_dev) ------------------------------------
+//  A: first stage of the three or four inner products (k_reduce1_multi);
+//  B: every workgroup finishes them and forms dtau (k_lp_dtau's expression), then dx += dtau x1 [dy += dtau y1], the step_post
+//     update of ds / dz / ws3 and the first stage of the step bounds max(-ds), max(-dz) of the new values; the host fetches the
+//     partial maxima with dtau and finishes them.
+__device__ __forceinline__ void lp_dtau_eval(const double *r, double dgi, double dtau0, double z1z1_host, int use_host, double *out)
+{
+    const double zz = use_host ? z1z1_host : r[3];
+    out[0] = dgi * (dtau0 + r[0] + r[1] + r[2]) / (1.0 + zz);
+    out[1] = zz;
+}
+__device__ __forceinline__ void lp_step_post_elem(int64_t i, double dtau, const double *__restrict__ z1, const double *__restrict__ lm,
+                                                  double *__restrict__ ds, double *__restrict__ dz, double *__restrict__ ws3,
+                                                  double &ss_out, double &zz_out)
+{
+    const double zz = dz[i] + dtau * z1[i];
+    const double ss = ds[i] - zz;
+    if (ws3) ws3[i] = ss * zz;
+    const double l = lm[i];
+    ss_out = ss / l;
+    zz_out = zz / l;
+    ds[i] = ss_out;
+    dz[i] = zz_out;
+}
+__global__ __launch_bounds__(256) void k_lp_half_b(LpHalf a, double dgi, double dtau0, double z1z1_host, int use_host,
+                                                   const double *__restrict__ part, double *__restrict__ part2, double *__restrict__ sc)
+{
+    __shared__ double sh[8];
+    __shared__ double s_dtau;
+    {   // second stage of the inner products of launch A and dtau, by every workgroup for itself (wave w: reduction w)
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const bool lv = !(wv == 1 && a.p <= 0) && !(wv == 3 && use_host);
+        const double v = lv ? reduce2_wave<false>(part + (int64_t)wv * RED_BLOCKS, lane) : 0.0;
+        if (lane == 0) sh[wv] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double o[2];
+            lp_dtau_eval(sh, dgi, dtau0, z1z1_host, use_host, o);
+            s_dtau = o[0];
+            if (blockIdx.x == 0) { sc[0] = o[0]; sc[1] = o[1]; }
+        }
+        __syncthreads();
+    }
+    const double dtau = s_dtau;
+    if (blockIdx.x >= RED_BLOCKS) {                                             // dx += dtau x1, dy += dtau y1
+        const int64_t t = (int64_t)(blockIdx.x - RED_BLOCKS) * 256 + threadIdx.x;
+        const int64_t stride = (int64_t)(gridDim.x - RED_BLOCKS) * 256;
+        for (int64_t i = t; i < a.n; i += stride) a.dxw[i] += dtau * a.x1[i];
+        for (int64_t i = t; i < a.p; i += stride) a.dyw[i] += dtau * a.y1[i];
+        return;
+    }
+    double as = -1.7976931348623157e308, az = -1.7976931348623157e308;
+    const int64_t per = (a.ml + RED_BLOCKS - 1) / RED_BLOCKS;
+    const int64_t b0 = per * blockIdx.x, b1 = min(a.ml, b0 + per);
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += 256) {
+        double ss, zz;
+        lp_step_post_elem(i, dtau, a.z1, a.lm, a.dsw, a.dzw, a.ws3, ss, zz);
+        as = fmax(as, -ss);
+        az = fmax(az, -zz);
+    }
+    as = wave_red<true>(as);
+    az = wave_red<true>(az);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = as; sh[4 + (threadIdx.x >> 6)] = az; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r0 = sh[0], r1 = sh[4];
+        for (int w = 1; w < 4; w++) { r0 = fmax(r0, sh[w]); r1 = fmax(r1, sh[4 + w]); }
+        part2[blockIdx.x] = r0;                                                 // first stage of max(-ds), max(-dz): the host finishes
+        part2[RED_BLOCKS + blockIdx.x] = r1;
+    }
+}
+// part: 4 * RED_BLOCKS partial sums (launch A) ; part2: 2 * RED_BLOCKS partial maxima + sc[2] = (dtau, z1'z1) behind them
+void launch_lp_second_half(hipStream_t st, const LpHalf &a, double dgi, double dtau0, double z1z1, double *part, double *part2)
+{
+    const int use_host = z1z1 < 0.0 ? 0 : 1;
+    MultiRed mr;
+    mr.count = use_host ? 3 : 4;
+    for (int i = 0; i < 32; i++) { mr.kind[i] = 0; mr.n[i] = 0; mr.x[i] = nullptr; mr.y[i] = nullptr; }
+    mr.n[0] = a.n; mr.x[0] = a.c; mr.y[0] = a.dx;
+    mr.n[1] = a.p > 0 ? a.p : 0; mr.x[1] = a.b; mr.y[1] = a.dy;                  // p = 0: an empty sum (its partials are not read)
+    mr.n[2] = a.ml; mr.x[2] = a.th; mr.y[2] = a.dz;
+    mr.n[3] = a.ml; mr.x[3] = a.z1; mr.y[3] = a.z1;
+    hipLaunchKernelGGL(k_reduce1_multi, dim3(RED_BLOCKS, (unsigned)mr.count), dim3(256), 0, st, mr, part);
+    const int64_t nx = std::max(a.n, a.p);
+    const unsigned nbx = (unsigned)std::min<int64_t>(std::max<int64_t>((nx + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(k_lp_half_b, dim3(RED_BLOCKS + nbx), dim3(256), 0, st, a, dgi, dtau0, z1z1, use_host, part, part2,
+                       part2 + 2 * RED_BLOCKS);
+}
+
+// ---- end of the iteration: the fused 'l'-cone update (k_lp_update) and x += step dx in one launch
+__global__ void k_lp_update_x(int64_t ml, int64_t n, unsigned nb_ml, double step, double *__restrict__ ds, double *__restrict__ dz,
+                              double *__restrict__ d, double *__restrict__ di, double *__restrict__ lm, double *__restrict__ s,
+                              double *__restrict__ z, const double *__restrict__ dx, double *__restrict__ x)
+{
+    if (blockIdx.x >= nb_ml) {
+        const int64_t stride = (int64_t)(gridDim.x - nb_ml) * blockDim.x;
+        for (int64_t i = (int64_t)(blockIdx.x - nb_ml) * blockDim.x + threadIdx.x; i < n; i += stride) x[i] += step * dx[i];
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ml; i += (int64_t)nb_ml * blockDim.x)
+        lp_update_elem(i, step, ds, dz, d, di, lm, s, z);
+}
+void launch_lp_update_x(hipStream_t st, int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lm,
+                        double *s, double *z, const double *dx, double *x)
+{
+    const unsigned nbm = ml > 0 ? grid_for(ml) : 0, nbx = n > 0 ? grid_for(n) : 0;
+    if (nbm + nbx == 0) return;
+    hipLaunchKernelGGL(k_lp_update_x, dim3(nbm + nbx), dim3(256), 0, st, ml, n, nbm, step, ds, dz, d, di, lm, s, z, dx, x);
 }
 
 }  // namespace kvx

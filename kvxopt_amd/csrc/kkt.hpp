@@ -12,6 +12,30 @@ struct MultiRed {
     const double *x[32];
     const double *y[32];
 };
+// one right-hand side of a KKT solve around the triangular solves (k_kkt_pre / k_kkt_post)
+struct KktSide {
+    const double *xin; double xs; const double *zin;
+    double *xout; double xos; double *zout; double zos;
+};
+struct KktSides { KktSide s[2]; };
+// operands of the second half of f6_no_ir (k_lp_half_a / k_lp_half_b)
+struct LpHalf {
+    int64_t ml, n, p;
+    const double *c, *dx, *b, *dy, *th, *dz, *z1, *x1, *y1, *lm;
+    double *dxw, *dyw, *dsw, *dzw, *ws3;
+};
+void launch_reduce_multi_stage1(hipStream_t st, const MultiRed &mr, double *part);   // RED_BLOCKS partial results per reduction
+int reduce_blocks();
+void launch_kkt_pre(hipStream_t st, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
+                    const KktSides &r, double *x2, int64_t ld);
+void launch_kkt_post(hipStream_t st, int64_t ml, int64_t n, const int64_t *tGp, const int64_t *tGi, const double *tGx, const double *di,
+                     int nrhs, const KktSides &r, const double *x2, int64_t ld);
+void launch_lp_residuals(hipStream_t st, int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *Tp,
+                         const int64_t *Ti, const double *Tx, const double *x, const double *z, const double *s, const double *c,
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz);
+void launch_lp_second_half(hipStream_t st, const LpHalf &a, double dgi, double dtau0, double z1z1, double *part, double *part2);
+void launch_lp_update_x(hipStream_t st, int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lm,
+                        double *s, double *z, const double *dx, double *x);
 void launch_dense_gemv(hipStream_t st, int64_t m, int64_t n, int64_t nrhs, double alpha, const double *A, int64_t lda, const double *x,
                        int64_t ldx, double beta, double *y, int64_t ldy);
 void launch_lincomb(hipStream_t st, int64_t n, double a, const double *x, double b, const double *y, double *z);
@@ -39,7 +63,7 @@ void launch_dot(hipStream_t st, int64_t n, const double *x, const double *y, dou
 void launch_maxneg(hipStream_t st, int64_t n, const double *x, double *part, double *out);
 int reduce_scratch_doubles();
 void launch_atda(hipStream_t st, int64_t snz, int64_t gnz, const int64_t *pp, const int32_t *pa, const int32_t *pb,
-                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx);
+                 const int32_t *gi, const double *gx, const double *w, double *wg, double *sx, bool w_is_di = false);
 void launch_add_at(hipStream_t st, int64_t pnz, const int64_t *slot, const double *px, double *sx);
 void launch_spmm_t(hipStream_t st, int64_t n, int64_t ncols, const int64_t *Ap, const int64_t *Ai, const double *Ax, const double *X,
                    int64_t ldx, double *Y, int64_t ldy);

@@ -6,6 +6,8 @@
 #include "kkt.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -40,9 +42,15 @@ namespace {
 
 struct Scratch {
     double *part = nullptr;
-    double *host = nullptr;     // pinned, 32 doubles
+    double *host = nullptr;     // pinned, as many doubles as `part`
     double *multi = nullptr;    // device, 32 results of kvx_nt_reduce_multi_dev
 };
+// KVX_LP_UNFUSED=1: the separate launches of rounds 1-2 (kept for the bitwise A/B of the fused kernels)
+bool lp_unfused()
+{
+    static const bool v = [] { const char *e = getenv("KVX_LP_UNFUSED"); return e && atoi(e) != 0; }();
+    return v;
+}
 Scratch &scratch()
 {
     static thread_local Scratch s;
@@ -53,7 +61,7 @@ int ensure_scratch()
     Scratch &s = scratch();
     if (s.part) return KVX_OK;
     HIPCHK(pool_malloc((void **)&s.part, reduce_scratch_doubles() * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&s.host, 32 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&s.host, reduce_scratch_doubles() * sizeof(double), hipHostMallocDefault));
     HIPCHK(pool_malloc((void **)&s.multi, 32 * sizeof(double)));
     return KVX_OK;
 }
@@ -211,6 +219,18 @@ int kvx_atda_assemble_dev(kvx_atda *T, const double *Gx, const double *w, const 
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
+// the same with the weights given by their square roots: S = G' diag(di)^2 G (+ P) -- what misc.kkt_chol2 forms (misc.py:1418-1426);
+// the square is taken while G is scaled (one launch less than ssqr + assemble, the same roundings)
+int kvx_atda_assemble_sq_dev(kvx_atda *T, const double *Gx, const double *di, const double *Px, double *Sx)
+{
+    if (!T) return KVX_EINVAL;
+    int rc = atda_device(T);
+    if (rc) return rc;
+    launch_atda(nullptr, T->snz, T->gnz, T->d_pp, T->d_pa, T->d_pb, T->d_gi, Gx, di, T->d_wg, Sx, true);
+    if (Px && T->pnz > 0) launch_add_at(nullptr, T->pnz, T->d_pslot, Px, Sx);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
 
 static int kvx_atda_assemble_impl(kvx_atda *T, const double *Gx, const double *w, const double *Px, double *Sx)
 {
@@ -273,12 +293,43 @@ int kvx_nt_sinv_dev(int64_t ml, double *x, const double *y)
 int kvx_nt_ssqr_dev(int64_t ml, double *x, const double *y)
 { launch_sqr(nullptr, ml, x, y); HIPCHK(hipGetLastError()); return KVX_OK; }
 
+// Second stage of the fixed reduction tree on the host: the arithmetic of k_reduce2 (64 lanes, each over its strided partial
+// results in ascending order, then the xor butterfly 32, 16, ..., 1; lane 0's value) -- the same bits as the device second stage.
+static double host_reduce2(const double *part, bool mx)
+{
+    const int nb = reduce_blocks();
+    double v[64], t[64];
+    for (int l = 0; l < 64; l++) {
+        double acc = mx ? -1.7976931348623157e308 : 0.0;
+        for (int i = l; i < nb; i += 64) acc = mx ? std::fmax(acc, part[i]) : acc + part[i];
+        v[l] = acc;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = mx ? std::fmax(v[l], v[l ^ o]) : v[l] + v[l ^ o];
+        std::memcpy(v, t, sizeof(v));
+    }
+    return v[0];
+}
+static MultiRed one_reduction(int kind, int64_t n, const double *x, const double *y)
+{
+    MultiRed mr;
+    mr.count = 1;
+    for (int i = 0; i < 32; i++) { mr.kind[i] = 0; mr.n[i] = 0; mr.x[i] = nullptr; mr.y[i] = nullptr; }
+    mr.kind[0] = kind; mr.n[0] = n; mr.x[0] = x; mr.y[0] = y;
+    return mr;
+}
 int kvx_nt_sdot_dev(int64_t ml, const double *x, const double *y, double *result_host)
 {
     if (!result_host) return KVX_EINVAL;
     int rc = ensure_scratch();
     if (rc) return rc;
     Scratch &s = scratch();
+    if (!lp_unfused()) {
+        launch_reduce_multi_stage1(nullptr, one_reduction(0, ml, x, y), s.part);
+        HIPCHK(hipMemcpy(s.host, s.part, reduce_blocks() * sizeof(double), hipMemcpyDeviceToHost));
+        *result_host = host_reduce2(s.host, false);
+        return KVX_OK;
+    }
     launch_dot(nullptr, ml, x, y, s.part, s.part + reduce_scratch_doubles() - 1);
     HIPCHK(hipMemcpy(s.host, s.part + reduce_scratch_doubles() - 1, sizeof(double), hipMemcpyDeviceToHost));
     *result_host = *s.host;
@@ -290,6 +341,12 @@ int kvx_nt_max_step_dev(int64_t ml, const double *x, double *result_host)
     int rc = ensure_scratch();
     if (rc) return rc;
     Scratch &s = scratch();
+    if (!lp_unfused()) {
+        launch_reduce_multi_stage1(nullptr, one_reduction(1, ml, x, x), s.part);
+        HIPCHK(hipMemcpy(s.host, s.part, reduce_blocks() * sizeof(double), hipMemcpyDeviceToHost));
+        *result_host = host_reduce2(s.host, true);
+        return KVX_OK;
+    }
     launch_maxneg(nullptr, ml, x, s.part, s.part + reduce_scratch_doubles() - 1);
     HIPCHK(hipMemcpy(s.host, s.part + reduce_scratch_doubles() - 1, sizeof(double), hipMemcpyDeviceToHost));
     *result_host = *s.host;
@@ -319,6 +376,12 @@ int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, co
         mr.x[i] = x[i];
         mr.y[i] = kind[i] == 0 ? y[i] : x[i];
     }
+    if (!lp_unfused()) {                                            // one launch; the second stage on the host
+        launch_reduce_multi_stage1(nullptr, mr, s.part);
+        HIPCHK(hipMemcpy(s.host, s.part, (size_t)count * reduce_blocks() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; i++) out_host[i] = host_reduce2(s.host + (size_t)i * reduce_blocks(), kind[i] != 0);
+        return KVX_OK;
+    }
     launch_reduce_multi(nullptr, mr, s.part, s.multi);              // all of them in two launches
     HIPCHK(hipMemcpy(s.host, s.multi, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < count; i++) out_host[i] = s.host[i];
@@ -337,6 +400,20 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
     if (rc) return rc;
     Scratch &s = scratch();
     double *r = s.multi, *sc = s.multi + 8, *mx = s.multi + 16;
+    if (!lp_unfused()) {
+        LpHalf a;
+        a.ml = ml; a.n = n; a.p = p;
+        a.c = c; a.dx = dx; a.b = b; a.dy = dy; a.th = th; a.dz = dz; a.z1 = z1; a.x1 = x1; a.y1 = y1; a.lm = lmbda;
+        a.dxw = dx; a.dyw = dy; a.dsw = ds; a.dzw = dz; a.ws3 = ws3;
+        const int nb = reduce_blocks();
+        double *part2 = s.part + 4 * nb;                            // 2 nb partial maxima, then (dtau, z1'z1)
+        launch_lp_second_half(nullptr, a, dgi, dtau0, z1z1, s.part, part2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(s.host, part2, (2 * nb + 2) * sizeof(double), hipMemcpyDeviceToHost));
+        out_host[0] = s.host[2 * nb]; out_host[1] = s.host[2 * nb + 1];
+        out_host[2] = host_reduce2(s.host, true); out_host[3] = host_reduce2(s.host + nb, true);
+        return KVX_OK;
+    }
     launch_dot(nullptr, n, c, dx, s.part, r + 0);
     if (p > 0) launch_dot(nullptr, p, b, dy, s.part, r + 1);
     else HIPCHK(hipMemsetAsync(r + 1, 0, sizeof(double), nullptr));
@@ -351,6 +428,58 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(s.host, s.multi, 18 * sizeof(double), hipMemcpyDeviceToHost));
     out_host[0] = s.host[8]; out_host[1] = s.host[9]; out_host[2] = s.host[16]; out_host[3] = s.host[17];
+    return KVX_OK;
+}
+
+// ---- round 3: the rest of an interior-point iteration in few launches (kkt.hip, "round 3") ----
+// KKT solve with the factor of S, the parts around the triangular solves (misc.py:1489-1563 with p = 0) for nrhs = 1 or 2 sides:
+//   pre :  x2(:,k) := xscale_k * xin_k + G' (di .* (zin_k .* di))
+//   post:  xout_k := xoscale_k * x2(:,k) ;  zout_k := zoscale_k * (di .* (G x2(:,k)) - zin_k .* di)
+// G by its CCS arrays (pre) and by the CCS arrays of its transpose (post), int64 indices on the device as for kvx_spmv_dev.
+int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
+                          const kvx_kkt_side *sides, double *x2, int64_t ldx2)
+{
+    if (ml < 0 || n < 0 || nrhs < 1 || nrhs > 2 || !sides || !x2 || ldx2 < std::max<int64_t>(n, 1)) return KVX_EINVAL;
+    KktSides r;
+    for (int k = 0; k < 2; k++) {
+        const kvx_kkt_side &q = sides[k < nrhs ? k : 0];
+        r.s[k] = KktSide{q.xin, q.xscale, q.zin, q.xout, q.xoscale, q.zout, q.zoscale};
+    }
+    launch_kkt_pre(nullptr, n, Gp, Gi, Gx, di, nrhs, r, x2, ldx2);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int64_t *GTi, const double *GTx, const double *di, int nrhs,
+                           const kvx_kkt_side *sides, const double *x2, int64_t ldx2)
+{
+    if (ml < 0 || n < 0 || nrhs < 1 || nrhs > 2 || !sides || !x2 || ldx2 < std::max<int64_t>(n, 1)) return KVX_EINVAL;
+    KktSides r;
+    for (int k = 0; k < 2; k++) {
+        const kvx_kkt_side &q = sides[k < nrhs ? k : 0];
+        r.s[k] = KktSide{q.xin, q.xscale, q.zin, q.xout, q.xoscale, q.zout, q.zoscale};
+    }
+    launch_kkt_post(nullptr, ml, n, GTp, GTi, GTx, di, nrhs, r, x2, ldx2);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+// residuals of an iteration without equality constraints (coneprog.py:861-896): hrx := -G'z, rx := hrx - tau c, hrz := G x + s,
+// rz := hrz - tau h in one launch
+int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *GTp,
+                         const int64_t *GTi, const double *GTx, const double *x, const double *z, const double *s, const double *c,
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
+{
+    if (ml < 0 || n < 0) return KVX_EINVAL;
+    launch_lp_residuals(nullptr, ml, n, Gp, Gi, Gx, GTp, GTi, GTx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
+    HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+// kvx_lp_update_dev and x += step dx in one launch
+int kvx_lp_update_x_dev(int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s,
+                        double *z, const double *dx, double *x)
+{
+    if (ml < 0 || n < 0) return KVX_EINVAL;
+    launch_lp_update_x(nullptr, ml, n, step, ds, dz, d, di, lmbda, s, z, dx, x);
+    HIPCHK(hipGetLastError());
     return KVX_OK;
 }
 

@@ -28,6 +28,19 @@ from .chol import Factor
 
 EXPON = 3          # coneprog.py:423
 STEP = 0.99        # coneprog.py:424
+# KVX_LP_UNFUSED=1: one launch per BLAS-1-sized operation, as in rounds 1-2 (the library reads the same variable); the fused launches
+# of round 3 do the same arithmetic with the same roundings -- tests/test_kkt_gpu.py compares the two bit for bit
+_UNFUSED = os.environ.get("KVX_LP_UNFUSED", "0") not in ("", "0")
+
+
+def _sides(items):
+    """ctypes array of kvx_kkt_side from (xin, xscale, zin, xout, xoscale, zout, zoscale) tuples of DVecs and floats."""
+    arr = (_lib.KktSide * 2)()
+    for k, (xin, xs, zin, xout, xos, zout, zos) in enumerate(items):
+        a = arr[k]
+        a.xin, a.xscale, a.zin = xin.ptr, float(xs), zin.ptr
+        a.xout, a.xoscale, a.zout, a.zoscale = xout.ptr, float(xos), zout.ptr, float(zos)
+    return arr
 
 
 class DVec:
@@ -217,12 +230,56 @@ class KKTChol2Dev:
         """S = G' diag(di)^2 G on the fixed pattern, numeric refactorisation (misc.py:1418-1462).
         Raises ArithmeticError when S is not positive definite -- with sync=False only the NEXT solve does (the solve
         is queued behind the factorisation without a host round trip)."""
-        self.w.sqr_of(di)
-        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
-                                              None if self.Px is None else self.Px.ptr, self.Sx.ptr))
+        self._assemble(di)
         self.fac.factorize_dev(self.Sx.ptr, sync=sync)
         self.di = di
         self.nfactor += 1
+
+    def _assemble(self, di):
+        if _UNFUSED:
+            self.w.sqr_of(di)
+            raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
+                                                  None if self.Px is None else self.Px.ptr, self.Sx.ptr))
+        else:                                            # the square is taken while G is scaled: one launch less
+            raise_for(lib().kvx_atda_assemble_sq_dev(self._plan, self.G.vx.ptr, di.ptr,
+                                                     None if self.Px is None else self.Px.ptr, self.Sx.ptr))
+
+    def _x2buf(self):
+        if getattr(self, "_x2", None) is None:
+            self._x2 = DVec(2 * max(self.n, 1))
+        return self._x2
+
+    def _pre(self, sides, nrhs):
+        G = self.G
+        raise_for(lib().kvx_kkt_solve_pre_dev(self.ml, self.n, G.cp.ptr, G.ri.ptr, G.vx.ptr, self.di.ptr, nrhs, sides,
+                                              self._x2buf().ptr, max(1, self.n)))
+
+    def _post(self, sides, nrhs):
+        G = self.G
+        raise_for(lib().kvx_kkt_solve_post_dev(self.ml, self.n, G.tcp.ptr, G.tri.ptr, G.tvx.ptr, self.di.ptr, nrhs, sides,
+                                               self._x2buf().ptr, max(1, self.n)))
+
+    def solve_sides(self, items):
+        """One or two KKT solves with the current factor, each side given as (xin, xscale, zin, xout, xoscale, zout, zoscale):
+        x2 := xscale*xin + Gs' W^-1 zin ; x2 := S^-1 x2 ; xout := xoscale*x2 ; zout := zoscale*(Gs x2 - W^-1 zin)
+        (misc.py:1489-1563 with p = 0) in three enqueues: kvx_kkt_solve_pre_dev, the triangular solves, kvx_kkt_solve_post_dev."""
+        nrhs = len(items)
+        sides = _sides(items)
+        self._pre(sides, nrhs)
+        self.fac.solve_dev(self._x2buf().ptr, 0, nrhs, max(1, self.n), sync=not self.async_solves)
+        self._post(sides, nrhs)
+
+    def factor_solve_sides(self, di, items):
+        """factor(di) and solve_sides(items) with the factorisation and the triangular solves as ONE enqueue
+        (kvx_chol_factorize_solve_async_dev).  Enqueue only -- check() after the next host synchronisation."""
+        nrhs = len(items)
+        sides = _sides(items)
+        self._assemble(di)
+        self.di = di
+        self.nfactor += 1
+        self._pre(sides, nrhs)
+        self.fac.factorize_solve_async_dev(self.Sx.ptr, self._x2buf().ptr, nrhs, max(1, self.n))
+        self._post(sides, nrhs)
 
     def factor_solve2(self, di, xa, za, xb, zb):
         """factor(di) and solve2(xa, za, xb, zb) as ONE enqueue (kvx_chol_factorize_solve_async_dev): the two right-hand sides
@@ -230,11 +287,10 @@ class KKTChol2Dev:
         the tree.  Same kernels, same order: bitwise what factor() followed by solve2() gives.  Enqueue only -- check() after
         the next host synchronisation."""
         n = self.n
-        if getattr(self, "_x2", None) is None:
-            self._x2 = DVec(2 * max(n, 1))
-        self.w.sqr_of(di)
-        raise_for(lib().kvx_atda_assemble_dev(self._plan, self.G.vx.ptr, self.w.ptr,
-                                              None if self.Px is None else self.Px.ptr, self.Sx.ptr))
+        if not _UNFUSED:
+            return self.factor_solve_sides(di, [(xa, 1.0, za, xa, 1.0, za, 1.0), (xb, 1.0, zb, xb, 1.0, zb, 1.0)])
+        self._x2buf()
+        self._assemble(di)
         self.di = di
         self.nfactor += 1
         for k, (x, z) in enumerate(((xa, za), (xb, zb))):
@@ -255,6 +311,8 @@ class KKTChol2Dev:
     def solve(self, x, z):
         """Overwrites (x, z) with (ux, W*uz) (misc.py:1489-1563 with p = 0)."""
         di = self.di
+        if not _UNFUSED:
+            return self.solve_sides([(x, 1.0, z, x, 1.0, z, 1.0)])
         z.mul(di)                                        # z := W^{-1} z                (misc.py:1513)
         self.t.xmy(1.0, di, z)                           # t := di .* z
         self.G.gemv(self.t, x, trans="T", alpha=1.0, beta=1.0)   # x += Gs' z       (misc.py:1524)
@@ -266,8 +324,9 @@ class KKTChol2Dev:
         """Two KKT systems with the same factor in ONE two-column triangular solve (the interior-point iteration has
         two right-hand sides that do not depend on each other: the (-c, h) system and the predictor)."""
         di, n = self.di, self.n
-        if getattr(self, "_x2", None) is None:
-            self._x2 = DVec(2 * max(n, 1))
+        if not _UNFUSED:
+            return self.solve_sides([(xa, 1.0, za, xa, 1.0, za, 1.0), (xb, 1.0, zb, xb, 1.0, zb, 1.0)])
+        self._x2buf()
         for k, (x, z) in enumerate(((xa, za), (xb, zb))):
             z.mul(di)
             self.t.xmy(1.0, di, z)
@@ -643,6 +702,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         ksolve = kkt.solve
         ksolve2 = kkt.solve2
         kfactor_solve2 = None
+        fused = False
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
     else:
@@ -655,6 +715,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             kkt.solve2(xa, za, xb, zb)
         def kfactor_solve2(dd, xa, ya, za, xb, yb, zb):
             kkt.factor_solve2(dd, xa, za, xb, zb)
+        fused = not _UNFUSED                             # p = 0: the short launches of an iteration fused (kkt.hip, "round 3")
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             if trans == "T" and beta == 0.0:
                 v.fill(0.0)                                          # A' y with p = 0: the zero vector
@@ -668,6 +729,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     resz0 = max(1.0, hv.nrm2())
 
     t_loop = [None]
+    t_phase = [0.0, 0.0, 0.0]
+    t_mark = [0.0]
 
     def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True, msg=None):
         if show:                                         # the reference's closing line (coneprog.py:791,941,961,985,1010,1094)
@@ -684,7 +747,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 "iterations": iters, "factorizations": kkt.nfactor,
                 # wall time of the interior-point loop proper (coneprog.py:859-1436), i.e. without the symbolic
                 # analysis and the starting point; not a key of the reference's dictionary
-                "loop seconds": (time.perf_counter() - t_loop[0]) if t_loop[0] is not None else 0.0}
+                "loop seconds": (time.perf_counter() - t_loop[0]) if t_loop[0] is not None else 0.0,
+                # the same, split at the three host synchronisations of an iteration: [residual norms -> first direction
+                # (assembly, factorisation, two solves), -> second direction (one solve), -> update + residuals of the next]
+                "phase seconds": list(t_phase)}
 
     # ---- starting point (coneprog.py:662-822): factor with W = I ------------------------------------
     d.fill(1.0); di.fill(1.0)
@@ -749,16 +815,24 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     t_loop[0] = time.perf_counter()
     for iters in range(MAXITERS + 1):
         # residuals (coneprog.py:861-896); their norms and the objectives come back in one reduction call
-        Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
-        Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=1.0)
-        rx.lincomb(1.0, hrx, -tau, cv)
-        Af(x, hry, trans="N")
-        ry.lincomb(1.0, hry, -tau, bv)
-        Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
-        rz.lincomb(1.0, hrz, -tau, hv)
+        if fused:                                        # the six launches below in one
+            raise_for(lib().kvx_lp_residuals_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr,
+                                                 x.ptr, z.ptr, s.ptr, cv.ptr, hv.ptr, tau, hrx.ptr, rx.ptr, hrz.ptr, rz.ptr))
+        else:
+            Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
+            Gd.gemv(z, hrx, trans="T", alpha=-1.0, beta=1.0)
+            rx.lincomb(1.0, hrx, -tau, cv)
+            Af(x, hry, trans="N")
+            ry.lincomb(1.0, hry, -tau, bv)
+            Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
+            rz.lincomb(1.0, hrz, -tau, hv)
         (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = reduce_multi(
             [("dot", hrx, hrx), ("dot", rx, rx), ("dot", hry, hry), ("dot", ry, ry), ("dot", hrz, hrz), ("dot", rz, rz),
              ("dot", cv, x), ("dot", bv, y), ("dot", hv, z), ("dot", lmbda, lmbda)])
+        t_now = time.perf_counter()
+        if iters > 0:
+            t_phase[2] += t_now - t_mark[0]
+        t_mark[0] = t_now
         hresx, resx = math.sqrt(v_hrx), math.sqrt(v_rx) / tau
         hresy, resy = math.sqrt(v_hry), math.sqrt(v_ry) / tau
         hresz, resz = math.sqrt(v_hrz), math.sqrt(v_rz) / tau
@@ -797,7 +871,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             dgi = math.sqrt(tau / kappa)
             lmbda_g = math.sqrt(tau * kappa)
             lam2 = lmbda.dot(lmbda)
-        lmbdasq.sqr_of(lmbda)
+        if not fused:
+            lmbdasq.sqr_of(lmbda)                        # (fused: formed inside kvx_lp_newton_rhs_dev)
         lmbdasq_g = lmbda_g ** 2
 
         mu = (lam2 + lmbda_g ** 2) / (1 + ml)
@@ -811,10 +886,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             if i == 1:
                 dkappa += wkappa3 - sigma * mu
             # ds := -(lmbdasq (+ ws3 - sigma mu)) o\ lmbda,  dz := -((1 - sigma) rz + W' ds): one fused kernel
-            raise_for(lib().kvx_lp_newton_rhs_dev(ml, lmbdasq.ptr, ws3.ptr if i == 1 else None, sigma * mu if i == 1 else 0.0,
-                                                  1.0 - sigma, rz.ptr, lmbda.ptr, d.ptr, ds.ptr, dz.ptr))
-            dx.lincomb(1.0 - sigma, rx)
-            dy.lincomb(-(1.0 - sigma), ry)
+            raise_for(lib().kvx_lp_newton_rhs_dev(ml, None if fused else lmbdasq.ptr, ws3.ptr if i == 1 else None,
+                                                  sigma * mu if i == 1 else 0.0, 1.0 - sigma, rz.ptr, lmbda.ptr, d.ptr, ds.ptr, dz.ptr))
+            if not fused:                                # fused: dx := (1 - sigma) rx is the first operation of the KKT solve
+                dx.lincomb(1.0 - sigma, rx)
+                dy.lincomb(-(1.0 - sigma), ry)
             st8["dtau"] = (1.0 - sigma) * rt
             st8["dkappa"] = dkappa
 
@@ -822,7 +898,12 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         # one two-column triangular solve with the new factor
         try:
             kkt.async_solves = True                      # enqueue only: the host runs ahead of the GPU up to the next scalar
-            if kfactor_solve2 is not None:
+            if fused:
+                # as below, with the vector operations around the solves inside their two launches: x1 := -c, z1 := h, the
+                # scaling of (x1, z1) by dgi, dx := (1 - sigma) rx
+                newton_rhs(0)
+                kkt.factor_solve_sides(di, [(cv, -1.0, hv, x1, dgi, z1, dgi), (rx, 1.0 - sigma, dz, dx, 1.0, dz, 1.0)])
+            elif kfactor_solve2 is not None:
                 # the factorisation and the two solves in one enqueue: their right-hand sides do not depend on the factor
                 x1.lincomb(-1.0, cv)
                 y1.copy_from(bv)
@@ -836,8 +917,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 z1.copy_from(hv)
                 newton_rhs(0)
                 ksolve2(x1, y1, z1, dx, dy, dz)
-            x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
-            th.copy_from(hv).mul(di)                     # th = W^{-T} h      (coneprog.py:1126-1128)
+            if fused:
+                th.xmy(1.0, hv, di)
+            else:
+                x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
+                th.copy_from(hv).mul(di)                 # th = W^{-T} h      (coneprog.py:1126-1128)
         except ArithmeticError:
             kkt.async_solves = False
             x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
@@ -848,7 +932,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         for i in (0, 1):
             if i == 1:
                 newton_rhs(1)
-                ksolve(dx, dy, dz)
+                if fused:
+                    kkt.solve_sides([(rx, 1.0 - sigma, dz, dx, 1.0, dz, 1.0)])
+                else:
+                    ksolve(dx, dy, dz)
             # second half of f6_no_ir (coneprog.py:1162-1195), dz += dtau z1, ds -= dz, [ws3 := ds o dz for the corrector
             # (coneprog.py:1303-1306)], the scaling by lmbda and the step bounds (coneprog.py:1314-1321): dtau is formed on the
             # device from the inner products, ONE host round trip per direction (the first one after the factorisation)
@@ -858,6 +945,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                                                    z1.ptr, lmbda.ptr, dx.ptr, dy.ptr if p else None, dz.ptr, ds.ptr,
                                                    ws3.ptr if i == 0 else None, dgi, dtau0, z1z1, out4))
             dtau, z1z1, ts, tz = out4[0], out4[1], out4[2], out4[3]
+            t_now = time.perf_counter()
+            t_phase[i] += t_now - t_mark[0]
+            t_mark[0] = t_now
             if i == 0:
                 try:
                     kkt.check()                          # the stream is idle by now: no extra wait
@@ -880,10 +970,13 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 sigma = (1.0 - step) ** EXPON
 
         # update (coneprog.py:1336-1436)
-        x.axpy(dx, step)
-        y.axpy(dy, step)
         # scaled iterates, NT scaling update and unscaled s, z (coneprog.py:1343-1432, misc.py:444-464): one fused kernel
-        raise_for(lib().kvx_lp_update_dev(ml, step, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr, s.ptr, z.ptr))
+        if fused:
+            raise_for(lib().kvx_lp_update_x_dev(ml, n, step, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr, s.ptr, z.ptr, dx.ptr, x.ptr))
+        else:
+            x.axpy(dx, step)
+            y.axpy(dy, step)
+            raise_for(lib().kvx_lp_update_dev(ml, step, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr, s.ptr, z.ptr))
         dg *= math.sqrt(1.0 - step * tk) / math.sqrt(1.0 - step * tt)
         dgi = 1.0 / dg
         lmbda_g *= math.sqrt(1.0 - step * tt) * math.sqrt(1.0 - step * tk)

@@ -1072,3 +1072,22 @@ def test_general_equality_kkt_solves_through_the_kept_solution_block(monkeypatch
     r3 = Gs @ ux - uz / di ** 2 - bz
     scale = max(np.abs(bx).max(), np.abs(by).max(), np.abs(bz).max())
     assert max(np.abs(r1).max(), np.abs(r2).max(), np.abs(r3).max()) < 1e-9 * scale * max(1.0, np.abs(uz).max())
+
+
+@pytest.mark.gpu
+def test_fused_iteration_is_bitwise():
+    """Round 3 fused the ~85 short launches of an interior-point iteration into ~17 (kkt.hip "round 3": residuals, the vector
+    operations around the KKT solves, the second half of f6_no_ir with its reductions, the update).  Same arithmetic, same
+    roundings: every array and scalar a run returns is bit for bit that of the one-launch-per-operation path (KVX_LP_UNFUSED=1)."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ipm_bits_probe.py")
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, KVX_LP_UNFUSED=flag)
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert all(v["status"] == "optimal" for v in outs[0].values())
