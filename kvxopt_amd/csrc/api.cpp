@@ -351,6 +351,10 @@ int ensure_solve_ws(kvx_chol *F, int64_t nrhs)
 {
     if (nrhs <= F->x_cap) return KVX_OK;
     Symbolic &S = F->S;
+    // room for two right-hand sides from the start: an interior-point loop solves with one at its starting point and with two
+    // inside the iteration, and growing the workspace drops the captured sweeps -- which WAITS for an instantiation in flight
+    // (10-20 ms inside the first iteration of a first call, measured)
+    nrhs = std::max<int64_t>(nrhs, 2);
     for (auto &g : F->g_solve) g.exec.drop();
     F->g_solve.clear();                          // the captured sweeps point into the old workspace
     for (auto &g : F->g_fused) g.exec.drop();
@@ -624,7 +628,12 @@ struct LevelStreams {
     SweepStreams S;
     hipStream_t lds, wave;
     bool fork_lds, fork_wave;
-    static SweepStreams own(kvx_chol *F) { return SweepStreams{F->stream, F->side[0], F->side[1], F->ev_fork, F->ev_join[0], F->ev_join[1]}; }
+    static SweepStreams own(kvx_chol *F)
+    {
+        static const bool nofork = [] { const char *e = getenv("KVX_SOLVE_NOFORK"); return e && atoi(e) != 0; }();
+        if (nofork) return SweepStreams{F->stream, F->stream, F->stream, F->ev_fork, F->ev_join[0], F->ev_join[1]};
+        return SweepStreams{F->stream, F->side[0], F->side[1], F->ev_fork, F->ev_join[0], F->ev_join[1]};
+    }
     LevelStreams(kvx_chol *F, bool have_big, bool have_lds, bool have_wave, const SweepStreams *ss = nullptr) : S(ss ? *ss : own(F))
     {
         fork_lds = have_lds && (have_big || have_wave) && S.lds != S.main;
@@ -1023,7 +1032,13 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
         return solve_dev(F, 0, B, nrhs, ldB, async);
     }
     const int nr = (int)nrhs;
+    static const bool dbg_t = getenv("KVX_DBG_T") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg_t) fprintf(stderr, "factor_solve_dev %s: %.0f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count());
+    };
     if ((rc = ensure_solve_ws(F, nr))) return rc;
+    lap("solve workspace");
     if (F->ev_lvl.empty()) {
         F->ev_lvl.assign((size_t)S.nlevels, nullptr);
         for (auto &e : F->ev_lvl) HIPCHK(pool_event_get(&e, false));
@@ -1054,6 +1069,7 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
             F->pipe_from = l;
         }
     }
+    lap("pipeline set-up");
     static const bool own_stream = [] { const char *e = getenv("KVX_PIPE_OWN_STREAM"); return e && e[0] == '1'; }();
     hipStream_t st = F->stream, s2 = own_stream ? F->side[2] : F->side[0];
     auto body = [&]() -> int {
@@ -1091,10 +1107,12 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
         }
         slot->calls++;
         if (!slot->exec.tried && slot->calls >= 2) capture_graph(F, body, slot->exec);
+        lap("capture");
         exec = slot->exec.ready();
     }
     if (exec) HIPCHK(hipGraphLaunch(exec, st));
     else if ((rc = body())) return rc;
+    lap(exec ? "graph launch" : "eager enqueue");
     HIPCHK(hipEventRecord(F->ev[1], st));                           // (the two parts are not separable here: last_timing reports the whole
     HIPCHK(hipGetLastError());                                      //  call as the factorisation and 0 for the solve)
     F->pending = true;

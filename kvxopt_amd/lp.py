@@ -18,6 +18,7 @@ import ctypes
 import hashlib
 import math
 import os
+import sys
 import time
 
 import numpy as np
@@ -31,6 +32,7 @@ STEP = 0.99        # coneprog.py:424
 # KVX_LP_UNFUSED=1: one launch per BLAS-1-sized operation, as in rounds 1-2 (the library reads the same variable); the fused launches
 # of round 3 do the same arithmetic with the same roundings -- tests/test_kkt_gpu.py compares the two bit for bit
 _UNFUSED = os.environ.get("KVX_LP_UNFUSED", "0") not in ("", "0")
+_TRACE = os.environ.get("KVX_LP_TRACE", "0") not in ("", "0")      # per-iteration wall times of conelp on stderr
 
 
 def _sides(items):
@@ -947,6 +949,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             dtau, z1z1, ts, tz = out4[0], out4[1], out4[2], out4[3]
             t_now = time.perf_counter()
             t_phase[i] += t_now - t_mark[0]
+            if _TRACE:
+                print("conelp iteration %d direction %d: %.0f us" % (iters, i, 1e6 * (t_now - t_mark[0])), file=sys.stderr)
             t_mark[0] = t_now
             if i == 0:
                 try:
