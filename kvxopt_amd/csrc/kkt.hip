@@ -545,6 +545,9 @@ __global__ __launch_bounds__(256) void k_kkt_pre(int64_t n, const int64_t *__res
         }
     }
 }
+// LPR lanes per row of G: 16, or 4 where no row holds more than four entries (every lane then holds at most one product and the
+// butterfly adds them in the order the 16-lane form does: the same bits)
+template <int LPR>
 __global__ __launch_bounds__(256) void k_kkt_post(int64_t ml, int64_t n, unsigned nb_rows, const int64_t *__restrict__ Ap,
                                                   const int64_t *__restrict__ Ai, const double *__restrict__ Ax,
                                                   const double *__restrict__ di, KktSides r, const double *__restrict__ x2, int64_t ld)
@@ -557,14 +560,14 @@ __global__ __launch_bounds__(256) void k_kkt_post(int64_t ml, int64_t n, unsigne
         for (int64_t j = (int64_t)(blockIdx.x - nb_rows) * 256 + threadIdx.x; j < n; j += stride) sd.xout[j] = xk[j] * sd.xos;
         return;
     }
-    const int sub = threadIdx.x & 15;
-    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int64_t stride = ((int64_t)nb_rows * 256) >> 4;
+    const int sub = threadIdx.x & (LPR - 1);
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+    const int64_t stride = ((int64_t)nb_rows * 256) / LPR;
     for (; i < ml; i += stride) {
         double acc = 0.0;
-        for (int64_t p = Ap[i] + sub; p < Ap[i + 1]; p += 16) acc = __builtin_fma(Ax[p], xk[Ai[p]], acc);
+        for (int64_t p = Ap[i] + sub; p < Ap[i + 1]; p += LPR) acc = __builtin_fma(Ax[p], xk[Ai[p]], acc);
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         if (sub == 0) {
             const double t = 0.0 + acc;                       // t := G x  (beta = 0, alpha = 1 of the mat-vec)
             const double dd = di[i];
@@ -575,22 +578,26 @@ __global__ __launch_bounds__(256) void k_kkt_post(int64_t ml, int64_t n, unsigne
         }
     }
 }
-static inline unsigned groups16(int64_t rows) { return (unsigned)std::min<int64_t>(std::max<int64_t>((rows * 16 + 255) / 256, 1), 16384); }
+static inline unsigned groups16(int64_t rows, int lanes = 16)
+{ return (unsigned)std::min<int64_t>(std::max<int64_t>((rows * lanes + 255) / 256, 1), 16384); }
 void launch_kkt_pre(hipStream_t st, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
                     const KktSides &r, double *x2, int64_t ld)
 {
     if (n > 0 && nrhs > 0) hipLaunchKernelGGL(k_kkt_pre, dim3(groups16(n), (unsigned)nrhs), dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
 }
 void launch_kkt_post(hipStream_t st, int64_t ml, int64_t n, const int64_t *tGp, const int64_t *tGi, const double *tGx, const double *di,
-                     int nrhs, const KktSides &r, const double *x2, int64_t ld)
+                     int nrhs, const KktSides &r, const double *x2, int64_t ld, int64_t max_row)
 {
     if (nrhs <= 0 || (ml <= 0 && n <= 0)) return;
-    const unsigned nbr = ml > 0 ? groups16(ml) : 0, nbx = n > 0 ? (unsigned)std::min<int64_t>((n + 255) / 256, 4096) : 0;
-    hipLaunchKernelGGL(k_kkt_post, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+    const bool narrow = max_row > 0 && max_row <= 4;
+    const unsigned nbr = ml > 0 ? groups16(ml, narrow ? 4 : 16) : 0, nbx = n > 0 ? (unsigned)std::min<int64_t>((n + 255) / 256, 4096) : 0;
+    if (narrow) hipLaunchKernelGGL(k_kkt_post<4>, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+    else hipLaunchKernelGGL(k_kkt_post<16>, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
 }
 
 // ---- residuals of an iteration (coneprog.py:861-896, p = 0): hrx := -G'z ; rx := hrx - tau c ; hrz := G x + s ; rz := hrz - tau h
 // in one launch (fill + two mat-vecs + axpy + two lincomb before): workgroups [0, nb_c) take the columns of G, the rest its rows.
+template <int LPR>
 __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, unsigned nb_c, const int64_t *__restrict__ Gp,
                                                       const int64_t *__restrict__ Gi, const double *__restrict__ Gx,
                                                       const int64_t *__restrict__ Tp, const int64_t *__restrict__ Ti,
@@ -617,14 +624,15 @@ __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, uns
             }
         }
     } else {
-        int64_t i = ((int64_t)(blockIdx.x - nb_c) * 256 + threadIdx.x) >> 4;
-        const int64_t stride = ((int64_t)(gridDim.x - nb_c) * 256) >> 4;
+        const int sr = threadIdx.x & (LPR - 1);
+        int64_t i = ((int64_t)(blockIdx.x - nb_c) * 256 + threadIdx.x) / LPR;
+        const int64_t stride = ((int64_t)(gridDim.x - nb_c) * 256) / LPR;
         for (; i < ml; i += stride) {
             double acc = 0.0;
-            for (int64_t p = Tp[i] + sub; p < Tp[i + 1]; p += 16) acc = __builtin_fma(Tx[p], x[Ti[p]], acc);
+            for (int64_t p = Tp[i] + sr; p < Tp[i + 1]; p += LPR) acc = __builtin_fma(Tx[p], x[Ti[p]], acc);
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (sub == 0) {
+            for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (sr == 0) {
                 const double t = __builtin_fma(1.0, acc, 0.0);                  // hrz := G x
                 const double v = __builtin_fma(1.0, s[i], t);                   // hrz += s
                 hrz[i] = v;
@@ -635,12 +643,13 @@ __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, uns
 }
 void launch_lp_residuals(hipStream_t st, int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *Tp,
                          const int64_t *Ti, const double *Tx, const double *x, const double *z, const double *s, const double *c,
-                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz, int64_t max_row)
 {
-    const unsigned nbc = n > 0 ? groups16(n) : 0, nbr = ml > 0 ? groups16(ml) : 0;
+    const bool narrow = max_row > 0 && max_row <= 4;
+    const unsigned nbc = n > 0 ? groups16(n) : 0, nbr = ml > 0 ? groups16(ml, narrow ? 4 : 16) : 0;
     if (nbc + nbr == 0) return;
-    hipLaunchKernelGGL(k_lp_residuals, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx,
-                       hrz, rz);
+    if (narrow) hipLaunchKernelGGL(k_lp_residuals<4>, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
+    else hipLaunchKernelGGL(k_lp_residuals<16>, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
 }
 
 // ---- second half of f6_no_ir in two launches (sixteen before; kvx_lp_second_half_dev) ------------------------------------

@@ -449,8 +449,8 @@ int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
-int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int64_t *GTi, const double *GTx, const double *di, int nrhs,
-                           const kvx_kkt_side *sides, const double *x2, int64_t ldx2)
+int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int64_t *GTi, const double *GTx, int64_t max_row_nnz,
+                           const double *di, int nrhs, const kvx_kkt_side *sides, const double *x2, int64_t ldx2)
 {
     if (ml < 0 || n < 0 || nrhs < 1 || nrhs > 2 || !sides || !x2 || ldx2 < std::max<int64_t>(n, 1)) return KVX_EINVAL;
     KktSides r;
@@ -458,18 +458,18 @@ int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int6
         const kvx_kkt_side &q = sides[k < nrhs ? k : 0];
         r.s[k] = KktSide{q.xin, q.xscale, q.zin, q.xout, q.xoscale, q.zout, q.zoscale};
     }
-    launch_kkt_post(nullptr, ml, n, GTp, GTi, GTx, di, nrhs, r, x2, ldx2);
+    launch_kkt_post(nullptr, ml, n, GTp, GTi, GTx, di, nrhs, r, x2, ldx2, max_row_nnz);
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
 // residuals of an iteration without equality constraints (coneprog.py:861-896): hrx := -G'z, rx := hrx - tau c, hrz := G x + s,
 // rz := hrz - tau h in one launch
 int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *GTp,
-                         const int64_t *GTi, const double *GTx, const double *x, const double *z, const double *s, const double *c,
-                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
+                         const int64_t *GTi, const double *GTx, int64_t max_row_nnz, const double *x, const double *z, const double *s,
+                         const double *c, const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
 {
     if (ml < 0 || n < 0) return KVX_EINVAL;
-    launch_lp_residuals(nullptr, ml, n, Gp, Gi, Gx, GTp, GTi, GTx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
+    launch_lp_residuals(nullptr, ml, n, Gp, Gi, Gx, GTp, GTi, GTx, x, z, s, c, h, tau, hrx, rx, hrz, rz, max_row_nnz);
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
