@@ -265,19 +265,19 @@ int kvx_lp_update_dev(int64_t ml, double step, double *ds, double *dz, double *d
  *   kkt_solve_pre / _post: misc.kkt_chol2's solve (misc.py:1489-1563, p = 0) around the triangular solves, for one or two right-hand
  *               sides:  x2(:,k) := xscale*xin + G'(di.*(zin.*di))   [z := W^-1 z, x += Gs'z]   and, after S^-1 on x2,
  *               xout := xoscale*x2(:,k),  zout := zoscale*(di.*(G*x2(:,k)) - zin.*di)           [z := Gs*x - z].
- *   max_row_nnz: the largest number of entries in a row of G (0 = not known): with at most four, a row is summed by 4 lanes
- *               instead of 16 -- the same association, the same bits. */
+ *   max_col_nnz / max_row_nnz: the largest number of entries in a column / row of G (0 = not known): with at most four (eight), a
+ *               column or row is summed by 4 (8) lanes instead of 16 -- the same association, the same bits. */
 typedef struct kvx_kkt_side {
     const double *xin;  double xscale;  const double *zin;     /* pre */
     double *xout;       double xoscale; double *zout; double zoscale;   /* post (zin is read again) */
 } kvx_kkt_side;
 int kvx_lp_update_x_dev(int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lmbda, double *s,
                         double *z, const double *dx, double *x);
-int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *GTp,
-                         const int64_t *GTi, const double *GTx, int64_t max_row_nnz, const double *x, const double *z, const double *s,
+int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, int64_t max_col_nnz,
+                         const int64_t *GTp, const int64_t *GTi, const double *GTx, int64_t max_row_nnz, const double *x, const double *z, const double *s,
                          const double *c, const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz);
-int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
-                          const kvx_kkt_side *sides, double *x2, int64_t ldx2);
+int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, int64_t max_col_nnz,
+                          const double *di, int nrhs, const kvx_kkt_side *sides, double *x2, int64_t ldx2);
 int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int64_t *GTi, const double *GTx, int64_t max_row_nnz,
                            const double *di, int nrhs, const kvx_kkt_side *sides, const double *x2, int64_t ldx2);
 /* count <= 32 reductions with one host synchronisation: kind[i] = 0 sdot(x_i, y_i), 1 max_step(x_i) -- bitwise the

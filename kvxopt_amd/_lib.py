@@ -116,8 +116,8 @@ _SIGS = {
     "kvx_lp_step_post_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp]),
     "kvx_lp_update_dev": (ctypes.c_int, [i64, f64, vp, vp, vp, vp, vp, vp, vp]),
     "kvx_lp_update_x_dev": (ctypes.c_int, [i64, i64, f64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    "kvx_lp_residuals_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp]),
-    "kvx_kkt_solve_pre_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, vp, ctypes.c_int, vp, vp, i64]),
+    "kvx_lp_residuals_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, f64, vp, vp, vp, vp]),
+    "kvx_kkt_solve_pre_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, i64, vp, ctypes.c_int, vp, vp, i64]),
     "kvx_kkt_solve_post_dev": (ctypes.c_int, [i64, i64, vp, vp, vp, i64, vp, ctypes.c_int, vp, vp, i64]),
     "kvx_lp_second_half_dev": (ctypes.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64p]),
     "kvx_nt_reduce_multi_dev": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), i64p, ctypes.POINTER(vp),

@@ -517,6 +517,7 @@ int reduce_blocks() { return RED_BLOCKS; }
 //   pre :  x2_k := xs_k xin_k + G' (di .* (zin_k .* di))                                     [z := W^-1 z ; x += Gs' z]
 //   post:  xout_k := xos_k x2_k ;  zout_k := zos_k (di .* (G x2_k) - zin_k .* di)            [z := Gs x - z]
 // for one or two right-hand sides (grid.y), one launch each: mul + xmy + spmv + copy, copy + spmv + xmy (+ two scal) before.
+template <int LPC>                                   // lanes per column of G: 16, 8 or 4 by the longest column (same bits, see k_kkt_post)
 __global__ __launch_bounds__(256) void k_kkt_pre(int64_t n, const int64_t *__restrict__ Ap, const int64_t *__restrict__ Ai,
                                                  const double *__restrict__ Ax, const double *__restrict__ di, KktSides r,
                                                  double *__restrict__ x2, int64_t ld)
@@ -525,12 +526,12 @@ __global__ __launch_bounds__(256) void k_kkt_pre(int64_t n, const int64_t *__res
     const KktSide sd = r.s[blockIdx.y];
     const double *__restrict__ z = sd.zin;
     double *__restrict__ out = x2 + (int64_t)blockIdx.y * ld;
-    const int sub = threadIdx.x & 15;
-    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int sub = threadIdx.x & (LPC - 1);
+    int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPC;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / LPC;
     for (; j < n; j += stride) {
         double acc = 0.0;
-        for (int64_t p = Ap[j] + sub; p < Ap[j + 1]; p += 16) {
+        for (int64_t p = Ap[j] + sub; p < Ap[j + 1]; p += LPC) {
             const int64_t i = Ai[p];
             const double dd = di[i];
             const double zs = z[i] * dd;                      // z := W^-1 z
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(256) void k_kkt_pre(int64_t n, const int64_t *__res
             acc = __builtin_fma(Ax[p], t, acc);
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        for (int o = LPC / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         if (sub == 0) {
             const double x0 = sd.xs * sd.xin[j];
             out[j] = x0 + acc;
@@ -580,24 +581,34 @@ __global__ __launch_bounds__(256) void k_kkt_post(int64_t ml, int64_t n, unsigne
 }
 static inline unsigned groups16(int64_t rows, int lanes = 16)
 { return (unsigned)std::min<int64_t>(std::max<int64_t>((rows * lanes + 255) / 256, 1), 16384); }
+// lanes that sum a row / column whose longest has `longest` entries (0 = not known): with at most L entries every lane of an L-lane
+// group holds at most one product and the butterfly L/2 .. 1 adds them as the 16-lane one does
+static inline int lanes_for(int64_t longest) { return longest > 0 && longest <= 4 ? 4 : (longest > 0 && longest <= 8 ? 8 : 16); }
 void launch_kkt_pre(hipStream_t st, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
-                    const KktSides &r, double *x2, int64_t ld)
+                    const KktSides &r, double *x2, int64_t ld, int64_t max_col)
 {
-    if (n > 0 && nrhs > 0) hipLaunchKernelGGL(k_kkt_pre, dim3(groups16(n), (unsigned)nrhs), dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
+    if (n <= 0 || nrhs <= 0) return;
+    const int lanes = lanes_for(max_col);
+    const dim3 grid(groups16(n, lanes), (unsigned)nrhs);
+    if (lanes == 4) hipLaunchKernelGGL(k_kkt_pre<4>, grid, dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
+    else if (lanes == 8) hipLaunchKernelGGL(k_kkt_pre<8>, grid, dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
+    else hipLaunchKernelGGL(k_kkt_pre<16>, grid, dim3(256), 0, st, n, Gp, Gi, Gx, di, r, x2, ld);
 }
 void launch_kkt_post(hipStream_t st, int64_t ml, int64_t n, const int64_t *tGp, const int64_t *tGi, const double *tGx, const double *di,
                      int nrhs, const KktSides &r, const double *x2, int64_t ld, int64_t max_row)
 {
     if (nrhs <= 0 || (ml <= 0 && n <= 0)) return;
-    const bool narrow = max_row > 0 && max_row <= 4;
-    const unsigned nbr = ml > 0 ? groups16(ml, narrow ? 4 : 16) : 0, nbx = n > 0 ? (unsigned)std::min<int64_t>((n + 255) / 256, 4096) : 0;
-    if (narrow) hipLaunchKernelGGL(k_kkt_post<4>, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
-    else hipLaunchKernelGGL(k_kkt_post<16>, dim3(nbr + nbx, (unsigned)nrhs), dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+    const int lanes = lanes_for(max_row);
+    const unsigned nbr = ml > 0 ? groups16(ml, lanes) : 0, nbx = n > 0 ? (unsigned)std::min<int64_t>((n + 255) / 256, 4096) : 0;
+    const dim3 grid(nbr + nbx, (unsigned)nrhs);
+    if (lanes == 4) hipLaunchKernelGGL(k_kkt_post<4>, grid, dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+    else if (lanes == 8) hipLaunchKernelGGL(k_kkt_post<8>, grid, dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
+    else hipLaunchKernelGGL(k_kkt_post<16>, grid, dim3(256), 0, st, ml, n, nbr, tGp, tGi, tGx, di, r, x2, ld);
 }
 
 // ---- residuals of an iteration (coneprog.py:861-896, p = 0): hrx := -G'z ; rx := hrx - tau c ; hrz := G x + s ; rz := hrz - tau h
 // in one launch (fill + two mat-vecs + axpy + two lincomb before): workgroups [0, nb_c) take the columns of G, the rest its rows.
-template <int LPR>
+template <int LPC, int LPR>
 __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, unsigned nb_c, const int64_t *__restrict__ Gp,
                                                       const int64_t *__restrict__ Gi, const double *__restrict__ Gx,
                                                       const int64_t *__restrict__ Tp, const int64_t *__restrict__ Ti,
@@ -608,15 +619,15 @@ __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, uns
                                                       double *__restrict__ rz)
 {
 #pragma clang fp contract(off)
-    const int sub = threadIdx.x & 15;
     if (blockIdx.x < nb_c) {
-        int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-        const int64_t stride = ((int64_t)nb_c * 256) >> 4;
+        const int sub = threadIdx.x & (LPC - 1);
+        int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPC;
+        const int64_t stride = ((int64_t)nb_c * 256) / LPC;
         for (; j < n; j += stride) {
             double acc = 0.0;
-            for (int64_t p = Gp[j] + sub; p < Gp[j + 1]; p += 16) acc = __builtin_fma(Gx[p], z[Gi[p]], acc);
+            for (int64_t p = Gp[j] + sub; p < Gp[j + 1]; p += LPC) acc = __builtin_fma(Gx[p], z[Gi[p]], acc);
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            for (int o = LPC / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
             if (sub == 0) {
                 const double v = __builtin_fma(-1.0, acc, 0.0);                 // hrx := 0 ; hrx := -G'z + hrx
                 hrx[j] = v;
@@ -643,13 +654,17 @@ __global__ __launch_bounds__(256) void k_lp_residuals(int64_t ml, int64_t n, uns
 }
 void launch_lp_residuals(hipStream_t st, int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *Tp,
                          const int64_t *Ti, const double *Tx, const double *x, const double *z, const double *s, const double *c,
-                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz, int64_t max_row)
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz, int64_t max_col, int64_t max_row)
 {
-    const bool narrow = max_row > 0 && max_row <= 4;
-    const unsigned nbc = n > 0 ? groups16(n) : 0, nbr = ml > 0 ? groups16(ml, narrow ? 4 : 16) : 0;
+    const int lc = lanes_for(max_col) == 16 ? 16 : 8, lr = lanes_for(max_row) == 4 ? 4 : 16;     // (four of the nine combinations)
+    const unsigned nbc = n > 0 ? groups16(n, lc) : 0, nbr = ml > 0 ? groups16(ml, lr) : 0;
     if (nbc + nbr == 0) return;
-    if (narrow) hipLaunchKernelGGL(k_lp_residuals<4>, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
-    else hipLaunchKernelGGL(k_lp_residuals<16>, dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx, hrz, rz);
+#define KVX_RES(LC, LR) hipLaunchKernelGGL((k_lp_residuals<LC, LR>), dim3(nbc + nbr), dim3(256), 0, st, ml, n, nbc, Gp, Gi, Gx, Tp, Ti, Tx, x, z, s, c, h, tau, hrx, rx, hrz, rz)
+    if (lc == 8 && lr == 4) KVX_RES(8, 4);
+    else if (lc == 8) KVX_RES(8, 16);
+    else if (lr == 4) KVX_RES(16, 4);
+    else KVX_RES(16, 16);
+#undef KVX_RES
 }
 
 // ---- second half of f6_no_ir in two launches (sixteen before; kvx_lp_second_half_dev) ------------------------------------

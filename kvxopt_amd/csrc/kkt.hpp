@@ -27,12 +27,12 @@ struct LpHalf {
 void launch_reduce_multi_stage1(hipStream_t st, const MultiRed &mr, double *part);   // RED_BLOCKS partial results per reduction
 int reduce_blocks();
 void launch_kkt_pre(hipStream_t st, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
-                    const KktSides &r, double *x2, int64_t ld);
+                    const KktSides &r, double *x2, int64_t ld, int64_t max_col = 0);
 void launch_kkt_post(hipStream_t st, int64_t ml, int64_t n, const int64_t *tGp, const int64_t *tGi, const double *tGx, const double *di,
                      int nrhs, const KktSides &r, const double *x2, int64_t ld, int64_t max_row = 0);
 void launch_lp_residuals(hipStream_t st, int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *Tp,
                          const int64_t *Ti, const double *Tx, const double *x, const double *z, const double *s, const double *c,
-                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz, int64_t max_row = 0);
+                         const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz, int64_t max_col = 0, int64_t max_row = 0);
 void launch_lp_second_half(hipStream_t st, const LpHalf &a, double dgi, double dtau0, double z1z1, double *part, double *part2);
 void launch_lp_update_x(hipStream_t st, int64_t ml, int64_t n, double step, double *ds, double *dz, double *d, double *di, double *lm,
                         double *s, double *z, const double *dx, double *x);

@@ -436,8 +436,8 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
 //   pre :  x2(:,k) := xscale_k * xin_k + G' (di .* (zin_k .* di))
 //   post:  xout_k := xoscale_k * x2(:,k) ;  zout_k := zoscale_k * (di .* (G x2(:,k)) - zin_k .* di)
 // G by its CCS arrays (pre) and by the CCS arrays of its transpose (post), int64 indices on the device as for kvx_spmv_dev.
-int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const double *di, int nrhs,
-                          const kvx_kkt_side *sides, double *x2, int64_t ldx2)
+int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, int64_t max_col_nnz,
+                          const double *di, int nrhs, const kvx_kkt_side *sides, double *x2, int64_t ldx2)
 {
     if (ml < 0 || n < 0 || nrhs < 1 || nrhs > 2 || !sides || !x2 || ldx2 < std::max<int64_t>(n, 1)) return KVX_EINVAL;
     KktSides r;
@@ -445,7 +445,7 @@ int kvx_kkt_solve_pre_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_
         const kvx_kkt_side &q = sides[k < nrhs ? k : 0];
         r.s[k] = KktSide{q.xin, q.xscale, q.zin, q.xout, q.xoscale, q.zout, q.zoscale};
     }
-    launch_kkt_pre(nullptr, n, Gp, Gi, Gx, di, nrhs, r, x2, ldx2);
+    launch_kkt_pre(nullptr, n, Gp, Gi, Gx, di, nrhs, r, x2, ldx2, max_col_nnz);
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }
@@ -464,12 +464,12 @@ int kvx_kkt_solve_post_dev(int64_t ml, int64_t n, const int64_t *GTp, const int6
 }
 // residuals of an iteration without equality constraints (coneprog.py:861-896): hrx := -G'z, rx := hrx - tau c, hrz := G x + s,
 // rz := hrz - tau h in one launch
-int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, const int64_t *GTp,
-                         const int64_t *GTi, const double *GTx, int64_t max_row_nnz, const double *x, const double *z, const double *s,
+int kvx_lp_residuals_dev(int64_t ml, int64_t n, const int64_t *Gp, const int64_t *Gi, const double *Gx, int64_t max_col_nnz,
+                         const int64_t *GTp, const int64_t *GTi, const double *GTx, int64_t max_row_nnz, const double *x, const double *z, const double *s,
                          const double *c, const double *h, double tau, double *hrx, double *rx, double *hrz, double *rz)
 {
     if (ml < 0 || n < 0) return KVX_EINVAL;
-    launch_lp_residuals(nullptr, ml, n, Gp, Gi, Gx, GTp, GTi, GTx, x, z, s, c, h, tau, hrx, rx, hrz, rz, max_row_nnz);
+    launch_lp_residuals(nullptr, ml, n, Gp, Gi, Gx, GTp, GTi, GTx, x, z, s, c, h, tau, hrx, rx, hrz, rz, max_col_nnz, max_row_nnz);
     HIPCHK(hipGetLastError());
     return KVX_OK;
 }

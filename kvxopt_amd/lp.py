@@ -152,7 +152,8 @@ class SpMatDev:
         tp = np.zeros(self.m + 1, dtype=np.int64)
         np.add.at(tp, rowind + 1, 1)
         np.cumsum(tp, out=tp)
-        self.max_row = int(np.diff(tp).max()) if self.m else 0         # most entries in a row (the fused kernels size their lane groups)
+        self.max_row = int(np.diff(tp).max()) if self.m else 0         # most entries in a row / column (the fused kernels size
+        self.max_col = int(np.diff(colptr).max()) if self.n else 0     # their lane groups by them)
         self.tcp = DeviceBuffer.from_array(tp)
         self.tri = DeviceBuffer.from_array(cols[order]) if len(rowind) else DeviceBuffer(8)
         self.tvx = DeviceBuffer.from_array(values[order]) if len(values) else DeviceBuffer(8)
@@ -254,7 +255,7 @@ class KKTChol2Dev:
 
     def _pre(self, sides, nrhs):
         G = self.G
-        raise_for(lib().kvx_kkt_solve_pre_dev(self.ml, self.n, G.cp.ptr, G.ri.ptr, G.vx.ptr, self.di.ptr, nrhs, sides,
+        raise_for(lib().kvx_kkt_solve_pre_dev(self.ml, self.n, G.cp.ptr, G.ri.ptr, G.vx.ptr, G.max_col, self.di.ptr, nrhs, sides,
                                               self._x2buf().ptr, max(1, self.n)))
 
     def _post(self, sides, nrhs):
@@ -819,7 +820,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     for iters in range(MAXITERS + 1):
         # residuals (coneprog.py:861-896); their norms and the objectives come back in one reduction call
         if fused:                                        # the six launches below in one
-            raise_for(lib().kvx_lp_residuals_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row,
+            raise_for(lib().kvx_lp_residuals_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.max_col, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row,
                                                  x.ptr, z.ptr, s.ptr, cv.ptr, hv.ptr, tau, hrx.ptr, rx.ptr, hrz.ptr, rz.ptr))
         else:
             Af(y, hrx, trans="T", alpha=-1.0, beta=0.0)
