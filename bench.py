@@ -292,7 +292,7 @@ def ipm_leg(args, pl):
                        "note": "back-to-back launches: time per launch includes the launch gap; the loop itself is bound by the factor/solve latency chains"}
     L.kvx_atda_free(h)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_ipm_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_ipm_pmc.json")))
         ipm["roofline"]["traffic"] = pm.get("k_atda_bytes_per_launch")
     except Exception:
         pass

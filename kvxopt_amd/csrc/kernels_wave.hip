@@ -382,9 +382,11 @@ __global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__res
     double *x = X + (int64_t)rh * ldx + fd.first;
     const double *wc = Wc + (int64_t)rh * wstride;
     double *wo = Wo + (int64_t)rh * wstride + fd.wx;
+    // strictly below the diagonal only: with a[j] = 0 for r <= j a step is one unconditional fma per lane (a lane above the pivot
+    // adds zero), and the finished y_r = w_r / d_r is formed once, after the sweep -- no select in the dependent chain
     double a[KMAX];
 #pragma unroll
-    for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+    for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m && r > j);
     const double dg = kvx_ld0(P, r + (int64_t)r * m, r < k);
     double w = kvx_ld0(x, r, r < k);
     if (fd.nchild > 0) {
@@ -414,10 +416,10 @@ __global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__res
         for (int j = 0; j < KMAX; j++) {
             if (j < k) {                           // workgroup-uniform
                 const double yj = kvx_readlane(w * rinv, j);
-                w = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w) : w);
+                w = __builtin_fma(-a[j], yj, w);
             }
         }
-        if (r < k) ysh[r] = w;
+        if (r < k) { w *= rinv; ysh[r] = w; }
     }
     __syncthreads();
     if (wv == 1) {
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(128) void k_bwd_lds(DevSym ds, const int32_t *__res
 #pragma unroll
     for (int rr = 0; rr < 64; rr++) {
         const int row = 64 * h + rr;
-        a[rr] = kvx_ld0(P, row + (int64_t)col * m, ln < k && row < m && row >= ln);
+        a[rr] = kvx_ld0(P, row + (int64_t)col * m, ln < k && row < m && row > ln);      // strictly lower: no select in the sweep
     }
     const double dg = kvx_ld0(P, ln + (int64_t)ln * m, ln < k);
     const int grow = (tid < m) ? (tid < k ? fd.first + tid : rows[tid]) : 0;
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(128) void k_bwd_lds(DevSym ds, const int32_t *__res
             if (rr < k) {                          // workgroup-uniform
                 const double xr = kvx_readlane((xv - acc) * rinv, rr);
                 xv = (ln == rr) ? xr : xv;
-                acc = (ln < rr) ? __builtin_fma(a[rr], xr, acc) : acc;
+                acc = __builtin_fma(a[rr], xr, acc);
             }
         }
         if (ln < k) xg[fd.first + ln] = xv;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__
         for (int j0 = 0; j0 < KMAX; j0 += 8) {
             if (j0 < k) {                          // wave-uniform: leaf fronts have few pivots, skip the unused column groups
 #pragma unroll
-                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m && r > j);   // strictly lower (k_fwd_lds)
             } else {
 #pragma unroll
                 for (int j = j0; j < j0 + 8; j++) a[j] = 0.0;
@@ -581,10 +583,10 @@ __global__ __launch_bounds__(64) void k_fwd_subtree(DevSym ds, const SubDesc *__
         for (int j = 0; j < KMAX; j++) {
             if (j < k) {                           // wave-uniform
                 const double yj = kvx_readlane(w * rinv, j);
-                w = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w) : w);
+                w = __builtin_fma(-a[j], yj, w);
             }
         }
-        if (r < k) xs[xo + r] = w;
+        if (r < k) xs[xo + r] = w * rinv;
         else if (r < m) {
             if (s == sd.hi) {
                 double *wo = ((depth[s] & 1) ? W1 : W0) + (int64_t)rh * wstride + fd.wx;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__
         for (int r0 = 0; r0 < MMAX; r0 += 16) {
             if (r0 < m) {                          // wave-uniform
 #pragma unroll
-                for (int rr = r0; rr < r0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+                for (int rr = r0; rr < r0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr > ln);   // strictly lower
             } else {
 #pragma unroll
                 for (int rr = r0; rr < r0 + 16; rr++) a[rr] = 0.0;
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(64) void k_bwd_subtree(DevSym ds, const SubDesc *__
                 } else {
                     xr = kvx_readlane(xv, rr);
                 }
-                acc = (ln < rr) ? __builtin_fma(a[rr], xr, acc) : acc;
+                acc = __builtin_fma(a[rr], xr, acc);
             }
         }
         if (ln < k) xs[fd.first - sd.col0 + ln] = xv;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(64) void k_fwd_subtree_mr(DevSym ds, const SubDesc 
         for (int j0 = 0; j0 < KMAX; j0 += 8) {
             if (j0 < k) {
 #pragma unroll
-                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m);
+                for (int j = j0; j < j0 + 8; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m && r > j);   // strictly lower (k_fwd_lds)
             } else {
 #pragma unroll
                 for (int j = j0; j < j0 + 8; j++) a[j] = 0.0;
@@ -738,13 +740,13 @@ __global__ __launch_bounds__(64) void k_fwd_subtree_mr(DevSym ds, const SubDesc 
 #pragma unroll
                 for (int b = 0; b < RB; b++) {
                     const double yj = kvx_readlane(w[b] * rinv, j);
-                    w[b] = (r == j) ? yj : (r > j ? __builtin_fma(-a[j], yj, w[b]) : w[b]);
+                    w[b] = __builtin_fma(-a[j], yj, w[b]);
                 }
             }
         }
         if (r < k) {
 #pragma unroll
-            for (int b = 0; b < RB; b++) xs[b][xo + r] = w[b];
+            for (int b = 0; b < RB; b++) xs[b][xo + r] = w[b] * rinv;
         } else if (r < m) {
             if (s == sd.hi) {
                 double *wo = ((depth[s] & 1) ? W1 : W0) + fd.wx + (r - k);
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(64) void k_bwd_subtree_mr(DevSym ds, const SubDesc 
         for (int q0 = 0; q0 < MMAX; q0 += 16) {
             if (q0 < m) {                          // wave-uniform
 #pragma unroll
-                for (int rr = q0; rr < q0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr >= ln);
+                for (int rr = q0; rr < q0 + 16; rr++) a[rr] = kvx_ld0(P, rr + (int64_t)col * m, ln < k && rr < m && rr > ln);
             } else {
 #pragma unroll
                 for (int rr = q0; rr < q0 + 16; rr++) a[rr] = 0.0;
@@ -829,7 +831,7 @@ __global__ __launch_bounds__(64) void k_bwd_subtree_mr(DevSym ds, const SubDesc 
                     } else {
                         xr = kvx_readlane(xv[b], rr);
                     }
-                    acc[b] = (ln < rr) ? __builtin_fma(a[rr], xr, acc[b]) : acc[b];
+                    acc[b] = __builtin_fma(a[rr], xr, acc[b]);
                 }
             }
         }

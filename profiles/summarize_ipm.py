@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 outputs of profiles/collect_ipm.sh into profiles/<tag>_ipm_kernel_stats.csv (per kernel: calls,
-total, average) and profiles/<tag>_ipm_pmc.json (FETCH_SIZE / WRITE_SIZE per launch of the KKT-layer kernels, raw counter
-values in bytes as rocprofv3 reports them on gfx950, next to their algorithmic bytes; bench.py reads
-"k_atda_bytes_per_launch")."""
+total, average) and profiles/<tag>_ipm_pmc.json (FETCH_SIZE / WRITE_SIZE per launch of the KKT-layer kernels in bytes -- counter
+values are KB, and FETCH_SIZE is scaled by the factor profiles/calibrate_fetch.py measured for 8-byte-per-lane reads (2.0, see
+profiles/<tag>_pmc_fetch_write_per_kernel.json) -- next to their algorithmic bytes; bench.py reads "k_atda_bytes_per_launch":
+the two launches of the assembly, k_atda_scale + k_atda)."""
 import csv, glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
@@ -20,7 +21,7 @@ st = glob.glob(os.path.join(out, tag + "_ipm_stats", "**", "*kernel_stats.csv"),
 if st:
     rows = list(csv.DictReader(open(st[0])))
     with open(os.path.join(prof, tag + "_ipm_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench_extra.py --cases lp4b --repeat 3  (conelp, ml = 200 000, n = 50 000: warm-up run of 2 iterations + 3 full runs)\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 tools/ipm_loop.py 3  (conelp, grid LP 250 x 200: ml = 200 000, n = 50 000; three full runs, the first on a new structure)\n")
         f.write("kernel,calls,total_us,avg_us,pct\n")
         for r in rows:
             f.write("%s,%s,%.1f,%.2f,%s\n" % (re.sub(r"\(.*", "", r["Name"]).replace("void ", "").replace("kvx::", "").replace(",", ";"),
@@ -41,6 +42,11 @@ def pmc(dirname, counter):
     return acc, cnt
 
 
+fetch_scale = 2.0
+try:
+    fetch_scale = float(json.load(open(os.path.join(prof, tag + "_pmc_fetch_write_per_kernel.json")))["calibration"]["fetch_scale"])
+except Exception:
+    pass
 fa, fc = pmc(tag + "_ipm_fetch", "FETCH_SIZE")
 wa, wc = pmc(tag + "_ipm_write", "WRITE_SIZE")
 if fa or wa:
@@ -51,13 +57,14 @@ if fa or wa:
         if not (k.startswith("k_") and not k.startswith(("k_front", "k_fwd", "k_bwd", "k_potrf", "k_trsm", "k_syrk", "k_assemble", "k_scatter", "k_perm"))):
             continue
         launches = max(fc.get(k, 0), wc.get(k, 0), 1)
-        per[k] = {"launches": launches, "fetch_bytes_per_launch": fa.get(k, 0.0) * 1024.0 / launches,
+        per[k] = {"launches": launches, "fetch_bytes_per_launch": fa.get(k, 0.0) * 1024.0 * fetch_scale / launches,
                   "write_bytes_per_launch": wa.get(k, 0.0) * 1024.0 / launches}
         per[k]["traffic_bytes_per_launch"] = per[k]["fetch_bytes_per_launch"] + per[k]["write_bytes_per_launch"]
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench_extra.py --cases lp4b --repeat 1",
-           "units": "bytes (counter values are KB: x 1024)", "kernels": per}
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/ipm_loop.py 1",
+           "units": "bytes (counter values are KB: x 1024; FETCH_SIZE x fetch_scale, the calibration of 8-byte-per-lane reads)",
+           "fetch_scale": fetch_scale, "kernels": per}
     if "k_atda" in per:
-        res["k_atda_bytes_per_launch"] = per["k_atda"]["traffic_bytes_per_launch"]
+        res["k_atda_bytes_per_launch"] = per["k_atda"]["traffic_bytes_per_launch"] + per.get("k_atda_scale", {}).get("traffic_bytes_per_launch", 0.0)
         res["k_atda_algorithmic_bytes_per_launch"] = 12.0 * nnzG + 8.0 * ml + 8.0 * 149550
     json.dump(res, open(os.path.join(prof, tag + "_ipm_pmc.json"), "w"), indent=1)
 print("summarised", tag)
