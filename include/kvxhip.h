@@ -46,9 +46,9 @@ typedef struct {
                              * 1 = natural; 2 = nested dissection only; 3 = approximate minimum degree only (the role of AMD) */
     int32_t postorder;      /* 1 (default) elimination-tree postorder on top of the ordering (cholmod.c:113-115) */
     int32_t relax_small;    /* relaxed-amalgamation: always merge if merged width <= this (default 4)    */
-    double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, .075)    */
-    double  relax_z2;
-    double  relax_z3;
+    double  relax_z1;       /* zero-fraction bounds for widths <=16, <=48, any (defaults .8, .1, and for any width    */
+    double  relax_z2;       /* relax_z3 < 0 = by the order of the matrix: .2 up to 150 000 columns, .075 beyond;      */
+    double  relax_z3;       /* 0 = no relaxation of wide supernodes)                                                   */
     double  dbound;         /* cholmod.options['dbound'] (cholmod.c:116-117); 0 = off: a pivot d <= 0 fails.  > 0: CHOLMOD's rule,
                              * L_kk < dbound is replaced by dbound; with reserved[3] = 1 by 1e64 (the row drops out of the solves) */
     int32_t reserved[8];    /* [0] nd_leaf, [1] leaf_cols, [2] leaf_rows, [3] dbound mode, [4] 1 = a given p competes with the library's own

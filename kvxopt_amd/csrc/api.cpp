@@ -1161,7 +1161,8 @@ void kvx_chol_default_opts(kvx_chol_opts *o)
     o->relax_small = 4;
     o->relax_z1 = 0.8;
     o->relax_z2 = 0.1;
-    o->relax_z3 = 0.075;    // (CHOLMOD's own default is 0.05: measured on MI355X, section 3 of DESIGN.md)
+    o->relax_z3 = -1.0;     // < 0: by the order of the matrix -- 0.075 (CHOLMOD's own default is 0.05: measured on MI355X, section 3 of
+                            // DESIGN.md), 0.2 up to 150 000 columns (see kvx_chol_analyze)
     // (experiments: KVX_RELAX_Z1 / _Z2 / _Z3 override the defaults of every analysis in the process)
     if (const char *e = getenv("KVX_RELAX_Z1")) o->relax_z1 = atof(e);
     if (const char *e = getenv("KVX_RELAX_Z2")) o->relax_z2 = atof(e);
@@ -1186,6 +1187,12 @@ int kvx_chol_analyze(int64_t n, const int64_t *colptr, const int64_t *rowind, in
         so.postorder = o.postorder;
         so.relax_small = o.relax_small;
         so.relax_z1 = o.relax_z1; so.relax_z2 = o.relax_z2; so.relax_z3 = o.relax_z3;
+        // Zero fraction a wide chain supernode may take on when it joins its parent.  A small factorisation is a chain of levels on an
+        // idle machine: explicit zeros cost nothing there and every level saved is 50-100 us (5-pt Laplacian 200 x 200: 12 -> 9
+        // levels, step 1.25 -> 1.08 ms; the KKT system of the interior-point leg, n = 50 000: 520 -> 565 iterations/s); from a few
+        // 10^5 columns on the merged fronts lengthen the pivot chains at the top of the tree by more than the levels save
+        // (1000 x 1000: 4.62 -> 4.81 ms with 0.2; 64^3: 17.2 -> 18.7 ms).  Crossover measured between 1.2e5 and 2.5e5 columns.
+        if (so.relax_z3 < 0) so.relax_z3 = n <= 150000 ? 0.2 : 0.075;
         if (o.reserved[0] > 0) so.nd_leaf = o.reserved[0];
         if (o.reserved[1] != 0) so.leaf_cols = o.reserved[1] < 0 ? 0 : o.reserved[1];
         if (o.reserved[2] > 0) so.leaf_rows = o.reserved[2];
