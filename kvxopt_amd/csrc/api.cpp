@@ -481,14 +481,24 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 launch_front_wave(sl, it.mcap, it.kmax, F->ds, lbase + it.off, it.cnt, F->d_Lx, Uch, Uout, F->d_status);
         }
         const int nchain = P.cnt[KVX_CLS_BIG];
+        // Few workgroups in the extend-add (the top of the tree, small systems): the first diagonal block is assembled and factored
+        // by a workgroup of the same launch (k_assemble_big_potrf) -- one launch less on the level's critical path.
+        // KVX_ASM_POTRF_WGS = largest extend-add launch (workgroups) that takes this form; 0 = never.
+        static const int64_t asm_potrf_wgs = [] { const char *e = getenv("KVX_ASM_POTRF_WGS"); return e ? atoll(e) : (int64_t)1024; }();
+        const bool asm_potrf = have_big && nchain > 0 &&
+                               (int64_t)P.cnt[KVX_CLS_BIG] * ((P.maxm[KVX_CLS_BIG] + KVX_ASM_TC - 1) / KVX_ASM_TC) <= asm_potrf_wgs;
         if (have_big) {                                     // extend-add of every big front of the level, one launch
             ProfScope ps(F, FAM_ASSEMBLE);
-            launch_assemble_big(st, F->ds, lbase + P.off[KVX_CLS_BIG], P.cnt[KVX_CLS_BIG], P.maxm[KVX_CLS_BIG], F->d_Lx, Uch, Uout);
+            if (asm_potrf)
+                launch_assemble_big_potrf(st, F->ds, lbase + P.off[KVX_CLS_BIG], P.cnt[KVX_CLS_BIG], P.maxm[KVX_CLS_BIG], F->d_Lx, Uch, Uout,
+                                          F->d_Linv, F->d_status);
+            else
+                launch_assemble_big(st, F->ds, lbase + P.off[KVX_CLS_BIG], P.cnt[KVX_CLS_BIG], P.maxm[KVX_CLS_BIG], F->d_Lx, Uch, Uout);
         }
         if (nchain > 0) {
             const int nbig = nchain, bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = lbase + P.off[KVX_CLS_BIG];
-            { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
+            if (!asm_potrf) { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
             if (bigm >= F->two_level_m) {
                 // outer blocks of `outer_block` (1024) columns, one rank-1024 update of the trailing matrix per block (128-tile kernel: 34 TF/s
                 // on a dense trailing matrix; rocBLAS dgemm at K = 256 reaches 48-59).  Measured on MI355X against the
@@ -1000,7 +1010,7 @@ int solve_dev(kvx_chol *F, int sys, double *B, int64_t nrhs, int64_t ldB, bool a
 
 // Numeric factorisation AND the solve of A X = B (sys 0) as ONE enqueue: the right-hand sides are known before the factorisation
 // starts, so the forward sweep does not have to wait for all of it -- level l of the sweep needs the fronts of level l and below
-// only.  The sweep runs on two streams of its own (side[2], side[3]) behind one event per level of the factorisation: by the
+// only.  The sweep runs on the stream of the factorisation's small-front launches (side[0], idle at the top of the tree) behind one event per level of the factorisation: by the
 // time the root front is factored the sweep has reached the top of the tree, and what is left of it is the root's own step
 // (config 2: 0.65 ms of forward sweep hidden under the pivot chain of the top levels).  Same kernels on the same data in the
 // same order per front as kvx_chol_factorize_dev + kvx_chol_solve_dev: bitwise the same factor and solution.  The whole

@@ -52,6 +52,9 @@ struct LazyExec {
             (void)hipGraphDestroy(graph);
             return e;
         };
+        // (KVX_GRAPH_SYNC_INSTANTIATE=1: on the calling thread.  Measured in round 3 against the suspicion that the thread of its own
+        // changes which hardware queues the executable's branches share: 8 alternating processes each way on one box, step
+        // 4.57-4.73 ms on the calling thread, 4.52-4.74 on its own -- the process-to-process spread is there either way.)
         const char *sy = getenv("KVX_GRAPH_SYNC_INSTANTIATE");
         if (sy && sy[0] == '1') { exec = work(); return; }
         fut = std::async(std::launch::async, work).share();
@@ -98,7 +101,7 @@ struct kvx_chol {
     hipEvent_t ev_in = nullptr;                 // orders the factor's stream after the caller's (null-stream) work
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // factor + solve in one call (kvx_chol_factorize_solve_dev): the forward sweep follows the factorisation level by level on
-    // streams of its own (side[2], side[3]) -- a level's fronts are swept while the levels above it are still being factored
+    // the stream of the small-front launches (side[0]) -- a level's fronts are swept while the levels above it are still being factored
     std::vector<hipEvent_t> ev_lvl;             // [nlevels]: recorded on the factor's stream when a level is complete (while pipe_on)
     bool pipe_on = false;
     int pipe_nr = 0;                            // right-hand sides of the sweep that follows the factorisation in flight

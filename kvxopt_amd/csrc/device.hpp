@@ -174,6 +174,9 @@ void launch_factor_subtree(hipStream_t st, int mcap, const DevSym &ds, const Sub
                            double *Lx, double *U0, double *U1, int *status);
 void launch_assemble_big(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
                          double *Lx, const double *Uchild, double *Uout);
+// extend-add + the first diagonal block (factor and inverse) in one launch: for launches of few workgroups (every one reserves 49 KB of LDS)
+void launch_assemble_big_potrf(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                               double *Lx, const double *Uchild, double *Uout, double *Linv, int *status);
 void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int jb,
                       double *Lx, double *Linv, int *status);
 void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,

@@ -50,8 +50,10 @@ constexpr int NB = KVX_NB;
 // wave works on its (up to) four child columns at once -- 16 independent row updates per lane in
 // flight -- and the next child's descriptor is fetched while the current child is added.
 // (256 threads, contains barriers: every thread of the workgroup must call it)
+// skip > 0: the entries (row < skip, column < skip) -- the first diagonal block -- are left to the workgroup of
+// k_assemble_big_potrf that assembles that block in LDS and factors it
 __device__ __forceinline__ void assemble_cols(const DevSym &ds, const FrontDesc &fd, const int ct, double *__restrict__ Lx,
-                                              const double *__restrict__ Uc, double *__restrict__ Uo)
+                                              const double *__restrict__ Uc, double *__restrict__ Uo, const int skip = 0)
 {
     const int k = fd.k, m = fd.m, u = m - k;
     const int c0 = ct * KVX_ASM_TC;
@@ -114,7 +116,7 @@ __device__ __forceinline__ void assemble_cols(const DevSym &ds, const FrontDesc 
                     for (int t = 0; t < 4; t++)
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            if (ok[t][q]) dst[t][r[t][q]] = old[t][q] + v[t][q];
+                            if (ok[t][q] && !(tcs[t] < skip && r[t][q] < skip)) dst[t][r[t][q]] = old[t][q] + v[t][q];
                 }
             }
         }
@@ -365,6 +367,85 @@ void launch_potrf_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int
 {
     if (count <= 0) return;
     hipLaunchKernelGGL(k_potrf_blk, dim3((unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Linv, status);
+}
+
+// Extend-add AND the first diagonal block in one launch, for the levels at the top of the tree (a handful of fronts: the
+// chain  extend-add -> diagonal block -> panel solve -> ...  is a sequence of nearly empty launches there, and the diagonal block
+// of a front needs only 64 x 64 of what the extend-add produces).  One more workgroup per front assembles that block in LDS --
+// the entries of A from the panel, then the children in the order the extend-add takes them, so the sums are bit for bit the
+// ones it would have stored -- and goes straight on to factor and invert it (potrf_lds); the other workgroups leave the block
+// alone.  Saves the k_potrf_blk launch of the level (~20 us of its critical path).  Every workgroup of this kernel reserves the
+// 49 KB of the block structure: used where the launch is small (launch_assemble_big_potrf's caller decides).
+__global__ __launch_bounds__(256) void k_assemble_big_potrf(DevSym ds, const int32_t *__restrict__ list, double *__restrict__ Lx,
+                                                            const double *__restrict__ Uc, double *__restrict__ Uo,
+                                                            double *__restrict__ Linv, int *status, unsigned nct)
+{
+    __shared__ PotrfLds lds;
+    const FrontDesc fd = ds.fd[list[blockIdx.y]];
+    const int k = fd.k, m = fd.m;
+    const int nbk = min(NB, k);
+    if (blockIdx.x < nct) {
+        if ((int)blockIdx.x * KVX_ASM_TC >= m) return;
+        assemble_cols(ds, fd, (int)blockIdx.x, Lx, Uc, Uo, nbk);
+        return;
+    }
+    const int tid = threadIdx.x, i = tid & 63, q = tid >> 6;
+    double *P = Lx + fd.px;
+    {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = q + 4 * t;
+            v[t] = kvx_ld0(P, i + (int64_t)c * m, i < nbk && c <= i);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+            const int c = q + 4 * t;
+            if ((c >> 4) <= (i >> 4)) lds.S[s_idx(i, c)] = (i < nbk && c <= i) ? v[t] : (c == i ? 1.0 : 0.0);   // identity padding
+        }
+    }
+    __syncthreads();
+    if (fd.nchild > 0) {
+        ChildDesc cd = ds.cd[fd.childptr];
+        for (int c = 0; c < fd.nchild; c++) {
+            ChildDesc nx = cd;
+            if (c + 1 < fd.nchild) nx = ds.cd[fd.childptr + c + 1];
+            const int uc = cd.uc;
+            if (uc > 0) {
+                const int32_t *rl = ds.rel + cd.rel;
+                const double *src = Uc + cd.ux;
+                const int J = ds.tiles[cd.tile + NB / KVX_ASM_TC];     // child columns that land left of parent column 64 (m > 128: the table is longer)
+                // wave q takes the child columns q, q + 4, ...: all loads of its (up to) 16 columns first, one round trip per child
+                int tc[16], rr[16];
+                double v[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    const int jc = q + 4 * t;
+                    const bool okc = jc < J;
+                    const int ii = jc + i;
+                    const bool okr = okc && ii < uc;
+                    tc[t] = okc ? rl[jc] : nbk;
+                    rr[t] = okr ? rl[ii] : nbk;
+                    v[t] = kvx_ld0(src, (int64_t)(okc ? jc : 0) * uc + (okr ? ii : 0), okr);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                    if (tc[t] < nbk && rr[t] < nbk) lds.S[s_idx(rr[t], tc[t])] += v[t];
+            }
+            __syncthreads();
+            cd = nx;
+        }
+    }
+    potrf_lds(lds, nbk, tid, status, fd.first, make_piv_rule(ds));
+    potrf_store(lds, nbk, tid, P, m, 0, Linv + fd.linv);
+}
+
+void launch_assemble_big_potrf(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m,
+                               double *Lx, const double *Uchild, double *Uout, double *Linv, int *status)
+{
+    if (count <= 0) return;
+    const unsigned nct = (unsigned)((max_m + KVX_ASM_TC - 1) / KVX_ASM_TC);
+    hipLaunchKernelGGL(k_assemble_big_potrf, dim3(nct + 1, (unsigned)count), dim3(256), 0, st, ds, list, Lx, Uchild, Uout, Linv, status, nct);
 }
 
 // ------------------------------------------------------------------------------------------

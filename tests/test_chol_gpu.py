@@ -837,3 +837,22 @@ def test_factorize_solve_with_host_buffers_and_linsolve():
         assert np.array_equal(got, ref[off:].reshape(ld, nrhs, order="F")), rep
     with pytest.raises(ArithmeticError):
         cholmod.linsolve(spmatrix.from_ccs(n, n, cp, ri, bad), matrix(buf[:n].copy()))
+
+
+@pytest.mark.gpu
+def test_fused_first_diagonal_block_is_bitwise():
+    """k_assemble_big_potrf (round 3): at the top of the tree the first 64 x 64 diagonal block of a big front is assembled in LDS --
+    A's entries, then the children in the order the extend-add takes them -- and factored by a workgroup of the extend-add launch.
+    The factor and a solve are bit for bit those of the separate k_potrf_blk launch (KVX_ASM_POTRF_WGS=0)."""
+    import json
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "factor_bits_probe.py")
+    outs = []
+    for flag in ("0", "1024"):
+        env = dict(os.environ, KVX_ASM_POTRF_WGS=flag)
+        r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert all(v["max_front"] > 128 for v in outs[0].values())      # every system has big fronts (the path under test)
