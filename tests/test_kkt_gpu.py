@@ -1091,3 +1091,84 @@ def test_fused_iteration_is_bitwise():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
     assert all(v["status"] == "optimal" for v in outs[0].values())
+
+
+@pytest.mark.gpu
+def test_fused_iteration_entries_against_numpy():
+    """The round-3 entries one by one against their definitions in numpy (misc.py:1489-1563, coneprog.py:861-896, 1250-1298,
+    1339-1432; tolerance 1e-13 relative -- the bitwise comparison with the call-by-call path is test_fused_iteration_is_bitwise):
+    kvx_kkt_solve_pre_dev / _post_dev with one and two right-hand sides and long rows, kvx_lp_residuals_dev, kvx_lp_update_x_dev,
+    kvx_atda_assemble_sq_dev, kvx_lp_newton_rhs_dev without lmbdasq."""
+    import ctypes
+    import scipy.sparse as sp
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    ml, n = 700, 90
+    G = sp.random(ml, n, density=0.06, random_state=3, format="csc") + sp.csc_matrix((rng.standard_normal(n), (rng.integers(0, ml, n), np.arange(n))), shape=(ml, n))
+    G = sp.csc_matrix(G); G.sort_indices()
+    assert np.diff(G.indptr).max() > 16 and np.diff(G.tocsr().indptr).max() > 8          # the 16-lane forms
+    Gd = lp.SpMatDev(ml, n, G.indptr.astype(np.int64), G.indices.astype(np.int64), G.data)
+    dv = lambda a: lp.DVec(len(a), a)
+    close = lambda a, b: np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(b).max())
+    di = rng.uniform(0.5, 2.0, ml)
+    xin = [rng.standard_normal(n) for _ in range(2)]
+    zin = [rng.standard_normal(ml) for _ in range(2)]
+    xs, xos, zos = [-1.0, 0.7], [0.3, 1.0], [0.3, 1.0]
+    did = dv(di)
+    for nrhs in (1, 2):
+        xi, zi = [dv(a) for a in xin], [dv(a) for a in zin]
+        xo, zo = [lp.DVec(n) for _ in range(2)], [lp.DVec(ml) for _ in range(2)]
+        sides = lp._sides([(xi[k], xs[k], zi[k], xo[k], xos[k], zo[k], zos[k]) for k in range(nrhs)])
+        x2 = lp.DVec(2 * n)
+        _lib.raise_for(L.kvx_kkt_solve_pre_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.max_col, did.ptr, nrhs, sides, x2.ptr, n))
+        got = x2.get()
+        for k in range(nrhs):
+            assert close(got[k * n:(k + 1) * n], xs[k] * xin[k] + G.T @ (di * (zin[k] * di))), (nrhs, k)
+        # (what the triangular solves would put there: anything -- the post step is a function of x2)
+        x2v = rng.standard_normal(2 * n); x2.set(x2v)
+        _lib.raise_for(L.kvx_kkt_solve_post_dev(ml, n, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row, did.ptr, nrhs, sides, x2.ptr, n))
+        for k in range(nrhs):
+            xk = x2v[k * n:(k + 1) * n]
+            assert close(xo[k].get(), xos[k] * xk), (nrhs, k)
+            assert close(zo[k].get(), zos[k] * (di * (G @ xk) - zin[k] * di)), (nrhs, k)
+    # residuals
+    x, z, s, c, h = rng.standard_normal(n), rng.uniform(0.1, 1, ml), rng.uniform(0.1, 1, ml), rng.standard_normal(n), rng.standard_normal(ml)
+    tau = 0.8125
+    out = [lp.DVec(n), lp.DVec(n), lp.DVec(ml), lp.DVec(ml)]
+    ins = [dv(a) for a in (x, z, s, c, h)]                   # (kept alive: a freed vector's block goes back to the pool)
+    _lib.raise_for(L.kvx_lp_residuals_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.max_col, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row,
+                                          *[a.ptr for a in ins], tau, *[o.ptr for o in out]))
+    hrx = -(G.T @ z); hrz = G @ x + s
+    for o, ref in zip(out, (hrx, hrx - tau * c, hrz, hrz - tau * h)):
+        assert close(o.get(), ref)
+    # update + x += step dx
+    ds, dz, d, lm = rng.uniform(-0.5, 0.5, ml), rng.uniform(-0.5, 0.5, ml), rng.uniform(0.5, 2, ml), rng.uniform(0.5, 2, ml)
+    dx, step = rng.standard_normal(n), 0.625
+    v = [dv(a) for a in (ds, dz, d, np.zeros(ml), lm, np.zeros(ml), np.zeros(ml))]
+    xd, dxd = dv(x), dv(dx)
+    _lib.raise_for(L.kvx_lp_update_x_dev(ml, n, step, *[a.ptr for a in v], dxd.ptr, xd.ptr))
+    ss, zz = np.sqrt((step * ds + 1) * lm), np.sqrt((step * dz + 1) * lm)
+    dd = d * ss / zz
+    for got, ref in zip(v, (ss, zz, dd, 1 / dd, ss * zz, ss * zz * dd, ss * zz / dd)):
+        assert close(got.get(), ref)
+    assert close(xd.get(), x + step * dx)
+    # S = G' diag(di)^2 G with the square taken inside the assembly
+    hpl = ctypes.c_void_p()
+    _lib.raise_for(L.kvx_atda_plan(ml, n, _lib.pi(G.indptr.astype(np.int64)), _lib.pi(G.indices.astype(np.int64)), None, None, ctypes.byref(hpl)))
+    snz = ctypes.c_int64()
+    _lib.raise_for(L.kvx_atda_pattern(hpl, ctypes.byref(snz), None, None))
+    Sp = np.empty(n + 1, dtype=np.int64); Si = np.empty(snz.value, dtype=np.int64)
+    _lib.raise_for(L.kvx_atda_pattern(hpl, ctypes.byref(snz), _lib.pi(Sp), _lib.pi(Si)))
+    Sx = lp.DVec(snz.value)
+    _lib.raise_for(L.kvx_atda_assemble_sq_dev(hpl, Gd.vx.ptr, did.ptr, None, Sx.ptr))
+    Sref = (G.T @ sp.diags(di * di) @ G).toarray()
+    cols = np.repeat(np.arange(n), np.diff(Sp))
+    assert close(Sx.get(), Sref[Si, cols])
+    L.kvx_atda_free(hpl)
+    # Newton right-hand side with lmbda o lmbda formed in the kernel
+    rz, ws3 = rng.standard_normal(ml), rng.standard_normal(ml)
+    o1, o2 = lp.DVec(ml), lp.DVec(ml)
+    keep = [dv(a) for a in (ws3, rz, lm, d)]
+    _lib.raise_for(L.kvx_lp_newton_rhs_dev(ml, None, keep[0].ptr, 0.25, 0.75, keep[1].ptr, keep[2].ptr, keep[3].ptr, o1.ptr, o2.ptr))
+    dsr = -((lm * lm + ws3) - 0.25) / lm
+    assert close(o1.get(), dsr) and close(o2.get(), -(0.75 * rz + dsr * d))
