@@ -535,7 +535,7 @@ def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mo
         elif dom in ("fwd_level", "bwd_level"):
             alg_bytes = (8.0 * st["lsize"] + 4.0 * st["sum_m"] + 16.0 * n) * nrhs
         elif dom == "scatter_a":
-            alg_bytes = 24.0 * len(values)
+            alg_bytes = 24.0 * len(values) + 8.0 * st["lsize"]      # (the family zeroes L in the same pass since round 3)
         else:
             alg_bytes = 8.0 * st["lsize"]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9

@@ -271,6 +271,29 @@ int ensure_device(kvx_chol *F)
     if ((rc = upload(&F->d_wx, S.wx))) return rc;
     if ((rc = upload(&F->d_childptr, S.childptr))) return rc;
     if ((rc = upload(&F->d_amap, S.amap))) return rc;
+    if (S.nnzA < INT32_MAX && F->part.empty() && !getenv("KVX_INIT_TWO_PASSES")) {
+        // the scatter map once more, grouped by the chunk of the factor an entry goes to (counting sort): k_init_factor zeroes L and
+        // scatters A in one pass.  (Sharded factors keep the two launches: their layout is trimmed afterwards.)
+        const int sh = init_factor_shift();
+        const int64_t nchunk = std::max<int64_t>((S.lsize + ((int64_t)1 << sh) - 1) >> sh, 1);
+        std::vector<int64_t> cptr((size_t)nchunk + 1, 0);
+        for (int64_t e = 0; e < S.nnzA; e++)
+            if (S.amap[(size_t)e] >= 0) cptr[(size_t)(S.amap[(size_t)e] >> sh) + 1]++;
+        for (int64_t q = 0; q < nchunk; q++) cptr[(size_t)q + 1] += cptr[(size_t)q];
+        const int64_t live = cptr[(size_t)nchunk];
+        std::vector<int64_t> sdst((size_t)std::max<int64_t>(live, 1)), at(cptr.begin(), cptr.end() - 1);
+        std::vector<int32_t> ssrc((size_t)std::max<int64_t>(live, 1));
+        for (int64_t e = 0; e < S.nnzA; e++) {
+            const int64_t d = S.amap[(size_t)e];
+            if (d < 0) continue;
+            const int64_t q = at[(size_t)(d >> sh)]++;
+            sdst[(size_t)q] = d; ssrc[(size_t)q] = (int32_t)e;
+        }
+        if ((rc = upload(&F->d_sdst, sdst))) return rc;
+        if ((rc = upload(&F->d_ssrc, ssrc))) return rc;
+        if ((rc = upload(&F->d_scptr, cptr))) return rc;
+        F->scnt = live;
+    }
     HIPCHK(pool_malloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
     for (int p = 0; p < 2; p++)
         HIPCHK(pool_malloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
@@ -396,13 +419,19 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
         // (7.0.51831, the one a process gets once torch is imported), the memset nodes of a SMALL factor were not ordered before
         // the kernels behind them -- a dense 200 x 200 K of misc.kkt_chol2 failed at column 0 in 28 of 30 replays
         // (scratch/graph_stress.py; ROCm 7.2's own runtime replays them correctly).  KVX_DBG_MEMSET_NODES=1 restores the nodes.
-        if (getenv("KVX_DBG_MEMSET_NODES")) {
-            HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
-            HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+        if (F->d_scptr && !getenv("KVX_DBG_MEMSET_NODES")) {
+            ProfScope ps(F, FAM_SCATTER);          // zero L, reset the status word and scatter A: one pass over L
+            launch_init_factor(st, F->d_Ax, F->d_ssrc, F->d_sdst, F->d_scptr, S.lsize, F->d_Lx, F->d_status);
         } else {
-            launch_clear_factor(st, F->d_Lx, S.lsize, F->d_status);
+            if (getenv("KVX_DBG_MEMSET_NODES")) {
+                HIPCHK(hipMemsetAsync(F->d_Lx, 0, std::max<int64_t>(S.lsize, 1) * sizeof(double), st));
+                HIPCHK(hipMemsetAsync(F->d_status, 0x7f, sizeof(int), st));   // 0x7f7f7f7f = "no failing column"
+            } else {
+                launch_clear_factor(st, F->d_Lx, S.lsize, F->d_status);
+            }
+            ProfScope ps(F, FAM_SCATTER);
+            launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx);
         }
-        { ProfScope ps(F, FAM_SCATTER); launch_scatter_a(st, F->d_Ax, F->d_amap, S.nnzA, F->d_Lx); }
     }
     if (lfrom < 0) lfrom = S.nlevels - 1;
     if (F->factor_subtrees && prologue && lfrom == S.nlevels - 1) {
@@ -1770,7 +1799,7 @@ void kvx_chol_free(kvx_chol *F)
         if (F->stream) (void)hipStreamSynchronize(F->stream);
         lap("sync");
         void *ptrs[] = {F->d_k, F->d_m, F->d_first, F->d_rowidx, F->d_rel, F->d_children, F->d_perm, F->d_lists,
-                        F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_Lx, F->d_U[0], F->d_U[1],
+                        F->d_px, F->d_rowptr, F->d_ux, F->d_wx, F->d_childptr, F->d_amap, F->d_sdst, F->d_ssrc, F->d_scptr, F->d_Lx, F->d_U[0], F->d_U[1],
                         F->d_Ax, F->d_X, F->d_X0, F->d_diag, F->d_W[0], F->d_W[1], F->d_status, F->d_WK, F->d_Linv, F->d_linv_off, F->d_fd, F->d_cd, F->d_tiles};
         for (void *p : ptrs)
             if (p) (void)pool_free(p);

@@ -117,10 +117,12 @@ struct kvx_chol {
     int32_t *d_k = nullptr, *d_m = nullptr, *d_first = nullptr, *d_rowidx = nullptr, *d_rel = nullptr,
             *d_children = nullptr, *d_perm = nullptr, *d_lists = nullptr;
     int64_t *d_px = nullptr, *d_rowptr = nullptr, *d_ux = nullptr, *d_wx = nullptr, *d_childptr = nullptr,
-            *d_amap = nullptr;
+            *d_amap = nullptr, *d_sdst = nullptr, *d_scptr = nullptr;   // d_sdst / d_ssrc / d_scptr: the scatter map grouped by chunk of L (k_init_factor)
     double *d_Lx = nullptr, *d_U[2] = {nullptr, nullptr}, *d_Ax = nullptr;
     double *d_X = nullptr, *d_X0 = nullptr, *d_W[2] = {nullptr, nullptr}, *d_WK = nullptr;   // d_X0: untouched copy of the rhs for the forward sweep
     double *d_Linv = nullptr;
+    int32_t *d_ssrc = nullptr;
+    int64_t scnt = 0;
     int64_t *d_linv_off = nullptr;
     FrontDesc *d_fd = nullptr;
     ChildDesc *d_cd = nullptr;

@@ -31,7 +31,7 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
-FAMILY = {"k_scatter_a": "scatter_a", "k_front_wave": "front_small", "k_front_lds": "front_small", "k_assemble_big": "assemble_big",
+FAMILY = {"k_scatter_a": "scatter_a", "k_init_factor": "scatter_a", "k_front_wave": "front_small", "k_front_lds": "front_small", "k_assemble_big": "assemble_big",
           "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing", "k_syrk_trailing128": "syrk_trailing",
           "k_fwd_wave": "fwd_level", "k_fwd_subtree": "fwd_level", "k_bwd_subtree": "bwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_step": "fwd_level",
           "k_bwd_wave": "bwd_level", "k_bwd_lds": "bwd_level", "k_bwd_big_init": "bwd_level", "k_bwd_big_step": "bwd_level"}
@@ -47,7 +47,7 @@ if os.path.exists(b):
 st = glob.glob(os.path.join(out, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
-    nfac = sum(int(r["Calls"]) for r in rows if clean(r["Name"]).startswith("k_clear_factor"))
+    nfac = sum(int(r["Calls"]) for r in rows if clean(r["Name"]).startswith(("k_clear_factor", "k_init_factor")))
     with open(os.path.join(prof, tag + "_kernel_stats.csv"), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ipm --no-extra --no-one-shot\n")
         f.write("# %d numeric factorisations in the process: 12 one-enqueue steps (factor + solve, forward sweep beside the top of the tree), 8 steps as two calls, "
@@ -86,7 +86,7 @@ fscale = cal.get("fetch_scale", 1.0)
 wscale = cal.get("write_scale", 1.0)
 
 res = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 1 --quick [--workload W]`. "
-                "Counter values are KiB; per_step = raw KiB per factor+solve step (steps counted from the k_clear_factor launches of the run); "
+                "Counter values are KiB; per_step = raw KiB per factor+solve step (steps counted from the k_init_factor launches of the run); "
                 "family_bytes_per_step = (FETCH_SIZE x fetch_scale + WRITE_SIZE x write_scale) x 1024 per step, the scales from the calibration kernel "
                 "(known byte count, the library's 8-byte-per-lane pattern) as MI355X_MICROARCH.md prescribes for access widths other than 16 bytes per lane.",
        "source_fingerprint": source_fingerprint(), "calibration": cal, "fetch_scale": round(fscale, 4), "write_scale": round(wscale, 4),
@@ -96,7 +96,7 @@ for key, W in (("config2", "lap2d"), ("stencil21", "stencil21")):
     wa, wc = pmc("%s_pmc_write_%s" % (tag, W), "WRITE_SIZE")
     if not (fa or wa):
         continue
-    steps = max(fc.get("k_clear_factor", wc.get("k_clear_factor", 1)), 1)
+    steps = max(fc.get("k_init_factor", wc.get("k_init_factor", fc.get("k_clear_factor", wc.get("k_clear_factor", 1)))), 1)
     per = {}
     for k in sorted(set(fa) | set(wa)):
         per[k] = {"dispatches": round(fc.get(k, wc.get(k, 0)) / steps, 1), "FETCH_SIZE_KB": round(fa.get(k, 0.0) / steps, 1),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of one interior-point iteration (k_clear_factor .. the next k_clear_factor) near the end of a rocprofv3 kernel trace."""
+"""Timeline of one interior-point iteration (k_init_factor .. the next k_clear_factor) near the end of a rocprofv3 kernel trace."""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = []
@@ -8,7 +8,7 @@ for r in rows:
     ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm, r.get("Queue_Id", "0"),
                int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1)))
 ks.sort()
-ci = [i for i, k in enumerate(ks) if k[2].startswith("k_clear_factor")]
+ci = [i for i, k in enumerate(ks) if k[2].startswith(("k_clear_factor", "k_init_factor"))]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 s, e = ci[-back - 1], ci[-back]
 t0 = ks[s][0]

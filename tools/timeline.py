@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the last bench step (k_clear_factor .. k_perm_scatter) from a rocprofv3 kernel trace csv."""
+"""Timeline of the last bench step (k_init_factor .. k_perm_scatter) from a rocprofv3 kernel trace csv."""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ks = []
@@ -9,7 +9,7 @@ for r in rows:
                int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1), int(r["Grid_Size_Y"]) // max(int(r["Workgroup_Size_Y"]), 1),
                int(r["Grid_Size_Z"]) // max(int(r["Workgroup_Size_Z"]), 1), r.get("VGPR_Count", ""), r.get("LDS_Block_Size", "")))
 ks.sort()
-ci = [i for i, k in enumerate(ks) if k[2].startswith("k_clear_factor")]
+ci = [i for i, k in enumerate(ks) if k[2].startswith(("k_clear_factor", "k_init_factor"))]
 si = [i for i, k in enumerate(ks) if k[2].startswith("k_perm_scatter")]
 s = ci[-1]
 e = max(i for i in si if i > s) if any(i > s for i in si) else len(ks) - 1
