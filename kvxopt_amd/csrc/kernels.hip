@@ -84,10 +84,13 @@ void launch_copy_d(hipStream_t st, double *dst, const double *src, int64_t n)
 // Zero the factor AND scatter the caller's values in ONE pass over L.  A's entries land in nearly every cache line of the small
 // fronts' panels (three entries per column of 20-60 rows on the 5-point system), so the scatter behind the zeroing was a second
 // full read-modify-write pass over L -- 64 us behind the 63 us of the zeroing on config 2.  Here a workgroup owns a chunk of
-// KVX_INIT_CHUNK doubles of L: zeros in LDS, the chunk's entries on top (the scatter map grouped by chunk on the host, api.cpp),
+// KVX_INIT_CHUNK doubles of L (16 KB; 4 / 8 / 16 / 32 / 64 KB measured: 101 / 105 / 87-95 / 91 / 84 us): zeros in LDS, the chunk's entries on top (the scatter map grouped by chunk on the host, api.cpp),
 // one coalesced store of the chunk.  The gather from the caller's value array (24 MB, cached) is the cheap side.
-constexpr int KVX_INIT_SHIFT = 10, KVX_INIT_CHUNK = 1 << KVX_INIT_SHIFT;
-__global__ __launch_bounds__(128) void k_init_factor(const double *__restrict__ Ax, const int32_t *__restrict__ src,
+#ifndef KVX_INIT_SHIFT_V
+#define KVX_INIT_SHIFT_V 11
+#endif
+constexpr int KVX_INIT_SHIFT = KVX_INIT_SHIFT_V, KVX_INIT_CHUNK = 1 << KVX_INIT_SHIFT, KVX_INIT_NT = KVX_INIT_CHUNK / 8;
+__global__ __launch_bounds__(KVX_INIT_NT) void k_init_factor(const double *__restrict__ Ax, const int32_t *__restrict__ src,
                                                      const int64_t *__restrict__ dst, const int64_t *__restrict__ cptr, int64_t lsize,
                                                      double *__restrict__ Lx, int *status)
 {
@@ -97,16 +100,16 @@ __global__ __launch_bounds__(128) void k_init_factor(const double *__restrict__ 
     if (blockIdx.x == 0 && tid == 0) *status = 0x7f7f7f7f;
     const int64_t e0 = cptr[blockIdx.x], e1 = cptr[blockIdx.x + 1];
 #pragma unroll
-    for (int i = tid; i < KVX_INIT_CHUNK; i += 128) t[i] = 0.0;
+    for (int i = tid; i < KVX_INIT_CHUNK; i += KVX_INIT_NT) t[i] = 0.0;
     __syncthreads();
-    for (int64_t e = e0 + tid; e < e1; e += 128) t[dst[e] & (KVX_INIT_CHUNK - 1)] = Ax[src[e]];
+    for (int64_t e = e0 + tid; e < e1; e += KVX_INIT_NT) t[dst[e] & (KVX_INIT_CHUNK - 1)] = Ax[src[e]];
     __syncthreads();
     if (base + KVX_INIT_CHUNK <= lsize) {                                        // (pool blocks are 256-byte aligned)
         double2 *o = (double2 *)(Lx + base);
 #pragma unroll
-        for (int i = tid; i < KVX_INIT_CHUNK / 2; i += 128) o[i] = make_double2(t[2 * i], t[2 * i + 1]);
+        for (int i = tid; i < KVX_INIT_CHUNK / 2; i += KVX_INIT_NT) o[i] = make_double2(t[2 * i], t[2 * i + 1]);
     } else {
-        for (int i = tid; base + i < lsize; i += 128) Lx[base + i] = t[i];
+        for (int i = tid; base + i < lsize; i += KVX_INIT_NT) Lx[base + i] = t[i];
     }
 }
 int init_factor_shift() { return KVX_INIT_SHIFT; }
@@ -114,7 +117,7 @@ void launch_init_factor(hipStream_t st, const double *Ax, const int32_t *src, co
                         double *Lx, int *status)
 {
     const int64_t nchunk = std::max<int64_t>((lsize + KVX_INIT_CHUNK - 1) >> KVX_INIT_SHIFT, 1);
-    hipLaunchKernelGGL(k_init_factor, dim3((unsigned)nchunk), dim3(128), 0, st, Ax, src, dst, cptr, lsize, Lx, status);
+    hipLaunchKernelGGL(k_init_factor, dim3((unsigned)nchunk), dim3(KVX_INIT_NT), 0, st, Ax, src, dst, cptr, lsize, Lx, status);
 }
 
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx)
