@@ -686,9 +686,42 @@ __global__ __launch_bounds__(LU_NT_LDS) void k_lub_panel(const LuDev d, const in
 // pivot; the row lands at its logical position when the panel is written back (identical to applying the
 // interchanges, which k_lub_trsm does for the other columns).  The pivot steps are expanded by template recursion so
 // that every index into the row is a compile-time constant (a `#pragma unroll` loop left the row in scratch memory).
+// Wave-wide max of a double / min of an int by DPP row operations (no LDS round trips: a __shfl_xor butterfly over 64 lanes is six
+// dependent ds_bpermute rounds of three permutes each -- 1400-1900 cycles of the 4200 a pivot step of the register panel took).
+// row_shr 1, 2, 4, 8 leave the row's result in its last lane, row_bcast 15 / 31 carry it across the rows; lane 63 holds the wave's.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double dpp_max_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWS, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWS, 0xf, false);
+    return fmax(v, __hiloint2double(hi, lo));
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ int dpp_min_i32(int v) { return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false)); }
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    v = dpp_max_f64<0x111>(v); v = dpp_max_f64<0x112>(v); v = dpp_max_f64<0x114>(v); v = dpp_max_f64<0x118>(v);
+    v = dpp_max_f64<0x142, 0xa>(v); v = dpp_max_f64<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    v = dpp_min_i32<0x111>(v); v = dpp_min_i32<0x112>(v); v = dpp_min_i32<0x114>(v); v = dpp_min_i32<0x118>(v);
+    v = dpp_min_i32<0x142, 0xa>(v); v = dpp_min_i32<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// the largest value of the wave and, among the lanes that hold it, the smallest slot (the rule of the butterfly it replaces)
+__device__ __forceinline__ void wave_argmax(double &bmax, int &bslot)
+{
+    const double vm = wave_max_f64(bmax);
+    bslot = wave_min_i32(bmax == vm ? bslot : 0x7fffffff);
+    bmax = vm;
+}
+
 template <int RPT>
 struct PanelCtx {
-    double *sh_b, *urow, *sh_diag;
+    double *sh_b, *urow, *sh_diag, *sh_rinv;
     int *sh_s, *sh_piv;
     int32_t *fail_slot;
     double tol, lmax;
@@ -715,29 +748,19 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
                     if (c && (av > bmax || (av == bmax && x.slot[q] < bslot))) { bmax = av; bslot = x.slot[q]; }
                     if (x.has[q] && x.slot[q] == J) {
                         sh_diag[0] = av;
+                        x.sh_rinv[J & 1] = 1.0 / a[q][J];         // the reciprocal travels with the row: one division per pivot, not one per row
 #pragma unroll
-                        for (int c2 = 0; c2 < NB; c2++) uspec[c2] = a[q][c2];
+                        for (int c2 = J; c2 < NB; c2++) uspec[c2] = a[q][c2];      // (columns left of the pivot are not read again)
                     }
                 }
-#pragma unroll
-                for (int off = 32; off; off >>= 1) {
-                    const double ob = __shfl_xor(bmax, off);
-                    const int os = __shfl_xor(bslot, off);
-                    if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
-                }
+                wave_argmax(bmax, bslot);
                 if (x.lane == 0) { sh_b[x.wave] = bmax; sh_s[x.wave] = bslot; }
             }
             __syncthreads();
-            double bmax = -1.0;
-            int bslot = 0x7fffffff;
-#pragma unroll
-            for (int w = 0; w < 16; w++) {
-                if (w < x.ncw) {
-                    const double ob = sh_b[w];
-                    const int os = sh_s[w];
-                    if (ob > bmax || (ob == bmax && os < bslot)) { bmax = ob; bslot = os; }
-                }
-            }
+            // the waves' results: lane w reads wave w's, one more wave-wide reduction (every wave for itself)
+            double bmax = x.lane < x.ncw ? sh_b[x.lane & 15] : -1.0;
+            int bslot = x.lane < x.ncw ? sh_s[x.lane & 15] : 0x7fffffff;
+            wave_argmax(bmax, bslot);
             const double dg = sh_diag[0];
             int r = (dg > 0.0 && dg >= x.tol * bmax) ? J : bslot;
             if (x.reuse) r = J + x.sh_piv[J];
@@ -747,8 +770,9 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
 #pragma unroll
                 for (int q = 0; q < RPT; q++) {
                     if (x.has[q] && x.slot[q] == r) {
+                        x.sh_rinv[J & 1] = 1.0 / a[q][J];
 #pragma unroll
-                        for (int c = 0; c < NB; c++) uspec[c] = a[q][c];
+                        for (int c = J; c < NB; c++) uspec[c] = a[q][c];
                         x.slot[q] = J;
                     } else if (x.has[q] && x.slot[q] == J) x.slot[q] = r;
                 }
@@ -758,6 +782,7 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
             const double ap = fabs(pv);
             const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);
             if (bad) pv = 1.0;
+            const double rpv = bad ? 1.0 : x.sh_rinv[J & 1];
             if (threadIdx.x == 0) {
                 if (bad && !x.failed && *x.fail_slot == 0) { x.failed = true; *x.fail_slot = x.jb + J + 1; }
                 x.sh_piv[J] = r - J;
@@ -765,7 +790,7 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 if (x.has[q] && x.slot[q] > J) {
-                    const double l = a[q][J] / pv;
+                    const double l = a[q][J] * rpv;
                     a[q][J] = l;
                     x.lmax = fmax(x.lmax, fabs(l));
 #pragma unroll
@@ -784,7 +809,7 @@ template <int NB, int RPT>
 __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
                                                          const double stol, const int reuse)
 {
-    __shared__ double sh_b[32], sh_diag[2], urow[2 * NB];
+    __shared__ double sh_b[32], sh_diag[2], urow[2 * NB], sh_rinv[2];
     __shared__ int sh_s[32], sh_piv[NB];
     const int tid = threadIdx.x, nth = blockDim.x;
     const int f = list[blockIdx.x];
@@ -797,7 +822,7 @@ __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int
     int32_t *ipiv = d.ipiv + F.p0 + jb;
     if (reuse && tid < nbk) sh_piv[tid] = ipiv[tid];
     PanelCtx<RPT> x;
-    x.sh_b = sh_b; x.sh_diag = sh_diag; x.urow = urow; x.sh_s = sh_s; x.sh_piv = sh_piv;
+    x.sh_b = sh_b; x.sh_diag = sh_diag; x.urow = urow; x.sh_s = sh_s; x.sh_piv = sh_piv; x.sh_rinv = sh_rinv;
     x.fail_slot = d.fail + f; x.tol = tol; x.lmax = 0.0;
     x.lane = tid & 63; x.wave = tid >> 6; x.nbk = nbk; x.cand = k - jb; x.reuse = reuse; x.jb = jb;
     x.ncw = RPT > 1 ? (nth >> 6) : (min(x.cand, rows) + 63) >> 6;     // with several rows per thread every wave may hold candidates
