@@ -198,6 +198,20 @@ struct TileCtx {
     bool failed;
 };
 
+// Reductions over the 16 lanes of a DPP row by row rotations (ror 8, 4, 2, 1: every lane of the row ends with the result): the pivot
+// search of a tiled front ran four rounds of six __shfl_xor (nine ds_bpermute, an LDS crossbar round trip each) per pivot.
+template <int N>
+__device__ __forceinline__ int row_ror_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false); }
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{ return __hiloint2double(row_ror_i32<N>(__double2hiint(v)), row_ror_i32<N>(__double2loint(v))); }
+__device__ __forceinline__ double row16_max_f64(double v)
+{ v = fmax(v, row_ror_f64<8>(v)); v = fmax(v, row_ror_f64<4>(v)); v = fmax(v, row_ror_f64<2>(v)); return fmax(v, row_ror_f64<1>(v)); }
+__device__ __forceinline__ int row16_min_i32(int v)
+{ v = min(v, row_ror_i32<8>(v)); v = min(v, row_ror_i32<4>(v)); v = min(v, row_ror_i32<2>(v)); return min(v, row_ror_i32<1>(v)); }
+__device__ __forceinline__ int row16_max_i32(int v)
+{ v = max(v, row_ror_i32<8>(v)); v = max(v, row_ror_i32<4>(v)); v = max(v, row_ror_i32<2>(v)); return max(v, row_ror_i32<1>(v)); }
+
 template <int T, int BJ>
 __device__ __forceinline__ void tile_block(double (&a)[T][T], TileCtx<T> &x)
 {
@@ -220,21 +234,23 @@ __device__ __forceinline__ void tile_block(double (&a)[T][T], TileCtx<T> &x)
                     } else if (cand && (av > bmax || (av == bmax && sl < bslot))) { bmax = av; bval = v; brow = i; bslot = sl; }
                     if (i < x.k && sl == j) { qrow = i; dval = v; }
                 }
-#pragma unroll
-                for (int off = 8; off; off >>= 1) {
-                    const double ob = __shfl_xor(bmax, off), ov = __shfl_xor(bval, off), od = __shfl_xor(dval, off);
-                    const int orow = __shfl_xor(brow, off), osl = __shfl_xor(bslot, off), oq = __shfl_xor(qrow, off);
-                    if (ob > bmax || (ob == bmax && osl < bslot)) { bmax = ob; bval = ov; brow = orow; bslot = osl; }
-                    if (oq >= 0) { qrow = oq; dval = od; }
-                }
-                if (x.tx == 0) {
-                    // KLU's rule: keep the diagonal (the row at logical position j) when |d| >= tol * max
-                    if (!x.reuse && qrow >= 0 && fabs(dval) > 0.0 && fabs(dval) >= x.tol * bmax) { brow = qrow; bval = dval; bslot = j; }
+                // the largest candidate of the 16 lanes, the smallest slot among those that hold it, the diagonal's row: three reductions
+                // by row rotations; the values of the chosen row never travel -- the lane that holds it publishes
+                const double gmax = row16_max_f64(bmax);
+                const int gslot = row16_min_i32(bmax == gmax ? bslot : 0x7fffffff);     // (0x7fffffff: no candidate row at all)
+                const int gq = row16_max_i32(qrow);
+                // KLU's rule: keep the diagonal (the row at logical position j) when |d| >= tol * max -- the lane that holds it decides
+                const int keep = row16_max_i32((!x.reuse && qrow >= 0 && fabs(dval) > 0.0 && fabs(dval) >= x.tol * gmax) ? 1 : 0);
+                bool me;
+                if (keep) { me = qrow >= 0; brow = qrow; bval = dval; bslot = j; }
+                else if (gslot != 0x7fffffff) me = bmax == gmax && bslot == gslot;
+                else { me = x.tx == 0; brow = -1; bval = 0.0; }
+                if (me) {
                     const double ap = fabs(bval);
                     const bool bad = brow < 0 || !(ap > 0.0) || !(ap <= 1.7e308);
-                    if (bad && !x.failed) { x.failed = true; *x.fail_slot = j + 1; }
-                    if (bad) { bval = 1.0; if (brow < 0) { brow = qrow; bslot = j; } }
-                    x.sh_r[0] = brow; x.sh_r[1] = qrow; x.sh_r[2] = bslot;
+                    if (bad && *x.fail_slot == 0) *x.fail_slot = j + 1;
+                    if (bad) { bval = 1.0; if (brow < 0) { brow = gq; bslot = j; } }
+                    x.sh_r[0] = brow; x.sh_r[1] = gq; x.sh_r[2] = bslot;
                     x.sh_pv[0] = bval;
                     x.sh_piv[j] = bslot - j;
                 }
