@@ -1114,18 +1114,28 @@ __global__ __launch_bounds__(256) void k_bwd_big_init(DevSym ds, const int32_t *
     if (ln == 0) wk[c] = x[f + c] - acc;
 }
 
-// sum over the 64 lanes of four values at once: after the call the lanes with (lane & 3) == j hold the
-// total of v[o], o = 2 * (j & 1) + (j >> 1).  Halving exchange first (4 -> 2 -> 1 values per lane), then a
-// plain butterfly; 7 shuffles instead of 24, fixed order.
+// sum over the 64 lanes of four values at once: after the call the lanes 0 .. 3 hold the total of v[o],
+// o = 2 * (lane & 1) + (lane >> 1) (the other lanes of a class (lane & 3) hold it up to the order of the additions).
+// Halving exchange first (4 -> 2 -> 1 values per lane), then the sum over the sixteen quads; fixed order.  Round 3: the
+// exchanges inside a row of 16 lanes are DPP moves (quad permutes, row rotations by 4 and 8) -- a __shfl_xor is two
+// ds_bpermute, an LDS crossbar round trip each, and a backward super-step chains up to ten of these calls; only the two
+// exchanges across rows (16, 32) remain shuffles.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, double v3, int lane)
 {
     const bool b0 = lane & 1, b1 = lane & 2;
     const double s0 = b0 ? v0 : v2, s1 = b0 ? v1 : v3;
-    const double k0 = (b0 ? v2 : v0) + __shfl_xor(s0, 1);
-    const double k1 = (b0 ? v3 : v1) + __shfl_xor(s1, 1);
-    double r = (b1 ? k1 : k0) + __shfl_xor(b1 ? k0 : k1, 2);
-    r += __shfl_xor(r, 4);
-    r += __shfl_xor(r, 8);
+    const double k0 = (b0 ? v2 : v0) + dpp_mov_f64<0xB1>(s0);                   // quad_perm [1, 0, 3, 2]: lane ^ 1
+    const double k1 = (b0 ? v3 : v1) + dpp_mov_f64<0xB1>(s1);
+    double r = (b1 ? k1 : k0) + dpp_mov_f64<0x4E>(b1 ? k0 : k1);                // quad_perm [2, 3, 0, 1]: lane ^ 2
+    r += dpp_mov_f64<0x124>(r);                                                 // row_ror 4
+    r += dpp_mov_f64<0x128>(r);                                                 // row_ror 8: the row's four quads
     r += __shfl_xor(r, 16);
     r += __shfl_xor(r, 32);
     return r;
