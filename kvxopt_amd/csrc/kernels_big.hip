@@ -1117,9 +1117,22 @@ __global__ __launch_bounds__(256) void k_bwd_big_init(DevSym ds, const int32_t *
 // sum over the 64 lanes of four values at once: after the call the lanes 0 .. 3 hold the total of v[o],
 // o = 2 * (lane & 1) + (lane >> 1) (the other lanes of a class (lane & 3) hold it up to the order of the additions).
 // Halving exchange first (4 -> 2 -> 1 values per lane), then the sum over the sixteen quads; fixed order.  Round 3: the
-// exchanges inside a row of 16 lanes are DPP moves (quad permutes, row rotations by 4 and 8) -- a __shfl_xor is two
-// ds_bpermute, an LDS crossbar round trip each, and a backward super-step chains up to ten of these calls; only the two
-// exchanges across rows (16, 32) remain shuffles.
+// exchanges inside a row of 16 lanes are DPP moves (quad permutes, row rotations by 4 and 8) and the two across the rows
+// gfx950's permlane swaps -- a __shfl_xor is two ds_bpermute, an LDS crossbar round trip each, and a backward super-step
+// chains up to ten of these calls.
+// the sum over the four 16-lane rows, position by position, in every lane: r[i] + r[i ^ 16] first, then + the same of i ^ 32 (the
+// order of the two shuffles this replaces).  v_permlane16_swap / v_permlane32_swap are gfx950 VALU instructions (no LDS crossbar).
+__device__ __forceinline__ double rows_sum_f64(double r)
+{
+    const int lo = __double2loint(r), hi = __double2hiint(r);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    const int lo2 = __double2loint(s), hi2 = __double2hiint(s);
+    const auto c = __builtin_amdgcn_permlane32_swap(lo2, lo2, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(hi2, hi2, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_f64(double v)
 {
@@ -1136,9 +1149,7 @@ __device__ __forceinline__ double wave_sum4(double v0, double v1, double v2, dou
     double r = (b1 ? k1 : k0) + dpp_mov_f64<0x4E>(b1 ? k0 : k1);                // quad_perm [2, 3, 0, 1]: lane ^ 2
     r += dpp_mov_f64<0x124>(r);                                                 // row_ror 4
     r += dpp_mov_f64<0x128>(r);                                                 // row_ror 8: the row's four quads
-    r += __shfl_xor(r, 16);
-    r += __shfl_xor(r, 32);
-    return r;
+    return rows_sum_f64(r);
 }
 
 // Backward super-step over the pivot columns [jb0, jb0 + nb), nb <= 256, the mirror image of the
