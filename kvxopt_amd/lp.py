@@ -15,7 +15,6 @@ pattern) and KKTGenEqDev (general S, dense K in HBM, any p).  `kvxopt_amd.misc.k
 """
 import collections
 import ctypes
-import hashlib
 import math
 import os
 import sys
@@ -631,12 +630,7 @@ def _opts_key(chol_opts):
 
 
 def _pattern_key(*arrays):
-    h = hashlib.blake2b(digest_size=16)
-    for a in arrays:
-        a = np.ascontiguousarray(a, dtype=np.int64)
-        h.update(a.shape[0].to_bytes(8, "little"))
-        h.update(a.tobytes())
-    return h.hexdigest()
+    return _lib.pattern_digest(*[np.ascontiguousarray(a, dtype=np.int64) for a in arrays])
 
 
 def _kkt_for(kind, dims_key, patterns, chol_opts, build, refresh):
