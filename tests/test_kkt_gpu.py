@@ -1172,3 +1172,28 @@ def test_fused_iteration_entries_against_numpy():
     _lib.raise_for(L.kvx_lp_newton_rhs_dev(ml, None, keep[0].ptr, 0.25, 0.75, keep[1].ptr, keep[2].ptr, keep[3].ptr, o1.ptr, o2.ptr))
     dsr = -((lm * lm + ws3) - 0.25) / lm
     assert close(o1.get(), dsr) and close(o2.get(), -(0.75 * rz + dsr * d))
+
+
+@pytest.mark.gpu
+def test_config4a_full_size_standard_form():
+    """BASELINE.json configs[3] in its literal form at full size (4a: 50 000 equality rows, 200 000 variables, x >= 0): the
+    device-resident conelp through the equality branch (K = A S^-1 A' on a fixed pattern, lp.KKTDiagEqDev).  No oracle run at
+    this size: optimality by its certificates -- primal and dual feasibility, complementarity, equal objectives -- checked on
+    the host with the caller's own arrays (golden sizes with the reference's iterates: test_conelp_standard_form_golden)."""
+    L = workloads.lp_grid_std(250, 200)
+    n, p = L["n"], L["p"]
+    assert (p, n) == (50000, 200000)
+    G = spmatrix.from_ccs(L["ml"], n, L["Gp"], L["Gi"], L["Gx"])
+    A = spmatrix.from_ccs(p, n, L["Ap"], L["Ai"], L["Ax"])
+    sol = lp.conelp(L["c"], G, L["h"], A=A, b=L["b"])
+    assert sol["status"] == "optimal" and sol["iterations"] <= 30
+    x, y, s, z = sol["x"], sol["y"], sol["s"], sol["z"]
+    acols = np.repeat(np.arange(n), np.diff(L["Ap"]))
+    Ax_ = np.zeros(p); np.add.at(Ax_, L["Ai"], L["Ax"] * x[acols])
+    assert np.linalg.norm(Ax_ - L["b"]) <= 1e-7 * np.linalg.norm(L["b"])             # A x = b
+    assert x.min() > -1e-8 and np.abs(s - x).max() <= 1e-8 * max(1.0, np.abs(x).max())   # G = -I, h = 0: s = x >= 0
+    Aty = L["Ax"] * y[L["Ai"]]                                                        # (A' y)_j = sum over column j
+    Aty = np.add.reduceat(Aty, L["Ap"][:-1]) * (np.diff(L["Ap"]) > 0)
+    assert z.min() > -1e-8 and np.linalg.norm(L["c"] + Aty - z) <= 1e-7 * np.linalg.norm(L["c"])   # c + A'y + G'z = 0, z >= 0
+    assert abs(s @ z) <= 1e-6 * max(1.0, abs(L["c"] @ x))                              # complementarity
+    assert abs(sol["primal objective"] - sol["dual objective"]) <= 1e-6 * max(1.0, abs(sol["primal objective"]))
