@@ -342,6 +342,46 @@ class KKTChol2Dev:
             z.xmy(1.0, di, self.t, -1.0)
 
 
+class KKTUserHost:
+    """The reference's plug-in point `kktsolver(W) -> f(x, y, z)` (coneprog.py:323-344, 571-585) under the device-resident
+    conelp: the caller's factory is handed the scaling on the host (W['d'], W['di'] as base.matrix; the other fields of the
+    'l'-cone scaling empty, as misc.compute_scaling leaves them) at every factorisation, and its f the right-hand sides as
+    base.matrix columns at every solve; (ux, uy, W uz) go back to HBM.  Functional, not fast -- every solve crosses PCIe --
+    and the place where `kvxopt_amd.misc.kkt_chol2` (host-array mirror of the reference's default) or any user solver plugs in."""
+
+    def __init__(self, ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, factory):
+        self.ml, self.n, self.p = ml, n, p
+        self.G = SpMatDev(ml, n, Gp, Gi, Gx)
+        self.A = SpMatDev(p, n, Ap, Ai, Ax) if p else None
+        self.factory = factory
+        self.f = None
+        self.di = None
+        self.nfactor = 0
+        self.async_solves = False
+
+    def factor(self, di, sync=True):
+        dih = di.get()
+        empty = base.matrix(0.0, (0, 1))
+        W = {"d": base.matrix(1.0 / dih), "di": base.matrix(dih), "dnl": empty, "dnli": base.matrix(0.0, (0, 1)),
+             "v": [], "beta": [], "r": [], "rti": []}
+        self.f = self.factory(W)                          # ArithmeticError / ValueError of the caller's factorisation pass through
+        self.di = di
+        self.nfactor += 1
+
+    def solve(self, x, y, z):
+        xm = base.matrix(x.get())
+        ym = base.matrix(y.get()) if self.p else base.matrix(0.0, (0, 1))
+        zm = base.matrix(z.get())
+        self.f(xm, ym, zm)
+        x.set(xm._a)
+        if self.p:
+            y.set(ym._a)
+        z.set(zm._a)
+
+    def check(self):
+        pass
+
+
 class KKTDiagEqDev:
     """Device-resident `misc.kkt_chol2` with equality constraints (p > 0) for a G whose columns have disjoint row
     supports (every row of G holds at most one entry -- G = -I of a standard-form LP).  Then
@@ -650,7 +690,7 @@ def _kkt_for(kind, dims_key, patterns, chol_opts, build, refresh):
     return kkt
 
 
-def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, primalstart=None, dualstart=None):
+def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, primalstart=None, dualstart=None, kktsolver=None):
     """Solve the LP  minimize c'x  s.t.  Gx <= h, Ax = b  on the GPU.  c: (n,), h: (ml,), G: spmatrix-like
     (ml x n, sparse); A (p x n, sparse), b (p,) optional -- with equality constraints either G has at most one entry per
     row (standard form: KKTDiagEqDev, sparse K on a fixed pattern) or any other sparse G (KKTGenEqDev, dense K in HBM).  primalstart = {'x', 's'},
@@ -688,7 +728,32 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         def get(self):
             return np.zeros(0)
 
-    if p > 0:
+    if kktsolver is not None:
+        # the reference's plug-in point (coneprog.py:323-344): kktsolver(W) returns f(x, y, z); host round trips per call
+        if not callable(kktsolver):
+            raise ValueError("kktsolver must be a function W -> f(x, y, z) (the reference's named solvers 'ldl', 'ldl2', 'qr', "
+                             "'chol', 'chol2' are not part of this path: 'chol2' is what runs on the GPU by default)")
+        if p == 0:
+            Ap, Ai, Ax = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0)
+        kkt = KKTUserHost(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, kktsolver)
+        fused = False
+        kfactor_solve2 = None
+        if p > 0:
+            Ad = kkt.A
+            bv = DVec(p, b_h)
+            y, dy, y1, ry, hry = (DVec(p) for _ in range(5))
+            def Af(u, v, trans="N", alpha=1.0, beta=0.0):
+                Ad.gemv(u, v, trans=trans, alpha=alpha, beta=beta)
+        else:
+            bv = y = dy = y1 = ry = hry = _NoY()
+            def Af(u, v, trans="N", alpha=1.0, beta=0.0):
+                if trans == "T" and beta == 0.0:
+                    v.fill(0.0)
+        ksolve = kkt.solve
+        def ksolve2(xa, ya, za, xb, yb, zb):
+            kkt.solve(xa, ya, za)
+            kkt.solve(xb, yb, zb)
+    elif p > 0:
         Gi64 = np.asarray(Gi, dtype=np.int64)
         diag_s = not (Gi64.size and np.bincount(Gi64, minlength=ml).max() > 1)
         cls = KKTDiagEqDev if diag_s else KKTGenEqDev

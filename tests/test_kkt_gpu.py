@@ -1197,3 +1197,57 @@ def test_config4a_full_size_standard_form():
     assert z.min() > -1e-8 and np.linalg.norm(L["c"] + Aty - z) <= 1e-7 * np.linalg.norm(L["c"])   # c + A'y + G'z = 0, z >= 0
     assert abs(s @ z) <= 1e-6 * max(1.0, abs(L["c"] @ x))                              # complementarity
     assert abs(sol["primal objective"] - sol["dual objective"]) <= 1e-6 * max(1.0, abs(sol["primal objective"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_eq", [False, True])
+def test_conelp_with_a_user_kktsolver(with_eq):
+    """The reference's plug-in point kktsolver(W) -> f(x, y, z) (coneprog.py:323-344; its own test: tests/test_custom_kkt.py)
+    under the device-resident conelp (lp.KKTUserHost): (1) a dense numpy solver of the 3 x 3 block system written against the
+    documented contract -- on entry (bx, by, bz), on exit (ux, uy, W uz); (2) kvxopt_amd.misc.kkt_chol2, the host-array mirror of
+    the reference's default.  Both reach the default path's solution in the same number of iterations."""
+    from kvxopt_amd import solvers
+    L = workloads.lp_grid_eq(9, 7, 5) if with_eq else workloads.lp_grid(9, 7)
+    ml, n = L["ml"], L["n"]
+    G = spmatrix.from_ccs(ml, n, L["Gp"], L["Gi"], L["Gx"])
+    kw = {}
+    Gd = np.zeros((ml, n)); Gd[L["Gi"], np.repeat(np.arange(n), np.diff(L["Gp"]))] = L["Gx"]
+    p = 0
+    Ad = np.zeros((0, n))
+    if with_eq:
+        p = L["p"]
+        kw = {"A": spmatrix.from_ccs(p, n, L["Ap"], L["Ai"], L["Ax"]), "b": L["b"]}
+        Ad = np.zeros((p, n)); Ad[L["Ai"], np.repeat(np.arange(n), np.diff(L["Ap"]))] = L["Ax"]
+    ref = solvers.conelp(L["c"], G, L["h"], options={"show_progress": False}, **kw)
+    calls = {"factor": 0, "solve": 0}
+
+    def dense_kkt(W):
+        d = np.asarray(W["d"]._a)
+        assert W["di"].size == (ml, 1) and np.allclose(np.asarray(W["di"]._a) * d, 1.0)
+        K = np.zeros((n + p + ml, n + p + ml))
+        K[:n, n:n + p] = Ad.T; K[:n, n + p:] = Gd.T
+        K[n:n + p, :n] = Ad; K[n + p:, :n] = Gd
+        K[n + p:, n + p:] = -np.diag(d * d)
+        lu = np.linalg.inv(K)
+        calls["factor"] += 1
+
+        def f(x, y, z):
+            calls["solve"] += 1
+            u = lu @ np.concatenate([x._a, y._a, z._a])
+            x._a[:] = u[:n]
+            y._a[:] = u[n:n + p]
+            z._a[:] = d * u[n + p:]
+        return f
+
+    s1 = solvers.conelp(L["c"], G, L["h"], options={"show_progress": False}, kktsolver=dense_kkt, **kw)
+    assert s1["status"] == "optimal" and s1["iterations"] == ref["iterations"]
+    assert calls["factor"] == ref["iterations"] + 1 and calls["solve"] == 3 * ref["iterations"] + 2
+    for k in ("x", "s", "z"):
+        assert rel(s1[k], ref[k]) < 1e-6, k
+    fac = misc.kkt_chol2(G, {"l": ml, "q": [], "s": []}, kw.get("A", spmatrix([], [], [], (0, n))))
+    s2 = solvers.lp(L["c"], G, L["h"], options={"show_progress": False}, kktsolver=lambda W: fac(W), **kw)
+    assert s2["status"] == "optimal" and s2["iterations"] == ref["iterations"]
+    for k in ("x", "s", "z"):
+        assert rel(s2[k], ref[k]) < 1e-7, k
+    with pytest.raises(NotImplementedError):
+        solvers.conelp(L["c"], G, L["h"], kktsolver="ldl", options={"show_progress": False}, **kw)
