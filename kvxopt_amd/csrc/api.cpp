@@ -272,27 +272,32 @@ int ensure_device(kvx_chol *F)
     if ((rc = upload(&F->d_childptr, S.childptr))) return rc;
     if ((rc = upload(&F->d_amap, S.amap))) return rc;
     if (S.nnzA < INT32_MAX && F->part.empty() && !getenv("KVX_INIT_TWO_PASSES")) {
-        // the scatter map once more, grouped by the chunk of the factor an entry goes to (counting sort): k_init_factor zeroes L and
-        // scatters A in one pass.  (Sharded factors keep the two launches: their layout is trimmed afterwards.)
+        // the scatter map once more, grouped by the chunk of the factor an entry goes to: k_init_factor zeroes L and scatters A in one
+        // pass.  A counting sort ON THE DEVICE over the map just uploaded (histogram, the scan of the ~10^5 chunk counters on the host,
+        // placement) -- on the host it was 12-18 ms of every first call on a new pattern with 3 M entries, more than a thousand of the
+        // steps it speeds up by 0.05 ms would give back.  (Sharded factors keep the two launches: their layout is trimmed afterwards.)
         const int sh = init_factor_shift();
         const int64_t nchunk = std::max<int64_t>((S.lsize + ((int64_t)1 << sh) - 1) >> sh, 1);
-        std::vector<int64_t> cptr((size_t)nchunk + 1, 0);
-        for (int64_t e = 0; e < S.nnzA; e++)
-            if (S.amap[(size_t)e] >= 0) cptr[(size_t)(S.amap[(size_t)e] >> sh) + 1]++;
-        for (int64_t q = 0; q < nchunk; q++) cptr[(size_t)q + 1] += cptr[(size_t)q];
-        const int64_t live = cptr[(size_t)nchunk];
-        std::vector<int64_t> sdst((size_t)std::max<int64_t>(live, 1)), at(cptr.begin(), cptr.end() - 1);
-        std::vector<int32_t> ssrc((size_t)std::max<int64_t>(live, 1));
-        for (int64_t e = 0; e < S.nnzA; e++) {
-            const int64_t d = S.amap[(size_t)e];
-            if (d < 0) continue;
-            const int64_t q = at[(size_t)(d >> sh)]++;
-            sdst[(size_t)q] = d; ssrc[(size_t)q] = (int32_t)e;
-        }
-        if ((rc = upload(&F->d_sdst, sdst))) return rc;
-        if ((rc = upload(&F->d_ssrc, ssrc))) return rc;
-        if ((rc = upload(&F->d_scptr, cptr))) return rc;
-        F->scnt = live;
+        int64_t *d_cnt = nullptr;
+        HIPCHK(pool_malloc((void **)&F->d_scptr, (size_t)(nchunk + 1) * sizeof(int64_t)));
+        HIPCHK(pool_malloc((void **)&d_cnt, (size_t)(nchunk + 1) * sizeof(int64_t)));
+        HIPCHK(pool_malloc((void **)&F->d_sdst, (size_t)std::max<int64_t>(S.nnzA, 1) * sizeof(int64_t)));
+        HIPCHK(pool_malloc((void **)&F->d_ssrc, (size_t)std::max<int64_t>(S.nnzA, 1) * sizeof(int32_t)));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nchunk + 1) * sizeof(int64_t), nullptr));
+        launch_scatter_group_count(nullptr, F->d_amap, S.nnzA, sh, d_cnt);
+        std::vector<int64_t> cptr((size_t)nchunk + 1);
+        HIPCHK(hipMemcpy(cptr.data(), d_cnt, (size_t)(nchunk + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        // slot q + 1 counted chunk q: the running sum turns the slots into "entries in the chunks before q", the start of chunk q
+        std::vector<int64_t> start((size_t)nchunk + 1);
+        int64_t run = 0;
+        for (int64_t q = 0; q < nchunk; q++) { start[(size_t)q] = run; run += cptr[(size_t)q + 1]; }
+        start[(size_t)nchunk] = run;
+        HIPCHK(hipMemcpy(F->d_scptr, start.data(), (size_t)(nchunk + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_cnt, start.data(), (size_t)(nchunk + 1) * sizeof(int64_t), hipMemcpyHostToDevice));          // the cursors
+        launch_scatter_group_place(nullptr, F->d_amap, S.nnzA, sh, d_cnt, F->d_sdst, F->d_ssrc);
+        HIPCHK(hipDeviceSynchronize());
+        (void)pool_free(d_cnt);
+        F->scnt = run;
     }
     HIPCHK(pool_malloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
     for (int p = 0; p < 2; p++)

@@ -162,6 +162,8 @@ __device__ __forceinline__ void kvx_part_front_rhs(unsigned &bx, unsigned &by, u
 void launch_scatter_a(hipStream_t st, const double *Ax, const int64_t *amap, int64_t nnz, double *Lx);
 // zero L + scatter A in one pass: the scatter map grouped by chunk of 2^init_factor_shift() doubles of L (cptr: nchunk + 1 offsets)
 int init_factor_shift();
+void launch_scatter_group_count(hipStream_t st, const int64_t *amap, int64_t nnz, int sh, int64_t *cnt);
+void launch_scatter_group_place(hipStream_t st, const int64_t *amap, int64_t nnz, int sh, int64_t *cursor, int64_t *sdst, int32_t *ssrc);
 void launch_init_factor(hipStream_t st, const double *Ax, const int32_t *src, const int64_t *dst, const int64_t *cptr, int64_t lsize,
                         double *Lx, int *status);
 void launch_publish_status(hipStream_t st, const int *d_status, int *host_status_dev);   // *host := *d_status (pinned, device-visible)

@@ -113,6 +113,38 @@ __global__ __launch_bounds__(KVX_INIT_NT) void k_init_factor(const double *__res
     }
 }
 int init_factor_shift() { return KVX_INIT_SHIFT; }
+// grouping of the scatter map by chunk on the device: cnt[chunk + 1] += 1 per live entry; after the host's scan the cursors hand out
+// the places (the order inside a chunk does not matter: destinations are distinct)
+__global__ void k_scatter_group_count(const int64_t *__restrict__ amap, int64_t nnz, int sh, unsigned long long *__restrict__ cnt)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = amap[e];
+        if (d >= 0) atomicAdd(&cnt[(d >> sh) + 1], 1ull);
+    }
+}
+__global__ void k_scatter_group_place(const int64_t *__restrict__ amap, int64_t nnz, int sh, unsigned long long *__restrict__ cursor,
+                                      int64_t *__restrict__ sdst, int32_t *__restrict__ ssrc)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d = amap[e];
+        if (d < 0) continue;
+        const unsigned long long q = atomicAdd(&cursor[d >> sh], 1ull);
+        sdst[q] = d;
+        ssrc[q] = (int32_t)e;
+    }
+}
+void launch_scatter_group_count(hipStream_t st, const int64_t *amap, int64_t nnz, int sh, int64_t *cnt)
+{
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(k_scatter_group_count, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 8192)), dim3(256), 0, st, amap, nnz, sh,
+                       (unsigned long long *)cnt);
+}
+void launch_scatter_group_place(hipStream_t st, const int64_t *amap, int64_t nnz, int sh, int64_t *cursor, int64_t *sdst, int32_t *ssrc)
+{
+    if (nnz <= 0) return;
+    hipLaunchKernelGGL(k_scatter_group_place, dim3((unsigned)std::min<int64_t>((nnz + 255) / 256, 8192)), dim3(256), 0, st, amap, nnz, sh,
+                       (unsigned long long *)cursor, sdst, ssrc);
+}
 void launch_init_factor(hipStream_t st, const double *Ax, const int32_t *src, const int64_t *dst, const int64_t *cptr, int64_t lsize,
                         double *Lx, int *status)
 {
