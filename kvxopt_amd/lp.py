@@ -146,11 +146,13 @@ class SpMatDev:
         self.ri = DeviceBuffer.from_array(rowind) if len(rowind) else DeviceBuffer(8)
         self.vx = DeviceBuffer.from_array(values) if len(values) else DeviceBuffer(8)
         cols = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(colptr))
-        order = np.lexsort((cols, rowind))
+        # (row, column) order: the entries come column by column, so a STABLE sort by row is the two-key sort; counts by bincount
+        # (lexsort + np.add.at were 6 of the 8 ms this constructor took for 400 000 entries)
+        order = np.argsort(rowind, kind="stable")
         self._order = order                               # CCS position of every entry of the transposed copy
         tp = np.zeros(self.m + 1, dtype=np.int64)
-        np.add.at(tp, rowind + 1, 1)
-        np.cumsum(tp, out=tp)
+        if len(rowind):
+            np.cumsum(np.bincount(rowind, minlength=self.m), out=tp[1:])
         self.max_row = int(np.diff(tp).max()) if self.m else 0         # most entries in a row / column (the fused kernels size
         self.max_col = int(np.diff(colptr).max()) if self.n else 0     # their lane groups by them)
         self.tcp = DeviceBuffer.from_array(tp)
