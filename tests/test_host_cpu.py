@@ -173,3 +173,26 @@ def test_object_caches_key_on_the_device_and_take_numpy_options(monkeypatch):
         return "ok"
     monkeypatch.setattr(_lib, "release_cached", lambda: calls.append("released"))
     assert _lib.retry_after_release(flaky) == "ok" and calls == [1, "released", 1]
+
+
+def test_pattern_digest_separates_dtype_length_and_content(monkeypatch):
+    """The digest behind the KKT-cache key (lp._pattern_key): arrays that differ in content, in length, in dtype, or in how a total is
+    split between two arrays hash differently; the blake2b fallback (no xxhash module) behaves the same."""
+    import builtins
+    from kvxopt_amd import _lib, lp
+    a = np.arange(12, dtype=np.int64)
+    def all_distinct():
+        ds = [_lib.pattern_digest(a), _lib.pattern_digest(a[:11]), _lib.pattern_digest(a.astype(np.int32)),
+              _lib.pattern_digest(a[:6], a[6:]), _lib.pattern_digest(a[:5], a[5:]), _lib.pattern_digest(a + (np.arange(12) == 7)),
+              _lib.pattern_digest(np.zeros(0, dtype=np.int64)), _lib.pattern_digest()]
+        assert len(set(ds)) == len(ds) and all(len(d) == 16 for d in ds)
+        assert _lib.pattern_digest(a) == _lib.pattern_digest(a.copy())
+    all_distinct()
+    assert lp._pattern_key(a, a[:3]) == lp._pattern_key(a.astype(np.int32), a[:3].tolist())     # (index arrays are taken as int64)
+    real_import = builtins.__import__
+    def no_xxhash(name, *args, **kw):
+        if name == "xxhash":
+            raise ImportError(name)
+        return real_import(name, *args, **kw)
+    monkeypatch.setattr(builtins, "__import__", no_xxhash)
+    all_distinct()
