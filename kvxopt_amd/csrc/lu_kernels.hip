@@ -547,25 +547,52 @@ constexpr int LU_PANEL_LDS_DOUBLES = 19456;       // 152 KB of the 160 KB a gfx9
 
 // Assembly of a big front, one workgroup per 16 columns: zero them, scatter the entries of A that land there, pull
 // the children's update-matrix columns that map there (children one after the other: their targets overlap).
-constexpr int LU_ASM_COLS = 16;
+// first index of the ascending list a[0..n) whose value is >= v (n if none), by the 64 lanes of a wavefront together: 64 probes per
+// round (two or three dependent loads for a list of thousands, where a bisection by one lane is eleven).  Uniform arguments, every
+// lane of the wave calls it.
+__device__ __forceinline__ int lu_lower_bound(const int32_t *__restrict__ a, int n, int v)
+{
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n;                                       // the answer is in [lo, hi]
+    while (hi - lo > 0) {
+        const int len = hi - lo, step = (len + 63) >> 6;      // probes at lo + step * lane (< hi)
+        const int idx = lo + step * lane;
+        const bool lt = idx < hi && a[idx] < v;
+        const int cnt = __popcll(__ballot(lt));               // ascending: the probes with a < v are the first cnt
+        if (cnt == 0) { hi = lo; break; }                     // a[lo] >= v
+        const int last = lo + step * (cnt - 1);               // a[last] < v, and the next probe (if any) is >= v
+        lo = last + 1;
+        hi = min(hi, last + step);
+    }
+    return lo;
+}
+// Round 3: the rows of the 16 columns are split over grid.z in chunks of LU_ASM_ROWS -- a workgroup with 16 whole columns of a front of
+// a few thousand rows moved ~1 MB through one CU (~25 GB/s): 63 us per level for work the machine does in 10.
+constexpr int LU_ASM_COLS = 16, LU_ASM_ROWS = 256;
 __global__ __launch_bounds__(256) void k_lub_assemble(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ Ax)
 {
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int f = list[blockIdx.y];
     const LuFrontD F = d.fr[f];
     const int m = F.m;
-    const int c0 = blockIdx.x * LU_ASM_COLS;
-    if (c0 >= m) return;
-    const int c1 = min(m, c0 + LU_ASM_COLS);
+    const int c0 = blockIdx.x * LU_ASM_COLS, r0 = blockIdx.z * LU_ASM_ROWS;
+    if (c0 >= m || r0 >= m) return;
+    const int c1 = min(m, c0 + LU_ASM_COLS), r1 = min(m, r0 + LU_ASM_ROWS);
     double *Fm = d.arena + (F.upd_off - F.k - (int64_t)F.k * m);
-    if (blockIdx.x == 0 && tid == 0) d.fail[f] = 0;
-    for (int64_t idx = (int64_t)c0 * m + tid; idx < (int64_t)c1 * m; idx += 256) Fm[idx] = 0.0;
+    if (blockIdx.x == 0 && blockIdx.z == 0 && tid == 0) d.fail[f] = 0;
+    for (int c = c0 + ty; c < c1; c += 4)
+        for (int i = r0 + tx; i < r1; i += 64) Fm[i + (int64_t)c * m] = 0.0;
     __syncthreads();
-    for (int64_t e = tid; e < F.acnt; e += 256) {
-        const int dst = d.a_dst[F.aptr + e];
-        if (dst >= c0 * m && dst < c1 * m) {
-            const int64_t src = d.a_src[F.aptr + e];
-            Fm[dst] += Ax[src] * d.rinv[d.ai32[src]];
+    {   // the entries of A in these columns: the front's list ascends by destination (lu_symbolic.cpp) -- bisected, not scanned
+        const int32_t *__restrict__ ad = d.a_dst + F.aptr;
+        const int e0 = lu_lower_bound(ad, (int)F.acnt, c0 * m), e1 = lu_lower_bound(ad, (int)F.acnt, c1 * m);
+        for (int e = e0 + tid; e < e1; e += 256) {
+            const int dst = ad[e];
+            const int row = dst % m;
+            if (row >= r0 && row < r1) {
+                const int64_t src = d.a_src[F.aptr + e];
+                Fm[dst] += Ax[src] * d.rinv[d.ai32[src]];
+            }
         }
     }
     __syncthreads();
@@ -574,10 +601,13 @@ __global__ __launch_bounds__(256) void k_lub_assemble(const LuDev d, const int32
         const int uc = C.m - C.k, ldc = C.upd_ld;
         const int32_t *__restrict__ relc = d.rel + C.rowptr + C.k;
         const double *__restrict__ Uc = d.arena + C.upd_off;
-        for (int jc = ty; jc < uc; jc += 4) {
+        // the child's rows / columns that land in this workgroup's columns [c0, c1) and rows [r0, r1): relc ascends, so both are
+        // ranges -- found by bisection (a scan of all uc columns with a dependent index load each was 20 us of latency per workgroup)
+        const int j0 = lu_lower_bound(relc, uc, c0), j1 = lu_lower_bound(relc, uc, c1);
+        const int i0 = lu_lower_bound(relc, uc, r0), i1 = lu_lower_bound(relc, uc, r1);
+        for (int jc = j0 + ty; jc < j1; jc += 4) {
             const int pc = relc[jc];
-            if (pc < c0 || pc >= c1) continue;                // wave-uniform
-            for (int ic = tx; ic < uc; ic += 64) Fm[relc[ic] + (int64_t)pc * m] += Uc[ic + (int64_t)jc * ldc];
+            for (int ic = i0 + tx; ic < i1; ic += 64) Fm[relc[ic] + (int64_t)pc * m] += Uc[ic + (int64_t)jc * ldc];
         }
         __syncthreads();
     }
@@ -591,24 +621,41 @@ __global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t 
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const LuFrontD F = d.fr[list[blockIdx.y]];
     const int m = F.m, k = F.k;
-    const int c0 = blockIdx.x * 64;
-    if (c0 >= m) return;
+    // Round 3: grid.z = chunks of 256 rows (of the L columns) / 256 pivot rows (of the U rows), and the U rows go through an LDS
+    // tile -- they are a transposition (Up[c + t m] = Fm[t + c m]), read with a stride of m before: 70 us per level, per-CU bandwidth.
+    __shared__ double tile[64][65];
+    const int c0 = blockIdx.x * 64, z0 = blockIdx.z * 256;
+    if (c0 >= m || z0 >= m) return;
     const double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
     double *__restrict__ Lp = d.Lx + F.px, *__restrict__ Up = d.Ux + F.px;
-    const int c = c0 + tx;
-    if (c < m)
-        for (int t = ty; t < k; t += 4) Up[c + (int64_t)t * m] = Fm[t + (int64_t)c * m];
+    for (int t0 = z0; t0 < min(k, z0 + 256); t0 += 64) {      // (workgroup-uniform bounds)
+        for (int cc = ty; cc < 64; cc += 4)                   // tile[cc][tt] = Fm[t0 + tt + (c0 + cc) m]: lanes along the rows
+            tile[cc][tx] = (t0 + tx < k && c0 + cc < m) ? Fm[(t0 + tx) + (int64_t)(c0 + cc) * m] : 0.0;
+        __syncthreads();
+        for (int tt = ty; tt < 64; tt += 4)                   // Up[c + t m]: lanes along the columns
+            if (t0 + tt < k && c0 + tx < m) Up[(c0 + tx) + (int64_t)(t0 + tt) * m] = tile[tx][tt];
+        __syncthreads();
+    }
     for (int cc = c0 + ty; cc < min(k, c0 + 64); cc += 4)
-        for (int i = tx; i < m; i += 64) Lp[i + (int64_t)cc * m] = Fm[i + (int64_t)cc * m];
-    if (blockIdx.x == 0) {
+        for (int i = z0 + tx; i < min(m, z0 + 256); i += 64) Lp[i + (int64_t)cc * m] = Fm[i + (int64_t)cc * m];
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
         int32_t *sh_lp = (int32_t *)smem, *sh_piv = sh_lp + k;
         for (int t = tid; t < k; t += 256) { sh_lp[t] = t; sh_piv[t] = d.ipiv[F.p0 + t]; }
         __syncthreads();
-        if (tid == 0)
-            for (int j = 0; j < k; j++) {
-                const int r = j + sh_piv[j];
-                if (r != j) { const int a = sh_lp[j]; sh_lp[j] = sh_lp[r]; sh_lp[r] = a; }
+        // the interchanges in order -- only the pivots that moved a row (few): wave 0 finds them 64 at a time by a ballot, its first
+        // lane applies them (a loop of one thread over all k pivots was 30 us of this kernel on a front of 757)
+        if (tid < 64) {
+            for (int base = 0; base < k; base += 64) {
+                unsigned long long mv = __ballot(base + tid < k && sh_piv[base + tid] != 0);
+                if (tid == 0)
+                    while (mv) {
+                        const int j = base + __builtin_ctzll(mv);
+                        const int r = j + sh_piv[j];
+                        const int a = sh_lp[j]; sh_lp[j] = sh_lp[r]; sh_lp[r] = a;
+                        mv &= mv - 1;
+                    }
             }
+        }
         __syncthreads();
         for (int t = tid; t < k; t += 256) d.lperm[F.p0 + t] = sh_lp[t];
     }
@@ -1197,7 +1244,8 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
 {
     if (cnt <= 0) return;
     allow_large_lds();
-    hipLaunchKernelGGL(k_lub_assemble, dim3((max_m + LU_ASM_COLS - 1) / LU_ASM_COLS, cnt), dim3(256), 0, st, d, list, Ax);
+    hipLaunchKernelGGL(k_lub_assemble, dim3((max_m + LU_ASM_COLS - 1) / LU_ASM_COLS, cnt, (max_m + LU_ASM_ROWS - 1) / LU_ASM_ROWS), dim3(256), 0, st,
+                       d, list, Ax);
     const int tiles = (max_m + 63) / 64;
     for (int jb = 0; jb < max_k;) {
         const int rows = max_m - jb;                          // tallest panel of this step
@@ -1216,7 +1264,7 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
         hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb, nbs);
         jb += nbs;
     }
-    hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list);
+    hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt, (max_m + 255) / 256), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list);
 }
 
 void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,

@@ -515,6 +515,17 @@ void lu_build_plan(const LuSymbolic &Y, LuPlan &P)
                 P.a_src[q] = p;
                 P.a_dst[q] = lr + lc * P.fr[f].m;
             }
+        // per front by ascending destination: the blocked assembly (k_lub_assemble) bisects the list for its columns instead of
+        // scanning it in every workgroup (destinations are distinct: the order is free)
+        std::vector<std::pair<int32_t, int64_t>> tmp;
+        for (int64_t f = 0; f < nf; f++) {
+            const int64_t a = P.aptr[f], b = P.aptr[f + 1];
+            if (b - a < 2) continue;
+            tmp.resize((size_t)(b - a));
+            for (int64_t q = a; q < b; q++) tmp[(size_t)(q - a)] = {P.a_dst[(size_t)q], P.a_src[(size_t)q]};
+            std::sort(tmp.begin(), tmp.end());
+            for (int64_t q = a; q < b; q++) { P.a_dst[(size_t)q] = tmp[(size_t)(q - a)].first; P.a_src[(size_t)q] = tmp[(size_t)(q - a)].second; }
+        }
     }
 }
 
