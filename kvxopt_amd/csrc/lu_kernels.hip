@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *
 // panel at ~10 GB/s.  The front's work vector (m doubles, at W + wx - k) lives in HBM; one launch per block of 32
 // pivots, every workgroup solves the 32 x 32 triangle redundantly in its first wavefront and applies the block to
 // its own 1024 rows (forward) / columns (backward).
-constexpr int LU_BIG_CHUNK = 1024;
+constexpr int LU_BIG_CHUNK = 256;         // rows (pivot columns in the backward steps) per workgroup: 1024 was ~256 KB through one CU per step, 15 us a launch
 
 template <bool UNIT>
 __device__ __forceinline__ void wave_tri_fwd(const double *__restrict__ panel, const int m, const int t0, const int nbk, const double *fvec,
