@@ -40,6 +40,7 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
             if (c == KVX_CLS_BIG) {
                 P.big_maxk = std::max(P.big_maxk, k);
                 P.chain_maxk = std::max(P.chain_maxk, k);
+                P.big_maxu = std::max(P.big_maxu, m - k);
                 P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
             }
             int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
@@ -138,6 +139,40 @@ void analyze_subtrees(kvx_chol *F)
 }
 
 // per-level solve lists without the subtree fronts, and the subtree tables, on the device
+// Lists for the LDS-staged trailing update (chol_internal.hpp: chain_steps / u_steps), from the plan the factorisation uses.
+int build_chain_lists(kvx_chol *F)
+{
+    Symbolic &S = F->S;
+    { const char *e = getenv("KVX_U_BLOCK"); if (e) F->u_block = std::max(64, atoi(e) / 64 * 64); }
+    const std::vector<LevelPlan> &plan = F->fplan_on ? F->fplan : F->plan;
+    const std::vector<int32_t> &lists = F->fplan_on ? F->flists_host : F->lists_host;
+    F->chain_steps.assign((size_t)S.nlevels, {});
+    F->u_steps.assign((size_t)S.nlevels, {});
+    F->chain_host.clear(); F->chain_m.clear(); F->chain_k.clear();
+    std::vector<int32_t> fr;
+    for (int l = 0; l < S.nlevels && l < (int)plan.size(); l++) {
+        const LevelPlan &P = plan[l];
+        const int nbig = P.cnt[KVX_CLS_BIG];
+        if (nbig == 0) continue;
+        fr.assign(lists.begin() + P.off[KVX_CLS_BIG], lists.begin() + P.off[KVX_CLS_BIG] + nbig);
+        auto emit = [&](std::vector<kvx_chol::ChainList> &out, int kb, bool far) {
+            // far: the fronts with anything right of column kb + 2 u_block (update matrix included), by the order of that region
+            auto region = [&](int32_t f) { return far ? S.sn_m[f] - std::min(kb + 2 * F->u_block, S.sn_k[f]) : S.sn_m[f]; };
+            std::vector<int32_t> act;
+            for (int32_t f : fr)
+                if (S.sn_k[f] > kb && region(f) > 0) act.push_back(f);
+            std::stable_sort(act.begin(), act.end(), [&](int32_t a, int32_t b) { return region(a) > region(b); });
+            out.push_back(kvx_chol::ChainList{(int64_t)F->chain_host.size(), (int)act.size()});
+            for (int32_t f : act) { F->chain_host.push_back(f); F->chain_m.push_back(S.sn_m[f]); F->chain_k.push_back(S.sn_k[f]); }
+        };
+        for (int jb = 0; jb < P.chain_maxk; jb += KVX_NB) emit(F->chain_steps[l], jb, false);
+        for (int kb = 0; kb < P.chain_maxk; kb += F->u_block) emit(F->u_steps[l], kb, true);
+    }
+    if (F->d_chain) { (void)pool_free(F->d_chain); F->d_chain = nullptr; }
+    if (F->chain_host.empty()) return KVX_OK;
+    return upload(&F->d_chain, F->chain_host);
+}
+
 int build_subtrees(kvx_chol *F)
 {
     Symbolic &S = F->S;
@@ -225,11 +260,12 @@ int build_subtrees(kvx_chol *F)
         if ((rc = upload(&F->d_flists, fl))) return rc;
         build_plan_from(S, fl, flp, F->fplan);
         F->fplan_on = true;
+        F->flists_host = fl;
     }
     std::vector<int32_t> dep(S.depth.begin(), S.depth.end());
     if (dep.empty()) dep.push_back(0);
     if ((rc = upload(&F->d_depth, dep))) return rc;
-    return KVX_OK;
+    return build_chain_lists(F);
 }
 
 int ensure_device(kvx_chol *F)
@@ -299,7 +335,7 @@ int ensure_device(kvx_chol *F)
         (void)pool_free(d_cnt);
         F->scnt = run;
     }
-    HIPCHK(pool_malloc((void **)&F->d_Lx, std::max<int64_t>(S.lsize, 1) * sizeof(double)));
+    HIPCHK(pool_malloc((void **)&F->d_Lx, (std::max<int64_t>(S.lsize, 1) + 2) * sizeof(double)));   // + 2: k_syrk_lds reads row pairs (16-byte loads at clamped rows)
     for (int p = 0; p < 2; p++)
         HIPCHK(pool_malloc((void **)&F->d_U[p], std::max<int64_t>(S.upd_size[p], 1) * sizeof(double)));
     HIPCHK(pool_malloc((void **)&F->d_Ax, std::max<int64_t>(S.nnzA, 1) * sizeof(double)));
@@ -533,7 +569,7 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
             const int nbig = nchain, bigm = P.maxm[KVX_CLS_BIG];
             const int32_t *list = lbase + P.off[KVX_CLS_BIG];
             if (!asm_potrf) { ProfScope ps(F, FAM_POTRF); launch_potrf_blk(st, F->ds, list, nbig, 0, F->d_Lx, F->d_Linv, F->d_status); }
-            if (bigm >= F->two_level_m) {
+            if (bigm >= F->two_level_m && (getenv("KVX_DEFER_U") ? atoi(getenv("KVX_DEFER_U")) == 0 : false)) {
                 // outer blocks of `outer_block` (1024) columns, one rank-1024 update of the trailing matrix per block (128-tile kernel: 34 TF/s
                 // on a dense trailing matrix; rocBLAS dgemm at K = 256 reaches 48-59).  Measured on MI355X against the
                 // single-level path: dense n = 10240 14.8 vs 16.7 ms, 3-D 80^3 49.6 vs 51.0 ms, but 21-point 1000^2
@@ -556,20 +592,94 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 // step waits for and the eight operand rounds of a K = 128 tile would lengthen the chain: one panel per launch there.
                 // KVX_PAIR_TILES = tile count (upper estimate: largest front x fronts in the launch) from which on pairs are used.
                 static const int64_t pair_tiles = [] { const char *e = getenv("KVX_PAIR_TILES"); return e ? atoll(e) : (int64_t)3000; }();
-                for (int jb = 0; jb < P.chain_maxk;) {
-                    const int64_t T = (bigm - jb - 1 + KVX_TILE - 1) / KVX_TILE;
-                    const bool pair = jb + KVX_NB < P.chain_maxk && T * (T + 1) / 2 * nbig >= pair_tiles;
-                    // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
-                    { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
-                    if (!pair) {
-                        { ProfScope ps(F, FAM_SYRK); launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
-                        jb += KVX_NB;
-                        continue;
+                // Round 4: the update matrices are left out of the chain (launches limited to the pivot columns) wherever a level's
+                // fronts have more than one panel, and brought up to date afterwards by rank-(<= u_block) updates with LDS-staged
+                // tiles (launch_syrk_u): K = 64 per pass over C moved 16 bytes per 128 flops and bound the ~20-nnz/row systems by
+                // exactly that traffic.  KVX_DEFER_U=0: the round-3 schedule; KVX_U_BLOCK: panel columns per pass (default 256).
+                static const int defer_u = [] { const char *e = getenv("KVX_DEFER_U"); return e ? atoi(e) : 1; }();
+                static const bool direct = [] { const char *e = getenv("KVX_SYRK_DIRECT"); return e && e[0] == '1'; }();
+                const bool have_lists = (size_t)l < F->chain_steps.size() && (int)F->chain_steps[(size_t)l].size() * KVX_NB >= P.chain_maxk &&
+                                        (int)F->u_steps[(size_t)l].size() * F->u_block >= P.chain_maxk;
+                const bool blocked = defer_u && !direct && have_lists;
+                const bool cls = !direct && have_lists;
+                // one trailing update of the chain: the fronts still in it at step jb, numbered over size classes (LDS-staged tiles),
+                // or the round-3 launches over (tiles of the largest front) x (all big fronts of the level)
+                auto syrk = [&](int jb, int klen, int col_lim) {
+                    ProfScope ps(F, FAM_SYRK);
+                    if (cls) {
+                        const kvx_chol::ChainList &cl = F->chain_steps[(size_t)l][(size_t)(jb / KVX_NB)];
+                        launch_syrk_step(st, F->ds, F->d_chain + cl.off, F->chain_m.data() + cl.off, F->chain_k.data() + cl.off, cl.cnt, jb, klen,
+                                         F->d_Lx, Uout, F->d_Linv, F->d_status, col_lim);
+                    } else if (klen == 2 * KVX_NB) {
+                        launch_syrk_pair(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status, col_lim);
+                    } else if (col_lim < KVX_COLS_PIVOT) {
+                        launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, col_lim, F->d_Lx, Uout, F->d_Linv, F->d_status);
+                    } else {
+                        launch_syrk_trailing(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status, col_lim);
                     }
-                    { ProfScope ps(F, FAM_SYRK); launch_syrk_inner(st, F->ds, list, nbig, bigm, jb, jb + 2 * KVX_NB, F->d_Lx, Uout, F->d_Linv, F->d_status); }
-                    { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb + KVX_NB, F->d_Lx, F->d_Linv); }
-                    { ProfScope ps(F, FAM_SYRK); launch_syrk_pair(st, F->ds, list, nbig, bigm, jb, F->d_Lx, Uout, F->d_Linv, F->d_status); }
-                    jb += 2 * KVX_NB;
+                };
+                if (blocked) {
+                    // Round 4, the blocked schedule.  The pivot columns go in blocks of OB = u_block (256).  On the chain's stream a
+                    // panel of block b updates only what is left of the block ("inner", at most three tile columns, K = 64); when the
+                    // block is solved, ONE rank-OB update ("near") brings the next block's columns up to date and factors its first
+                    // diagonal block; everything further right -- later pivot columns and the update matrix -- gets its rank-OB update
+                    // ("far") on a stream of its own, beside the next block's chain: K = 64 per pass over C moved 16 bytes per 128
+                    // flops and bound the ~20-nnz/row systems by exactly that traffic.  near(b + 1) and far(b) meet in the columns of
+                    // block b + 2: near(b + 1) waits for far(b); far(b + 1) follows far(b) on its stream.
+                    // KVX_DEFER_U=0: the round-3 schedule; KVX_U_STREAM=0: the far updates on the chain's stream.
+                    static const int u_stream = [] { const char *e = getenv("KVX_U_STREAM"); return e ? atoi(e) : 1; }();
+                    const int OB = F->u_block;
+                    hipStream_t su = u_stream ? F->side[2] : st;
+                    bool forked = false;
+                    for (int ob = 0, b = 0; ob < P.chain_maxk; ob += OB, b++) {
+                        const int bend = std::min(ob + OB, P.chain_maxk);
+                        for (int jb = ob; jb < bend; jb += KVX_NB) {
+                            { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
+                            if (jb + KVX_NB < bend) syrk(jb, KVX_NB, ob + OB);
+                        }
+                        const kvx_chol::ChainList &fl = F->u_steps[(size_t)l][(size_t)b];
+                        if (fl.cnt > 0) {
+                            if (su != st) {
+                                while ((int)F->ev_u.size() <= 2 * b + 1) { hipEvent_t e = nullptr; HIPCHK(pool_event_get(&e, false)); F->ev_u.push_back(e); }
+                                HIPCHK(hipEventRecord(F->ev_u[(size_t)(2 * b)], st));
+                                HIPCHK(hipStreamWaitEvent(su, F->ev_u[(size_t)(2 * b)], 0));
+                                forked = true;
+                            }
+                            {
+                                ProfScope ps(F, FAM_SYRK, su);
+                                launch_syrk_far(su, F->ds, F->d_chain + fl.off, F->chain_m.data() + fl.off, F->chain_k.data() + fl.off, fl.cnt, ob, OB,
+                                                ob + 2 * OB, F->d_Lx, Uout);
+                            }
+                            if (su != st) HIPCHK(hipEventRecord(F->ev_u[(size_t)(2 * b + 1)], su));
+                        }
+                        if (bend < P.chain_maxk) {
+                            // near(b) touches the columns of block b + 1, which far(b - 1) has updated with block b - 1
+                            if (su != st && b >= 1 && F->u_steps[(size_t)l][(size_t)(b - 1)].cnt > 0)
+                                HIPCHK(hipStreamWaitEvent(st, F->ev_u[(size_t)(2 * (b - 1) + 1)], 0));
+                            syrk(ob, OB, ob + 2 * OB);
+                        }
+                    }
+                    if (forked) {
+                        if (!F->ev_ujoin) HIPCHK(pool_event_get(&F->ev_ujoin, false));
+                        HIPCHK(hipEventRecord(F->ev_ujoin, su));
+                        HIPCHK(hipStreamWaitEvent(st, F->ev_ujoin, 0));
+                    }
+                } else {
+                    for (int jb = 0; jb < P.chain_maxk;) {
+                        const int64_t T = (bigm - jb - 1 + KVX_TILE - 1) / KVX_TILE;
+                        const bool pair = jb + KVX_NB < P.chain_maxk && T * (T + 1) / 2 * nbig >= pair_tiles;
+                        // the trailing update of panel jb also factors and inverts the diagonal block of panel jb + 64
+                        { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb, F->d_Lx, F->d_Linv); }
+                        if (!pair) {
+                            syrk(jb, KVX_NB, INT_MAX);
+                            jb += KVX_NB;
+                            continue;
+                        }
+                        syrk(jb, KVX_NB, jb + 2 * KVX_NB);
+                        { ProfScope ps(F, FAM_TRSM); launch_trsm_blk(st, F->ds, list, nbig, bigm, jb + KVX_NB, F->d_Lx, F->d_Linv); }
+                        syrk(jb, 2 * KVX_NB, INT_MAX);
+                        jb += 2 * KVX_NB;
+                    }
                 }
             }
         }
@@ -1828,11 +1938,15 @@ void kvx_chol_free(kvx_chol *F)
         if (F->d_inv_src) (void)pool_free(F->d_inv_src);
         if (F->d_keep) (void)pool_free(F->d_keep);
         if (F->d_flists) (void)pool_free(F->d_flists);
+        if (F->d_chain) (void)pool_free(F->d_chain);
         dist_release(F);
         for (void *p : {(void *)F->d_subs, (void *)F->d_subs_f, (void *)F->d_subs_lvl, (void *)F->d_cd_woff, (void *)F->d_lists_sw, (void *)F->d_depth})
             if (p) (void)pool_free(p);
         if (F->ev_fork) pool_event_put(F->ev_fork, false);
         if (F->ev_fork2) pool_event_put(F->ev_fork2, false);
+        for (hipEvent_t e : F->ev_u)
+            if (e) pool_event_put(e, false);
+        if (F->ev_ujoin) pool_event_put(F->ev_ujoin, false);
         for (hipEvent_t e : F->ev_lvl)
             if (e) pool_event_put(e, false);
         for (int i = 0; i < 4; i++)

@@ -77,6 +77,7 @@ struct LevelPlan {
     int maxk[KVX_NCLS];
     int big_maxk = 0;          // largest pivot count among the big fronts (solves)
     int chain_maxk = 0;        // ... among those factored by the batched multi-workgroup chain (all of them)
+    int big_maxu = 0;          // largest update matrix (m - k) among the big fronts
     int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
     // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
     int64_t soff[3];
@@ -141,6 +142,17 @@ struct kvx_chol {
     kvx::DistState *dist = nullptr;
     bool fplan_on = false;
     std::vector<LevelPlan> fplan;
+    std::vector<int32_t> flists_host;              // host copy of d_flists
+    // Per (level, panel step) the big fronts still in the chain, largest trailing matrix first, and per (level, block of
+    // u_block pivot columns) those whose update matrix the block updates, largest update matrix first: the LDS-staged
+    // trailing update numbers its workgroups over size classes of these lists (api.cpp build_chain_lists, device.hpp TileClasses)
+    struct ChainList { int64_t off; int cnt; };
+    std::vector<std::vector<ChainList>> chain_steps, u_steps;     // [level][jb / 64], [level][kb / u_block]
+    std::vector<int32_t> chain_host, chain_m, chain_k;            // the lists concatenated; order and pivot count of every entry
+    int32_t *d_chain = nullptr;
+    std::vector<hipEvent_t> ev_u;                  // per block of a level's chain: its panels are solved (the deferred updates' stream waits)
+    hipEvent_t ev_ujoin = nullptr;
+    int u_block = 256;                             // pivot columns per pass of the deferred update (KVX_U_BLOCK)
     int32_t *d_flists = nullptr;
     std::vector<int64_t> linv_off_host;        // per front: offset of its inverted diagonal blocks in d_Linv (-1: not a big front)
     uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
@@ -233,6 +245,7 @@ inline void prof_collect(kvx_chol *F)
 void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const std::vector<int64_t> &lptr, std::vector<LevelPlan> &plan);
 void build_plan(kvx_chol *F);
 int build_subtrees(kvx_chol *F);
+int build_chain_lists(kvx_chol *F);
 int ensure_device(kvx_chol *F);
 int ensure_solve_ws(kvx_chol *F, int64_t nrhs);
 int wait_for_caller(kvx_chol *F);

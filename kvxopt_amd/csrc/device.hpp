@@ -129,6 +129,18 @@ __device__ __forceinline__ void kvx_col_steps(double (&a)[KMAX], int k, int r, i
 }
 #endif
 
+// Workgroup numbering of a launch over fronts of very different sizes: up to KVX_MAXCLS size classes, class c = the fronts
+// list[first[c] .. first[c + 1]), each given the tiles of a T[c]-tile-row update region (TC[c] > 0: T[c] x TC[c] tiles, a
+// column-limited region; 0: the lower triangle), workgroup ids wg[c] .. wg[c + 1).  Passed by value as a kernel argument.
+constexpr int KVX_MAXCLS = 16;
+struct TileClasses {
+    int32_t ncls;
+    int32_t first[KVX_MAXCLS + 1];
+    int32_t T[KVX_MAXCLS];
+    int32_t TC[KVX_MAXCLS];
+    uint32_t wg[KVX_MAXCLS + 1];
+};
+
 constexpr int KVX_NB = 64;           // panel width of the blocked big-front factorisation
 constexpr int KVX_SMALL_MAX = 128;   // fronts up to this order are factored inside LDS
 constexpr int KVX_TILE = 64;         // trailing-update tile
@@ -189,8 +201,19 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
                      double *Lx, const double *Linv);
 // C -= X X' on the trailing tiles; the workgroup of tile (0, 0) also factors + inverts the NEXT diagonal
 // block (jb + 64), so launch_potrf_blk is needed for the first panel of a front only
+// col_lim: INT_MAX = the whole trailing matrix; KVX_COLS_PIVOT = the pivot columns only (the update matrix is brought up to
+// date by launch_syrk_u afterwards, with all of the front's panels in few passes)
+constexpr int KVX_COLS_PIVOT = 0x7ffffffe;
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout, double *Linv, int *status);
+                          double *Lx, double *Uout, double *Linv, int *status, int col_lim = 0x7fffffff);
+// LDS-staged trailing update over size classes of the fronts (kernels_big.hip): list = the fronts still in the chain at panel
+// step kb, sorted by the order of their update region (largest first); hm / hk = their orders and pivot counts (host arrays)
+void launch_syrk_step(hipStream_t st, const DevSym &ds, const int32_t *list, const int32_t *hm, const int32_t *hk, int count, int kb, int klen,
+                      double *Lx, double *Uout, double *Linv, int *status, int col_lim);
+// deferred ("far") update with the panel block [kb, kb + klen): C -= X X' on everything from column t0 on (later pivot columns
+// and the update matrix; t0 >= k: the update matrix alone)
+void launch_syrk_far(hipStream_t st, const DevSym &ds, const int32_t *list, const int32_t *hm, const int32_t *hk, int count, int kb, int klen,
+                     int t0, double *Lx, double *Uout);
 
 // two-level blocking (fronts that are flop-bound): per panel only the rest of the 256-column outer block [.., ob_end),
 // then one rank-(<= ob_len) update of everything right of the outer block [ob, ob + ob_len)
@@ -201,7 +224,7 @@ void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, in
 // pair schedule: the panels jb and jb + 64 in ONE pass over everything right of them (64-tile kernel, K = 128; tile (0, 0) factors
 // the diagonal block at jb + 128); launch_syrk_inner(jb, jb + 128) goes in front of the second panel's solve
 void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                      double *Lx, double *Uout, double *Linv, int *status);
+                      double *Lx, double *Uout, double *Linv, int *status, int col_lim = 0x7fffffff);
 
 // sharded mode: rank-ob_len update with the panel [ob, ob + ob_len) of the columns in [c_from, c_to) that rank own_r owns
 void launch_syrk_outer_dist(hipStream_t st, const DevSym &ds, const int32_t *list, int max_m, int ob, int ob_len,

@@ -414,6 +414,7 @@ int dist_setup_impl(kvx_chol *F, int rank, int nranks, int ob, int min_m, int64_
     if ((rc = upload(&F->d_lists, F->lists_host))) return rc;
     if (F->d_flists) { HIPCHK(pool_free(F->d_flists)); F->d_flists = nullptr; }
     if ((rc = upload(&F->d_flists, flists))) return rc;
+    F->flists_host = flists;
     if ((rc = upload(&D.d_dist_ids, dist_ids))) return rc;
     build_plan(F);
     build_plan_from(S, flists, flptr, F->fplan);

@@ -21,6 +21,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 namespace kvx {
@@ -661,6 +662,289 @@ extern "C" int kvx_dbg_phase_read(unsigned long long *out, int reset)
 #endif
 
 // ------------------------------------------------------------------------------------------
+// Round 4: the trailing update with its operands staged through LDS.  k_syrk_trailing has every one of its four waves fetch
+// the whole 64-row column strip of the tile for itself, 8 bytes per lane: 320 K doubles of L2 traffic per 64 x 64 x K tile.
+// Here the workgroup stages the two strips ONCE (128 K doubles), 16 bytes per lane, in chunks of 16 panel columns, double
+// buffered (the global loads of chunk c + 1 are in flight under the MFMAs of chunk c, one barrier per chunk); wave (wr, wc)
+// owns a 32 x 32 quarter (2 x 2 MFMA tiles, 4 LDS operand reads per 4 MFMAs).  Measured on MI355X (scratch/syrk_lab.hip, dense
+// u = 5000, K = 512): 39.4 TF/s against 29.2 for the direct form and 37.4 for 128 x 128 tiles -- v_mfma_f64_16x16x4_f64 issues
+// once per 99 cycles per SIMD with two or more waves resident (130 with one), i.e. the pipe's ceiling is 50.7 TF/s, not the
+// nominal 78.6 (tools/fp64_peak.hip, profiles/r04_fp64_peak.txt), and small tiles keep three workgroups per CU.
+// The update region is rows and columns >= t0, lower triangle, columns < cend; the K range is the panel columns
+// [kb, kb + min(klen, k - kb)).
+//   UONLY = false (chain step): t0 = kb + K range, cend = min(col_lim, k) or the whole front (col_lim = INT_MAX); the
+//                 workgroup of tile (0, 0) factors and inverts the next diagonal block as in k_syrk_trailing.
+//   UONLY = true  (deferred, "far" update): t0 = min(col_lim, k), cend = m -- everything from column col_lim on, update matrix
+//                 included (col_lim >= k: the update matrix alone); any K range; never a diagonal block that is factored next.
+// Reads one double past row m - 1 of a panel column (16-byte loads at clamped rows): Lx carries two doubles of slack.
+constexpr int SL_KC = 16, SL_LD = KVX_TILE + 16;        // LD = 64 + 16: the lanes of one LDS pass (32 lanes = 2 k) hit distinct banks
+typedef double d2v __attribute__((ext_vector_type(2)));
+struct SyrkLdsStage {
+    double xa[2][SL_KC * SL_LD];       // X[columns of the tile][k chunk], k-major
+    double xb[2][SL_KC * SL_LD];       // X[rows of the tile][k chunk]
+};
+union SyrkLdsU {
+    SyrkLdsStage st;
+    PotrfLds po;
+};
+struct SyrkLdsOnly {
+    SyrkLdsStage st;
+    struct { double S[1]; } po;      // (never used)
+};
+
+// Numbering of the workgroups of one launch (TileClasses, device.hpp).  A launch updates every big front of a level that is still
+// in the chain; their trailing matrices differ by an order of magnitude, and a (tiles of the largest front) x (fronts) grid is
+// mostly workgroups that find nothing to do -- the dispatcher starts one per ~2.6 ns, and the bottom levels of the 21-point
+// system launched 870 000 of them per step for 30 000 tiles of work (2.3 ms, measured).  The host therefore hands the kernel
+// the fronts sorted by size and cut into classes of similar tile counts; a class is a (tiles of ITS largest front) x (its
+// fronts) block of consecutive workgroup ids.
+// tile t of a front -> (ti, tj).  Triangular classes of 16 or more tile rows: the 8 XCDs (workgroup ids go round-robin over them,
+// each has its own L2) take contiguous eighths of the row-major tile order, so that the workgroups resident on one XCD work on
+// neighbouring tiles of a few tile rows and share their operand strips.
+__device__ __forceinline__ void tri_inv(unsigned L, int &ti, int &tj)
+{
+    unsigned si = (unsigned)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= L) si++;
+    while (si * (si + 1) / 2 > L) si--;
+    ti = (int)si;
+    tj = (int)(L - si * (si + 1) / 2);
+}
+static inline unsigned cls_tiles_per_front(int T, int TC)
+{
+    if (TC > 0) return (unsigned)T * (unsigned)TC;
+    const unsigned tri = (unsigned)T * (unsigned)(T + 1) / 2;
+    return T >= 16 ? ((tri + 7) / 8) * 8 : tri;
+}
+
+template <bool UONLY>
+__global__ __launch_bounds__(256, 2) void k_syrk_lds(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
+                                                     double *__restrict__ Lx, double *__restrict__ Uo,
+                                                     double *__restrict__ Linv, int *status, int col_lim, const TileClasses tc)
+{
+    // (the update of the update matrices never factors a diagonal block: 40 KB instead of 50, four workgroups per CU)
+    __shared__ __attribute__((aligned(16))) typename std::conditional<UONLY, SyrkLdsOnly, SyrkLdsU>::type lds;
+    int ti, tj, fi;
+    {
+        int c = 0;
+        while (c + 1 < tc.ncls && blockIdx.x >= tc.wg[c + 1]) c++;             // (uniform)
+        const unsigned local = blockIdx.x - tc.wg[c];
+        const int T = tc.T[c], TC = tc.TC[c];
+        if (TC > 0) {                                  // a few tile columns of T tile rows (column-limited launches)
+            const unsigned tpf = (unsigned)T * (unsigned)TC;
+            const unsigned t = local % tpf;
+            fi = tc.first[c] + (int)(local / tpf);
+            ti = (int)(t % (unsigned)T);
+            tj = (int)(t / (unsigned)T);
+        } else {
+            const unsigned tri = (unsigned)T * (unsigned)(T + 1) / 2;
+            if (T >= 16) {
+                const unsigned chunk = (tri + 7) / 8, tpf = 8 * chunk;
+                const unsigned t = local % tpf;
+                fi = tc.first[c] + (int)(local / tpf);
+                const unsigned L = (t & 7u) * chunk + (t >> 3);
+                if (L >= tri) return;
+                tri_inv(L, ti, tj);
+            } else {
+                fi = tc.first[c] + (int)(local / tri);
+                tri_inv(local % tri, ti, tj);
+            }
+        }
+    }
+    if (tj > ti || fi >= tc.first[tc.ncls]) return;    // (ids in the padding in front of an XCD-numbered class)
+    const FrontDesc fd = ds.fd[list[fi]];
+    const int k = fd.k, m = fd.m, u = m - k;
+    if (kb >= k) return;
+    const int nbk = min(klen, k - kb);
+    const int t0 = UONLY ? min(col_lim, k) : kb + nbk;
+    const int r0 = t0 + KVX_TILE * ti, c0 = t0 + KVX_TILE * tj;
+    if (r0 >= m) return;
+    const int cend = (UONLY || col_lim == INT_MAX) ? m : min(col_lim, k);
+    if (c0 >= cend) return;
+    double *P = Lx + fd.px;
+    double *U = Uo + fd.ux;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+    const int l = tid & 63, lr = l & 15, lk = l >> 4;
+    // staging map: a strip chunk is 32 row pairs x 16 k = 512 16-byte units, two per thread
+    const int spr = tid & 31, sk = tid >> 5;           // unit j: k = sk + 8 j
+    const double *Pa = P + min(c0 + 2 * spr, m - 1) + (int64_t)kb * m;
+    const double *Pb = P + min(r0 + 2 * spr, m - 1) + (int64_t)kb * m;
+    d2v ga[2], gb[2];
+    auto ldg = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int kk = k0 + sk + 8 * j;
+            const int64_t off = (int64_t)min(kk, nbk - 1) * m;
+            ga[j] = *(const d2v *)(Pa + off);
+            gb[j] = *(const d2v *)(Pb + off);
+            if (kk >= nbk) { ga[j] = (d2v){0.0, 0.0}; gb[j] = (d2v){0.0, 0.0}; }
+        }
+    };
+    d4 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) acc[s][t] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (nbk + SL_KC - 1) / SL_KC;
+    ldg(0);
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *xa = lds.st.xa[ch & 1], *xb = lds.st.xb[ch & 1];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            *(d2v *)(xa + (sk + 8 * j) * SL_LD + 2 * spr) = ga[j];
+            *(d2v *)(xb + (sk + 8 * j) * SL_LD + 2 * spr) = gb[j];
+        }
+        if (ch + 1 < nchunk) ldg((ch + 1) * SL_KC);
+        __syncthreads();
+        const double *oa = xa + 32 * wc + lr;
+        const double *ob = xb + 32 * wr + lr;
+#pragma unroll
+        for (int ks = 0; ks < SL_KC; ks += 4) {
+            const double a0 = oa[(ks + lk) * SL_LD], a1 = oa[(ks + lk) * SL_LD + 16];
+            const double b0 = ob[(ks + lk) * SL_LD], b1 = ob[(ks + lk) * SL_LD + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        // (the other buffer is free again once every wave has passed this chunk's barrier: one barrier per chunk)
+    }
+    // epilogue: lane holds C[row = r0 + 32 wr + 16 s + lr][col = c0 + 32 wc + 16 t + lk + 4 q]; branch-free read-modify-write
+    const bool fused = !UONLY && ti == 0 && tj == 0 && t0 < cend && t0 < k;      // workgroup-uniform
+    const int nb2 = min(NB, k - t0);
+    const int dend = fused ? t0 + nb2 : 0;             // rows below dend (a partial last block) are written as always
+    if (fused) __syncthreads();                        // the staging buffers become the image of the diagonal block
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int rr = r0 + 32 * wr + 16 * s + lr;
+        const bool rin = rr < m;
+        const int rs = min(rr, m - 1);
+        double *ptr[2][4];
+        double old[2][4];
+        bool ok[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = c0 + 32 * wc + 16 * t + lk + 4 * q;
+                ok[t][q] = rin && c <= rr && c < cend;
+                const int cs = min(c, rs);
+                ptr[t][q] = (cs < k) ? P + rs + (int64_t)cs * m : U + (rs - k) + (int64_t)(cs - k) * u;
+                old[t][q] = *ptr[t][q];
+            }
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double v = old[t][q] - acc[s][t][q];
+                if (ok[t][q] && rr >= dend) *ptr[t][q] = v;
+                if constexpr (!UONLY) if (fused) {
+                    const int i = 32 * wr + 16 * s + lr, cc = 32 * wc + 16 * t + lk + 4 * q;
+                    if ((cc >> 4) <= (i >> 4)) lds.po.S[s_idx(i, cc)] = (i < nb2 && cc <= i) ? v : (cc == i ? 1.0 : 0.0);
+                }
+            }
+    }
+    if constexpr (!UONLY) if (fused) {
+        __syncthreads();
+        potrf_lds(lds.po, nb2, tid, status, fd.first + t0, make_piv_rule(ds));
+        potrf_store(lds.po, nb2, tid, P, m, t0, Linv + fd.linv + (int64_t)(t0 / NB) * NB * NB);
+    }
+}
+
+// Size classes of a launch.  hm / hk: order and pivot columns of the fronts in list order (host copies; the list is sorted by the
+// order of the update region, largest first, so classes are runs of the list).  A class ends where the tile count of the next
+// front falls below ~0.7 of the class's largest, or rises above it.
+static TileClasses make_tile_classes(bool uonly, const int32_t *hm, const int32_t *hk, int count, int kb, int klen, int col_lim)
+{
+    TileClasses tc;
+    int c = -1;
+    for (int i = 0; i < count; i++) {
+        const int m = hm[i], k = hk[i];
+        int R = 0, C = 0;
+        if (kb < k) {
+            const int t0 = uonly ? std::min(col_lim, k) : kb + std::min(klen, k - kb);
+            const int cend = (uonly || col_lim == INT_MAX) ? m : std::min(col_lim, k);
+            R = std::max(m - t0, 0);
+            C = std::max(cend - t0, 0);
+        }
+        const int T = (R + KVX_TILE - 1) / KVX_TILE, TCf = (C + KVX_TILE - 1) / KVX_TILE;
+        if (c == KVX_MAXCLS - 1) {                     // out of classes: the last one takes the rest, whatever its sizes
+            tc.T[c] = std::max(tc.T[c], T);
+            tc.TC[c] = std::max(tc.TC[c], TCf);
+            continue;
+        }
+        if (c >= 0 && T <= tc.T[c] && T * 10 >= tc.T[c] * 7) {
+            tc.TC[c] = std::max(tc.TC[c], TCf);
+            continue;
+        }
+        c++;
+        tc.first[c] = i;
+        tc.T[c] = T;
+        tc.TC[c] = TCf;
+    }
+    tc.ncls = c + 1;
+    tc.wg[0] = 0;
+    tc.first[tc.ncls] = count;
+    for (int q = 0; q < tc.ncls; q++) {
+        const int T = tc.T[q];
+        if (tc.TC[q] * 2 >= T) tc.TC[q] = 0;           // rectangular numbering only where it saves at least half of the workgroups
+        unsigned w0 = tc.wg[q];
+        if (tc.TC[q] == 0 && T >= 16) w0 = (w0 + 7u) & ~7u;                   // XCD numbering: the class starts on XCD 0
+        tc.wg[q] = w0;
+        tc.wg[q + 1] = w0 + (T > 0 ? cls_tiles_per_front(T, tc.TC[q]) : 0u) * (unsigned)(tc.first[q + 1] - tc.first[q]);
+    }
+    return tc;
+}
+
+static void launch_syrk_lds_cls(hipStream_t st, bool uonly, const DevSym &ds, const int32_t *list, const TileClasses &tc, int kb, int klen,
+                                double *Lx, double *Uout, double *Linv, int *status, int col_lim)
+{
+    if (tc.ncls <= 0) return;
+    const unsigned gx = tc.wg[tc.ncls];
+    if (gx == 0) return;
+    if (uonly)
+        hipLaunchKernelGGL(k_syrk_lds<true>, dim3(gx), dim3(256), 0, st, ds, list, kb, klen, Lx, Uout, Linv, status, col_lim, tc);
+    else
+        hipLaunchKernelGGL(k_syrk_lds<false>, dim3(gx), dim3(256), 0, st, ds, list, kb, klen, Lx, Uout, Linv, status, col_lim, tc);
+}
+
+// without size information: one class, every front gets the tiles of an update region of order `rows`
+// (an over-estimate is fine: empty tiles exit at once)
+static void launch_syrk_lds(hipStream_t st, bool uonly, const DevSym &ds, const int32_t *list, int count, int rows, int kb, int klen,
+                            double *Lx, double *Uout, double *Linv, int *status, int col_lim)
+{
+    if (count <= 0 || rows <= 0) return;
+    TileClasses tc;
+    tc.ncls = 1;
+    tc.first[0] = 0; tc.first[1] = count;
+    tc.T[0] = (rows + KVX_TILE - 1) / KVX_TILE;
+    const int TC = col_lim >= KVX_COLS_PIVOT ? tc.T[0] : std::min(tc.T[0], (std::max(col_lim - kb - klen, 1) + KVX_TILE - 1) / KVX_TILE);
+    tc.TC[0] = TC * 2 < tc.T[0] ? TC : 0;
+    tc.wg[0] = 0;
+    tc.wg[1] = cls_tiles_per_front(tc.T[0], tc.TC[0]) * (unsigned)count;
+    launch_syrk_lds_cls(st, uonly, ds, list, tc, kb, klen, Lx, Uout, Linv, status, col_lim);
+}
+
+// the launches of the single-GPU chain: `list` = the big fronts still in the chain at panel step kb, largest update region
+// first (api.cpp build_chain_lists), hm / hk their orders and pivot counts
+void launch_syrk_step(hipStream_t st, const DevSym &ds, const int32_t *list, const int32_t *hm, const int32_t *hk, int count, int kb, int klen,
+                      double *Lx, double *Uout, double *Linv, int *status, int col_lim)
+{
+    if (count <= 0) return;
+    const TileClasses tc = make_tile_classes(false, hm, hk, count, kb, klen, col_lim);
+    launch_syrk_lds_cls(st, false, ds, list, tc, kb, klen, Lx, Uout, Linv, status, col_lim);
+}
+// deferred ("far") update with the panel block [kb, kb + klen): everything from column t0 on -- later pivot columns and the
+// update matrix; t0 >= k: the update matrix alone -- for the fronts of the list
+void launch_syrk_far(hipStream_t st, const DevSym &ds, const int32_t *list, const int32_t *hm, const int32_t *hk, int count, int kb, int klen,
+                     int t0, double *Lx, double *Uout)
+{
+    if (count <= 0) return;
+    const TileClasses tc = make_tile_classes(true, hm, hk, count, kb, klen, t0);
+    launch_syrk_lds_cls(st, true, ds, list, tc, kb, klen, Lx, Uout, nullptr, nullptr, t0);
+}
+
+// ------------------------------------------------------------------------------------------
 // The same update on 128 x 128 tiles (opt-in, see launch_syrk_trailing for the measurement): the
 // two operand strips X[rows, :] and X[cols, :] staged through LDS in chunks of 16 panel columns
 // (k-major, double-buffered, global loads of chunk c + 1 in flight under the MFMAs of chunk c).
@@ -849,12 +1133,20 @@ static dim3 syrk128_grid(int rows, int count)
     return dim3(nsb * 64u, 1, (unsigned)count);
 }
 
+// KVX_SYRK_DIRECT=1: the round-3 kernels (every wave loads its operands from global memory) instead of the LDS-staged tiles
+static bool syrk_direct()
+{
+    static const bool v = [] { const char *e = getenv("KVX_SYRK_DIRECT"); return e && e[0] == '1'; }();
+    return v;
+}
+
 void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                          double *Lx, double *Uout, double *Linv, int *status)
+                          double *Lx, double *Uout, double *Linv, int *status, int col_lim)
 {
     if (count <= 0) return;
     int rows = max_m - jb - 1;
     if (rows <= 0) return;
+    if (!syrk_direct()) { launch_syrk_lds(st, false, ds, list, count, rows, jb, NB, Lx, Uout, Linv, status, col_lim); return; }
     const int64_t T = (rows + KVX_TILE - 1) / KVX_TILE;
     // Measured (MI355X): with 64-column panels the 128-tile kernel LOSES (21-point stencil, n = 1e6: factor 24 -> 35 ms):
     // a rank-64 update is bound by the read-modify-write of C (16 B per 128 flops), not by operand traffic, and the
@@ -866,20 +1158,21 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     if (T * (T + 1) / 2 * count >= big_limit) {
         hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
     } else {                                          // latency regime: more, smaller workgroups
-        hipLaunchKernelGGL(k_syrk_trailing<64>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
+        hipLaunchKernelGGL(k_syrk_trailing<64>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim);
     }
 }
 
 // Pair schedule, second launch: the panels [jb, jb + 64) and [jb + 64, jb + 128) applied together to everything right of them
 // (the first launch -- launch_syrk_inner(jb, jb + 128) -- has brought the second panel's own columns up to date with the first).
 void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int jb,
-                      double *Lx, double *Uout, double *Linv, int *status)
+                      double *Lx, double *Uout, double *Linv, int *status, int col_lim)
 {
     if (count <= 0) return;
     int rows = max_m - jb - 1;                        // (an over-estimate of the trailing order: empty tiles exit at once)
     if (rows <= 0) return;
+    if (!syrk_direct()) { launch_syrk_lds(st, false, ds, list, count, rows, jb, 2 * NB, Lx, Uout, Linv, status, col_lim); return; }
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
-    hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(T, T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, INT_MAX);
+    hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(T, T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim);
 }
 
 // Two-level blocking for the fronts that are flop-bound (level with a front of order >= KVX_TWO_LEVEL_M): the pivot
@@ -893,6 +1186,7 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (count <= 0 || jb + NB >= ob_end) return;
     int rows = max_m - jb - 1;
     if (rows <= 0) return;
+    if (!syrk_direct()) { launch_syrk_lds(st, false, ds, list, count, rows, jb, NB, Lx, Uout, Linv, status, ob_end); return; }
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     const unsigned TC = (unsigned)std::min<int>((int)T, (ob_end - jb - NB + KVX_TILE - 1) / KVX_TILE);
     hipLaunchKernelGGL(k_syrk_trailing<64>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
