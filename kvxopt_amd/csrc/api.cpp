@@ -41,6 +41,7 @@ void build_plan_from(const Symbolic &S, const std::vector<int32_t> &lists, const
                 P.big_maxk = std::max(P.big_maxk, k);
                 P.chain_maxk = std::max(P.chain_maxk, k);
                 P.big_maxu = std::max(P.big_maxu, m - k);
+                P.big_flops += (double)k * k * k / 3.0 + (double)(m - k) * k * (double)m;   // potrf + panel solve + trailing update
                 P.big_u_len = S.ux[s] + (int64_t)(m - k) * (m - k);
             }
             int g = c == KVX_CLS_BIG ? 0 : (c < KVX_CLS_WAVE0 ? 1 : 2);
@@ -600,7 +601,13 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 static const bool direct = [] { const char *e = getenv("KVX_SYRK_DIRECT"); return e && e[0] == '1'; }();
                 const bool have_lists = (size_t)l < F->chain_steps.size() && (int)F->chain_steps[(size_t)l].size() * KVX_NB >= P.chain_maxk &&
                                         (int)F->u_steps[(size_t)l].size() * F->u_block >= P.chain_maxk;
-                const bool blocked = defer_u && !direct && have_lists;
+                // ... where a level's chain is bound by throughput: its flops per panel step would keep the machine busy for longer
+                // than the ~30 us of latency a step has anyway (KVX_BLOCKED_GF: Gflop per step from which on, default 0.25.  21-point
+                // system, one box, thresholds 0 / 0.3 / 0.7 / 1.5 / never: 23.6 / 23.8 / 23.9 / 24.4 / 26.3 ms; config 2, where no level
+                // reaches 0.3: blocked everywhere 4.97 - 5.45 ms against 4.76 - 4.97)
+                static const double blocked_gf = [] { const char *e = getenv("KVX_BLOCKED_GF"); return e ? atof(e) : 0.25; }();
+                const int nsteps = (P.chain_maxk + KVX_NB - 1) / KVX_NB;
+                const bool blocked = defer_u && !direct && have_lists && P.big_flops * 1e-9 >= blocked_gf * nsteps;
                 const bool cls = !direct && have_lists;
                 // one trailing update of the chain: the fronts still in it at step jb, numbered over size classes (LDS-staged tiles),
                 // or the round-3 launches over (tiles of the largest front) x (all big fronts of the level)

@@ -78,6 +78,7 @@ struct LevelPlan {
     int big_maxk = 0;          // largest pivot count among the big fronts (solves)
     int chain_maxk = 0;        // ... among those factored by the batched multi-workgroup chain (all of them)
     int big_maxu = 0;          // largest update matrix (m - k) among the big fronts
+    double big_flops = 0.0;    // flops of the big fronts of the level
     int64_t big_u_len = 0;   // doubles of the parity buffer used by the big fronts (head)
     // solve groups: [big], [LDS classes: 256 threads], [wave classes: 64 threads]
     int64_t soff[3];

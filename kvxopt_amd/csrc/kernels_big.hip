@@ -716,18 +716,16 @@ static inline unsigned cls_tiles_per_front(int T, int TC)
     return T >= 16 ? ((tri + 7) / 8) * 8 : tri;
 }
 
-template <bool UONLY>
-__global__ __launch_bounds__(256, 2) void k_syrk_lds(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
-                                                     double *__restrict__ Lx, double *__restrict__ Uo,
-                                                     double *__restrict__ Linv, int *status, int col_lim, const TileClasses tc)
+template <bool UONLY, class Lds>
+__device__ __forceinline__ void syrk_lds_tile(Lds &lds, const unsigned wgid, const DevSym &ds, const int32_t *__restrict__ list, int kb, int klen,
+                                              double *__restrict__ Lx, double *__restrict__ Uo,
+                                              double *__restrict__ Linv, int *status, int col_lim, const TileClasses &tc)
 {
-    // (the update of the update matrices never factors a diagonal block: 40 KB instead of 50, four workgroups per CU)
-    __shared__ __attribute__((aligned(16))) typename std::conditional<UONLY, SyrkLdsOnly, SyrkLdsU>::type lds;
     int ti, tj, fi;
     {
         int c = 0;
-        while (c + 1 < tc.ncls && blockIdx.x >= tc.wg[c + 1]) c++;             // (uniform)
-        const unsigned local = blockIdx.x - tc.wg[c];
+        while (c + 1 < tc.ncls && wgid >= tc.wg[c + 1]) c++;                   // (uniform)
+        const unsigned local = wgid - tc.wg[c];
         const int T = tc.T[c], TC = tc.TC[c];
         if (TC > 0) {                                  // a few tile columns of T tile rows (column-limited launches)
             const unsigned tpf = (unsigned)T * (unsigned)TC;
@@ -851,6 +849,26 @@ __global__ __launch_bounds__(256, 2) void k_syrk_lds(DevSym ds, const int32_t *_
     }
 }
 
+// One workgroup per tile, or (opt-in, KVX_FAR_WGS) a fixed number of resident workgroups that walk the tiles with stride
+// gridDim.x.  Beside a far launch the chain's launches wait (an inner step of 27 us took 200, a panel solve of 11 us 38:
+// rocprofv3 timeline of the 21-point system); neither two resident far workgroups per CU (nothing of the far launch pending in
+// the dispatcher, room for a 50 KB chain workgroup on every CU) nor LDS padding to the same effect changed that (21-point
+// 23.0 - 23.6 ms against 23.3 - 23.5, 100^3 122 against 109 ms): the chain's tiles share SIMDs whose matrix pipe the far
+// tiles keep busy.
+template <bool UONLY>
+__global__ __launch_bounds__(256, 2) void k_syrk_lds(DevSym ds, const int32_t *__restrict__ list, int kb, int klen,
+                                                     double *__restrict__ Lx, double *__restrict__ Uo,
+                                                     double *__restrict__ Linv, int *status, int col_lim, const TileClasses tc)
+{
+    // (the update of the update matrices never factors a diagonal block: 40 KB instead of 50)
+    __shared__ __attribute__((aligned(16))) typename std::conditional<UONLY, SyrkLdsOnly, SyrkLdsU>::type lds;
+    const unsigned total = tc.wg[tc.ncls];
+    for (unsigned wgid = blockIdx.x; wgid < total; wgid += gridDim.x) {
+        syrk_lds_tile<UONLY>(lds, wgid, ds, list, kb, klen, Lx, Uo, Linv, status, col_lim, tc);
+        if (gridDim.x < total) __syncthreads();        // (the next tile's first chunk goes into the buffer the last one may still be read from)
+    }
+}
+
 // Size classes of a launch.  hm / hk: order and pivot columns of the fronts in list order (host copies; the list is sorted by the
 // order of the update region, largest first, so classes are runs of the list).  A class ends where the tile count of the next
 // front falls below ~0.7 of the class's largest, or rises above it.
@@ -902,8 +920,10 @@ static void launch_syrk_lds_cls(hipStream_t st, bool uonly, const DevSym &ds, co
     if (tc.ncls <= 0) return;
     const unsigned gx = tc.wg[tc.ncls];
     if (gx == 0) return;
+    // KVX_FAR_WGS > 0: a far launch as that many resident workgroups walking the tiles (measured: no gain, see k_syrk_lds)
+    static const unsigned far_wgs = [] { const char *e = getenv("KVX_FAR_WGS"); return e ? (unsigned)atoi(e) : 0u; }();
     if (uonly)
-        hipLaunchKernelGGL(k_syrk_lds<true>, dim3(gx), dim3(256), 0, st, ds, list, kb, klen, Lx, Uout, Linv, status, col_lim, tc);
+        hipLaunchKernelGGL(k_syrk_lds<true>, dim3(far_wgs ? std::min(gx, far_wgs) : gx), dim3(256), 0, st, ds, list, kb, klen, Lx, Uout, Linv, status, col_lim, tc);
     else
         hipLaunchKernelGGL(k_syrk_lds<false>, dim3(gx), dim3(256), 0, st, ds, list, kb, klen, Lx, Uout, Linv, status, col_lim, tc);
 }
