@@ -108,6 +108,53 @@ def spawn_ranks(args):
     return rc
 
 
+class TorchRanks:
+    """The ranks of the job through torch.distributed (KVX_DIST_BACKEND=nccl: RCCL through torch; gloo: rehearsal on fewer GPUs)."""
+
+    def __init__(self, torch, dist, dev):
+        self.torch, self.dist, self.dev = torch, dist, dev
+        self.backend, self.world, self.comm = dist.get_backend(), dist.get_world_size(), None
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, v):
+        t = self.torch.tensor([float(v)], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, values):
+        mine = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64, device=self.dev)
+        got = [mine.clone() for _ in range(self.world)]
+        self.dist.all_gather(got, mine)
+        return [[float(x) for x in t.cpu().tolist()] for t in got]
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class RcclRanks:
+    """The ranks of the job through librccl.so itself (kvxopt_amd.rccl.World, csrc/rccl_comm.cpp): no torch in the process, the
+    system's HIP runtime, collectives enqueued from C.  The default for N > 1."""
+
+    def __init__(self, W):
+        self.comm, self.backend, self.world = W, "rccl-direct (librccl %d)" % W.version, W.world
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def max(self, v):
+        return self.comm.max(v)
+
+    def gather(self, values):
+        return [[float(x) for x in row] for row in self.comm.all_gather(values)]
+
+    def close(self):
+        self.comm.barrier()
+        self.comm.close()
+
+
 def front_stats(F):
     """Algorithmic work per kernel family from the symbolic analysis (host side)."""
     sup, nrows, parent, level = F.supernodes()
@@ -414,7 +461,8 @@ def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mo
     t0 = time.time()
     if mode == "subtree":
         from kvxopt_amd.dist import DistFactor
-        DF = DistFactor(n, colptr, rowind, "L", None, chol_opts, device=dev, ob=args.dist_ob, min_m=args.dist_min_m)
+        DF = DistFactor(n, colptr, rowind, "L", None, chol_opts, device=dev, ob=args.dist_ob, min_m=args.dist_min_m,
+                        comm=(dist.comm if dist is not None else None))
         F = DF.F
     else:
         F = Factor(n, colptr, rowind, "L", None, chol_opts)
@@ -462,9 +510,7 @@ def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mo
     barrier()
     dt = time.perf_counter() - t0
     if collective:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = dist.max(dt)
     ms_factor, ms_solve = F.timing()
     ms_sep = None
     if DF is None and not args.separate_calls:
@@ -633,25 +679,40 @@ def main():
         pl = Plumbing()
         dev = None
     else:
-        import torch
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-        # one GPU per rank; KVX_DIST_BACKEND=gloo rehearses the N > 1 paths on a box with fewer GPUs than ranks
-        backend = os.environ.get("KVX_DIST_BACKEND", "nccl")
-        ndev = max(torch.cuda.device_count(), 1)
-        if backend != "nccl":
-            local_rank = local_rank % ndev
-        elif world > ndev:
-            raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
-        torch.cuda.set_device(local_rank)
-        dev = torch.device("cuda", local_rank)
-        pl = Plumbing(torch, dev)
-        import torch.distributed as dist_
-        dist = dist_
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+        # one GPU per rank.  KVX_DIST_BACKEND: "rccl" (default) = librccl.so bound directly, no torch in the process; "nccl" = RCCL
+        # through torch.distributed; "gloo" rehearses the N > 1 paths on a box with fewer GPUs than ranks (torch, host-staged)
+        backend = os.environ.get("KVX_DIST_BACKEND", "rccl")
+        if backend == "rccl":
+            try:
+                _kvx_lib.require_device()
+            except Exception:
+                raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+            ndev = int(_kvx_lib.lib().kvx_device_count())
+            if world > ndev:
+                raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
+            from kvxopt_amd.rccl import World
+            dist = RcclRanks(World(rank, world, local_rank))
+            pl = Plumbing()
+            dev = None
+            assert "torch" not in sys.modules
         else:
-            dist.init_process_group(backend)
+            import torch
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+            ndev = max(torch.cuda.device_count(), 1)
+            if backend != "nccl":
+                local_rank = local_rank % ndev
+            elif world > ndev:
+                raise SystemExit("bench.py: %d ranks but %d visible GPU(s); RCCL needs one GPU per rank (KVX_DIST_BACKEND=gloo rehearses the sharded path on fewer)" % (world, ndev))
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            pl = Plumbing(torch, dev)
+            import torch.distributed as dist_
+            if backend == "nccl":
+                dist_.init_process_group("nccl", device_id=dev)
+            else:
+                dist_.init_process_group(backend)
+            dist = TorchRanks(torch, dist_, dev)
     mode = "single" if world == 1 else (args.dist or "subtree")
 
     g = args.grid or (100 if args.workload == "lap3d" else 1000)
@@ -663,19 +724,15 @@ def main():
         if rank == 0:
             print(json.dumps(dict(public(res), opts=args.chol_opts, n_gpus=world)))
         if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+            dist.close()
         return
     # per-rank device memory: the factor's own large buffers (library count) and what the device reports in use
     free_b, total_b = pl.mem_info()
     mine_l = [float(res["_F"].info()["dev_bytes"]), float(total_b - free_b)]
     per_rank = [mine_l]
     if dist is not None:
-        mine = pl.torch.tensor(mine_l, dtype=pl.torch.float64, device=dev)
-        gathered = [mine.clone() for _ in range(world)]
-        dist.all_gather(gathered, mine)
-        per_rank = [[float(t[0].item()), float(t[1].item())] for t in gathered]
-    ranks = {"backend": (dist.get_backend() if dist is not None else "none"), "world_size": (dist.get_world_size() if dist is not None else 1),
+        per_rank = dist.gather(mine_l)
+    ranks = {"backend": (dist.backend if dist is not None else "none"), "world_size": (dist.world if dist is not None else 1),
              "factor_bytes_by_rank": [int(t[0]) for t in per_rank], "device_bytes_in_use_by_rank": [int(t[1]) for t in per_rank],
              "hip_runtime": pl.runtime()}
 
@@ -744,8 +801,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
-        dist.barrier()                  # rank 0 has extra legs (CPU baseline, IPM): leave together
-        dist.destroy_process_group()
+        dist.close()                    # (barrier first: rank 0 has extra legs -- CPU baseline, IPM -- leave together)
 
 
 if __name__ == "__main__":

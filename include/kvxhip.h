@@ -65,6 +65,8 @@ int  kvx_device_count(void);            /* number of visible HIP devices (0 on a
 int  kvx_current_device(void);          /* the calling thread's current HIP device, -1 without one: device objects (factors, plans,
                                          * KKT objects) live on the device that was current when they were built; the host layer's
                                          * caches key on it                                    */
+int  kvx_set_device(int dev);           /* make `dev` the calling thread's current HIP device (a rank process of the sharded mode
+                                         * picks its GPU with this before anything else touches HIP) */
 const char *kvx_last_error(void);       /* text of the last error on this thread               */
 
 /* ---- sparse Cholesky: replaces kvxopt.cholmod ------------------------------------------ */
@@ -155,6 +157,11 @@ int kvx_chol_get_front_rows(kvx_chol *F, int64_t *rowptr, int64_t *rowidx);
 /* Dominant-kernel timing of the last factorize/solve, measured with HIP events on the
  * factor's own stream (bench.py roofline leg). ms_factor / ms_solve may be NULL. */
 int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve);
+/* Which form the last kvx_chol_factorize_solve* call took: 1 = the one-enqueue form (forward sweep pipelined behind the
+ * factorisation, one launch graph), 2 = factorisation and solve as two enqueues (sharded / LDL' factors, more than 16
+ * right-hand sides, family timing, KVX_NO_GRAPH, and every process whose HIP runtime is older than 7.2 -- the runtime inside
+ * the PyTorch wheel, 7.0.51831, crashes in hipGraphLaunch of the one-enqueue graph), 0 = no such call yet. */
+int kvx_chol_last_fused_path(kvx_chol *F);
 /* Per-kernel-family timing for the roofline leg of bench.py: HIP events are recorded around
  * every launch of ONE family on the factor's own stream while it is selected.
  * family: -1 off, 0 scatter_a, 1 front_small (LDS fronts), 2 assemble_big, 3 potrf_diag,
@@ -203,6 +210,27 @@ int kvx_chol_dist_set_xchg(kvx_chol *F, double *xchg_dev, int64_t count);
 int kvx_chol_dist_factorize(kvx_chol *F, const double *values_dev, kvx_dist_comm_fn comm, void *ctx, int64_t *minor);
 /* A X = B in place: B_dev (n x nrhs, ld = ldB) identical on all ranks on entry, the full solution on every rank on return. */
 int kvx_chol_dist_solve(kvx_chol *F, double *B_dev, int64_t nrhs, int64_t ldB, kvx_dist_comm_fn comm, void *ctx);
+
+/* ---- RCCL bound directly: the collectives of the sharded mode without torch.distributed -------------------------------
+ * One process per GPU.  librccl.so is opened with dlopen at the first of these calls (KVX_RCCL_LIB overrides the path).
+ * Rank 0 makes the id (kvx_rccl_unique_id) and hands its 128 bytes to the other ranks by any channel (kvxopt_amd/rccl.py: a
+ * TCP socket on MASTER_ADDR:MASTER_PORT); every rank then calls kvx_rccl_init on the device it has made current (one rank per
+ * device: RCCL refuses two).  kvx_rccl_split is collective over ALL ranks and creates the communicator of one rank range of
+ * the factor's map (the ranges of kvx_chol_dist_groups, same order on every rank).  kvx_rccl_comm is a kvx_dist_comm_fn whose
+ * ctx is the kvx_rccl*: pass both to kvx_chol_dist_factorize / kvx_chol_dist_solve.  The *_host calls move a few doubles
+ * (at most 1024) through a device scratch buffer: timing rules and barriers of a benchmark.  Nothing here has a counterpart in
+ * the reference (single process, src/C/cholmod.c:85). */
+typedef struct kvx_rccl kvx_rccl;
+int kvx_rccl_version(int *version);                       /* ncclGetVersion of the library that was opened */
+int kvx_rccl_unique_id(char id[128]);
+int kvx_rccl_init(int rank, int nranks, const char id[128], kvx_rccl **out);
+int kvx_rccl_split(kvx_rccl *W, int lo, int hi);
+int kvx_rccl_comm(void *ctx, const kvx_dist_op *op);
+int kvx_rccl_allreduce_host(kvx_rccl *W, double *vals, int n, int op /* 0 SUM, 1 MAX, 2 MIN */);
+int kvx_rccl_allgather_host(kvx_rccl *W, const double *mine, int n, double *all /* n * nranks */);
+int kvx_rccl_barrier(kvx_rccl *W);                        /* every rank is here and its earlier device work is complete */
+int kvx_rccl_stats(kvx_rccl *W, int64_t out[2]);          /* collectives through kvx_rccl_comm, bytes they moved */
+void kvx_rccl_free(kvx_rccl *W);
 
 void kvx_chol_free(kvx_chol *F);
 void kvx_free(void *p);

@@ -69,6 +69,7 @@ _SIGS = {
     "kvx_version": (ctypes.c_char_p, []),
     "kvx_device_count": (ctypes.c_int, []),
     "kvx_current_device": (ctypes.c_int, []),
+    "kvx_set_device": (ctypes.c_int, [ctypes.c_int]),
     "kvx_last_error": (ctypes.c_char_p, []),
     "kvx_chol_default_opts": (None, [ctypes.POINTER(CholOpts)]),
     "kvx_chol_analyze": (ctypes.c_int, [i64, i64p, i64p, ctypes.c_int, i64p, ctypes.POINTER(CholOpts), ctypes.POINTER(vp)]),
@@ -91,6 +92,7 @@ _SIGS = {
     "kvx_chol_get_supernodes": (ctypes.c_int, [vp, i64p, i64p, i64p, i64p]),
     "kvx_chol_get_front_rows": (ctypes.c_int, [vp, i64p, i64p]),
     "kvx_chol_last_timing": (ctypes.c_int, [vp, f64p, f64p]),
+    "kvx_chol_last_fused_path": (ctypes.c_int, [vp]),
     "kvx_chol_prof_select": (ctypes.c_int, [vp, ctypes.c_int]),
     "kvx_chol_prof_read": (ctypes.c_int, [vp, f64p, i64p]),
     "kvx_chol_dist_map": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
@@ -100,6 +102,16 @@ _SIGS = {
     "kvx_chol_dist_set_xchg": (ctypes.c_int, [vp, vp, i64]),
     "kvx_chol_dist_factorize": (ctypes.c_int, [vp, vp, DIST_COMM_FN, vp, i64p]),
     "kvx_chol_dist_solve": (ctypes.c_int, [vp, vp, i64, i64, DIST_COMM_FN, vp]),
+    "kvx_rccl_version": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "kvx_rccl_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "kvx_rccl_init": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(vp)]),
+    "kvx_rccl_split": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
+    "kvx_rccl_comm": (ctypes.c_int, [vp, ctypes.POINTER(DistOp)]),
+    "kvx_rccl_allreduce_host": (ctypes.c_int, [vp, f64p, ctypes.c_int, ctypes.c_int]),
+    "kvx_rccl_allgather_host": (ctypes.c_int, [vp, f64p, ctypes.c_int, f64p]),
+    "kvx_rccl_barrier": (ctypes.c_int, [vp]),
+    "kvx_rccl_stats": (ctypes.c_int, [vp, i64p]),
+    "kvx_rccl_free": (None, [vp]),
     "kvx_chol_free": (None, [vp]),
     "kvx_free": (None, [vp]),
     "kvx_atda_plan": (ctypes.c_int, [i64, i64, i64p, i64p, i64p, i64p, ctypes.POINTER(vp)]),

@@ -93,6 +93,10 @@ class Factor:
         raise_for(lib().kvx_chol_last_timing(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def last_fused_path(self):
+        """1: the last factorize_solve* call was one enqueue; 2: two enqueues (kvxhip.h kvx_chol_last_fused_path)."""
+        return int(lib().kvx_chol_last_fused_path(self._h))
+
     FAMILIES = ("scatter_a", "front_small", "assemble_big", "potrf_diag", "trsm_panel", "syrk_trailing",
                 "fwd_level", "bwd_level")
 

@@ -1181,16 +1181,22 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
     static const bool old_runtime = [] {
         int v = 0;
         if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); return true; }
-        const char *e = getenv("KVX_FUSED_ANY_RUNTIME");
+        const char *e = getenv("KVX_DBG_FUSED_ANY_RUNTIME");          // debugging only: reproduces the crash of DESIGN.md section 5
         return v < 70200000 && !(e && e[0] == '1');
     }();
     const bool plain = F->dist_nranks != 1 || !F->is_ll || nrhs == 0 || nrhs > 16 || n == 0 || F->prof_family >= 0 || F->factor_subtrees ||
                        old_runtime || !F->use_graph;
     if ((rc = wait_for_caller(F))) return rc;
     if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
+    F->last_fused_path = plain ? 2 : 1;
     if (plain) {
         if ((rc = enqueue_factor(F))) return rc;
-        return solve_dev(F, 0, B, nrhs, ldB, async);
+        rc = solve_dev(F, 0, B, nrhs, ldB, async);
+        // the factorisation was enqueued by THIS call: its failure is the call's result (KVX_ENOTPOSDEF and the failing column, as
+        // the one-enqueue form and kvx_chol_factorize report it), not solve_dev's "singular matrix" for a factor found unusable.
+        // (Enqueue-only form: the status stays deferred to kvx_chol_status, which reports KVX_ENOTPOSDEF too.)
+        if (rc == KVX_ESINGULAR && !async && F->numeric && F->minor < S.n) { set_err("matrix is not positive definite"); return KVX_ENOTPOSDEF; }
+        return rc;
     }
     const int nr = (int)nrhs;
     static const bool dbg_t = getenv("KVX_DBG_T") != nullptr;
@@ -1311,6 +1317,15 @@ int kvx_current_device(void)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return -1; }
     if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return d;
+}
+
+int kvx_set_device(int dev)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); set_err("no HIP device visible"); return KVX_EDEVICE; }
+    if (dev < 0 || dev >= n) { set_err("kvx_set_device: no such device"); return KVX_EINVAL; }
+    HIPCHK(hipSetDevice(dev));
+    return KVX_OK;
 }
 
 void kvx_chol_default_opts(kvx_chol_opts *o)
@@ -1889,6 +1904,8 @@ int kvx_chol_last_timing(kvx_chol *F, double *ms_factor, double *ms_solve)
     if (ms_solve) *ms_solve = F->have_stime ? F->ms_solve : -1.0;
     return KVX_OK;
 }
+
+int kvx_chol_last_fused_path(kvx_chol *F) { return F ? F->last_fused_path : 0; }
 
 int kvx_chol_prof_select(kvx_chol *F, int family)
 {

@@ -856,3 +856,28 @@ def test_fused_first_diagonal_block_is_bitwise():
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
     assert all(v["max_front"] > 128 for v in outs[0].values())      # every system has big fronts (the path under test)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["no_graph", "torch_first"])
+def test_two_enqueue_form_reports_like_the_one_enqueue_form(mode):
+    """The fall-back of kvx_chol_factorize_solve* (factorisation and solve as two enqueues: KVX_NO_GRAPH=1, and every process that
+    imported torch first and therefore runs on the HIP runtime of the wheel, older than 7.2) gives bit for bit the answer of the
+    two calls and reports an indefinite matrix as the one-enqueue form and numeric() do: ArithmeticError(failing column),
+    cholmod.c:308-310 -- not solve's 'singular matrix' (round-3 advisor finding).  A process of its own: the runtime is chosen by
+    what a process loads first."""
+    import json, os, subprocess, sys
+    env = dict(os.environ)
+    env.pop("KVX_NO_GRAPH", None)
+    if mode == "no_graph":
+        env["KVX_NO_GRAPH"] = "1"
+    else:
+        pytest.importorskip("torch")
+        env["WITH_TORCH"] = "1"
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fused_path_child.py")
+    r = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert out["equal"]
+    assert out["paths"] == [2, 2, 2], out                   # the fall-back was taken (on the 7.2 runtime without KVX_NO_GRAPH: [1, 1, 1])
+    assert out["minor_fused"] == out["minor_numeric"] and out["minor_linsolve"] == out["minor_numeric"], out
