@@ -698,10 +698,13 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     row (standard form: KKTDiagEqDev, sparse K on a fixed pattern) or any other sparse G (KKTGenEqDev, dense K in HBM).  primalstart = {'x', 's'},
     dualstart = {'y', 'z'} (y optional) as in the reference (coneprog.py:683-737): s and z must be strictly positive.  Returns the reference's result dictionary (coneprog.py:962-974) with numpy arrays."""
     _lib.require_device()
-    opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False}
+    opts = {"maxiters": 100, "abstol": 1e-7, "reltol": 1e-6, "feastol": 1e-7, "show_progress": False, "refinement": 0}
     opts.update(options or {})
     MAXITERS, ABSTOL, RELTOL, FEASTOL = opts["maxiters"], opts["abstol"], opts["reltol"], opts["feastol"]
     show = opts["show_progress"]
+    REFINEMENT = opts["refinement"]                      # coneprog.py:502-507: default 0 when there are no 'q' / 's' cones
+    if not isinstance(REFINEMENT, (int, np.integer)) or REFINEMENT < 0:
+        raise ValueError("options['refinement'] must be a nonnegative integer")
     ml, n, Gp, Gi, Gx = base._as_ccs(G)
     if dims is not None and (dims.get("q") or dims.get("s") or dims.get("l", ml) != ml):
         raise NotImplementedError("only the orthant cone dims = {'l': G.size[0], 'q': [], 's': []} runs on the GPU")
@@ -780,7 +783,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             kkt.solve2(xa, za, xb, zb)
         def kfactor_solve2(dd, xa, ya, za, xb, yb, zb):
             kkt.factor_solve2(dd, xa, za, xb, zb)
-        fused = not _UNFUSED                             # p = 0: the short launches of an iteration fused (kkt.hip, "round 3")
+        fused = not _UNFUSED and REFINEMENT == 0         # p = 0: the short launches of an iteration fused (kkt.hip, "round 3")
         def Af(u, v, trans="N", alpha=1.0, beta=0.0):
             if trans == "T" and beta == 0.0:
                 v.fill(0.0)                                          # A' y with p = 0: the zero vector
@@ -796,6 +799,58 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     t_loop = [None]
     t_phase = [0.0, 0.0, 0.0]
     t_mark = [0.0]
+
+    if REFINEMENT:
+        # iterative refinement of the Newton systems (coneprog.py:599-631 res(), :1110-1195 f6_no_ir, :1211-1235 f6), operation by
+        # operation on the device vectors; scalars (tau, kappa blocks) travel in one-element lists.  For the orthant cone
+        # W = diag(d): scale(., W, inverse='I') multiplies by di, scale(., W, trans='T') by d.
+        wx, wx2 = DVec(n), DVec(n)
+        wy, wy2 = (DVec(p), DVec(p)) if p else (_NoY(), _NoY())
+        wz, ws, wz2, ws2, rs3, rz3 = (DVec(ml) for _ in range(6))
+
+        def f6_no_ir_g(sc, bx, by, bz, btau, bs, bkappa):
+            by.scal(-1.0)
+            bs.div(lmbda).scal(-1.0)                     # s := -lmbda o\ bs
+            rs3.copy_from(bs).mul(d)
+            bz.axpy(rs3).scal(-1.0)                      # z := -(bz + W' s)
+            ksolve(bx, by, bz)
+            bkappa[0] = -bkappa[0] / sc["lmbda_g"]
+            btau[0] += bkappa[0] / sc["dgi"]
+            btau[0] = sc["dgi"] * (btau[0] + cv.dot(bx) + bv.dot(by) + th.dot(bz)) / (1.0 + z1.dot(z1))
+            bx.axpy(x1, btau[0]); by.axpy(y1, btau[0]); bz.axpy(z1, btau[0])
+            bs.axpy(bz, -1.0)
+            bkappa[0] -= btau[0]
+
+        def res_g(sc, ux, uy, uz, utau, us, ukappa, vx, vy, vz, vtau, vs, vkappa):
+            dg_ = 1.0 / sc["dgi"]
+            Af(uy, vx, trans="T", alpha=-1.0, beta=1.0)
+            rz3.copy_from(uz).mul(di)                    # W^{-1} uz
+            Gd.gemv(rz3, vx, trans="T", alpha=-1.0, beta=1.0)
+            vx.axpy(cv, -utau[0] / dg_)
+            Af(ux, vy, trans="N", alpha=1.0, beta=1.0)
+            vy.axpy(bv, -utau[0] / dg_)
+            Gd.gemv(ux, vz, trans="N", alpha=1.0, beta=1.0)
+            vz.axpy(hv, -utau[0] / dg_)
+            rs3.copy_from(us).mul(d)
+            vz.axpy(rs3)
+            vtau[0] += dg_ * ukappa[0] + cv.dot(ux) + bv.dot(uy) + hv.dot(rz3)
+            rs3.copy_from(us).axpy(uz).mul(lmbda)
+            vs.axpy(rs3)
+            vkappa[0] += sc["lmbda_g"] * (utau[0] + ukappa[0])
+
+        def f6_g(sc, bx, by, bz, btau, bs, bkappa):
+            wx.copy_from(bx); wy.copy_from(by); wz.copy_from(bz); ws.copy_from(bs)
+            wtau, wkappa = [btau[0]], [bkappa[0]]
+            f6_no_ir_g(sc, bx, by, bz, btau, bs, bkappa)
+            for _ in range(REFINEMENT):
+                wx2.copy_from(wx); wy2.copy_from(wy); wz2.copy_from(wz); ws2.copy_from(ws)
+                wtau2, wkappa2 = [wtau[0]], [wkappa[0]]
+                res_g(sc, bx, by, bz, btau, bs, bkappa, wx2, wy2, wz2, wtau2, ws2, wkappa2)
+                f6_no_ir_g(sc, wx2, wy2, wz2, wtau2, ws2, wkappa2)
+                bx.axpy(wx2); by.axpy(wy2); bz.axpy(wz2)
+                btau[0] += wtau2[0]
+                bs.axpy(ws2)
+                bkappa[0] += wkappa2[0]
 
     def result(status, iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, xs=True, zs=True, msg=None):
         if show:                                         # the reference's closing line (coneprog.py:791,941,961,985,1010,1094)
@@ -968,6 +1023,12 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 # scaling of (x1, z1) by dgi, dx := (1 - sigma) rx
                 newton_rhs(0)
                 kkt.factor_solve_sides(di, [(cv, -1.0, hv, x1, dgi, z1, dgi), (rx, 1.0 - sigma, dz, dx, 1.0, dz, 1.0)])
+            elif REFINEMENT:
+                kkt.factor(di, sync=False)               # (the directions are solved one by one inside f6_g)
+                x1.lincomb(-1.0, cv)
+                y1.copy_from(bv)
+                z1.copy_from(hv)
+                ksolve(x1, y1, z1)
             elif kfactor_solve2 is not None:
                 # the factorisation and the two solves in one enqueue: their right-hand sides do not depend on the factor
                 x1.lincomb(-1.0, cv)
@@ -995,6 +1056,41 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         z1z1 = -1.0                                      # computed on the device with the first direction
         out4 = (ctypes.c_double * 4)()
         for i in (0, 1):
+            if REFINEMENT:
+                # the direction with iterative refinement (coneprog.py:1250-1333 around f6): right-hand side as the reference
+                # sets it up, then f6, the Mehrotra products, the scaling by lmbda and the step bounds, one operation at a time
+                sc = {"dgi": dgi, "lmbda_g": lmbda_g}
+                if i == 0:
+                    try:
+                        kkt.check()                      # (a failed factorisation must not be refined)
+                    except ArithmeticError:
+                        kkt.async_solves = False
+                        x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+                        return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres,
+                                      msg="Terminated (singular KKT matrix).")
+                ds.copy_from(lmbdasq)
+                dkap = [lmbdasq_g]
+                if i == 1:
+                    ds.axpy(ws3).addc(-sigma * mu)
+                    dkap[0] += wkappa3 - sigma * mu
+                dx.lincomb(1.0 - sigma, rx)
+                dy.lincomb(1.0 - sigma, ry)
+                dz.lincomb(1.0 - sigma, rz)
+                dta = [(1.0 - sigma) * rt]
+                f6_g(sc, dx, dy, dz, dta, ds, dkap)
+                dtau, dkappa = dta[0], dkap[0]
+                if i == 0:
+                    ws3.copy_from(ds).mul(dz)
+                    wkappa3 = dtau * dkappa
+                ds.div(lmbda); dz.div(lmbda)             # misc.scale2(lmbda, .) on the orthant
+                ts, tz = ds.max_step(), dz.max_step()
+                tt = -dtau / lmbda_g
+                tk = -dkappa / lmbda_g
+                t = max(0.0, ts, tz, tt, tk)
+                step = 1.0 if t == 0.0 else (min(1.0, 1.0 / t) if i == 0 else min(1.0, STEP / t))
+                if i == 0:
+                    sigma = (1.0 - step) ** EXPON
+                continue
             if i == 1:
                 newton_rhs(1)
                 if fused:
@@ -1090,7 +1186,7 @@ def _lower_ccs(P, n):
     return cp, Pi[keep].copy(), Px[keep].copy()
 
 
-def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=None):
+def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=None, kktsolver=None):
     """Solve the convex QP  minimize (1/2) x'Px + q'x  s.t.  Gx <= h, Ax = b  on the GPU (orthant cone): the reference's coneqp (coneprog.py:1440-2547) with its default KKT solver for sparse G,
     misc.kkt_chol2 with H = P.  P: spmatrix-like, its lower triangle is used.  Returns the reference's result
     dictionary (coneprog.py:2216-2221) with numpy arrays, plus "factorizations"."""
@@ -1116,9 +1212,22 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         b_h = np.asarray(b._a if isinstance(b, base.matrix) else b, dtype=np.float64).reshape(-1)
         if b_h.size != p:
             raise TypeError("'b' must have length %d" % p)
-    if p > 0:
+    if kktsolver is not None:
+        # the reference's plug-in point (coneprog.py:1969-1981): kktsolver(W) returns f(x, y, z) for the system with H = P; host
+        # round trips per factorisation and solve (KKTUserHost, as under conelp)
+        if not callable(kktsolver):
+            raise ValueError("kktsolver must be a function W -> f(x, y, z) (the reference's named solvers are not part of this path: "
+                             "'chol2' is what runs on the GPU by default)")
+        if p == 0:
+            Ap, Ai, Ax = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0)
+        kkt = KKTUserHost(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, kktsolver)
+    elif p > 0:
         kkt = _kkt_for("KKTGenEqDev+P", (ml, n, p), (Gp, Gi, Ap, Ai, Pp, Pi), chol_opts,
                        lambda: KKTGenEqDev(ml, n, Gp, Gi, Gx, p, Ap, Ai, Ax, chol_opts, Pp, Pi, Px), lambda k: k.reset(Gx, Ax, Px))
+    else:
+        kkt = _kkt_for("KKTChol2Dev+P", (ml, n, 0), (Gp, Gi, Pp, Pi), chol_opts,
+                       lambda: KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px), lambda k: k.reset(Gx, Px))
+    if p > 0:
         Ad = kkt.A
         bv = DVec(p, b_h)
         y, dy, ry = DVec(p), DVec(p), DVec(p)
@@ -1127,12 +1236,13 @@ def coneqp(P, q, G, h, options=None, chol_opts=None, A=None, b=None, initvals=No
         resy0 = max(1.0, bv.nrm2())
         ksolve = kkt.solve
     else:
-        kkt = _kkt_for("KKTChol2Dev+P", (ml, n, 0), (Gp, Gi, Pp, Pi), chol_opts,
-                       lambda: KKTChol2Dev(ml, n, Gp, Gi, Gx, chol_opts, Pp, Pi, Px), lambda k: k.reset(Gx, Px))
         y = dy = ry = wy = wy2 = None
         resy0 = 1.0
-        def ksolve(xx, yy, zz):
-            kkt.solve(xx, zz)
+        if kktsolver is not None:
+            ksolve = kkt.solve
+        else:
+            def ksolve(xx, yy, zz):
+                kkt.solve(xx, zz)
     Gd, Pd = kkt.G, SymSpMatDev(n, Pp, Pi, Px)
     qv, hv = DVec(n, q_h), DVec(ml, h_h)
     x, dx, rx, tmpx = (DVec(n) for _ in range(4))

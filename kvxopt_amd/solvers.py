@@ -7,9 +7,9 @@
     options                                                                          the module-level dict of the reference
 
 Like the reference, algorithm parameters come from `solvers.options` ('maxiters', 'abstol', 'reltol', 'feastol',
-'refinement', 'show_progress'); a keyword `options=` overrides it per call.  `conelp(..., kktsolver=f)` / `lp(..., kktsolver=f)`
-take the reference's plug-in, a function `W -> g(x, y, z)` (coneprog.py:323-344; host round trips per factorisation and
-solve, lp.KKTUserHost); the named solvers ('ldl', 'ldl2', 'qr', 'chol', 'chol2') and `solver=` (external codes) are not part of
+'refinement', 'show_progress'); a keyword `options=` overrides it per call.  `conelp / lp / coneqp / qp (..., kktsolver=f)`
+take the reference's plug-in, a function `W -> g(x, y, z)` (coneprog.py:323-344, 1969-1981; host round trips per factorisation
+and solve, lp.KKTUserHost); the named solvers ('ldl', 'ldl2', 'qr', 'chol', 'chol2') and `solver=` (external codes) are not part of
 this path and raise.
 """
 from . import lp as _lp
@@ -42,11 +42,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
 
 
 def coneqp(P, q, G, h, dims=None, A=None, b=None, initvals=None, **kw):
-    if kw.pop("kktsolver", None) is not None:
-        raise NotImplementedError("kvxopt_amd.solvers.coneqp runs misc.kkt_chol2 on the GPU; 'kktsolver' is taken by conelp / lp only")
+    k = _kkt(kw)
     if dims is not None and (dims.get("q") or dims.get("s")):
         raise NotImplementedError("only the orthant cone runs on the GPU")
-    return _lp.coneqp(P, q, G, h, _opts(kw), None, A=A, b=b, initvals=initvals)
+    return _lp.coneqp(P, q, G, h, _opts(kw), None, A=A, b=b, initvals=initvals, kktsolver=k)
 
 
 def lp(c, G, h, A=None, b=None, primalstart=None, dualstart=None, **kw):

@@ -754,6 +754,81 @@ def g13_gemv_subblocks():
     out["cases"] = np.array(json.dumps(cases))
     np.savez(os.path.join(HERE, "g13_gemv_subblocks.npz"), **out)
 
+def g17_conelp_refinement():
+    """conelp with options['refinement'] = 1, 2 (coneprog.py:502-507 default 0 for an LP; :599-631 res(), :1211-1235 the
+    refinement wrap of f6): pure reference, dense-G LAPACK branch.  An ill-scaled variant (rows of G scaled over six decades)
+    makes the refinement steps change the iterates visibly."""
+    from kvxopt import matrix, solvers, spmatrix
+    from kvxopt_amd import workloads
+    solvers.options["show_progress"] = False
+    out, meta = {}, {}
+    L = workloads.lp_grid(6, 5)
+    E = workloads.lp_grid_eq(6, 5, 4)
+    rng = np.random.default_rng(17)
+    sc = 10.0 ** rng.uniform(-3, 3, L["ml"])
+    cases = [("grid6x5", L, None), ("grid6x5_scaled", L, sc), ("eq6x5p4", E, None)]
+    for name, P, rs in cases:
+        ml, n = P["ml"], P["n"]
+        cols = np.repeat(np.arange(n), np.diff(P["Gp"]))
+        gx = P["Gx"] * (rs[P["Gi"]] if rs is not None else 1.0)
+        hh = P["h"] * (rs if rs is not None else 1.0)
+        G = matrix(spmatrix(gx.tolist(), P["Gi"].tolist(), cols.tolist(), (ml, n)))
+        kw = {}
+        if "Ap" in P:
+            acols = np.repeat(np.arange(n), np.diff(P["Ap"]))
+            kw = {"A": matrix(spmatrix(P["Ax"].tolist(), P["Ai"].tolist(), acols.tolist(), (P["p"], n))), "b": matrix(P["b"])}
+        if rs is not None:
+            out[name + "_rowscale"] = rs
+        for ref in (0, 1, 2):
+            solvers.options["refinement"] = ref
+            sol = solvers.conelp(matrix(P["c"]), G, matrix(hh), kktsolver="chol2", **kw)
+            key = "%s_r%d" % (name, ref)
+            for k in "xsz":
+                out[key + "_" + k] = tolist(sol[k])
+            meta[key] = {k: sol[k] for k in ("status", "iterations", "gap", "relative gap", "primal objective", "dual objective",
+                                             "primal infeasibility", "dual infeasibility")}
+    del solvers.options["refinement"]
+    np.savez_compressed(os.path.join(HERE, "g17_conelp_refinement.npz"), **out)
+    json.dump({"via": "reference (dense LAPACK branch of misc.kkt_chol2), options['refinement'] = 0, 1, 2", "cases": meta},
+              open(os.path.join(HERE, "g17_conelp_refinement.json"), "w"), indent=1, default=float)
+
+
+def g18_nt_scaling_long():
+    """The NT-scaling 'l' operations at the vector length of BASELINE configs[3] (ml = 200 000): inputs are regenerated from the
+    seed by the test; of every output the fixture keeps each 997th entry, the sum and the 2-norm."""
+    from kvxopt import matrix, misc, misc_solvers
+    ml = 200000
+    rng = np.random.default_rng(100 + ml)
+    s = rng.uniform(0.1, 3.0, ml); z = rng.uniform(0.1, 3.0, ml)
+    dims = {"l": ml, "q": [], "s": []}
+    lm = matrix(0.0, (ml, 1))
+    W = misc.compute_scaling(matrix(s), matrix(z), lm, dims)
+    full = {"d": tolist(W["d"]), "di": tolist(W["di"]), "lmbda": tolist(lm)}
+    X = rng.standard_normal((ml, 2))
+    for tr in "NT":
+        for inv in "NI":
+            x = matrix(X.copy(order="F"))
+            misc_solvers.scale(x, W, trans=tr, inverse=inv)
+            full["scale_%s%s" % (tr, inv)] = np.array(x).reshape(-1, order="F")
+    x1 = rng.standard_normal(ml); y1 = rng.uniform(0.5, 2.0, ml)
+    for name, fn in (("scale2_N", lambda a: misc_solvers.scale2(lm, a, dims)),
+                     ("scale2_I", lambda a: misc_solvers.scale2(lm, a, dims, inverse="I")),
+                     ("sprod", lambda a: misc_solvers.sprod(a, matrix(y1), dims)),
+                     ("sinv", lambda a: misc_solvers.sinv(a, matrix(y1), dims))):
+        a = matrix(x1.copy()); fn(a); full[name] = tolist(a)
+    a = matrix(0.0, (ml, 1)); misc.ssqr(a, matrix(x1), dims); full["ssqr"] = tolist(a)
+    ds = rng.uniform(0.2, 2.0, ml); dz = rng.uniform(0.2, 2.0, ml)
+    W2 = {"d": matrix(tolist(W["d"])), "di": matrix(tolist(W["di"])), "v": [], "beta": [], "r": [], "rti": []}
+    lm2 = matrix(tolist(lm)); ms, mz = matrix(ds.copy()), matrix(dz.copy())
+    misc.update_scaling(W2, lm2, ms, mz)
+    full.update({"us_s": tolist(ms), "us_z": tolist(mz), "us_d": tolist(W2["d"]), "us_di": tolist(W2["di"]), "us_lmbda": tolist(lm2)})
+    out = {"ml": np.array(ml), "seed": np.array(100 + ml), "stride": np.array(997),
+           "sdot": np.array(misc_solvers.sdot(matrix(x1), matrix(y1), dims)), "max_step": np.array(misc_solvers.max_step(matrix(x1), dims))}
+    for k, v in full.items():
+        v = np.asarray(v, dtype=float).reshape(-1)
+        out[k + "_sample"] = v[::997].copy(); out[k + "_sum"] = np.array(v.sum()); out[k + "_nrm2"] = np.array(np.linalg.norm(v))
+    np.savez_compressed(os.path.join(HERE, "g18_nt_scaling_long.npz"), **out)
+
 
 if __name__ == "__main__":
     stage()
@@ -779,4 +854,6 @@ if __name__ == "__main__":
     g14_kkt_singular()
     g15_q_cone_scaling()
     g16_s_cone_scaling()
+    g17_conelp_refinement()
+    g18_nt_scaling_long()
     print("goldens written to", HERE)

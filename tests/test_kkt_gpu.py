@@ -1251,3 +1251,131 @@ def test_conelp_with_a_user_kktsolver(with_eq):
         assert rel(s2[k], ref[k]) < 1e-7, k
     with pytest.raises(NotImplementedError):
         solvers.conelp(L["c"], G, L["h"], kktsolver="ldl", options={"show_progress": False}, **kw)
+
+
+def test_nt_scaling_at_the_vector_length_of_config_4(golden_dir):
+    """G18: the NT-scaling 'l' operations of the reference at ml = 200 000 (BASELINE configs[3]): inputs regenerated from the
+    fixture's seed in the generator's order; every 997th entry, the sum and the 2-norm of every output."""
+    g = np.load(os.path.join(golden_dir, "g18_nt_scaling_long.npz"))
+    ml, st = int(g["ml"]), int(g["stride"])
+    rng = np.random.default_rng(int(g["seed"]))
+    s = rng.uniform(0.1, 3.0, ml); z = rng.uniform(0.1, 3.0, ml)
+    dims = {"l": ml, "q": [], "s": []}
+
+    def check(name, got, tol=1e-14):
+        got = np.asarray(got, dtype=float).reshape(-1, order="F")
+        assert rel(got[::st], g[name + "_sample"]) < tol, name
+        assert abs(got.sum() - float(g[name + "_sum"])) <= 1e-11 * max(1.0, np.abs(got).sum()), name
+        assert abs(np.linalg.norm(got) - float(g[name + "_nrm2"])) <= 1e-12 * float(g[name + "_nrm2"]), name
+    lm = matrix(0.0, (ml, 1))
+    W = misc.compute_scaling(matrix(s), matrix(z), lm, dims)
+    check("d", W["d"]._a); check("di", W["di"]._a); check("lmbda", lm._a)
+    X = rng.standard_normal((ml, 2))
+    for tr in "NT":
+        for inv in "NI":
+            x = matrix(X.copy(order="F"))
+            misc.scale(x, W, trans=tr, inverse=inv)
+            check("scale_%s%s" % (tr, inv), x.a)
+    x1 = rng.standard_normal(ml); y1 = rng.uniform(0.5, 2.0, ml)
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims); check("scale2_N", a._a)
+    a = matrix(x1.copy()); misc.scale2(lm, a, dims, inverse="I"); check("scale2_I", a._a)
+    a = matrix(x1.copy()); misc.sprod(a, matrix(y1), dims); check("sprod", a._a)
+    a = matrix(x1.copy()); misc.sinv(a, matrix(y1), dims); check("sinv", a._a)
+    a = matrix(0.0, (ml, 1)); misc.ssqr(a, matrix(x1), dims); check("ssqr", a._a)
+    assert abs(misc.sdot(matrix(x1), matrix(y1), dims) - float(g["sdot"])) <= 1e-11 * max(1.0, abs(float(g["sdot"])))
+    assert misc.max_step(matrix(x1), dims) == float(g["max_step"])
+    ds = rng.uniform(0.2, 2.0, ml); dz = rng.uniform(0.2, 2.0, ml)
+    W2 = W_of(W["d"]._a.copy(), W["di"]._a.copy())
+    lm2, ms, mz = matrix(lm._a.copy()), matrix(ds.copy()), matrix(dz.copy())
+    misc.update_scaling(W2, lm2, ms, mz)
+    for got, name in ((ms, "us_s"), (mz, "us_z"), (W2["d"], "us_d"), (W2["di"], "us_di"), (lm2, "us_lmbda")):
+        check(name, got._a)
+
+
+@pytest.mark.parametrize("name", ["grid6x5", "grid6x5_scaled", "eq6x5p4"])
+@pytest.mark.parametrize("refinement", [0, 1, 2])
+def test_conelp_refinement_golden(golden_dir, name, refinement):
+    """G17: conelp with options['refinement'] (coneprog.py:502-507, 599-631, 1211-1235; pure reference, dense-G branch): same
+    status, iteration count and solution.  The row-scaled case (rows of G over six decades) takes 32 iterations."""
+    g = np.load(os.path.join(golden_dir, "g17_conelp_refinement.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "g17_conelp_refinement.json")))["cases"]["%s_r%d" % (name, refinement)]
+    P = workloads.lp_grid_eq(6, 5, 4) if name.startswith("eq") else workloads.lp_grid(6, 5)
+    gx, hh = P["Gx"], P["h"]
+    if name.endswith("scaled"):
+        rs = g[name + "_rowscale"]
+        gx, hh = gx * rs[P["Gi"]], hh * rs
+    G = spmatrix.from_ccs(P["ml"], P["n"], P["Gp"], P["Gi"], gx)
+    kw = {"A": spmatrix.from_ccs(P["p"], P["n"], P["Ap"], P["Ai"], P["Ax"]), "b": P["b"]} if "Ap" in P else {}
+    sol = lp.conelp(P["c"], G, hh, options={"refinement": refinement}, **kw)
+    assert sol["status"] == meta["status"] == "optimal"
+    assert sol["iterations"] == meta["iterations"]
+    key = "%s_r%d_" % (name, refinement)
+    tol = 1e-5 if name.endswith("scaled") else 1e-6
+    for k in "xsz":
+        assert rel(sol[k], g[key + k]) < tol, k
+    assert abs(sol["primal objective"] - meta["primal objective"]) < 1e-7 * max(1.0, abs(meta["primal objective"]))
+    with pytest.raises(ValueError):
+        lp.conelp(P["c"], G, hh, options={"refinement": -1}, **kw)
+
+
+@pytest.mark.parametrize("with_eq", [False, True])
+def test_refinement_and_coneqp_through_a_user_kktsolver(with_eq):
+    """(1) conelp with refinement r solves 1 + 2 (1 + r) systems per iteration (one for the constant part, 1 + r per direction,
+    coneprog.py:1211-1235) -- counted through the reference's plug-in point; (2) coneqp / qp take the plug-in too
+    (coneprog.py:1969-1981: f solves the system with H = P): same iterates as the default path, 1 factorisation and 2 solves
+    per iteration (coneprog.py:2357-2423) after the starting point's one."""
+    from kvxopt_amd import solvers
+    L = workloads.lp_grid_eq(7, 6, 4) if with_eq else workloads.lp_grid(7, 6)
+    Q = workloads.qp_grid(7, 6)
+    ml, n = L["ml"], L["n"]
+    G = spmatrix.from_ccs(ml, n, L["Gp"], L["Gi"], L["Gx"])
+    Gd = np.zeros((ml, n)); Gd[L["Gi"], np.repeat(np.arange(n), np.diff(L["Gp"]))] = L["Gx"]
+    p, Ad, kw = 0, np.zeros((0, n)), {}
+    if with_eq:
+        p = L["p"]
+        kw = {"A": spmatrix.from_ccs(p, n, L["Ap"], L["Ai"], L["Ax"]), "b": L["b"]}
+        Ad = np.zeros((p, n)); Ad[L["Ai"], np.repeat(np.arange(n), np.diff(L["Ap"]))] = L["Ax"]
+    Pd = np.zeros((n, n)); Pd[Q["Pi"], np.repeat(np.arange(n), np.diff(Q["Pp"]))] = Q["Px"]
+    Pd = Pd + Pd.T - np.diag(np.diag(Pd))
+    calls = {"factor": 0, "solve": 0}
+
+    def dense_kkt(H):
+        def factory(W):
+            d = np.asarray(W["d"]._a)
+            K = np.zeros((n + p + ml, n + p + ml))
+            K[:n, :n] = H
+            K[:n, n:n + p] = Ad.T; K[:n, n + p:] = Gd.T
+            K[n:n + p, :n] = Ad; K[n + p:, :n] = Gd
+            K[n + p:, n + p:] = -np.diag(d * d)
+            Ki = np.linalg.inv(K)
+            calls["factor"] += 1
+
+            def f(x, y, z):
+                calls["solve"] += 1
+                u = Ki @ np.concatenate([x._a, y._a, z._a])
+                x._a[:] = u[:n]
+                y._a[:] = u[n:n + p]
+                z._a[:] = d * u[n + p:]
+            return f
+        return factory
+
+    quiet = {"show_progress": False}
+    for r in (0, 1, 2):
+        ref = solvers.conelp(L["c"], G, L["h"], options=dict(quiet, refinement=r), **kw)
+        calls.update(factor=0, solve=0)
+        s1 = solvers.conelp(L["c"], G, L["h"], options=dict(quiet, refinement=r), kktsolver=dense_kkt(np.zeros((n, n))), **kw)
+        assert s1["status"] == ref["status"] == "optimal" and s1["iterations"] == ref["iterations"]
+        assert calls["factor"] == s1["iterations"] + 1
+        assert calls["solve"] == 2 + s1["iterations"] * (1 + 2 * (1 + r)), (r, calls)
+        for k in ("x", "s", "z"):
+            assert rel(s1[k], ref[k]) < 1e-6, (r, k)
+    Pm = spmatrix.from_ccs(n, n, Q["Pp"], Q["Pi"], Q["Px"])
+    ref = solvers.coneqp(Pm, Q["q"], G, L["h"], options=quiet, **kw)
+    calls.update(factor=0, solve=0)
+    s2 = solvers.qp(Pm, Q["q"], G, L["h"], options=quiet, kktsolver=dense_kkt(Pd), **kw)
+    assert s2["status"] == ref["status"] == "optimal" and s2["iterations"] == ref["iterations"]
+    assert calls["factor"] == s2["iterations"] + 1 and calls["solve"] == 1 + 2 * s2["iterations"], calls
+    for k in ("x", "s", "z"):
+        assert rel(s2[k], ref[k]) < 1e-6, k
+    with pytest.raises(NotImplementedError):
+        solvers.coneqp(Pm, Q["q"], G, L["h"], options=quiet, kktsolver="ldl", **kw)
