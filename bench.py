@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--nrhs", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
+    ap.add_argument("--no-klu", action="store_true", help="skip the klu leg (BASELINE configs[2]: ACTIVSg2000 and the 600 x 600 convection-diffusion matrix)")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` systems (21-point stencil, 100^3 cube)")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the time-to-first-solution leg")
     ap.add_argument("--separate-calls", action="store_true", help="the step as two calls (factorize, then solve) instead of the one-enqueue "
@@ -186,11 +187,32 @@ def front_stats(F):
             "n_small": int(small.sum()), "n_big": int((~small).sum())}
 
 
-def host_cores():
+def cgroup_cpu_quota():
+    """CPUs' worth of time the process's cgroup may use (cgroup v2 cpu.max, v1 cfs quota), None when unlimited / unknown."""
     try:
-        return len(os.sched_getaffinity(0))
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
     except Exception:
-        return os.cpu_count() or 1
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def host_cores():
+    """Cores this process can keep busy: its affinity mask, capped by the cgroup's CPU quota (a GPU box hands one GPU's share of
+    the node's cores to a job as a quota, not as a mask: 32 threads on a 16-CPU quota lose to 16 -- round 3's by_threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    q = cgroup_cpu_quota()
+    if q is not None:
+        n = max(1, min(n, int(q + 0.5)))
+    return n
 
 
 def host_threads(args):
@@ -215,7 +237,7 @@ def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu,
     (the parity checker).  lite: (1) only, one repetition per thread count (the `extra` systems)."""
     import ctypes.util
     B = np.asfortranarray(b_host.reshape(n, nrhs, order="F").copy())
-    out = {"cholmod_found": bool(ctypes.util.find_library("cholmod")), "os_cpu_count": os.cpu_count(), "cores_available": host_cores(),
+    out = {"cholmod_found": bool(ctypes.util.find_library("cholmod")), "os_cpu_count": os.cpu_count(), "cores_available": host_cores(), "cgroup_cpu_quota": cgroup_cpu_quota(),
            "env_threads": {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS") if os.environ.get(k)}}
     others = {}
     runs = []
@@ -224,7 +246,7 @@ def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu,
         for cores in host_threads(args):
             S = OracleSupernodal.from_factor(n, colptr, rowind, F, threads=cores)
             best = None
-            for _ in range(1 if lite else 3):               # first pass pays page faults and thread start-up: best of three
+            for _ in range(2 if lite else 3):               # first pass pays page faults and thread start-up: best of three (two on the `extra` systems)
                 xb = B.copy(order="F")
                 t0 = time.perf_counter(); S.factorize(values); t1 = time.perf_counter(); S.solve(xb); t2 = time.perf_counter()
                 if best is None or t2 - t0 < best[0]:
@@ -237,7 +259,7 @@ def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu,
                     "library": "host supernodal multifrontal restatement (oracle/kvx_supernodal.c): OpenMP over elimination-tree subtrees, "
                                "OpenBLAS dpotrf/dtrsm/dsyrk inside the fronts (the OpenBLAS that ships in scipy)",
                     "sample": "same system, permutation and supernodes as the GPU run: numeric factorisation %.3f s + solve %.3f s on %d threads, best of %d"
-                              % (top["factor_s"], top["solve_s"], top["cores"], 1 if lite else 3),
+                              % (top["factor_s"], top["solve_s"], top["cores"], 2 if lite else 3),
                     "max_rel_diff_vs_gpu": top["max_rel_diff_vs_gpu"], "by_threads": runs})
     except Exception as e:
         out["supernodal_error"] = repr(e)
@@ -285,6 +307,9 @@ def cpu_baselines(args, F, n, colptr, rowind, values, b_host, nrhs, work, x_gpu,
             out.update({k: bestv[k] for k in ("value", "unit", "cores", "kind", "library")})
             out["sample"] = "same system and permutation, 1 numeric factorisation + 1 solve"
     return out
+
+
+IPM_PMC_FILE = "r04_ipm_pmc.json"
 
 
 def ipm_leg(args, pl):
@@ -337,12 +362,58 @@ def ipm_leg(args, pl):
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": reps,
                        "note": "back-to-back launches: time per launch includes the launch gap; the loop itself is bound by the factor/solve latency chains"}
-    L.kvx_atda_free(h)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_ipm_pmc.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", IPM_PMC_FILE)))
         ipm["roofline"]["traffic"] = pm.get("k_atda_bytes_per_launch")
     except Exception:
         pass
+    # The family that DOMINATES an iteration is not the assembly (0.3 % of the GPU time) but the factorisation of S and its
+    # solves: the same per-family timing as the headline's roofline leg, on S itself (pattern of G'G from the plan, values of the
+    # assembly above), one factorisation + a two-column solve per step as an iteration's first direction does.
+    ipm["roofline_assembly"] = ipm["roofline"]
+    try:
+        from kvxopt_amd.chol import Factor
+        Sp = np.zeros(nl + 1, dtype=np.int64); Si = np.zeros(max(snz.value, 1), dtype=np.int64)
+        _lib.raise_for(L.kvx_atda_pattern(h, ctypes.byref(snz), _lib.pi(Sp), _lib.pi(Si)))
+        FS = Factor(nl, Sp, Si[:snz.value], "L", None, None)
+        rhs = pl.to_dev(np.random.default_rng(1).standard_normal(2 * nl))
+        xs = pl.empty(2 * nl)
+
+        def step_s():
+            pl.copy(xs, rhs, 2 * nl)
+            FS.factorize_solve_dev(pl.ptr(sx), pl.ptr(xs), 2, nl)
+        for _ in range(4):
+            step_s()
+        stS = front_stats(FS)
+        famS = {}
+        for fam in Factor.FAMILIES:
+            smp = []
+            for _ in range(3):
+                FS.prof_select(fam); step_s(); smp.append(FS.prof_read())
+            smp.sort(key=lambda t: t[0])
+            famS[fam] = smp[1]
+        FS.prof_select(None)
+        dom = max(famS, key=lambda f: famS[f][0])
+        dom_ms, dom_l = famS[dom]
+        if dom == "syrk_trailing":
+            ach = stS["flops_syrk"] / (dom_ms * 1e-3) / 1e12
+            rf = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF}
+        else:
+            ab = stS["bytes_small"] if dom == "front_small" else ((8.0 * stS["lsize"] + 4.0 * stS["sum_m"] + 16.0 * nl) * 2 if dom in ("fwd_level", "bwd_level")
+                                                                   else 8.0 * stS["lsize"])
+            ach = ab / (dom_ms * 1e-3) / 1e9
+            rf = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                  "algorithmic_bytes_per_step": ab}
+        rf.update({"traffic": None, "ms_per_step": dom_ms, "launches_per_step": dom_l,
+                   "family_ms_per_step": {f: round(v[0], 4) for f, v in famS.items()},
+                   "what": "dominant kernel family of the factorisation of S (order %d, nnz(L) %d, %d fronts in %d levels) + two-column solve that "
+                           "an iteration's first direction enqueues; HIP events around every launch of the family, graphs off for these passes"
+                           % (nl, int(FS.info()["lnz"]), int(FS.info()["nsuper"]), int(FS.info()["nlevels"]))})
+        ipm["roofline"] = rf
+        del FS
+    except Exception as e:
+        ipm["roofline_dominant_error"] = repr(e)
+    L.kvx_atda_free(h)
     # CPU run of the same loop (oracle/lp_oracle.py: coneprog.py:859-1436 restated over the host supernodal Cholesky)
     if not args.no_cpu_baseline:
         try:
@@ -620,6 +691,47 @@ def public(res):
     return {k: v for k, v in res.items() if not k.startswith("_")}
 
 
+def klu_leg(args):
+    """BASELINE configs[2]: kvxopt.klu on ACTIVSg2000 (refactor + solve on the GPU, klu.linsolve with host buffers, SciPy SuperLU
+    beside it) and the blocked path on a 600 x 600 convection-diffusion matrix, each with the roofline of a refactorisation:
+    algorithmic bytes 8 (panel entries + 2 update entries) + 12 nnz(A) (kvx_lu_num_work) for the latency-bound small case, flops
+    against the FP64 MFMA peak for the blocked one."""
+    import bench_extra
+    from kvxopt_amd import klu as kvx_klu
+    from kvxopt_amd.base import spmatrix
+    out = {}
+    r = bench_extra.klu_case(20, 5)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ACTIVSg2000.npz"))
+    A = spmatrix.from_ccs(int(z["n"]), int(z["n"]), z["colptr"], z["rowind"], z["values"])
+    Fn = kvx_klu.numeric(A, kvx_klu.symbolic(A))
+    w = Fn.num.work()
+    ab = 8.0 * (w["panel_entries"] + 2.0 * w["update_entries"]) + 12.0 * r["nnz"]
+    ach = ab / (r["ms_refactor_dev"] * 1e-3) / 1e9
+    r["roofline"] = {"kernel": "LU refactorisation, all launches (k_lu_* one-workgroup fronts: %d of %d fronts blocked)" % (int(w["blocked_fronts"]), r["lu_nfront"]),
+                     "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes": ab, "flops": w["flops"], "ms": r["ms_refactor_dev"],
+                     "note": "%d fronts in %d dependent levels: latency-bound, as the number says" % (r["lu_nfront"], r["lu_nlevels"])}
+    out["activsg2000"] = r
+    try:
+        g = 600
+        r2 = bench_extra.lu2d_case(g, 5)
+        from kvxopt_amd import workloads
+        n2, cp2, ri2, v2 = workloads.convdiff_2d(g)
+        A2 = spmatrix.from_ccs(n2, n2, cp2, ri2, v2)
+        F2 = kvx_klu.numeric(A2, kvx_klu.symbolic(A2))
+        w2 = F2.num.work()
+        ach2 = w2["flops"] / (r2["ms_refactor_dev"] * 1e-3) / 1e12
+        r2["roofline"] = {"kernel": "LU refactorisation, all launches (k_lub_* blocked fronts carry %.0f %% of the flops)" % (100.0 * w2["blocked_flops"] / max(w2["flops"], 1.0)),
+                          "bound": "mfma", "achieved": ach2, "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach2 / FP64_MFMA_PEAK_TF,
+                          "traffic": None, "flops": w2["flops"], "ms": r2["ms_refactor_dev"],
+                          "algorithmic_bytes": 8.0 * (w2["panel_entries"] + 2.0 * w2["update_entries"]) + 12.0 * r2["nnz"]}
+        del F2
+        out["convdiff600"] = r2
+    except Exception as e:
+        out["convdiff600"] = {"error": repr(e)}
+    return out
+
+
 def one_shot_leg(args, wl):
     """Time to first solution on a NEW pattern with HOST buffers -- what one cholmod.linsolve call costs (cholmod.c:618-753:
     analysis + upload + numeric factorisation + solve + download) -- next to SciPy's splu (ordering + factorisation + solve) on
@@ -759,6 +871,12 @@ def main():
     # (inequality form), rank 0 only, a few hundred ms; never part of `value`
     ipm = None
     one_shot = None
+    klu = None
+    if rank == 0 and world == 1 and not args.no_klu and headline_cfg2:
+        try:
+            klu = klu_leg(args)
+        except Exception as e:
+            klu = {"error": repr(e)}
     if rank == 0 and world == 1:
         if not args.no_ipm:
             try:
@@ -796,7 +914,7 @@ def main():
             "ms_factor": res["ms_factor"], "ms_solve": res["ms_solve"], "as_two_calls": res.get("as_two_calls"), "step_form": res["step_form"],
             "rel_residual": res["rel_residual"],
             "roofline": res["roofline"], "cpu_baseline": cpu, "ranks": ranks, "sharding": res.get("sharding"),
-            "extra": extra, "ipm": ipm, "one_shot": one_shot,
+            "extra": extra, "ipm": ipm, "klu": klu, "one_shot": one_shot,
         }
         print(json.dumps(out))
         sys.stdout.flush()

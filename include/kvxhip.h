@@ -469,6 +469,12 @@ int kvx_lu_refactor_dev(kvx_lu_num *N, int64_t nnz, const double *values_dev);
 void kvx_lu_free_numeric(kvx_lu_num *N);
 /* info: fronts, levels, largest front order, largest pivot block, panel doubles, arena doubles, numeric passes, factored */
 int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8]);
+/* Work of one numeric factorisation of the plan (bench.py roofline of the LU path): work[0] = flops (2 per multiply-add: pivot
+ * block, the two panels and the rank-k update of every front), [1] = sum over fronts of the L and U panel entries 2 m k - k^2,
+ * [2] = sum over fronts of u^2 (update matrices written once and read once by the parent), [3] = fronts with m > the
+ * one-workgroup limit (blocked path), [4] = their share of the flops.  Algorithmic bytes of a factorisation:
+ * 8 (work[1] + 2 work[2]) + 12 nnz(A). */
+int kvx_lu_num_work(kvx_lu_num *N, double work[5]);
 
 /* solve(A, Fs, Fn, B, trans) -- klu.c:593-690 (klu_solve / klu_tsolve :651-665).  trans: 0 = 'N', 1 = 'T'.
  * B is n x nrhs column-major with leading dimension ldB >= max(1, n), overwritten by the solution. */

@@ -602,10 +602,10 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                 const bool have_lists = (size_t)l < F->chain_steps.size() && (int)F->chain_steps[(size_t)l].size() * KVX_NB >= P.chain_maxk &&
                                         (int)F->u_steps[(size_t)l].size() * F->u_block >= P.chain_maxk;
                 // ... where a level's chain is bound by throughput: its flops per panel step would keep the machine busy for longer
-                // than the ~30 us of latency a step has anyway (KVX_BLOCKED_GF: Gflop per step from which on, default 0.25.  21-point
+                // than the ~30 us of latency a step has anyway (KVX_BLOCKED_GF: Gflop per step from which on, default 0.5.  21-point
                 // system, one box, thresholds 0 / 0.3 / 0.7 / 1.5 / never: 23.6 / 23.8 / 23.9 / 24.4 / 26.3 ms; config 2, where no level
                 // reaches 0.3: blocked everywhere 4.97 - 5.45 ms against 4.76 - 4.97)
-                static const double blocked_gf = [] { const char *e = getenv("KVX_BLOCKED_GF"); return e ? atof(e) : 0.25; }();
+                static const double blocked_gf = [] { const char *e = getenv("KVX_BLOCKED_GF"); return e ? atof(e) : 0.5; }();
                 const int nsteps = (P.chain_maxk + KVX_NB - 1) / KVX_NB;
                 const bool blocked = defer_u && !direct && have_lists && P.big_flops * 1e-9 >= blocked_gf * nsteps;
                 const bool cls = !direct && have_lists;
@@ -636,7 +636,9 @@ int enqueue_factor_body(kvx_chol *F, int lfrom, int lto, bool prologue, bool epi
                     // KVX_DEFER_U=0: the round-3 schedule; KVX_U_STREAM=0: the far updates on the chain's stream.
                     static const int u_stream = [] { const char *e = getenv("KVX_U_STREAM"); return e ? atoi(e) : 1; }();
                     const int OB = F->u_block;
-                    hipStream_t su = u_stream ? F->side[2] : st;
+                    // (family timing sums the durations of single launches: the far updates stay behind the chain then, so that a launch's
+                    //  duration is its own and not that of two kernels sharing the machine)
+                    hipStream_t su = (u_stream && F->prof_family < 0) ? F->side[2] : st;
                     bool forked = false;
                     for (int ob = 0, b = 0; ob < P.chain_maxk; ob += OB, b++) {
                         const int bend = std::min(ob + OB, P.chain_maxk);

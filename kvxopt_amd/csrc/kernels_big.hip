@@ -520,6 +520,45 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
     hipLaunchKernelGGL(k_trsm_blk, grid, dim3(256), 0, st, ds, list, jb, Lx, Linv);
 }
 
+// Numbering of the workgroups of a trailing-update launch over size classes of fronts (TileClasses, device.hpp; the host side
+// is make_tile_classes below): workgroup id -> front index in the launch's list and tile (ti, tj).  false: nothing to do.
+__device__ __forceinline__ void tri_inv(unsigned L, int &ti, int &tj)
+{
+    unsigned si = (unsigned)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
+    while ((si + 1) * (si + 2) / 2 <= L) si++;
+    while (si * (si + 1) / 2 > L) si--;
+    ti = (int)si;
+    tj = (int)(L - si * (si + 1) / 2);
+}
+__device__ __forceinline__ bool cls_decode(const TileClasses &tc, const unsigned wgid, int &fi, int &ti, int &tj)
+{
+    int c = 0;
+    while (c + 1 < tc.ncls && wgid >= tc.wg[c + 1]) c++;                   // (uniform)
+    const unsigned local = wgid - tc.wg[c];
+    const int T = tc.T[c], TC = tc.TC[c];
+    if (TC > 0) {                                      // a few tile columns of T tile rows (column-limited launches)
+        const unsigned tpf = (unsigned)T * (unsigned)TC;
+        const unsigned t = local % tpf;
+        fi = tc.first[c] + (int)(local / tpf);
+        ti = (int)(t % (unsigned)T);
+        tj = (int)(t / (unsigned)T);
+    } else {
+        const unsigned tri = (unsigned)T * (unsigned)(T + 1) / 2;
+        if (T >= 16) {
+            const unsigned chunk = (tri + 7) / 8, tpf = 8 * chunk;
+            const unsigned t = local % tpf;
+            fi = tc.first[c] + (int)(local / tpf);
+            const unsigned L = (t & 7u) * chunk + (t >> 3);
+            if (L >= tri) return false;
+            tri_inv(L, ti, tj);
+        } else {
+            fi = tc.first[c] + (int)(local / tri);
+            tri_inv(local % tri, ti, tj);
+        }
+    }
+    return tj <= ti && fi < tc.first[tc.ncls];         // (ids in the padding in front of an XCD-numbered class)
+}
+
 // ------------------------------------------------------------------------------------------
 // Trailing update C -= X X' on 64x64 tiles (FP64 MFMA).  The trailing matrix spans the rest of
 // the panel (columns < k, ld = m, in Lx) and the update matrix (columns >= k, ld = u).
@@ -539,12 +578,17 @@ void launch_trsm_blk(hipStream_t st, const DevSym &ds, const int32_t *list, int 
 template <int KW>
 __global__ __launch_bounds__(256) void k_syrk_trailing(DevSym ds, const int32_t *__restrict__ list, int jb,
                                                        double *__restrict__ Lx, double *__restrict__ Uo,
-                                                       double *__restrict__ Linv, int *status, int col_lim)
+                                                       double *__restrict__ Linv, int *status, int col_lim, const TileClasses tc)
 {
-    const int ti = blockIdx.x, tj = blockIdx.y;
-    if (tj > ti) return;
+    int ti, tj, fi;
+    if (tc.ncls > 0) {                                  // numbered over size classes of the fronts (round 4)
+        if (!cls_decode(tc, blockIdx.x, fi, ti, tj)) return;
+    } else {                                            // (tiles of the largest front) x (fronts): sharded mode, KVX_SYRK_DIRECT=1
+        ti = blockIdx.x; tj = blockIdx.y; fi = blockIdx.z;
+        if (tj > ti) return;
+    }
     KVX_STAMP(q0);
-    const FrontDesc fd = ds.fd[list[blockIdx.z]];
+    const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, u = m - k;
     if (jb >= k) return;
     const int nbk = min(KW, k - jb);
@@ -701,14 +745,6 @@ struct SyrkLdsOnly {
 // tile t of a front -> (ti, tj).  Triangular classes of 16 or more tile rows: the 8 XCDs (workgroup ids go round-robin over them,
 // each has its own L2) take contiguous eighths of the row-major tile order, so that the workgroups resident on one XCD work on
 // neighbouring tiles of a few tile rows and share their operand strips.
-__device__ __forceinline__ void tri_inv(unsigned L, int &ti, int &tj)
-{
-    unsigned si = (unsigned)((__builtin_sqrtf(8.0f * (float)L + 1.0f) - 1.0f) * 0.5f);
-    while ((si + 1) * (si + 2) / 2 <= L) si++;
-    while (si * (si + 1) / 2 > L) si--;
-    ti = (int)si;
-    tj = (int)(L - si * (si + 1) / 2);
-}
 static inline unsigned cls_tiles_per_front(int T, int TC)
 {
     if (TC > 0) return (unsigned)T * (unsigned)TC;
@@ -722,33 +758,7 @@ __device__ __forceinline__ void syrk_lds_tile(Lds &lds, const unsigned wgid, con
                                               double *__restrict__ Linv, int *status, int col_lim, const TileClasses &tc)
 {
     int ti, tj, fi;
-    {
-        int c = 0;
-        while (c + 1 < tc.ncls && wgid >= tc.wg[c + 1]) c++;                   // (uniform)
-        const unsigned local = wgid - tc.wg[c];
-        const int T = tc.T[c], TC = tc.TC[c];
-        if (TC > 0) {                                  // a few tile columns of T tile rows (column-limited launches)
-            const unsigned tpf = (unsigned)T * (unsigned)TC;
-            const unsigned t = local % tpf;
-            fi = tc.first[c] + (int)(local / tpf);
-            ti = (int)(t % (unsigned)T);
-            tj = (int)(t / (unsigned)T);
-        } else {
-            const unsigned tri = (unsigned)T * (unsigned)(T + 1) / 2;
-            if (T >= 16) {
-                const unsigned chunk = (tri + 7) / 8, tpf = 8 * chunk;
-                const unsigned t = local % tpf;
-                fi = tc.first[c] + (int)(local / tpf);
-                const unsigned L = (t & 7u) * chunk + (t >> 3);
-                if (L >= tri) return;
-                tri_inv(L, ti, tj);
-            } else {
-                fi = tc.first[c] + (int)(local / tri);
-                tri_inv(local % tri, ti, tj);
-            }
-        }
-    }
-    if (tj > ti || fi >= tc.first[tc.ncls]) return;    // (ids in the padding in front of an XCD-numbered class)
+    if (!cls_decode(tc, wgid, fi, ti, tj)) return;
     const FrontDesc fd = ds.fd[list[fi]];
     const int k = fd.k, m = fd.m, u = m - k;
     if (kb >= k) return;
@@ -946,12 +956,22 @@ static void launch_syrk_lds(hipStream_t st, bool uonly, const DevSym &ds, const 
 }
 
 // the launches of the single-GPU chain: `list` = the big fronts still in the chain at panel step kb, largest update region
-// first (api.cpp build_chain_lists), hm / hk their orders and pivot counts
+// first (api.cpp build_chain_lists), hm / hk their orders and pivot counts.  Launches of few tiles with one or two panels go
+// to the direct kernel (every wave requests all operands of a tile up front: one memory round trip on the chain's critical
+// path where the LDS-staged kernel has one per 16 panel columns); KVX_SYRK_LDS_TILES = tile count from which on the staged one.
 void launch_syrk_step(hipStream_t st, const DevSym &ds, const int32_t *list, const int32_t *hm, const int32_t *hk, int count, int kb, int klen,
                       double *Lx, double *Uout, double *Linv, int *status, int col_lim)
 {
     if (count <= 0) return;
     const TileClasses tc = make_tile_classes(false, hm, hk, count, kb, klen, col_lim);
+    static const unsigned lds_tiles = [] { const char *e = getenv("KVX_SYRK_LDS_TILES"); return e ? (unsigned)atoll(e) : 3000u; }();
+    const unsigned gx = tc.ncls > 0 ? tc.wg[tc.ncls] : 0u;
+    if (gx == 0) return;
+    if (gx < lds_tiles && klen <= 2 * NB) {
+        if (klen <= NB) hipLaunchKernelGGL(k_syrk_trailing<64>, dim3(gx), dim3(256), 0, st, ds, list, kb, Lx, Uout, Linv, status, col_lim, tc);
+        else hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(gx), dim3(256), 0, st, ds, list, kb, Lx, Uout, Linv, status, col_lim, tc);
+        return;
+    }
     launch_syrk_lds_cls(st, false, ds, list, tc, kb, klen, Lx, Uout, Linv, status, col_lim);
 }
 // deferred ("far") update with the panel block [kb, kb + klen): everything from column t0 on -- later pivot columns and the
@@ -1153,6 +1173,8 @@ static dim3 syrk128_grid(int rows, int count)
     return dim3(nsb * 64u, 1, (unsigned)count);
 }
 
+static TileClasses no_classes() { TileClasses tc; tc.ncls = 0; return tc; }
+
 // KVX_SYRK_DIRECT=1: the round-3 kernels (every wave loads its operands from global memory) instead of the LDS-staged tiles
 static bool syrk_direct()
 {
@@ -1178,7 +1200,7 @@ void launch_syrk_trailing(hipStream_t st, const DevSym &ds, const int32_t *list,
     if (T * (T + 1) / 2 * count >= big_limit) {
         hipLaunchKernelGGL(k_syrk_trailing128<false>, syrk128_grid(rows, count), dim3(512), 0, st, ds, list, jb, NB, Lx, Uout, Linv, status, ColOwner{1, 1, 0, 0, INT_MAX, 0});
     } else {                                          // latency regime: more, smaller workgroups
-        hipLaunchKernelGGL(k_syrk_trailing<64>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim);
+        hipLaunchKernelGGL(k_syrk_trailing<64>, dim3((unsigned)T, (unsigned)T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim, no_classes());
     }
 }
 
@@ -1192,7 +1214,7 @@ void launch_syrk_pair(hipStream_t st, const DevSym &ds, const int32_t *list, int
     if (rows <= 0) return;
     if (!syrk_direct()) { launch_syrk_lds(st, false, ds, list, count, rows, jb, 2 * NB, Lx, Uout, Linv, status, col_lim); return; }
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
-    hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(T, T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim);
+    hipLaunchKernelGGL(k_syrk_trailing<128>, dim3(T, T, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, col_lim, no_classes());
 }
 
 // Two-level blocking for the fronts that are flop-bound (level with a front of order >= KVX_TWO_LEVEL_M): the pivot
@@ -1209,7 +1231,7 @@ void launch_syrk_inner(hipStream_t st, const DevSym &ds, const int32_t *list, in
     if (!syrk_direct()) { launch_syrk_lds(st, false, ds, list, count, rows, jb, NB, Lx, Uout, Linv, status, ob_end); return; }
     const unsigned T = (unsigned)((rows + KVX_TILE - 1) / KVX_TILE);
     const unsigned TC = (unsigned)std::min<int>((int)T, (ob_end - jb - NB + KVX_TILE - 1) / KVX_TILE);
-    hipLaunchKernelGGL(k_syrk_trailing<64>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end);
+    hipLaunchKernelGGL(k_syrk_trailing<64>, dim3(T, TC, (unsigned)count), dim3(256), 0, st, ds, list, jb, Lx, Uout, Linv, status, ob_end, no_classes());
 }
 
 void launch_syrk_outer(hipStream_t st, const DevSym &ds, const int32_t *list, int count, int max_m, int ob, int ob_len,

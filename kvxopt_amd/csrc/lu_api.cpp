@@ -622,6 +622,22 @@ int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8])
     return KVX_OK;
 }
 
+int kvx_lu_num_work(kvx_lu_num *N, double work[5])
+{
+    if (!N || !work) return KVX_EINVAL;
+    for (int i = 0; i < 5; i++) work[i] = 0.0;
+    for (const LuFrontH &f : N->P.fr) {
+        const double k = f.k, m = f.m, u = m - k;
+        // columns j = 0 .. k-1 of a front of order m: (m - j - 1) divisions + 2 (m - j - 1)^2 flops of the rank-1 update
+        const double fl = 2.0 * (k * u * u + u * k * (k - 1.0) + (k - 1.0) * k * (2.0 * k - 1.0) / 6.0) + k * u + k * (k - 1.0) / 2.0;
+        work[0] += fl;
+        work[1] += 2.0 * m * k - k * k;
+        work[2] += u * u;
+        if (f.m > KVX_LU_LDS_M) { work[3] += 1.0; work[4] += fl; }
+    }
+    return KVX_OK;
+}
+
 static int kvx_lu_extract_impl(kvx_lu_num *N, int64_t *lnz, int64_t **Lp, int64_t **Li, double **Lx, int64_t *unz, int64_t **Up,
                    int64_t **Ui, double **Ux, int64_t *fnz, int64_t **Fp, int64_t **Fi, double **Fx, int64_t *P_out,
                    int64_t *Q_out, double *Rs, int64_t *nblocks, int64_t **r_out)

@@ -83,6 +83,12 @@ class LuNumeric:
         keys = ("nfront", "nlevels", "max_front", "max_pivot_block", "panel_doubles", "arena_doubles", "passes", "factored")
         return dict(zip(keys, (int(x) for x in a)))
 
+    def work(self):
+        """flops, panel entries, update-matrix entries of one numeric factorisation; blocked fronts and their flops (kvx_lu_num_work)."""
+        w = np.zeros(5)
+        raise_for(lib().kvx_lu_num_work(self._h, pd(w)))
+        return dict(zip(("flops", "panel_entries", "update_entries", "blocked_fronts", "blocked_flops"), (float(x) for x in w)))
+
     def solve(self, B, trans="N", nrhs=None, ldB=None, offset=0):
         """B: 1-D float64 buffer holding an n x nrhs column-major block at `offset` with leading dimension ldB."""
         n = self.n

@@ -331,7 +331,64 @@ int kvxs_factorize(kvxs_factor *F, const double *Ax)
     return 0;
 }
 
-/* A x = b for nrhs columns (ld = ldB), in place; x in the caller's (unpermuted) order */
+/* forward / backward step of one front on the permuted vector x; w: m doubles of scratch.  Fronts of up to 64 pivot columns
+ * are swept column by column in place (one contiguous pass over the panel: a BLAS call costs more than the arithmetic of a
+ * front of a dozen columns, and there are tens of thousands of them); larger ones go to dtrsv / dgemv.
+ * lim: rows below lim belong to the calling thread's own subtree and are updated plainly, the others atomically. */
+static void front_fwd(const kvxs_factor *F, i64 s, double *x, double *w, i64 lim)
+{
+    const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
+    const double *P = F->Lx + F->px[s];
+    const i64 *rows = F->rowidx + F->rowptr[s] + k;
+    if (k <= 64) {
+        for (i64 i = 0; i < u; i++) w[i] = 0.0;
+        for (i64 j = 0; j < k; j++) {
+            const double *c = P + j * m;
+            const double xj = x[f + j] / c[j];
+            x[f + j] = xj;
+            for (i64 i = j + 1; i < k; i++) x[f + i] -= c[i] * xj;
+            for (i64 i = 0; i < u; i++) w[i] += c[k + i] * xj;
+        }
+    } else {
+        const int one = 1, ik = (int)k, im = (int)m, iu = (int)u;
+        const double d1 = 1.0, d0 = 0.0;
+        scipy_dtrsv_("L", "N", "N", &ik, P, &im, x + f, &one);
+        if (u > 0) scipy_dgemv_("N", &iu, &ik, &d1, P + k, &im, x + f, &one, &d0, w, &one);
+    }
+    for (i64 i = 0; i < u; i++) {
+        const i64 r = rows[i];
+        if (r < lim) x[r] -= w[i];
+        else {
+#pragma omp atomic
+            x[r] -= w[i];
+        }
+    }
+}
+
+static void front_bwd(const kvxs_factor *F, i64 s, double *x, double *w)
+{
+    const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
+    const double *P = F->Lx + F->px[s];
+    const i64 *rows = F->rowidx + F->rowptr[s] + k;
+    for (i64 i = 0; i < u; i++) w[i] = x[rows[i]];
+    if (k <= 64) {
+        for (i64 j = k - 1; j >= 0; j--) {
+            const double *c = P + j * m;
+            double t = x[f + j];
+            for (i64 i = j + 1; i < k; i++) t -= c[i] * x[f + i];
+            for (i64 i = 0; i < u; i++) t -= c[k + i] * w[i];
+            x[f + j] = t / c[j];
+        }
+    } else {
+        const int one = 1, ik = (int)k, im = (int)m, iu = (int)u;
+        const double d1 = 1.0, dm1 = -1.0;
+        if (u > 0) scipy_dgemv_("T", &iu, &ik, &dm1, P + k, &im, w, &one, &d1, x + f, &one);
+        scipy_dtrsv_("L", "T", "N", &ik, P, &im, x + f, &one);
+    }
+}
+
+/* A x = b for nrhs columns (ld = ldB), in place; x in the caller's (unpermuted) order.  Subtrees in parallel (their fronts
+ * update ancestor rows above the subtree atomically), then the top of the tree in sequence; the backward sweep mirrors it. */
 int kvxs_solve(const kvxs_factor *F, double *B, i64 nrhs, i64 ldB)
 {
     if (F->minor < F->n) return 1;
@@ -339,83 +396,37 @@ int kvxs_solve(const kvxs_factor *F, double *B, i64 nrhs, i64 ldB)
     double *x = malloc(sizeof(double) * (n ? n : 1));
     i64 maxm = 1;
     for (i64 s = 0; s < ns; s++) if (F->rowptr[s + 1] - F->rowptr[s] > maxm) maxm = F->rowptr[s + 1] - F->rowptr[s];
-    double *w = malloc(sizeof(double) * maxm);
-    if (!x || !w) { free(x); free(w); return -1; }
-    const int one = 1;
-    const double d1 = 1.0, dm1 = -1.0, d0 = 0.0;
+    const int nt = F->nthreads;
+    double *wall = malloc(sizeof(double) * (size_t)maxm * (size_t)(nt + 1));
+    if (!x || !wall) { free(x); free(wall); return -1; }
     scipy_openblas_set_num_threads(1);
     for (i64 r = 0; r < nrhs; r++) {
         double *b = B + r * ldB;
+#pragma omp parallel for schedule(static) num_threads(nt)
         for (i64 i = 0; i < n; i++) x[i] = b[F->perm[i]];
-        /* forward: subtrees in parallel (their updates of ancestor rows may collide: atomic), then the top */
-#pragma omp parallel num_threads(F->nthreads)
+#pragma omp parallel num_threads(nt)
         {
-            double *wl = malloc(sizeof(double) * maxm);
+            double *wl = wall + (size_t)maxm * (size_t)omp_get_thread_num();
 #pragma omp for schedule(dynamic, 1)
-            for (i64 t = 0; t < F->nsub; t++)
-                for (i64 q = F->subptr[t]; q < F->subptr[t + 1]; q++) {
-                    const i64 s = F->sublist[q];
-                    const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
-                    const double *P = F->Lx + F->px[s];
-                    const int ik = (int)k, im = (int)m, iu = (int)u;
-                    scipy_dtrsv_("L", "N", "N", &ik, P, &im, x + f, &one);
-                    if (u > 0) {
-                        scipy_dgemv_("N", &iu, &ik, &d1, P + k, &im, x + f, &one, &d0, wl, &one);
-                        const i64 *rows = F->rowidx + F->rowptr[s] + k;
-                        for (i64 i = 0; i < u; i++) {
-#pragma omp atomic
-                            x[rows[i]] -= wl[i];
-                        }
-                    }
-                }
-            free(wl);
-        }
-        for (i64 q = 0; q < F->ntop; q++) {
-            const i64 s = F->toplist[q];
-            const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
-            const double *P = F->Lx + F->px[s];
-            const int ik = (int)k, im = (int)m, iu = (int)u;
-            scipy_dtrsv_("L", "N", "N", &ik, P, &im, x + f, &one);
-            if (u > 0) {
-                scipy_dgemv_("N", &iu, &ik, &d1, P + k, &im, x + f, &one, &d0, w, &one);
-                const i64 *rows = F->rowidx + F->rowptr[s] + k;
-                for (i64 i = 0; i < u; i++) x[rows[i]] -= w[i];
+            for (i64 t = 0; t < F->nsub; t++) {
+                /* (the fronts of a subtree are a contiguous postorder range: its columns end where its root's do) */
+                const i64 lim = F->super[F->sublist[F->subptr[t + 1] - 1] + 1];
+                for (i64 q = F->subptr[t]; q < F->subptr[t + 1]; q++) front_fwd(F, F->sublist[q], x, wl, lim);
             }
         }
-        /* backward: the top downwards, then the subtrees in parallel (they only read ancestor entries) */
-        for (i64 q = F->ntop - 1; q >= 0; q--) {
-            const i64 s = F->toplist[q];
-            const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
-            const double *P = F->Lx + F->px[s];
-            const int ik = (int)k, im = (int)m, iu = (int)u;
-            if (u > 0) {
-                const i64 *rows = F->rowidx + F->rowptr[s] + k;
-                for (i64 i = 0; i < u; i++) w[i] = x[rows[i]];
-                scipy_dgemv_("T", &iu, &ik, &dm1, P + k, &im, w, &one, &d1, x + f, &one);
-            }
-            scipy_dtrsv_("L", "T", "N", &ik, P, &im, x + f, &one);
-        }
-#pragma omp parallel num_threads(F->nthreads)
+        double *w = wall + (size_t)maxm * (size_t)nt;
+        for (i64 q = 0; q < F->ntop; q++) front_fwd(F, F->toplist[q], x, w, n);
+        for (i64 q = F->ntop - 1; q >= 0; q--) front_bwd(F, F->toplist[q], x, w);
+#pragma omp parallel num_threads(nt)
         {
-            double *wl = malloc(sizeof(double) * maxm);
+            double *wl = wall + (size_t)maxm * (size_t)omp_get_thread_num();
 #pragma omp for schedule(dynamic, 1)
             for (i64 t = 0; t < F->nsub; t++)
-                for (i64 q = F->subptr[t + 1] - 1; q >= F->subptr[t]; q--) {
-                    const i64 s = F->sublist[q];
-                    const i64 k = F->super[s + 1] - F->super[s], m = F->rowptr[s + 1] - F->rowptr[s], u = m - k, f = F->super[s];
-                    const double *P = F->Lx + F->px[s];
-                    const int ik = (int)k, im = (int)m, iu = (int)u;
-                    if (u > 0) {
-                        const i64 *rows = F->rowidx + F->rowptr[s] + k;
-                        for (i64 i = 0; i < u; i++) wl[i] = x[rows[i]];
-                        scipy_dgemv_("T", &iu, &ik, &dm1, P + k, &im, wl, &one, &d1, x + f, &one);
-                    }
-                    scipy_dtrsv_("L", "T", "N", &ik, P, &im, x + f, &one);
-                }
-            free(wl);
+                for (i64 q = F->subptr[t + 1] - 1; q >= F->subptr[t]; q--) front_bwd(F, F->sublist[q], x, wl);
         }
+#pragma omp parallel for schedule(static) num_threads(nt)
         for (i64 i = 0; i < n; i++) b[F->perm[i]] = x[i];
     }
-    free(x); free(w);
+    free(x); free(wall);
     return 0;
 }
