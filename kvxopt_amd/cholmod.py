@@ -20,9 +20,11 @@ CHOLMOD's flops / nnz(L) >= 40 rule.  One set of HIP kernels computes the LL' fa
 as L = Lc diag(Lc)^-1, D = diag(Lc)^2 -- `solve`/`spsolve` with sys = 2..6, `getfactor` (D on the diagonal) and `diag`
 (refused, cholmod.c:919-922) follow the reference's behaviour for such a factor.
 Complex Hermitian ('z') matrices (cholmod.c:144,153,463) are SOLVED -- symbolic / numeric / solve and spsolve with sys = 0,
-linsolve, splinsolve -- through the real symmetric 2n x 2n embedding [[Re A, -Im A], [Im A, Re A]] (positive definite exactly
-when A is) on the same real kernels; the partial systems (sys = 1..8), `diag` and `getfactor` of a complex factor are not
-available (the factor of the embedding is not the embedding of the complex factor) and raise NotImplementedError.
+linsolve, splinsolve, and since round 4 every system code sys = 0..8, `diag` and `getfactor` -- through the real symmetric
+2n x 2n embedding in interleaved numbering (every a_ij a 2 x 2 block [[Re, -Im], [Im, Re]]; positive definite exactly when A
+is) on the same real kernels: eliminated pair by pair in a complex elimination order, the real factor IS the embedding of the
+complex one (`_embed_hermitian`), and a complex vector in memory is its own embedding.  Only LDL' factors of complex matrices
+(options['supernodal'] = 0) keep to sys = 0 / diag-free use.
 """
 import collections
 import os
@@ -72,10 +74,17 @@ class _F:
 
 
 def _embed_hermitian(n, cp, ri, v, uplo):
-    """Lower-triangular CCS (colptr, rowind, values, source map) of the real embedding [[B, -C], [C, B]] of the Hermitian
-    matrix A = B + iC given by its `uplo` triangle: every stored a_ij, i > j, lands in (i, j), (n+i, n+j) with Re a_ij and in
-    (n+i, j), (n+j, i) with +-Im a_ij; the (real part of the) diagonal in (i, i), (n+i, n+i).  Built once per pattern: the
-    returned gather turns a value array of A into the value array of the embedding."""
+    """Lower-triangular CCS (colptr, rowind, values, source map) of the real embedding of the Hermitian matrix A = B + iC given
+    by its `uplo` triangle, in INTERLEAVED numbering (real part of unknown j at 2j, imaginary part at 2j + 1 -- the memory
+    layout of a complex vector): every a_ij becomes the 2 x 2 block [[Re, -Im], [Im, Re]].  A stored a_ij, i > j, lands in
+    (2i, 2j), (2i+1, 2j+1) with Re a_ij and in (2i+1, 2j), (2j+1, 2i) -> lower (2i, 2j+1) with +-Im a_ij; the (real part of
+    the) diagonal in (2i, 2i), (2i+1, 2i+1).  Built once per pattern: the returned gather turns a value array of A into the
+    value array of the embedding.
+    Why interleaved: eliminated pair by pair in a complex elimination order, the real Cholesky factor R of the embedding IS
+    the embedding of the complex factor L -- block (i, j) of R is [[Re l_ij, -Im l_ij], [Im l_ij, Re l_ij]], the diagonal
+    blocks are l_jj I (uniqueness of the Cholesky factor: that matrix is lower triangular with a positive diagonal and its
+    product with its transpose is the embedding of L L^H).  So every system of cholmod.solve, diag and getfactor of a complex
+    factor are read off the real one."""
     col = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp))
     keep = ri >= col if uplo == "L" else ri <= col
     idx = np.nonzero(keep)[0]
@@ -86,8 +95,9 @@ def _embed_hermitian(n, cp, ri, v, uplo):
         flip[:] = True
     off = i > j
     # entries: (row, col, source index, kind)  kind 0: Re, 1: +Im, 2: -Im (before the conjugation of an upper triangle)
-    rows = np.concatenate([i, n + i, n + i[off], n + j[off]])
-    cols = np.concatenate([j, n + j, j[off], i[off]])
+    # lower-triangle positions: Re at (2i, 2j) and (2i+1, 2j+1); Im a_ij at (2i+1, 2j); -Im a_ij (block entry (2i, 2j+1))
+    rows = np.concatenate([2 * i, 2 * i + 1, 2 * i[off] + 1, 2 * i[off]])
+    cols = np.concatenate([2 * j, 2 * j + 1, 2 * j[off], 2 * j[off] + 1])
     src = np.concatenate([idx, idx, idx[off], idx[off]])
     kind = np.concatenate([np.zeros(idx.size, np.int8), np.zeros(idx.size, np.int8), np.ones(off.sum(), np.int8),
                            np.full(off.sum(), 2, np.int8)])
@@ -161,17 +171,33 @@ def symbolic(A, p=None, uplo="L"):
     elif q is not None:
         fopts["compare_given"] = 1
     if v.dtype.kind == "c":
-        if q is not None:
-            q = np.concatenate([q, q + n])                  # the same symmetric permutation on both halves
-        ecp, eri, evals = _embed_hermitian(n, cp, ri, v, uplo)
+        # the ordering is chosen on the n x n pattern of A (host analysis only) and the embedding eliminates the two unknowns of
+        # a complex one side by side in that order: the real factor is then the embedding of the complex one (_embed_hermitian)
+        keep, tcp, tri = _triangle(n, cp, ri, uplo)
         try:
-            fac = Factor(2 * n, ecp, eri, "L", q, fopts)
+            f0 = Factor(n, tcp, tri, uplo, q, fopts)
         except ValueError as e:
             if "permutation" in str(e):
                 raise ValueError("p is not a valid permutation")
             raise
+        p0 = f0.perm()
+        del f0
+        q2 = np.empty(2 * n, dtype=np.int64)
+        q2[0::2], q2[1::2] = 2 * p0, 2 * p0 + 1
+        ecp, eri, evals = _embed_hermitian(n, cp, ri, v, uplo)
+        fo2 = {k: fopts[k] for k in ("dbound", "supernodal") if k in fopts}
+        fo2["postorder"] = 0                                # (p0 is a postorder of the complex tree; the pairs stay together)
+        fac = Factor(2 * n, ecp, eri, "L", q2, fo2)
         F = _F(fac, uplo, (cp.copy(), ri.copy()), None, (ecp, eri))
         F.name, F.complex, F.evals, F.n = "CHOLMOD SYM Z FACTOR " + uplo, True, evals, n
+        # The library postorders whatever it is given (supernodes need contiguous subtrees): siblings may change places -- Re and
+        # Im of one unknown are siblings of the real tree -- which permutes the real factor without changing an entry.  What the
+        # complex reading needs is that the two stay next to each other; which of them comes first is kept per pair.
+        P2 = fac.perm()
+        F.paired = bool(np.all(P2[0::2] // 2 == P2[1::2] // 2))
+        F.pair_swap = (P2[0::2] % 2) == 1                    # pair t has its imaginary part first
+        F.pair_perm = P2[0::2] // 2                          # the complex permutation (sys = 7 / 8)
+        F.real_perm = P2
         return F
     keep, tcp, tri = _triangle(n, cp, ri, uplo)
     try:
@@ -261,16 +287,22 @@ def solve(F, B, sys=0, nrhs=-1, ldB=0, offsetB=0):
     if offsetB + (nrhs - 1) * ldB + n > buf.size:
         raise TypeError("length of B is too small")
     if cplx:
-        if sys != 0:
-            raise NotImplementedError("complex factors solve A X = B (sys = 0) through their real embedding; the partial "
-                                      "systems sys = 1..8 are not available")
-        cols = [buf[offsetB + j * ldB: offsetB + j * ldB + n] for j in range(nrhs)]
-        R = np.empty((2 * n, nrhs), order="F")
-        for j, c in enumerate(cols):
-            R[:n, j], R[n:, j] = c.real, c.imag
-        F.fac.solve(R.reshape(-1, order="F"), sys=0, nrhs=nrhs, ldB=2 * n, offset=0)
-        for j, c in enumerate(cols):
-            c[:] = R[:n, j] + 1j * R[n:, j]
+        # a complex vector in memory IS its interleaved embedding: the same system code on the real factor, in place
+        # (L x = b <-> R e(x) = e(b), L^H <-> R', the permutation of the pairs <-> P; cholmod.c:463 z-typed solve)
+        if sys != 0 and not getattr(F, "paired", False):
+            raise NotImplementedError("this complex factor's ordering split a (Re, Im) pair: only A X = B (sys = 0) is available")
+        fb = buf.view(np.float64)
+        sw = F.pair_swap if sys != 0 and F.pair_swap.any() else None
+
+        def swap_pairs():                                   # vectors in the factor's permuted order: pairs stored Im first
+            for j in range(nrhs):
+                c = fb[2 * (offsetB + j * ldB): 2 * (offsetB + j * ldB + n)].reshape(n, 2)
+                c[sw] = c[sw][:, ::-1]
+        if sw is not None and sys != 7:                     # (sys = 7 takes b in the caller's order)
+            swap_pairs()
+        F.fac.solve(fb, sys=sys, nrhs=nrhs, ldB=2 * ldB, offset=2 * offsetB)
+        if sw is not None and sys != 8:                     # (sys = 8 returns x in the caller's order)
+            swap_pairs()
         return
     F.fac.solve(buf, sys=sys, nrhs=nrhs, ldB=ldB, offset=offsetB)
 
@@ -290,13 +322,11 @@ def spsolve(F, B, sys=0):
     if getattr(F, "complex", False):
         if m != F.n:
             raise ValueError("incompatible dimensions for B")
-        if sys != 0:
-            raise NotImplementedError("complex factors solve A X = B (sys = 0) only")
         # columns of B as dense complex vectors through the embedding; exact zeros are dropped as CHOLMOD's own spsolve does
         n = F.n
         D = np.zeros((n, ncol), dtype=np.complex128, order="F")
         D[ri, np.repeat(np.arange(ncol, dtype=np.int64), np.diff(cp))] = v
-        solve(F, D, 0)
+        solve(F, D, sys)
         I, J = np.nonzero(D.T != 0)
         return spmatrix(D[J, I], J, I, (n, ncol), "z")
     if m != F.fac.n:
@@ -376,11 +406,15 @@ def diag(F):
     _check_options()
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
-    if getattr(F, "complex", False):
-        raise NotImplementedError("diag of a complex factor (complex systems are solved through their real embedding)")
     inf = F.fac.info()
     if not inf["is_numeric"] or inf["minor"] < F.fac.n or not inf["is_ll"]:
         raise ValueError("F must be a nonsingular supernodal Cholesky factor")
+    if getattr(F, "complex", False):
+        # cholmod.c:900-945 on a 'z' factor: the diagonal of L (real and positive) as a 'z' matrix; the diagonal blocks of the
+        # real factor are l_jj I
+        if not getattr(F, "paired", False):
+            raise NotImplementedError("this complex factor's ordering split a (Re, Im) pair: diag is not available")
+        return matrix(F.fac.diag()[0::2].astype(np.complex128), (F.n, 1))
     return matrix(F.fac.diag(), (F.fac.n, 1))
 
 
@@ -388,9 +422,25 @@ def getfactor(F):
     _check_options()
     if not isinstance(F, _F):
         raise TypeError("F is not a CHOLMOD factor")
-    if getattr(F, "complex", False):
-        raise NotImplementedError("getfactor of a complex factor (complex systems are solved through their real embedding)")
     if not F.fac.info()["is_numeric"]:
         raise ValueError("F must be a numeric Cholesky factor")
+    if getattr(F, "complex", False):
+        # cholmod.c:948-985 on a 'z' factor: column 2j of the real factor holds Re l_ij at row 2i and Im l_ij at row 2i + 1
+        if not getattr(F, "paired", False) or not F.fac.info()["is_ll"]:
+            raise NotImplementedError("getfactor of this complex factor (LDL' form, or an ordering that split a (Re, Im) pair)")
+        Rp, Ri, Rx = F.fac.get_factor()
+        n = F.n
+        cpos = np.repeat(np.arange(2 * n, dtype=np.int64), np.diff(Rp))
+        P2 = F.real_perm
+        ev = (P2[cpos] % 2) == 0                            # the column that carries the real part of its pair
+        rpos, cp_, xx = Ri[ev], cpos[ev], Rx[ev]
+        re = (P2[rpos] % 2) == 0
+        key = rpos // 2 + (cp_ // 2) * n                    # entries of one complex l_ij share (pair of the row, pair of the column)
+        uniq = np.unique(key)
+        val = np.zeros(uniq.size, dtype=np.complex128)
+        np.add.at(val, np.searchsorted(uniq, key), np.where(re, xx, 1j * xx))
+        dg = (uniq % n) == (uniq // n)
+        val[dg] = val[dg].real                              # (the entry between the two halves of a pair is zero up to rounding)
+        return spmatrix(val, uniq % n, uniq // n, (n, n), "z")
     Lp, Li, Lx = F.fac.get_factor()
     return spmatrix.from_ccs(F.fac.n, F.fac.n, Lp, Li, Lx)

@@ -559,8 +559,10 @@ def test_device_pool_recycles_and_trims():
 
 def test_complex_hermitian_systems():
     """cholmod with 'z' matrices (cholmod.c:144,153,463): Hermitian positive definite A given by either triangle, complex
-    right-hand sides -- symbolic / numeric / solve (sys = 0), linsolve, spsolve, splinsolve against dense numpy solves.  Runs
-    through the real symmetric 2n x 2n embedding; the partial systems, diag and getfactor of a complex factor are refused."""
+    right-hand sides -- symbolic / numeric / solve with every system code 0..8, linsolve, spsolve, splinsolve, diag and getfactor
+    (cholmod.c:900-985 on a 'z' factor) against dense numpy: L = getfactor(F) is lower triangular with a real positive diagonal
+    and P A P^T = L L^H for the P of sys = 7; the partial systems agree with that L.  Runs through the real 2n x 2n embedding
+    in interleaved numbering, whose real factor is the embedding of the complex one (cholmod._embed_hermitian)."""
     import scipy.sparse as sp
     from kvxopt_amd import cholmod
     from kvxopt_amd.base import matrix, spmatrix
@@ -588,12 +590,38 @@ def test_complex_hermitian_systems():
         Bs = spmatrix([1.0 + 2.0j, -1.0j, 3.0], [0, 7, 7], [0, 0, 1], (n, 2))
         Xs = cholmod.splinsolve(A, Bs, uplo=uplo)
         assert Xs.typecode == "z" and rel(Xs.todense(), np.linalg.solve(Ad, Bs.todense())) < 1e-11
-        with pytest.raises(NotImplementedError):
-            cholmod.solve(F, X, sys=4)
-        with pytest.raises(NotImplementedError):
-            cholmod.diag(F)
-        with pytest.raises(NotImplementedError):
-            cholmod.getfactor(F)
+        cholmod.numeric(A, F)
+        Lm = cholmod.getfactor(F)
+        assert Lm.typecode == "z"
+        L = np.array(Lm.todense())
+        assert np.allclose(np.triu(L, 1), 0.0) and np.all(np.diag(L).real > 0) and np.abs(np.diag(L).imag).max() == 0.0
+        e = matrix(np.arange(n, dtype=np.complex128)); cholmod.solve(F, e, sys=7)          # x = P b: the permutation itself
+        perm = np.array(e.a).real.astype(int).ravel()
+        assert sorted(perm.tolist()) == list(range(n))
+        PAPt = Ad[np.ix_(perm, perm)]
+        assert rel(L @ L.conj().T, PAPt) < 1e-12
+        assert rel(np.array(cholmod.diag(F).a).ravel(), np.diag(L)) < 1e-14
+        P = np.eye(n)[perm]
+        expect = {1: lambda b: np.linalg.solve(L @ L.conj().T, b), 2: lambda b: np.linalg.solve(L, b), 3: lambda b: np.linalg.solve(L.conj().T, b),
+                  4: lambda b: np.linalg.solve(L, b), 5: lambda b: np.linalg.solve(L.conj().T, b), 6: lambda b: b,
+                  7: lambda b: P @ b, 8: lambda b: P.T @ b}
+        for sysc, fn in expect.items():
+            Y = matrix(B.copy(order="F")); cholmod.solve(F, Y, sys=sysc)
+            assert rel(np.array(Y.a), fn(B)) < 1e-11, (uplo, sysc)
+        Ys = cholmod.spsolve(F, Bs, sys=4)
+        assert Ys.typecode == "z" and rel(Ys.todense(), np.linalg.solve(L, np.array(Bs.todense()))) < 1e-11
+        # ld / offset of a complex right-hand side
+        buf = matrix(np.zeros((n + 5) * 3 + 2, dtype=np.complex128))
+        arr = np.array(buf.a).reshape(-1)
+        Bo = np.zeros((n + 5) * 3 + 2, dtype=np.complex128)
+        for c in range(3):
+            Bo[2 + c * (n + 5): 2 + c * (n + 5) + n] = B[:, c]
+        bo = matrix(Bo.copy())
+        cholmod.solve(F, bo, sys=0, nrhs=3, ldB=n + 5, offsetB=2)
+        got = np.array(bo.a).reshape(-1)
+        for c in range(3):
+            assert rel(got[2 + c * (n + 5): 2 + c * (n + 5) + n], Xref[:, c]) < 1e-11
+            assert np.all(got[2 + c * (n + 5) + n: 2 + (c + 1) * (n + 5)] == 0) if c < 2 else True
         with pytest.raises(TypeError):
             cholmod.solve(F, matrix(np.ones(n)))                       # real B with a complex factor (cholmod.c:461-465)
     bad = Ad.copy(); bad[5, 5] = -1.0
