@@ -24,6 +24,8 @@ struct DistState {
     std::vector<int32_t> dist_pos;                 // front -> index into d_dist_ids (block-cyclic fronts of this rank), -1 otherwise
     int32_t *d_dist_ids = nullptr;
     std::vector<int32_t> groups;                   // distinct (lo, hi) ranges of >= 2 ranks
+    struct Report { int32_t root; int64_t col0, len; };
+    std::vector<Report> report;                    // column intervals of x and the rank that hands them to the others after a solve
     int64_t nshared = 0, ncyclic = 0;
 };
 
@@ -308,7 +310,23 @@ int dist_solve_impl(kvx_chol *F, double *B, int64_t nrhs, int64_t ldB, kvx_dist_
     if (run_from >= 0) enqueue_fwd(F, F->d_X, n, nr, run_from, 0);
     // backward: every rank holds x of all ancestors of its fronts (it is in their ranges): no exchange
     enqueue_bwd(F, F->d_X, n, nr, 0, S.nlevels - 1);
-    if (D.nranks > 1) {
+    static const bool allreduce_x = [] { const char *e = getenv("KVX_DIST_ALLREDUCE_X"); return e && e[0] == '1'; }();
+    if (D.nranks > 1 && !allreduce_x) {
+        // Round 4: after the backward sweep a rank holds x of its own subtrees and of every shared front above them; what it lacks
+        // is the other ranks' parts.  The first rank of a front's range broadcasts that front's entries (runs of fronts merged
+        // into intervals, packed into messages): n nrhs doubles received per rank, where the all-reduce of the whole masked
+        // vector that stood here moved twice that and added zeros (KVX_DIST_ALLREDUCE_X=1 restores it).
+        std::vector<Region> regs;
+        for (int r = 0; r < D.nranks; r++) {
+            regs.clear();
+            for (const DistState::Report &q : D.report)
+                if (q.root == r)
+                    for (int64_t o = 0; o < q.len; o += D.xchg_cap)      // (a message holds whole columns of a region: no longer than the buffer)
+                        regs.push_back(Region{F->d_X + q.col0 + o, n, std::min(D.xchg_cap, q.len - o), (int64_t)nr});
+            if (regs.empty()) continue;
+            if ((rc = bcast_regions(C, r, 0, D.nranks, regs))) return rc;
+        }
+    } else if (D.nranks > 1) {
         // every entry of x is reported by ONE rank (the first of its front's range); the sum over the ranks is x
         launch_mask_rows(st, F->d_keep, n, nr, F->d_X, n);
         const int64_t total = n * nr;
@@ -429,6 +447,14 @@ int dist_setup_impl(kvx_chol *F, int rank, int nranks, int ob, int min_m, int64_
             for (int64_t j = S.super[s]; j < S.super[s + 1]; j++) keep[j] = 1;
     if (F->d_keep) { HIPCHK(pool_free(F->d_keep)); F->d_keep = nullptr; }
     if ((rc = upload(&F->d_keep, keep))) return rc;
+    // who hands which part of x to the others at the end of a solve: the first rank of a front's range, runs of fronts merged
+    D.report.clear();
+    for (int64_t s = 0; s < S.nsuper; s++) {
+        const int64_t c0 = S.super[s], len = S.super[s + 1] - S.super[s];
+        if (len <= 0) continue;
+        if (!D.report.empty() && D.report.back().root == M.glo[s] && D.report.back().col0 + D.report.back().len == c0) D.report.back().len += len;
+        else D.report.push_back(DistState::Report{M.glo[s], c0, len});
+    }
     // distinct ranges of >= 2 ranks (the caller creates one communicator per range)
     for (int64_t s = 0; s < S.nsuper; s++) {
         if (M.ghi[s] - M.glo[s] < 2) continue;
