@@ -454,7 +454,7 @@ def source_fingerprint():
     return h.hexdigest()[:16]
 
 
-PMC_FILE = "r03_pmc_fetch_write_per_kernel.json"
+PMC_FILE = "r04_pmc_fetch_write_per_kernel.json"
 
 
 def build_workload(name, g):

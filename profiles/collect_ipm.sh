@@ -5,7 +5,7 @@
 # 1. rocprofv3 --kernel-trace --stats of three conelp runs; 2./3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE: the
 # TCC block cannot hold both).  The program goes directly after `--`.  profiles/summarize_ipm.py condenses them.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

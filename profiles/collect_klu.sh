@@ -4,7 +4,7 @@
 # 1. bench_extra.py JSON lines (klu3 = BASELINE configs[2], lu2d = unsymmetric 600 x 600 grid), 2. rocprofv3 kernel
 # stats of ten refactor+solve steps on ACTIVSg2000 (tools/lu_prof.py).
 set -e -o pipefail
-TAG=${1:-r01c}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

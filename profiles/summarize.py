@@ -9,7 +9,7 @@
                                   the library sources the profile was taken on."""
 import csv, glob, hashlib, json, os, re, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")
@@ -32,7 +32,8 @@ def source_fingerprint():
 
 
 FAMILY = {"k_scatter_a": "scatter_a", "k_init_factor": "scatter_a", "k_front_wave": "front_small", "k_front_lds": "front_small", "k_assemble_big": "assemble_big",
-          "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing", "k_syrk_trailing128": "syrk_trailing",
+          "k_potrf_blk": "potrf_diag", "k_trsm_blk": "trsm_panel", "k_syrk_trailing": "syrk_trailing", "k_syrk_trailing128": "syrk_trailing", "k_syrk_lds": "syrk_trailing",
+          "k_assemble_big_potrf": "assemble_big",
           "k_fwd_wave": "fwd_level", "k_fwd_subtree": "fwd_level", "k_bwd_subtree": "bwd_level", "k_fwd_lds": "fwd_level", "k_fwd_big_step": "fwd_level",
           "k_bwd_wave": "bwd_level", "k_bwd_lds": "bwd_level", "k_bwd_big_init": "bwd_level", "k_bwd_big_step": "bwd_level"}
 
@@ -49,12 +50,37 @@ if st:
     rows = list(csv.DictReader(open(st[0])))
     nfac = sum(int(r["Calls"]) for r in rows if clean(r["Name"]).startswith(("k_clear_factor", "k_init_factor")))
     with open(os.path.join(prof, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ipm --no-extra --no-one-shot\n")
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ipm --no-klu --no-extra --no-one-shot\n")
         f.write("# %d numeric factorisations in the process: 12 one-enqueue steps (factor + solve, forward sweep beside the top of the tree), 8 steps as two calls, "
                 "24 in the per-family timing loop (graphs off)\n" % nfac)
         f.write("kernel,calls,total_us,avg_us,pct\n")
         for r in rows:
             f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+
+
+st21 = glob.glob(os.path.join(out, tag + "_stats21", "**", "*kernel_stats.csv"), recursive=True)
+if st21:
+    rows = list(csv.DictReader(open(st21[0])))
+    nfac = sum(int(r["Calls"]) for r in rows if clean(r["Name"]).startswith(("k_clear_factor", "k_init_factor")))
+    with open(os.path.join(prof, tag + "_kernel_stats_stencil21.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --quick --workload stencil21  (%d numeric factorisations, one-enqueue steps)\n" % nfac)
+        f.write("kernel,calls,total_us,avg_us,pct\n")
+        for r in rows:
+            f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+pk = os.path.join(out, tag + "_fp64_peak.txt")
+if os.path.exists(pk):
+    shutil.copy(pk, os.path.join(prof, tag + "_fp64_peak.txt"))
+lu = glob.glob(os.path.join(out, tag + "_lustats", "**", "*kernel_stats.csv"), recursive=True)
+if lu:
+    rows = list(csv.DictReader(open(lu[0])))
+    with open(os.path.join(prof, tag + "_lu_kernel_stats.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 tools/lu_prof.py  (kvxopt.klu on ACTIVSg2000: refactor + solve steps)\n")
+        f.write("kernel,calls,total_us,avg_us,pct\n")
+        for r in rows:
+            f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+lj = os.path.join(out, tag + "_lu.jsonl")
+if os.path.exists(lj):
+    shutil.copy(lj, os.path.join(prof, tag + "_lu.jsonl"))
 
 
 def pmc(dirname, counter):

@@ -6,7 +6,7 @@ profiles/<tag>_pmc_fetch_write_per_kernel.json) -- next to their algorithmic byt
 the two launches of the assembly, k_atda_scale + k_atda)."""
 import csv, glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 prof = os.path.join(root, "profiles")

@@ -66,8 +66,11 @@ int main()
     for (auto &v : h) v = (rand() % 2001 - 1000) / 1000.0;
     CHK(hipMemcpy(in, h.data(), 512 * 8, hipMemcpyHostToDevice));
     const int it = 20000;
+    printf("-- v_fma_f64 alone: NV independent chains per wave (128 flops per instruction)\n");
     run<0, 32>(1, out, st, in, it); run<0, 32>(2, out, st, in, it); run<0, 32>(4, out, st, in, it);
-    run<4, 0>(2, out, st, in, it);
+    printf("-- v_mfma_f64_16x16x4_f64 alone: NM independent accumulators per wave\n");
+    run<4, 0>(1, out, st, in, it); run<4, 0>(2, out, st, in, it); run<4, 0>(4, out, st, in, it); run<16, 0>(1, out, st, in, it); run<16, 0>(2, out, st, in, it);
+    printf("-- interleaved\n");
     run<4, 32>(1, out, st, in, it); run<4, 32>(2, out, st, in, it);
     run<4, 64>(1, out, st, in, it); run<4, 64>(2, out, st, in, it);
     run<4, 96>(1, out, st, in, it); run<4, 96>(2, out, st, in, it);
