@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--no-ipm", action="store_true", help="skip the secondary IPM iterations/s measurement")
     ap.add_argument("--no-klu", action="store_true", help="skip the klu leg (BASELINE configs[2]: ACTIVSg2000 and the 600 x 600 convection-diffusion matrix)")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` systems (21-point stencil, 100^3 cube)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 200^3 cube (BASELINE configs[4]) on one GPU among the `extra` systems")
     ap.add_argument("--no-one-shot", action="store_true", help="skip the time-to-first-solution leg")
     ap.add_argument("--separate-calls", action="store_true", help="the step as two calls (factorize, then solve) instead of the one-enqueue "
                     "form whose forward sweep is pipelined behind the factorisation")
@@ -584,7 +585,8 @@ def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mo
         dt = dist.max(dt)
     ms_factor, ms_solve = F.timing()
     ms_sep = None
-    if DF is None and not args.separate_calls:
+    heavy = info["flops"] > 2e13                             # (the 200^3 cube: seconds per step -- no split, one reading of one family)
+    if DF is None and not args.separate_calls and not heavy:
         # the one-enqueue step cannot tell its two parts apart: a few steps as two calls (factorize, then solve) for the split
         acc = [0.0, 0.0]
         for it in range(8):                                  # (three to capture and warm the two graphs of this form, five measured)
@@ -623,13 +625,16 @@ def measure_system(args, pl, dist, rank, world, dev, wl, nrhs, steps, warmup, mo
     st = front_stats(F)
     fam_times = {}
     for fam in Factor.FAMILIES:
+        if heavy and fam != (family if family != "auto" else "syrk_trailing"):
+            fam_times[fam] = (0.0, 0)
+            continue
         samples = []
-        for _ in range(3):                         # median of three single-step readings: one hiccup must not pick the family
+        for _ in range(1 if heavy else 3):         # median of three single-step readings: one hiccup must not pick the family
             F.prof_select(fam)
             step()
             samples.append(F.prof_read())
         samples.sort(key=lambda t: t[0])
-        fam_times[fam] = (samples[1][0], samples[1][1])
+        fam_times[fam] = (samples[len(samples) // 2][0], samples[len(samples) // 2][1])
     F.prof_select(None)
     pick = args.roofline_family if family == "auto" else family
     dom = max(fam_times, key=lambda f: fam_times[f][0]) if pick == "auto" else pick
@@ -851,7 +856,12 @@ def main():
     # --- the north-star systems in the same run (every N; CPU baselines at N = 1): ~20 nnz/row at n = 1e6, and the flop-bound cube
     extra = []
     if not args.no_extra and headline_cfg2:
-        for name, gg, st_, wu in (("stencil21", 1000, 5, 2), ("lap3d", 100, 3, 1)):
+        systems = [("stencil21", 1000, 5, 2), ("lap3d", 100, 3, 1)]
+        if world == 1 and not args.no_config5:
+            # BASELINE configs[4] on ONE GPU: the N = 1 anchor of the 8-GPU configuration (n = 8e6; no CPU run: the restated CPU path
+            # would take minutes).  Two steps; ~73 GB of factor.
+            systems.append(("lap3d", 200, 1, 1))
+        for name, gg, st_, wu in systems:
             try:
                 del res["_F"], res["_DF"]                   # (one factor resident at a time)
             except KeyError:
@@ -859,7 +869,7 @@ def main():
             try:
                 w2 = build_workload(name, gg)
                 r2 = measure_system(args, pl, dist, rank, world, dev, w2, 1, st_, wu, mode, family="syrk_trailing",
-                                    cpu=("lite" if world == 1 else "none"), pmc_key=("stencil21" if (name == "stencil21" and mode == "single") else None))
+                                    cpu=("lite" if (world == 1 and not (name == "lap3d" and gg == 200)) else "none"), pmc_key=("stencil21" if (name == "stencil21" and mode == "single") else None))
                 if r2.get("cpu_baseline") and r2["cpu_baseline"].get("value"):
                     r2["vs_cpu_baseline"] = r2["value"] / r2["cpu_baseline"]["value"]
                 extra.append(public(r2))
