@@ -318,6 +318,29 @@ int kvx_lp_second_half_dev(int64_t ml, int64_t n, int64_t p, const double *c, co
                            double *ws3, double dgi, double dtau0, double z1z1, double out_host[4]);
 int kvx_nt_reduce_multi_dev(int count, const int32_t *kind, const int64_t *n, const double *const *x,
                             const double *const *y, double *out_host);
+/* One interior-point iteration of conelp on the orthant without equality constraints (coneprog.py:859-1436, p = 0) in FOUR calls
+ * instead of fifteen (round 4): the same kernels in the same order as the calls above -- bit for bit the same iterates -- but
+ * the launches between two host synchronisations are issued from C back to back (a Python -> ctypes hop costs 10-15 us, and
+ * the GPU waited for them after every synchronisation: ~250 us of a 1.9 ms iteration, rocprofv3 timeline).  All pointers are
+ * device pointers; plan / F / Sx / x2 are the KKT object's (S = G' W^-2 G on its fixed pattern, its factor, two columns of work).
+ *   residuals : kvx_lp_residuals_dev + the reductions of coneprog.py:861-896 -> out[10] = hrx'hrx, rx'rx, 0, 0, hrz'hrz, rz'rz,
+ *               c'x, 0, h'z, lmbda'lmbda (the order lp.py reads them in);
+ *   predictor : kvx_lp_newton_rhs_dev (predictor), assembly of S, kvx_kkt_solve_pre_dev, factorisation + two-column solve as one
+ *               enqueue, kvx_kkt_solve_post_dev [x1 := dgi S^-1(-c ..), z1; dx, dz], th := h .* di, kvx_lp_second_half_dev
+ *               -> out[4] = dtau, z1'z1, max(-ds), max(-dz); the factorisation's status stays deferred (kvx_chol_status);
+ *   corrector : kvx_lp_newton_rhs_dev (shift = sigma mu, scale = 1 - sigma, ws3), KKT solve with the factor, second half;
+ *   update    : kvx_lp_update_x_dev(step), then `residuals` of the next iteration with tau_next. */
+typedef struct kvx_lp_ctx {
+    int64_t ml, n;
+    const int64_t *Gp, *Gi; const double *Gx; int64_t max_col;
+    const int64_t *GTp, *GTi; const double *GTx; int64_t max_row;
+    kvx_atda *plan; kvx_chol *F; double *Sx, *x2;
+    double *x, *s, *z, *c, *h, *hrx, *rx, *hrz, *rz, *lmbda, *d, *di, *ds, *dz, *dx, *x1, *z1, *th, *ws3;
+} kvx_lp_ctx;
+int kvx_lp_iter_residuals(const kvx_lp_ctx *L, double tau, double out[10]);
+int kvx_lp_iter_predictor(const kvx_lp_ctx *L, double dgi, double dtau0, double out[4]);
+int kvx_lp_iter_corrector(const kvx_lp_ctx *L, double shift, double scale, double dgi, double dtau0, double z1z1, double out[4]);
+int kvx_lp_iter_update(const kvx_lp_ctx *L, double step, double tau_next, double out[10]);
 
 /* ---- BLAS-1 glue on device vectors: replaces the blas.axpy / scal / copy calls and elementwise
  * products the interior-point loop makes between KKT solves (coneprog.py:1126-1433). ------------- */

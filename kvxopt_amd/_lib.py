@@ -59,6 +59,13 @@ class KktSide(ctypes.Structure):
     _fields_ = [("xin", vp), ("xscale", f64), ("zin", vp), ("xout", vp), ("xoscale", f64), ("zout", vp), ("zoscale", f64)]
 
 
+class LpCtx(ctypes.Structure):
+    """kvx_lp_ctx of include/kvxhip.h: the device pointers of one conelp run (orthant, p = 0) for the four-call iteration."""
+    _fields_ = [("ml", i64), ("n", i64), ("Gp", vp), ("Gi", vp), ("Gx", vp), ("max_col", i64), ("GTp", vp), ("GTi", vp), ("GTx", vp), ("max_row", i64),
+                ("plan", vp), ("F", vp), ("Sx", vp), ("x2", vp)] + [(k, vp) for k in (
+                    "x", "s", "z", "c", "h", "hrx", "rx", "hrz", "rz", "lmbda", "d", "di", "ds", "dz", "dx", "x1", "z1", "th", "ws3")]
+
+
 class CholInfo(ctypes.Structure):
     _fields_ = [("n", i64), ("nnz_a", i64), ("lnz", i64), ("flops", f64), ("nsuper", i64), ("lsize", i64),
                 ("nlevels", i64), ("max_front", i64), ("upd_size", i64), ("is_numeric", i64), ("minor", i64),
@@ -153,6 +160,10 @@ _SIGS = {
     "kvx_lp_second_half_dev": (ctypes.c_int, [i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f64, f64, f64, f64p]),
     "kvx_nt_reduce_multi_dev": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int32), i64p, ctypes.POINTER(vp),
                                                 ctypes.POINTER(vp), f64p]),
+    "kvx_lp_iter_residuals": (ctypes.c_int, [ctypes.POINTER(LpCtx), f64, f64p]),
+    "kvx_lp_iter_predictor": (ctypes.c_int, [ctypes.POINTER(LpCtx), f64, f64, f64p]),
+    "kvx_lp_iter_corrector": (ctypes.c_int, [ctypes.POINTER(LpCtx), f64, f64, f64, f64, f64, f64p]),
+    "kvx_lp_iter_update": (ctypes.c_int, [ctypes.POINTER(LpCtx), f64, f64, f64p]),
     "kvx_nt_max_step_dev": (ctypes.c_int, [i64, vp, f64p]),
     "kvx_vec_axpy_dev": (ctypes.c_int, [i64, f64, vp, vp]),
     "kvx_dense_gemv_dev": (ctypes.c_int, [i64, i64, i64, f64, vp, i64, vp, i64, f64, vp, i64]),

@@ -548,4 +548,72 @@ int kvx_pack_lower_dev(int64_t p, const double *K, int64_t ld, double *out)
     return KVX_OK;
 }
 
+// ---- round 4: an interior-point iteration in four calls (include/kvxhip.h, kvx_lp_ctx) ---------------------------------
+// The calls above, in the order lp.py made them, from C: no arithmetic of their own.
+static int lp_stats(const kvx_lp_ctx *L, double out[10])
+{
+    const int32_t kind[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t nn[7] = {L->n, L->n, L->ml, L->ml, L->n, L->ml, L->ml};
+    const double *xs[7] = {L->hrx, L->rx, L->hrz, L->rz, L->c, L->h, L->lmbda};
+    const double *ys[7] = {L->hrx, L->rx, L->hrz, L->rz, L->x, L->z, L->lmbda};
+    double r[7];
+    int rc = kvx_nt_reduce_multi_dev(7, kind, nn, xs, ys, r);
+    if (rc) return rc;
+    out[0] = r[0]; out[1] = r[1]; out[2] = 0.0; out[3] = 0.0; out[4] = r[2]; out[5] = r[3]; out[6] = r[4]; out[7] = 0.0; out[8] = r[5]; out[9] = r[6];
+    return KVX_OK;
+}
+
+int kvx_lp_iter_residuals(const kvx_lp_ctx *L, double tau, double out[10])
+{
+    if (!L || !out) return KVX_EINVAL;
+    int rc = kvx_lp_residuals_dev(L->ml, L->n, L->Gp, L->Gi, L->Gx, L->max_col, L->GTp, L->GTi, L->GTx, L->max_row, L->x, L->z, L->s, L->c, L->h,
+                                  tau, L->hrx, L->rx, L->hrz, L->rz);
+    if (rc) return rc;
+    return lp_stats(L, out);
+}
+
+static int lp_kkt(const kvx_lp_ctx *L, int nrhs, const kvx_kkt_side *sides, bool with_factor)
+{
+    const int64_t ld = std::max<int64_t>(1, L->n);
+    int rc;
+    if (with_factor && (rc = kvx_atda_assemble_sq_dev(L->plan, L->Gx, L->di, nullptr, L->Sx))) return rc;
+    if ((rc = kvx_kkt_solve_pre_dev(L->ml, L->n, L->Gp, L->Gi, L->Gx, L->max_col, L->di, nrhs, sides, L->x2, ld))) return rc;
+    if (with_factor) rc = kvx_chol_factorize_solve_async_dev(L->F, L->Sx, L->x2, nrhs, ld);
+    else rc = kvx_chol_solve_async_dev(L->F, 0, L->x2, nrhs, ld);
+    if (rc) return rc;
+    return kvx_kkt_solve_post_dev(L->ml, L->n, L->GTp, L->GTi, L->GTx, L->max_row, L->di, nrhs, sides, L->x2, ld);
+}
+
+int kvx_lp_iter_predictor(const kvx_lp_ctx *L, double dgi, double dtau0, double out[4])
+{
+    if (!L || !out) return KVX_EINVAL;
+    int rc = kvx_lp_newton_rhs_dev(L->ml, nullptr, nullptr, 0.0, 1.0, L->rz, L->lmbda, L->d, L->ds, L->dz);
+    if (rc) return rc;
+    // (x1, z1) := dgi * K^-1 (-c, h) and the predictor's (dx, dz) := K^-1 (rx, dz): two right-hand sides, one factorisation
+    const kvx_kkt_side sides[2] = {{L->c, -1.0, L->h, L->x1, dgi, L->z1, dgi}, {L->rx, 1.0, L->dz, L->dx, 1.0, L->dz, 1.0}};
+    if ((rc = lp_kkt(L, 2, sides, true))) return rc;
+    if ((rc = kvx_vec_xmy_dev(L->ml, 1.0, L->h, L->di, 0.0, L->th))) return rc;
+    return kvx_lp_second_half_dev(L->ml, L->n, 0, L->c, nullptr, L->th, L->x1, nullptr, L->z1, L->lmbda, L->dx, nullptr, L->dz, L->ds, L->ws3, dgi,
+                                  dtau0, -1.0, out);
+}
+
+int kvx_lp_iter_corrector(const kvx_lp_ctx *L, double shift, double scale, double dgi, double dtau0, double z1z1, double out[4])
+{
+    if (!L || !out) return KVX_EINVAL;
+    int rc = kvx_lp_newton_rhs_dev(L->ml, nullptr, L->ws3, shift, scale, L->rz, L->lmbda, L->d, L->ds, L->dz);
+    if (rc) return rc;
+    const kvx_kkt_side sides[2] = {{L->rx, scale, L->dz, L->dx, 1.0, L->dz, 1.0}, {L->rx, scale, L->dz, L->dx, 1.0, L->dz, 1.0}};
+    if ((rc = lp_kkt(L, 1, sides, false))) return rc;
+    return kvx_lp_second_half_dev(L->ml, L->n, 0, L->c, nullptr, L->th, L->x1, nullptr, L->z1, L->lmbda, L->dx, nullptr, L->dz, L->ds, nullptr, dgi,
+                                  dtau0, z1z1, out);
+}
+
+int kvx_lp_iter_update(const kvx_lp_ctx *L, double step, double tau_next, double out[10])
+{
+    if (!L || !out) return KVX_EINVAL;
+    int rc = kvx_lp_update_x_dev(L->ml, L->n, step, L->ds, L->dz, L->d, L->di, L->lmbda, L->s, L->z, L->dx, L->x);
+    if (rc) return rc;
+    return kvx_lp_iter_residuals(L, tau_next, out);
+}
+
 }  // extern "C"

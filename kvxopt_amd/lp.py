@@ -32,6 +32,9 @@ STEP = 0.99        # coneprog.py:424
 # of round 3 do the same arithmetic with the same roundings -- tests/test_kkt_gpu.py compares the two bit for bit
 _UNFUSED = os.environ.get("KVX_LP_UNFUSED", "0") not in ("", "0")
 _TRACE = os.environ.get("KVX_LP_TRACE", "0") not in ("", "0")      # per-iteration wall times of conelp on stderr
+# KVX_LP_PYCALLS=1: the fused launches of an iteration issued one by one from Python (round 3) instead of through the four calls
+# kvx_lp_iter_* (round 4: same kernels, same order, issued from C)
+_PYCALLS = os.environ.get("KVX_LP_PYCALLS", "0") not in ("", "0")
 
 
 def _sides(items):
@@ -799,6 +802,13 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     t_loop = [None]
     t_phase = [0.0, 0.0, 0.0]
     t_mark = [0.0]
+    fast = fused and not _PYCALLS and isinstance(kkt, KKTChol2Dev) and kkt.Px is None
+    if fast:
+        ctx = _lib.LpCtx(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.max_col, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row,
+                         kkt._plan, kkt.fac._h, kkt.Sx.ptr, kkt._x2buf().ptr, x.ptr, s.ptr, z.ptr, cv.ptr, hv.ptr, hrx.ptr, rx.ptr,
+                         hrz.ptr, rz.ptr, lmbda.ptr, d.ptr, di.ptr, ds.ptr, dz.ptr, dx.ptr, x1.ptr, z1.ptr, th.ptr, ws3.ptr)
+        out10 = (ctypes.c_double * 10)()
+    next_stats = None                                    # the residual statistics of the coming iteration, when the update has made them
 
     if REFINEMENT:
         # iterative refinement of the Newton systems (coneprog.py:599-631 res(), :1110-1195 f6_no_ir, :1211-1235 f6), operation by
@@ -935,7 +945,11 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
     t_loop[0] = time.perf_counter()
     for iters in range(MAXITERS + 1):
         # residuals (coneprog.py:861-896); their norms and the objectives come back in one reduction call
-        if fused:                                        # the six launches below in one
+        if fast:
+            if next_stats is None:
+                raise_for(lib().kvx_lp_iter_residuals(ctypes.byref(ctx), tau, out10))
+                next_stats = tuple(out10)
+        elif fused:                                      # the six launches below in one
             raise_for(lib().kvx_lp_residuals_dev(ml, n, Gd.cp.ptr, Gd.ri.ptr, Gd.vx.ptr, Gd.max_col, Gd.tcp.ptr, Gd.tri.ptr, Gd.tvx.ptr, Gd.max_row,
                                                  x.ptr, z.ptr, s.ptr, cv.ptr, hv.ptr, tau, hrx.ptr, rx.ptr, hrz.ptr, rz.ptr))
         else:
@@ -946,9 +960,13 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             ry.lincomb(1.0, hry, -tau, bv)
             Gd.gemv(x, hrz, trans="N"); hrz.axpy(s)
             rz.lincomb(1.0, hrz, -tau, hv)
-        (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = reduce_multi(
-            [("dot", hrx, hrx), ("dot", rx, rx), ("dot", hry, hry), ("dot", ry, ry), ("dot", hrz, hrz), ("dot", rz, rz),
-             ("dot", cv, x), ("dot", bv, y), ("dot", hv, z), ("dot", lmbda, lmbda)])
+        if fast:
+            (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = next_stats
+            next_stats = None
+        else:
+            (v_hrx, v_rx, v_hry, v_ry, v_hrz, v_rz, cx, by, hz, lam2) = reduce_multi(
+                [("dot", hrx, hrx), ("dot", rx, rx), ("dot", hry, hry), ("dot", ry, ry), ("dot", hrz, hrz), ("dot", rz, rz),
+                 ("dot", cv, x), ("dot", bv, y), ("dot", hv, z), ("dot", lmbda, lmbda)])
         t_now = time.perf_counter()
         if iters > 0:
             t_phase[2] += t_now - t_mark[0]
@@ -1018,7 +1036,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         # one two-column triangular solve with the new factor
         try:
             kkt.async_solves = True                      # enqueue only: the host runs ahead of the GPU up to the next scalar
-            if fused:
+            if fast:
+                pass                                     # (the predictor's launches go out with its second half, below: kvx_lp_iter_predictor)
+            elif fused:
                 # as below, with the vector operations around the solves inside their two launches: x1 := -c, z1 := h, the
                 # scaling of (x1, z1) by dgi, dx := (1 - sigma) rx
                 newton_rhs(0)
@@ -1043,7 +1063,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 z1.copy_from(hv)
                 newton_rhs(0)
                 ksolve2(x1, y1, z1, dx, dy, dz)
-            if fused:
+            if fast:
+                pass
+            elif fused:
                 th.xmy(1.0, hv, di)
             else:
                 x1.scal(dgi); y1.scal(dgi); z1.scal(dgi)
@@ -1091,7 +1113,23 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
                 if i == 0:
                     sigma = (1.0 - step) ** EXPON
                 continue
-            if i == 1:
+            if fast:
+                # the launches of the direction up to its scalars in ONE call (kvx_lp_iter_predictor / _corrector: what newton_rhs,
+                # factor_solve_sides / solve_sides, th.xmy and kvx_lp_second_half_dev enqueue, in that order, issued from C)
+                dkappa = -(lmbdasq_g if i == 0 else lmbdasq_g + (wkappa3 - sigma * mu)) / lmbda_g      # (newton_rhs's association)
+                dtau0 = (1.0 - sigma) * rt + dkappa / dgi
+                try:
+                    if i == 0:
+                        kkt.di = di
+                        kkt.nfactor += 1
+                        raise_for(lib().kvx_lp_iter_predictor(ctypes.byref(ctx), dgi, dtau0, out4))
+                    else:
+                        raise_for(lib().kvx_lp_iter_corrector(ctypes.byref(ctx), sigma * mu, 1.0 - sigma, dgi, dtau0, z1z1, out4))
+                except ArithmeticError:
+                    kkt.async_solves = False
+                    x.scal(1.0 / tau); y.scal(1.0 / tau); s.scal(1.0 / tau); z.scal(1.0 / tau)
+                    return result("unknown", iters, gap, relgap, pcost, dcost, pres, dres, pinfres, dinfres, msg="Terminated (singular KKT matrix).")
+            elif i == 1:
                 newton_rhs(1)
                 if fused:
                     kkt.solve_sides([(rx, 1.0 - sigma, dz, dx, 1.0, dz, 1.0)])
@@ -1100,11 +1138,12 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
             # second half of f6_no_ir (coneprog.py:1162-1195), dz += dtau z1, ds -= dz, [ws3 := ds o dz for the corrector
             # (coneprog.py:1303-1306)], the scaling by lmbda and the step bounds (coneprog.py:1314-1321): dtau is formed on the
             # device from the inner products, ONE host round trip per direction (the first one after the factorisation)
-            dkappa = -st8["dkappa"] / lmbda_g
-            dtau0 = st8["dtau"] + dkappa / dgi
-            raise_for(lib().kvx_lp_second_half_dev(ml, n, p, cv.ptr, bv.ptr if p else None, th.ptr, x1.ptr, y1.ptr if p else None,
-                                                   z1.ptr, lmbda.ptr, dx.ptr, dy.ptr if p else None, dz.ptr, ds.ptr,
-                                                   ws3.ptr if i == 0 else None, dgi, dtau0, z1z1, out4))
+            if not fast:
+                dkappa = -st8["dkappa"] / lmbda_g
+                dtau0 = st8["dtau"] + dkappa / dgi
+                raise_for(lib().kvx_lp_second_half_dev(ml, n, p, cv.ptr, bv.ptr if p else None, th.ptr, x1.ptr, y1.ptr if p else None,
+                                                       z1.ptr, lmbda.ptr, dx.ptr, dy.ptr if p else None, dz.ptr, ds.ptr,
+                                                       ws3.ptr if i == 0 else None, dgi, dtau0, z1z1, out4))
             dtau, z1z1, ts, tz = out4[0], out4[1], out4[2], out4[3]
             t_now = time.perf_counter()
             t_phase[i] += t_now - t_mark[0]
@@ -1134,7 +1173,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
 
         # update (coneprog.py:1336-1436)
         # scaled iterates, NT scaling update and unscaled s, z (coneprog.py:1343-1432, misc.py:444-464): one fused kernel
-        if fused:
+        if fast:
+            pass                                         # (with the residuals of the next iteration, below)
+        elif fused:
             raise_for(lib().kvx_lp_update_x_dev(ml, n, step, ds.ptr, dz.ptr, d.ptr, di.ptr, lmbda.ptr, s.ptr, z.ptr, dx.ptr, x.ptr))
         else:
             x.axpy(dx, step)
@@ -1144,6 +1185,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, options=None, chol_opts=None, pri
         dgi = 1.0 / dg
         lmbda_g *= math.sqrt(1.0 - step * tt) * math.sqrt(1.0 - step * tk)
         kappa, tau = lmbda_g / dgi, lmbda_g * dgi
+        if fast:
+            # the update, the residuals of the next iteration (with the new tau) and their reductions in ONE call
+            raise_for(lib().kvx_lp_iter_update(ctypes.byref(ctx), step, tau, out10))
+            next_stats = tuple(out10)
     raise AssertionError("unreachable")
 
 

@@ -1084,12 +1084,14 @@ def test_fused_iteration_is_bitwise():
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ipm_bits_probe.py")
     outs = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, KVX_LP_UNFUSED=flag)
+    # ... and round 4 issues the fused launches of an iteration from C in four calls (kvx_lp_iter_*): the third arm is the round-3
+    # form, one ctypes call per launch (KVX_LP_PYCALLS=1)
+    for flags in ({"KVX_LP_UNFUSED": "0"}, {"KVX_LP_UNFUSED": "1"}, {"KVX_LP_UNFUSED": "0", "KVX_LP_PYCALLS": "1"}):
+        env = dict(os.environ, **flags)
         r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] and outs[0] == outs[2]
     assert all(v["status"] == "optimal" for v in outs[0].values())
 
 
