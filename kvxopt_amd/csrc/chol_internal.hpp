@@ -154,7 +154,7 @@ struct kvx_chol {
     std::vector<hipEvent_t> ev_u;                  // per block of a level's chain: its panels are solved (the deferred updates' stream waits)
     hipEvent_t ev_ujoin = nullptr;
     int last_fused_path = 0;                       // kvx_chol_last_fused_path
-    int u_block = 256;                             // pivot columns per pass of the deferred update (KVX_U_BLOCK)
+    int u_block = 384;                             // pivot columns per pass of the deferred update (KVX_U_BLOCK)
     int32_t *d_flists = nullptr;
     std::vector<int64_t> linv_off_host;        // per front: offset of its inverted diagonal blocks in d_Linv (-1: not a big front)
     uint8_t *d_keep = nullptr;                 // per permuted column: 1 = this rank reports the entry of x
