@@ -68,6 +68,8 @@ int  kvx_current_device(void);          /* the calling thread's current HIP devi
 int  kvx_set_device(int dev);           /* make `dev` the calling thread's current HIP device (a rank process of the sharded mode
                                          * picks its GPU with this before anything else touches HIP) */
 const char *kvx_last_error(void);       /* text of the last error on this thread               */
+int  kvx_graph_instantiate_failures(void); /* launch graphs whose instantiation (on a thread of the library) failed since the process
+                                         * started: those handles run their launches eagerly -- correct, slower */
 
 /* ---- sparse Cholesky: replaces kvxopt.cholmod ------------------------------------------ */
 

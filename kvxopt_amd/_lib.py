@@ -77,6 +77,7 @@ _SIGS = {
     "kvx_device_count": (ctypes.c_int, []),
     "kvx_current_device": (ctypes.c_int, []),
     "kvx_set_device": (ctypes.c_int, [ctypes.c_int]),
+    "kvx_graph_instantiate_failures": (ctypes.c_int, []),
     "kvx_last_error": (ctypes.c_char_p, []),
     "kvx_chol_default_opts": (None, [ctypes.POINTER(CholOpts)]),
     "kvx_chol_analyze": (ctypes.c_int, [i64, i64p, i64p, ctypes.c_int, i64p, ctypes.POINTER(CholOpts), ctypes.POINTER(vp)]),

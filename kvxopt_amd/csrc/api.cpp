@@ -11,11 +11,38 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <vector>
 
 using namespace kvx;
 
 static thread_local std::string g_err;
+
+// ---- launch-graph instantiations in flight (chol_internal.hpp, LazyExec) ------------------------------------------------
+namespace {
+struct LazyRegistry {
+    std::mutex mu;
+    std::vector<std::shared_future<hipGraphExec_t>> futs;
+    ~LazyRegistry()                                  // static destruction = process exit: nothing of HIP may run behind this point
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &f : futs)
+            if (f.valid()) f.wait();
+    }
+};
+LazyRegistry &lazy_registry() { static LazyRegistry R; return R; }
+}  // namespace
+std::atomic<int> &lazy_exec_failures() { static std::atomic<int> n{0}; return n; }
+void lazy_exec_track(const std::shared_future<hipGraphExec_t> &f)
+{
+    LazyRegistry &R = lazy_registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    // finished ones go; the list stays as short as the number of instantiations in flight
+    R.futs.erase(std::remove_if(R.futs.begin(), R.futs.end(), [](const std::shared_future<hipGraphExec_t> &g) {
+                     return !g.valid() || g.wait_for(std::chrono::seconds(0)) == std::future_status::ready; }), R.futs.end());
+    R.futs.push_back(f);
+}
+extern "C" int kvx_graph_instantiate_failures(void) { return lazy_exec_failures().load(); }
 namespace kvx { void set_last_error(const std::string &s) { g_err = s; } }   // (also used by lu_api.cpp, dist_api.cpp)
 
 

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <future>
 #include <string>
 #include <vector>
@@ -30,6 +31,11 @@ using namespace kvx;
 // under ROCm 7.2's runtime (1-2 ms under 7.0.51831) -- as much as a dozen replays save -- while the capture itself is ~1 ms.  The
 // calls that arrive before the executable is ready run their launches eagerly, as the first call does; results do not depend on
 // which way a call ran.  KVX_GRAPH_SYNC_INSTANTIATE=1: instantiate in the calling thread (as before).
+// instantiations in flight are joined before the HIP runtime is torn down at exit (a cached handle -- cholmod._SYMBOLIC_CACHE,
+// lp._KKT_CACHE -- may still be alive then); failures are counted (round-3 advisor finding)
+std::atomic<int> &lazy_exec_failures();
+void lazy_exec_track(const std::shared_future<hipGraphExec_t> &f);
+
 struct LazyExec {
     hipGraphExec_t exec = nullptr;
     std::shared_future<hipGraphExec_t> fut;
@@ -48,7 +54,11 @@ struct LazyExec {
         auto work = [graph, dev]() -> hipGraphExec_t {
             (void)hipSetDevice(dev);
             hipGraphExec_t e = nullptr;
-            if (hipGraphInstantiate(&e, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+            if (hipGraphInstantiate(&e, graph, nullptr, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                e = nullptr;
+                lazy_exec_failures()++;              // (the handle then runs eagerly for good: kvx_graph_instantiate_failures says so)
+            }
             (void)hipGraphDestroy(graph);
             return e;
         };
@@ -59,6 +69,7 @@ struct LazyExec {
         if (sy && sy[0] == '1') { exec = work(); return; }
         fut = std::async(std::launch::async, work).share();
         pending = true;
+        lazy_exec_track(fut);                        // joined at process exit if the handle is still alive then (api.cpp)
     }
     void drop()
     {

@@ -1900,9 +1900,21 @@ void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
                     double *WK, int64_t ldw, const double *Wchild, double *Wout, int64_t wstride, int level_count)
 {
     if (count <= 0 || nrhs <= 0) return;
+    // 64-row workgroups while the launch stays within ~two workgroups per CU (KVX_FWD_NARROW_WGS, 0 = never), 256-row ones beyond
+    static const int narrow_wgs = [] { const char *e = getenv("KVX_FWD_NARROW_WGS"); return e ? atoi(e) : 512; }();
     if (nrhs >= KVX_BIG_MR_FROM) {
         for (int jb = 0; jb < max_k; jb += SB) {
             int rows = max_m - jb - 1;
+            // The rhs-blocked kernels add a row's partial sums in the association of the 256-row form.  Where the single-rhs sweep
+            // of this level takes 64-row workgroups (sixteen partials added in sequence) they would give a column other bits than
+            // a solve with fewer right-hand sides does: those steps -- the top of the tree, a handful of fronts -- go to the
+            // single-rhs kernel, one grid layer per right-hand side (round-3 advisor finding; test_solution_bits_do_not_depend_on_nrhs).
+            if ((int64_t)std::max(1, (rows + 63) / 64) * std::max(level_count, count) <= narrow_wgs) {
+                dim3 grid((unsigned)std::max(1, (rows + 63) / 64), (unsigned)count, (unsigned)nrhs);
+                if (jb == 0) hipLaunchKernelGGL((k_fwd_big_step<true, 64>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+                else hipLaunchKernelGGL((k_fwd_big_step<false, 64>), grid, dim3(SOLVE_NT), 0, st, ds, list, jb, Lx, Linv, X, X0, ldx, WK, ldw, Wchild, Wout, wstride);
+                continue;
+            }
             const unsigned gz = (unsigned)((nrhs + KVX_BIG_RB - 1) / KVX_BIG_RB);
             // (blocks of 1 for the diagonal launch -- more, shorter workgroups -- were measured and lost: 18.5 -> 20.4 ms at 64 rhs,
             // n = 1e6: a 1024-thread workgroup per front and right-hand side is the cost, not the length of its chain)
@@ -1917,8 +1929,6 @@ void launch_fwd_big(hipStream_t st, const DevSym &ds, const int32_t *list, int c
         }
         return;
     }
-    // 64-row workgroups while the launch stays within ~two workgroups per CU (KVX_FWD_NARROW_WGS, 0 = never), 256-row ones beyond
-    static const int narrow_wgs = [] { const char *e = getenv("KVX_FWD_NARROW_WGS"); return e ? atoi(e) : 512; }();
     for (int jb = 0; jb < max_k; jb += SB) {
         int rows = max_m - jb - 1;
         // (a function of the LEVEL -- its big fronts, all of them -- not of this launch: a sweep over a part of the level (spsolve's

@@ -383,7 +383,12 @@ __global__ __launch_bounds__(128) void k_fwd_lds(DevSym ds, const int32_t *__res
     const double *wc = Wc + (int64_t)rh * wstride;
     double *wo = Wo + (int64_t)rh * wstride + fd.wx;
     // strictly below the diagonal only: with a[j] = 0 for r <= j a step is one unconditional fma per lane (a lane above the pivot
-    // adds zero), and the finished y_r = w_r / d_r is formed once, after the sweep -- no select in the dependent chain
+    // adds zero), and the finished y_r = w_r / d_r is formed once, after the sweep -- no select in the dependent chain.
+    // FINITE DATA ASSUMED: 0 * y_j is 0 only for a finite y_j -- an Inf / NaN in one component of a front's part of y reaches all
+    // of its rows (the select form left the rows above j alone).  A valid factor and a finite right-hand side give finite y; the
+    // enqueue-only entry points (kvx_chol_*_async_dev) may run these sweeps through a FAILED factor before its status is read:
+    // what they leave in X is then garbage as a whole, never partly valid (kvx_chol_status / the next synchronising call
+    // reports KVX_ENOTPOSDEF, and the host layer discards X: lp.py checks the status before it uses a direction).
     double a[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; j++) a[j] = kvx_ld0(P, r + (int64_t)j * m, j < k && r < m && r > j);

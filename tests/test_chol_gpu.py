@@ -909,3 +909,27 @@ def test_two_enqueue_form_reports_like_the_one_enqueue_form(mode):
     assert out["equal"]
     assert out["paths"] == [2, 2, 2], out                   # the fall-back was taken (on the 7.2 runtime without KVX_NO_GRAPH: [1, 1, 1])
     assert out["minor_fused"] == out["minor_numeric"] and out["minor_linsolve"] == out["minor_numeric"], out
+
+
+@pytest.mark.gpu
+def test_solution_bits_do_not_depend_on_nrhs(monkeypatch):
+    """With the rhs-major path off (KVX_WIDE_FROM=0: the column-major kernels at any count), a right-hand side solved alone and
+    as one of 64 has the same bits: the rhs-blocked big-front steps keep to the row association of the single-rhs sweep, also on
+    the levels where that sweep takes 64-row workgroups (round-3 advisor finding).  150 x 140 grid: big fronts on several levels,
+    narrow ones at the top."""
+    monkeypatch.setenv("KVX_WIDE_FROM", "0")
+    n, cp, ri, v = workloads.laplacian_2d(150, 140)
+    F = Factor(n, cp, ri)
+    F.factorize(v)
+    rng = np.random.default_rng(64)
+    B = np.asfortranarray(rng.standard_normal((n, 64)))
+    X64 = B.copy(order="F")
+    F.solve(X64.reshape(-1, order="F"), 0, 64, n)
+    X64 = X64 if X64.flags.f_contiguous else np.asfortranarray(X64)
+    for j in (0, 17, 63):
+        x1 = B[:, j].copy()
+        F.solve(x1, 0, 1, n)
+        assert np.array_equal(x1, X64[:, j]), j
+    X3 = np.asfortranarray(B[:, :3].copy())
+    F.solve(X3.reshape(-1, order="F"), 0, 3, n)
+    assert np.array_equal(X3, X64[:, :3])
