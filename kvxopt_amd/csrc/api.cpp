@@ -1213,7 +1213,10 @@ int factor_solve_dev(kvx_chol *F, const double *values_dev, double *B, int64_t n
         const char *e = getenv("KVX_DBG_FUSED_ANY_RUNTIME");          // debugging only: reproduces the crash of DESIGN.md section 5
         return v < 70200000 && !(e && e[0] == '1');
     }();
-    const bool plain = F->dist_nranks != 1 || !F->is_ll || nrhs == 0 || nrhs > 16 || n == 0 || F->prof_family >= 0 || F->factor_subtrees ||
+    // (KVX_FACTOR_SUBTREES=1 keeps the pipelined form since round 4 -- the subtree launches precede the level loop on the factor's
+    //  stream, so a level's completion event covers them: config 4b's first direction 1.41 -> 1.29 ms, still behind the level
+    //  schedule's 1.20-1.26; KVX_SUBTREES_PLAIN=1: two enqueues as before)
+    const bool plain = F->dist_nranks != 1 || !F->is_ll || nrhs == 0 || nrhs > 16 || n == 0 || F->prof_family >= 0 || (F->factor_subtrees && getenv("KVX_SUBTREES_PLAIN")) ||
                        old_runtime || !F->use_graph;
     if ((rc = wait_for_caller(F))) return rc;
     if (S.nnzA > 0) HIPCHK(hipMemcpyAsync(F->d_Ax, values_dev, S.nnzA * sizeof(double), hipMemcpyDeviceToDevice, F->stream));
