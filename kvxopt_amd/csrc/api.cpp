@@ -101,7 +101,11 @@ void analyze_subtrees(kvx_chol *F)
     const int64_t ns = S.nsuper;
     std::vector<int32_t> cnt((size_t)ns, 1), minidx((size_t)ns);
     std::vector<uint8_t> ok((size_t)ns, 0);
-    int maxf = 12;     // fronts per subtree: longer walks serialise more fronts in one wavefront, shorter ones leave more to the level loop (flat optimum 8..16)
+    // fronts per subtree: longer walks serialise more fronts in one wavefront, shorter ones leave more to the level loop (flat
+    // optimum 8..16 on the 1e6-unknown systems).  Round 4: a small system has a few hundred subtrees on an idle machine and its
+    // sweeps are chains of dependent launches -- a walk of 12 fronts is then the longest link (41 / 56 us of config 4b's 440 us
+    // solve); with 4 fronts per walk the loop of config 4b runs at 587-599 it/s against 548-575 (2: 560-598, 3: 513-601, 5: 557-588).
+    int maxf = S.n <= 150000 ? 4 : 12;
     { const char *e = getenv("KVX_SUB_MAXF"); if (e) maxf = std::max(1, std::min(atoi(e), KVX_SUB_MAXF)); }
     F->in_sub.assign((size_t)ns, 0);
     F->subs_host.clear();
