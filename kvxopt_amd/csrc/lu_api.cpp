@@ -241,6 +241,18 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     }
     HIPCHK(hipEventRecord(N->ev0, N->st));
     HIPCHK(hipStreamWaitEvent(N->st2, N->ev0, 0));
+    if (std::getenv("KVX_LU_DUMP_PLAN")) {                        // per level: fronts, LDS-resident, largest m / k / child count, children of the level
+        for (int32_t l = P.nlevels - 1; l >= 0; l--) {
+            int mm = 0, mk = 0, mc = 0; int64_t nc = 0, mku = 0;
+            for (int64_t q = P.levelptr[l]; q < P.levelptr[l + 1]; q++) {
+                const LuFrontH &f = P.fr[P.levellist[q]];
+                mm = std::max(mm, f.m); mk = std::max(mk, f.k); mc = std::max(mc, f.nchild); nc += f.nchild;
+                mku = std::max<int64_t>(mku, (int64_t)f.k * f.m);
+            }
+            fprintf(stderr, "  lu level %2d: %6lld fronts (%lld in LDS)  max m %4d  max k %4d  max children %3d  children %lld  max k*m %lld\n", (int)l,
+                    (long long)(P.levelptr[l + 1] - P.levelptr[l]), (long long)P.nlds[l], mm, mk, mc, (long long)nc, (long long)mku);
+        }
+    }
     int32_t lastA = -1, lastB = -1;                            // deepest-so-far levels with work recorded on st / st2
     for (int32_t l = P.nlevels - 1; l >= 0; l--) {
         const int64_t b = P.levelptr[l], e = P.levelptr[l + 1], nl = P.nlds[l];

@@ -376,6 +376,516 @@ __global__ __launch_bounds__(256, 1) void k_lu_front_tiled(const LuDev d, const 
         for (int i = tx; i < u; i += 64) Uo[i + (int64_t)j * u] = Fm[(k + i) + (int64_t)(k + j) * ld];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Round 4: blocked elimination of an LDS-resident front, the pivot panels factored by ONE wavefront.
+// k_lu_front_tiled pays two workgroup barriers and three LDS round trips per pivot (rocprofv3, ACTIVSg2000: 1.3 us per pivot on a
+// leaf level of k <= 28, 2.5 us on the 106-pivot root -- 260 of the refactorisation's 720 us).  Here the pivot columns go in
+// panels of 32: wave 0 holds the panel in registers (lane = physical row, two rows per lane from order 65 on) and runs its
+// pivot steps without a barrier; then every thread solves one column of U12 against the panel's unit triangle (staged in LDS,
+// broadcast reads), and the 16 x 16 thread grid applies the rank-32 update to the columns right of the panel from register
+// tiles: three barriers per 32 pivots.
+// Rows never move: `slot` (logical position under the LAPACK-style interchange sequence, the same record k_lu_front_tiled and
+// the blocked HBM path keep in ipiv) and `prow` (physical row of every pivot) live in LDS; the store reads through them.  A
+// refactorisation (reuse: klu.c:296-308, the recorded pivot sequence) knows both before it starts -- lperm of the previous
+// factorisation IS prow -- so its pivot steps carry no search, no ballot and no relabelling at all.
+// The front has one row more than its order, kept zero (the lanes past the last row read it), and an odd leading dimension
+// (the column-per-lane accesses of the U12 solve hit distinct banks).
+// What the steps cost (MI355X, phase counters of a development build): the steps are bound by instruction issue of the one
+// wave, and v_readlane_b32 is ~12 cycles apiece -- broadcasting the pivot row's 31 remaining entries by 62 of them made a
+// step 1270 cycles.  The owner lane now writes its row to LDS (b128) and every lane reads it back as a broadcast.
+constexpr int LU_PB = 32;
+#ifdef KVX_LU_PHASE
+__device__ unsigned long long g_lu_phase[16];
+#define LU_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_lu_phase[i], t_ - lu_t_); lu_t_ = t_; } } while (0)
+#define LU_TPARAM , unsigned long long &lu_t_
+#define LU_TARG , lu_t_
+#else
+#define LU_STAMP(i) do { } while (0)
+#define LU_TPARAM
+#define LU_TARG
+#endif
+
+// lanes of one wavefront exchanging data through LDS: the hardware runs a wave's LDS operations in order, the compiler has to be
+// told that another lane's store is visible to this lane's load (it forwarded the lane's own stored value otherwise)
+__device__ __forceinline__ void wp_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wp_max_f64(double v)
+{
+    v = row16_max_f64(v);
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
+__device__ __forceinline__ int wp_min_i32(int v)
+{
+    v = row16_min_i32(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+struct WpCtx {
+    int j0, nb, k, lane;
+    int pivreg;                    // lane jj: reuse -- physical row of pivot j0 + jj
+    int32_t *sh_piv, *sh_prow;
+    int32_t *fail_slot;
+    double *bc;                    // 32 doubles of LDS: the pivot row on its way to the other lanes
+    double tol, lmax;
+};
+
+// Pivot step jj of the panel (pivot j = j0 + jj).  The panel lives in a WINDOW of W register columns per row: a[r][Q] is the
+// step's pivot column, a[r][c], c > Q, the columns right of it (lane's physical rows lane + 64 r).
+template <int R, int W, int Q, bool REUSE>
+__device__ __forceinline__ void wp_step(double (&a)[R][W], int (&slot)[R], WpCtx &x, const int jj)
+{
+    if (jj >= x.nb) return;                                       // uniform
+    const int j = x.j0 + jj;
+    int rl, rh;                                                   // lane and register row of the pivot row (uniform)
+    if (REUSE) {
+        const int pr = __builtin_amdgcn_readlane(x.pivreg, jj);
+        rl = pr & 63; rh = pr >> 6;
+    } else {
+        // KLU's rule (see lu_factor_front): the diagonal if |d| >= tol * max|candidates|, else the largest candidate (the smallest
+        // logical position among equals); candidates are the rows of the pivot block not used yet
+        double bmax = -1.0, dabs = -1.0;
+        int bslot = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const double av = fabs(a[r][Q]);
+            const bool cand = x.lane + 64 * r < x.k && slot[r] >= j;
+            if (cand && (av > bmax || (av == bmax && slot[r] < bslot))) { bmax = av; bslot = slot[r]; }
+            if (slot[r] == j) dabs = av;
+        }
+        const double gmax = wp_max_f64(bmax);
+        const int gslot = wp_min_i32(bmax == gmax ? bslot : 0x7fffffff);
+        const double gd = wp_max_f64(dabs);                       // (one lane holds the row at position j; NaN compares false below)
+        const int want = (gd > 0.0 && gd >= x.tol * gmax) ? j : (gslot != 0x7fffffff ? gslot : j);
+        // the lane and register row of `want`, and of the row at position j; interchange = relabel
+        const unsigned long long w0 = __ballot(slot[0] == want), w1 = R == 2 ? __ballot(slot[R - 1] == want) : 0ull;
+        const unsigned long long q0 = __ballot(slot[0] == j), q1 = R == 2 ? __ballot(slot[R - 1] == j) : 0ull;
+        rh = w0 ? 0 : 1;
+        const int qh = q0 ? 0 : 1;
+        rl = __builtin_amdgcn_readfirstlane(__ffsll((long long)(w0 ? w0 : w1)) - 1);
+        const int ql = __builtin_amdgcn_readfirstlane(__ffsll((long long)(q0 ? q0 : q1)) - 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (x.lane == rl && r == rh) slot[r] = j;
+            else if (x.lane == ql && r == qh) slot[r] = want;
+        }
+        if (x.lane == 0) { x.sh_piv[j] = want - j; x.sh_prow[j] = rl + 64 * rh; }
+    }
+#ifndef WP_BCAST_READLANE
+    wp_wave_sync();                                               // (the previous step's reads are done)
+    if (x.lane == rl) {                                           // the pivot row, columns right of the pivot, on its way to everybody
+#pragma unroll
+        for (int c = Q + 1; c < W; c++) x.bc[c] = R == 2 && rh ? a[R - 1][c] : a[0][c];
+    }
+    wp_wave_sync();
+#endif
+    double pv = readlane_d(R == 2 && rh ? a[R - 1][Q] : a[0][Q], rl);
+    const double ap = fabs(pv);
+    const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);            // uniform
+    if (bad) {
+        if (x.lane == 0 && *x.fail_slot == 0) *x.fail_slot = j + 1;
+        pv = 1.0;                                                 // keep going with finite numbers; the result is discarded
+    }
+    double l[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const bool on = slot[r] > j;                              // rows not used yet (pivot block and update rows)
+        const double q = a[r][Q] / pv;
+        l[r] = on ? q : 0.0;
+        a[r][Q] = on ? q : a[r][Q];
+        x.lmax = fmax(x.lmax, fabs(l[r]));
+    }
+#pragma unroll
+    for (int c = Q + 1; c < W; c++) {
+#ifdef WP_BCAST_READLANE
+        const double uc = readlane_d(R == 2 && rh ? a[R - 1][c] : a[0][c], rl);
+#else
+        const double uc = x.bc[c];
+#endif
+#pragma unroll
+        for (int r = 0; r < R; r++) a[r][c] -= l[r] * uc;
+    }
+}
+
+// Four pivot steps per round on the window, then the four finished columns go out to the front and the window moves on.
+template <int R, int W, bool REUSE>
+__device__ __forceinline__ void wp_window(double (&a)[R][W], int (&slot)[R], const bool (&mine)[R], WpCtx &x, int &jj, const int stop,
+                                          double *Fm, const int ld)
+{
+    while (x.nb - jj > stop) {
+        wp_step<R, W, 0, REUSE>(a, slot, x, jj);
+        wp_step<R, W, 1, REUSE>(a, slot, x, jj + 1);
+        wp_step<R, W, 2, REUSE>(a, slot, x, jj + 2);
+        wp_step<R, W, 3, REUSE>(a, slot, x, jj + 3);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (mine[r]) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (jj + q < x.nb) Fm[x.lane + 64 * r + (x.j0 + jj + q) * ld] = a[r][q];
+            }
+#pragma unroll
+            for (int c = 0; c < W - 4; c++) a[r][c] = a[r][c + 4];
+#pragma unroll
+            for (int c = W - 4; c < W; c++) a[r][c] = 0.0;
+        }
+        jj += 4;
+    }
+}
+// (columns past the panel: whatever the front holds there -- they are updated along and never written back)
+template <int R, int W>
+__device__ __forceinline__ void wp_window_load(double (&a)[R][W], const double *Fm, const int ld, const int m, const WpCtx &x, const int jj)
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = min(x.lane + 64 * r, m);                    // row m: zeros
+#pragma unroll
+        for (int c = 0; c < W; c++) a[r][c] = Fm[i + min(x.j0 + jj + c, m - 1) * ld];
+    }
+}
+
+// the panel of the nb <= 32 pivot columns from j0 on: wave 0; windows of 32, 16 and 8 columns as the panel shrinks
+template <int R, bool REUSE>
+__device__ __forceinline__ void wp_panel(double *Fm, const int ld, const int m, WpCtx &x, int32_t *sh_slot, double *L11)
+{
+    const int lane = x.lane, nb = x.nb, j0 = x.j0;
+    int slot[R];
+    bool mine[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = lane + 64 * r;
+        slot[r] = i < m ? sh_slot[i] : 0x3fffffff;
+        mine[r] = i < m && slot[r] >= j0;                         // rows used by earlier panels hold finished entries of U
+    }
+    x.pivreg = (REUSE && lane < nb) ? x.sh_prow[j0 + lane] : 0;
+    int jj = 0;
+    double a16[R][16], a8[R][8];
+    if (nb > 16) {
+        double a32[R][32];
+        wp_window_load<R, 32>(a32, Fm, ld, m, x, 0);
+        wp_window<R, 32, REUSE>(a32, slot, mine, x, jj, 16, Fm, ld);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < 16; c++) a16[r][c] = a32[r][c];
+    } else if (nb > 8) wp_window_load<R, 16>(a16, Fm, ld, m, x, 0);
+    if (nb > 8) {
+        wp_window<R, 16, REUSE>(a16, slot, mine, x, jj, 8, Fm, ld);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) a8[r][c] = a16[r][c];
+    } else wp_window_load<R, 8>(a8, Fm, ld, m, x, 0);
+    wp_window<R, 8, REUSE>(a8, slot, mine, x, jj, 0, Fm, ld);
+    // the new logical positions, and the rows of the pivot block in logical order for the solve that follows
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = lane + 64 * r;
+        if (mine[r]) {
+            if (!REUSE) sh_slot[i] = slot[r];
+            if (slot[r] < j0 + nb) {
+                double *Lr = L11 + (slot[r] - j0);
+                const double *Fr = Fm + i;
+                for (int c0 = 0; c0 < nb; c0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) v[t] = Fr[min(j0 + c0 + t, m - 1) * ld];     // (past the panel: columns of the front, unused entries of L11)
+#pragma unroll
+                    for (int t = 0; t < 8; t++) Lr[(c0 + t) * LU_PB] = v[t];
+                }
+            }
+        }
+    }
+}
+
+// U12 = L11^-1 A12 for column c of the front (one thread), rows = the panel's pivot rows in order, by the same moving window
+template <int W>
+__device__ __forceinline__ void wp_solve_window(double (&xv)[W], int &jb, const int stop, double *Fm, const int ld, const int c, const int j0,
+                                                const int nb, const int32_t *sh_prow, const double *L11)
+{
+    while (nb - jb > stop) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (jb + q < nb) {                                    // uniform
+                const double xq = xv[q];
+                const double *Lc = L11 + (jb + q) * LU_PB + jb;
+#pragma unroll
+                for (int j2 = q + 1; j2 < W; j2++) xv[j2] -= Lc[j2] * xq;
+                Fm[sh_prow[j0 + jb + q] + c * ld] = xq;
+            }
+#pragma unroll
+        for (int t = 0; t < W - 4; t++) xv[t] = xv[t + 4];
+#pragma unroll
+        for (int t = W - 4; t < W; t++) xv[t] = 0.0;
+        jb += 4;
+    }
+}
+template <int W>
+__device__ __forceinline__ void wp_solve_load(double (&xv)[W], const double *Fm, const int ld, const int c, const int j0, const int nb,
+                                              const int32_t *sh_prow)
+{
+#pragma unroll
+    for (int t = 0; t < W; t++) {
+        const double v = Fm[sh_prow[j0 + min(t, nb - 1)] + c * ld];
+        xv[t] = t < nb ? v : 0.0;
+    }
+}
+__device__ __forceinline__ void wp_solve(double *Fm, const int ld, const int c, const int j0, const int nb, const int32_t *sh_prow, const double *L11)
+{
+    int jb = 0;
+    double x16[16], x8[8];
+    if (nb > 16) {
+        double x32[32];
+        wp_solve_load<32>(x32, Fm, ld, c, j0, nb, sh_prow);
+        wp_solve_window<32>(x32, jb, 16, Fm, ld, c, j0, nb, sh_prow, L11);
+#pragma unroll
+        for (int t = 0; t < 16; t++) x16[t] = x32[t];
+    } else if (nb > 8) wp_solve_load<16>(x16, Fm, ld, c, j0, nb, sh_prow);
+    if (nb > 8) {
+        wp_solve_window<16>(x16, jb, 8, Fm, ld, c, j0, nb, sh_prow, L11);
+#pragma unroll
+        for (int t = 0; t < 8; t++) x8[t] = x16[t];
+    } else wp_solve_load<8>(x8, Fm, ld, c, j0, nb, sh_prow);
+    wp_solve_window<8>(x8, jb, 0, Fm, ld, c, j0, nb, sh_prow, L11);
+}
+
+// Assemble an LDS front of leading dimension ld (m + 1 rows): zero, A's entries (a_dst encodes r + c m), then the children's
+// update matrices.  A child costs three dependent trips to memory (its record, its relative indices, its update matrix:
+// ~1.6 us measured) and a front of a power-grid matrix has up to 28 children, so: the records of up to 32 children are fetched
+// together, then their index lists (into LDS), and the columns of the update matrices go in batches of 16 loads in flight per
+// wavefront.  Wave w owns the target columns c with c % 4 == w and walks the children in their order: a target entry
+// receives its contributions in the order of lu_assemble_front whatever the waves' pace (reproducible sums), and no barrier
+// stands between two children.
+constexpr int WP_CH = 32, WP_REL = 2048, WP_Q = 16;
+struct WpAsmLds {
+    int64_t ch_off[WP_CH], ch_relptr[WP_CH];
+    int32_t ch_uc[WP_CH], ch_ldc[WP_CH], ch_rel[WP_CH];
+    int32_t rel[WP_REL];
+    int64_t q_src[4][WP_Q];
+    int32_t q_rel[4][WP_Q], q_dst[4][WP_Q], q_n[4][WP_Q];
+    int32_t cnt;
+};
+
+__device__ __forceinline__ void wp_run_batch(const LuDev &d, WpAsmLds &S, double *Fm, const int w, const int lane, const int n)
+{
+    double v[WP_Q];
+#pragma unroll
+    for (int t = 0; t < WP_Q; t++) v[t] = (t < n && lane < S.q_n[w][t]) ? d.arena[S.q_src[w][t] + lane] : 0.0;
+#pragma unroll
+    for (int t = 0; t < WP_Q; t++)
+        if (t < n && lane < S.q_n[w][t]) Fm[S.rel[S.q_rel[w][t] + lane] + S.q_dst[w][t]] += v[t];
+}
+
+__device__ __forceinline__ void wp_assemble(const LuDev &d, const LuFrontD &F, double *Fm, const int ld, const double *__restrict__ Ax,
+                                            WpAsmLds &S LU_TPARAM)
+{
+    const int tid = threadIdx.x, m = F.m;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int idx = tid; idx < m * ld; idx += 256) Fm[idx] = 0.0;
+    __syncthreads();
+    for (int e = tid; e < F.acnt; e += 256) {                    // every entry has its own slot
+        const int64_t src = d.a_src[F.aptr + e];
+        const int dst = d.a_dst[F.aptr + e];
+        const int c = dst / m;
+        Fm[(dst - c * m) + c * ld] += Ax[src] * d.rinv[d.ai32[src]];
+    }
+    LU_STAMP(5);
+    for (int c0 = 0; c0 < F.nchild;) {
+        const int nc = min(WP_CH, F.nchild - c0);
+        __syncthreads();                                          // (the tables of the previous chunk are no longer read; A's entries are in)
+        if (tid < nc) {
+            const LuFrontD C = d.fr[d.children[F.childptr + c0 + tid]];
+            S.ch_uc[tid] = C.m - C.k; S.ch_ldc[tid] = C.upd_ld; S.ch_off[tid] = C.upd_off; S.ch_relptr[tid] = C.rowptr + C.k;
+        }
+        __syncthreads();
+        if (tid == 0) {                                           // as many children as the index table holds (a child has <= 112 rows)
+            int off = 0, n = 0;
+            while (n < nc && off + S.ch_uc[n] <= WP_REL) { S.ch_rel[n] = off; off += S.ch_uc[n]; n++; }
+            S.cnt = n;
+        }
+        __syncthreads();
+        const int n = S.cnt;
+        for (int c = w; c < n; c += 4) {
+            const int uc = S.ch_uc[c];
+            const int32_t *__restrict__ relc = d.rel + S.ch_relptr[c];
+            for (int i = lane; i < uc; i += 64) S.rel[S.ch_rel[c] + i] = relc[i];
+        }
+        __syncthreads();
+        int nq = 0;
+        for (int c = 0; c < n; c++) {
+            const int uc = S.ch_uc[c], ldc = S.ch_ldc[c], ro = S.ch_rel[c];
+            const int64_t off = S.ch_off[c];
+            for (int base = 0; base < uc; base += 64) {
+                const int tj = base + lane < uc ? S.rel[ro + base + lane] : -1;
+                unsigned long long mask = __ballot(tj >= 0 && (tj & 3) == w);
+                while (mask) {
+                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                    mask &= mask - 1;
+                    const int tjv = __builtin_amdgcn_readlane(tj, b);
+                    for (int half = 0; half < uc; half += 64) {
+                        if (lane == 0) {
+                            S.q_src[w][nq] = off + (int64_t)(base + b) * ldc + half;
+                            S.q_rel[w][nq] = ro + half;
+                            S.q_dst[w][nq] = tjv * ld;
+                            S.q_n[w][nq] = min(64, uc - half);
+                        }
+                        if (++nq == WP_Q) { wp_wave_sync(); wp_run_batch(d, S, Fm, w, lane, WP_Q); wp_wave_sync(); nq = 0; }
+                    }
+                }
+            }
+        }
+        if (nq) { wp_wave_sync(); wp_run_batch(d, S, Fm, w, lane, nq); wp_wave_sync(); }
+        c0 += n;
+    }
+    __syncthreads();
+}
+
+// LDS of a workgroup: the front, 16 T rows x (16 T + 2) (every tile access of the update stays inside it whatever m), one dump slot
+constexpr size_t wp_lds_bytes(int T) { return ((size_t)(16 * T) * (16 * T + 2) + 2) * sizeof(double); }
+
+template <int T>
+__global__ __launch_bounds__(256, (T <= 4 ? 2 : 1)) void k_lu_front_wp(const LuDev d, const int32_t *__restrict__ list, const double *__restrict__ Ax,
+                                                      const double tol, const double stol, const int reuse)
+{
+    constexpr int R = T > 4 ? 2 : 1;
+    constexpr int DUMP = 16 * T * (16 * T + 2);
+    extern __shared__ double smem[];
+    __shared__ __attribute__((aligned(16))) double L11[LU_PB * LU_PB + 8 * LU_PB];   // the panel's rows of the pivot block in logical order: L11[j * 32 + j2]
+    __shared__ __attribute__((aligned(16))) double bcast[LU_PB];
+    __shared__ int32_t sh_slot[16 * T], sh_prow[16 * T], sh_piv[16 * T];
+    __shared__ WpAsmLds asm_lds;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int f = list[blockIdx.x];
+    const LuFrontD F = d.fr[f];
+    const int m = F.m, k = F.k, u = m - k;
+    const int ld = (m + 1) | 1;
+    double *Fm = smem;
+#ifdef KVX_LU_PHASE
+    unsigned long long lu_t_ = wall_clock64();
+#endif
+    if (tid == 0) d.fail[f] = 0;
+    for (int t = tid; t < 16 * T; t += 256) {
+        if (reuse && t < k) {                                     // the recorded sequence: pivot t is physical row lperm[t]
+            const int pr = d.lperm[F.p0 + t];
+            sh_prow[t] = pr; sh_slot[pr] = t; sh_piv[t] = d.ipiv[F.p0 + t];
+        } else {
+            if (!reuse || t >= k) sh_slot[t] = t;
+            if (t >= k || !reuse) { sh_prow[t] = t; sh_piv[t] = 0; }
+        }
+    }
+    wp_assemble(d, F, Fm, ld, Ax, asm_lds LU_TARG);
+    LU_STAMP(0);
+    double lmax = 0.0;
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int j0 = 0; j0 < k; j0 += LU_PB) {
+        const int nb = min(LU_PB, k - j0);
+        // ---- (a) the panel: wave 0, registers
+        if (wv == 0) {
+            WpCtx x;
+            x.j0 = j0; x.nb = nb; x.k = k; x.lane = lane; x.sh_piv = sh_piv; x.sh_prow = sh_prow; x.bc = bcast;
+            x.fail_slot = d.fail + f; x.tol = tol; x.lmax = lmax;
+            if (reuse) wp_panel<R, true>(Fm, ld, m, x, sh_slot, L11);
+            else wp_panel<R, false>(Fm, ld, m, x, sh_slot, L11);
+            lmax = x.lmax;
+        }
+        __syncthreads();
+        LU_STAMP(1);
+        if (j0 + nb >= m) break;                                  // nothing right of the panel
+        // ---- (b) U12 = L11^-1 A12: one column per thread
+        {
+            const int c = j0 + nb + tid;
+            if (c < m) wp_solve(Fm, ld, c, j0, nb, sh_prow, L11);
+        }
+        __syncthreads();
+        LU_STAMP(2);
+        // ---- (c) rank-nb update of the rows not used yet, columns right of the panel: thread (tx, ty) owns rows tx + 16 a, columns
+        // ty + 16 b.  Entries outside the region are computed along on whatever the LDS holds there and not stored: no predicate
+        // in the loop (a tile element depends on its own row and column operands only).
+        {
+            const int cfirst = j0 + nb;
+            double acc[T][T];
+            bool rowon[T], colon[T];
+#pragma unroll
+            for (int bc = 0; bc < T; bc++) { const int c = ty + 16 * bc; colon[bc] = c >= cfirst && c < m; }
+#pragma unroll
+            for (int ar = 0; ar < T; ar++) {
+                const int i = tx + 16 * ar;
+                rowon[ar] = i < m && sh_slot[min(i, 16 * T - 1)] >= cfirst;
+#pragma unroll
+#ifdef WP_UPDATE_MASKED
+                for (int bc = 0; bc < T; bc++) acc[ar][bc] = (rowon[ar] && colon[bc]) ? Fm[i + (ty + 16 * bc) * ld] : 0.0;
+#else
+                for (int bc = 0; bc < T; bc++) acc[ar][bc] = Fm[i + (ty + 16 * bc) * ld];
+#endif
+            }
+            int prr = lane < nb ? sh_prow[j0 + lane] : 0;         // the panel's pivot rows, one per lane
+            for (int jq = 0; jq < nb; jq += 4) {                  // four pivots per round: their operand reads are in flight together
+                double lr[4][T], ub[4][T];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int pr = __builtin_amdgcn_readlane(prr, min(jq + q, nb - 1));
+                    const double z = jq + q < nb ? 1.0 : 0.0;     // uniform
+#pragma unroll
+#ifdef WP_UPDATE_MASKED
+                    for (int ar = 0; ar < T; ar++) lr[q][ar] = (z != 0.0 && rowon[ar]) ? Fm[tx + 16 * ar + (j0 + min(jq + q, nb - 1)) * ld] : 0.0;
+#pragma unroll
+                    for (int bc = 0; bc < T; bc++) ub[q][bc] = colon[bc] ? Fm[pr + (ty + 16 * bc) * ld] : 0.0;
+#else
+                    for (int ar = 0; ar < T; ar++) lr[q][ar] = z * Fm[tx + 16 * ar + (j0 + min(jq + q, nb - 1)) * ld];
+#pragma unroll
+                    for (int bc = 0; bc < T; bc++) ub[q][bc] = Fm[pr + (ty + 16 * bc) * ld];
+#endif
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int ar = 0; ar < T; ar++)
+#pragma unroll
+                        for (int bc = 0; bc < T; bc++) acc[ar][bc] -= lr[q][ar] * ub[q][bc];
+            }
+#pragma unroll
+            for (int ar = 0; ar < T; ar++)
+#pragma unroll
+                for (int bc = 0; bc < T; bc++) Fm[(rowon[ar] && colon[bc]) ? tx + 16 * ar + (ty + 16 * bc) * ld : DUMP] = acc[ar][bc];
+        }
+        __syncthreads();
+        LU_STAMP(3);
+    }
+    // |pivot| >= stol * max|column|  <=>  max|multiplier| <= 1 / stol : one test per front instead of one per pivot
+    if (wv == 0 && !(lmax * stol <= 1.0)) atomicMax(d.fail + f, 1);
+    // ---- store: panels (L(:, 0:k) as is, U(0:k, :) transposed, both m x k column-major), in-front permutation, update matrix
+    for (int t = tid; t < k; t += 256) {
+        d.lperm[F.p0 + t] = sh_prow[t];
+        if (!reuse) d.ipiv[F.p0 + t] = sh_piv[t];
+    }
+    double *__restrict__ Lp = d.Lx + F.px, *__restrict__ Up = d.Ux + F.px;
+    for (int j = wv; j < k; j += 4)
+        for (int i = lane; i < m; i += 64) Lp[i + (int64_t)j * m] = Fm[(i < k ? sh_prow[i] : i) + j * ld];
+    for (int t = wv; t < k; t += 4) {
+        const int pr = sh_prow[t];
+        for (int c = lane; c < m; c += 64) Up[c + (int64_t)t * m] = Fm[pr + c * ld];
+    }
+    double *__restrict__ Uo = d.arena + F.upd_off;
+    for (int j = wv; j < u; j += 4)
+        for (int i = lane; i < u; i += 64) Uo[i + (int64_t)j * u] = Fm[(k + i) + (k + j) * ld];
+    LU_STAMP(4);
+}
+
+#ifdef KVX_LU_PHASE
+extern "C" int kvx_dbg_lu_phase_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lu_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lu_phase), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+
 // Forward sweep of one front: f = [x(pivots); 0] + children's update vectors; (row permutation); solve with the
 // k x k lower block; f(update) -= panel21 * y.  UNIT: L panel (unit diagonal, permutation); else U' (divide).
 template <bool UNIT>
@@ -865,13 +1375,51 @@ __device__ __forceinline__ void panel_step(double (&a)[RPT][NB], PanelCtx<RPT> &
     }
 }
 
+// A refactorisation (reuse: the recorded interchanges) knows where every row ends before the panel starts: slot = final position,
+// the row with slot J is pivot row J, rows with a larger slot are the ones still to be eliminated.  No search, no reduction
+// across the waves, one barrier per pivot (the publishing buffers alternate by parity of J).
+template <int J, int NB, int RPT>
+__device__ __forceinline__ void panel_step_reuse(double (&a)[RPT][NB], PanelCtx<RPT> &x)
+{
+    if constexpr (J < NB) {
+        if (J < x.nbk) {                                          // uniform
+            double *uspec = x.urow + (J & 1) * NB;
+#pragma unroll
+            for (int q = 0; q < RPT; q++)
+                if (x.slot[q] == J) {
+                    x.sh_rinv[J & 1] = 1.0 / a[q][J];
+#pragma unroll
+                    for (int c2 = J; c2 < NB; c2++) uspec[c2] = a[q][c2];
+                }
+            __syncthreads();
+            const double pv = uspec[J];
+            const double ap = fabs(pv);
+            const bool bad = !(ap > 0.0) || !(ap <= 1.7e308);
+            const double rpv = bad ? 1.0 : x.sh_rinv[J & 1];
+            if (bad && threadIdx.x == 0 && !x.failed && *x.fail_slot == 0) { x.failed = true; *x.fail_slot = x.jb + J + 1; }
+#pragma unroll
+            for (int q = 0; q < RPT; q++) {
+                if (x.has[q] && x.slot[q] > J) {
+                    const double l = a[q][J] * rpv;
+                    a[q][J] = l;
+                    x.lmax = fmax(x.lmax, fabs(l));
+#pragma unroll
+                    for (int c = J + 1; c < NB; c++) a[q][c] -= l * uspec[c];
+                }
+            }
+        }
+        panel_step_reuse<J + 1, NB, RPT>(a, x);
+    }
+}
+
 // The acceptance test |pivot| >= stol * max|column| of lu_factor_front is applied afterwards in its equivalent form
 // max|multiplier| <= 1 / stol (one reduction per panel instead of one per pivot).  NB pivots per panel, RPT rows per
 // thread: <32, 1> up to 1024 rows, <16, 2> up to 2048, <8, 4> up to 4096 (the register budget of a 1024-thread workgroup).
-template <int NB, int RPT>
+template <int NB, int RPT, bool REUSE>
 __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int32_t *__restrict__ list, const int jb, const double tol,
-                                                         const double stol, const int reuse)
+                                                         const double stol)
 {
+    constexpr int reuse = REUSE ? 1 : 0;
     __shared__ double sh_b[32], sh_diag[2], urow[2 * NB], sh_rinv[2];
     __shared__ int sh_s[32], sh_piv[NB];
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -900,7 +1448,19 @@ __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int
         for (int c = 0; c < NB; c++) a[q][c] = (x.has[q] && c < nbk) ? G[row + (int64_t)c * m] : 0.0;
     }
     __syncthreads();
-    panel_step<0, NB, RPT>(a, x);
+    if constexpr (REUSE) {
+        // where the recorded interchanges take every row: follow them (32 steps of integer work, the sequence read as a broadcast)
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            int pos = x.slot[q];
+            for (int j = 0; j < nbk; j++) {
+                const int r = j + sh_piv[j];
+                pos = pos == j ? r : (pos == r ? j : pos);
+            }
+            x.slot[q] = pos;
+        }
+        panel_step_reuse<0, NB, RPT>(a, x);
+    } else panel_step<0, NB, RPT>(a, x);
     double lm = x.lmax;
 #pragma unroll
     for (int off = 32; off; off >>= 1) lm = fmax(lm, __shfl_xor(lm, off));
@@ -941,11 +1501,44 @@ __global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *_
     __syncthreads();
     const int c = c0 + tid;
     const bool inpanel = c >= jb && c < jb + nbk;
-    if (c < m && !inpanel) {                                  // the block's row interchanges, every column outside the panel
-        double *col = Fm + jb + (int64_t)c * m;
-        for (int j = 0; j < nbk; j++) {
-            const int r = sw[j];
-            if (r != j) { const double a = col[j], b = col[r]; col[j] = b; col[r] = a; }
+    // The block's row interchanges, every column outside the panel.  Applied one after the other they are a chain of dependent
+    // trips to memory (22 us a launch, rocprofv3); their net effect is a permutation of at most 2 nbk rows: the sequence is
+    // followed backwards once per touched position (src = the row whose entry ends there), then every column loads ALL its
+    // sources (parked in LDS) before it stores any.
+    __shared__ int mv_dst[2 * LU_NB], mv_src[2 * LU_NB], mv_n;
+    __shared__ double park[2 * LU_NB][65];
+    {
+        {                                                         // touched positions: the block rows and the partners outside the block, each once
+            const int r = tid < nbk ? sw[tid] : 0;
+            bool first = tid < nbk && r >= nbk;
+            for (int j = 0; j < nbk; j++) first = first && !(j < tid && sw[j] == r);
+            const unsigned long long mask = __ballot(first);
+            if (tid < nbk) mv_dst[tid] = tid;
+            if (first) mv_dst[nbk + __popcll(mask & ((1ull << tid) - 1ull))] = r;
+            if (tid == 0) mv_n = nbk + __popcll(mask);
+        }
+        __syncthreads();
+        const int n = mv_n;
+        for (int t = tid; t < n; t += 64) {                     // undo the swaps last to first
+            int pos = mv_dst[t];
+            for (int j = nbk - 1; j >= 0; j--) {
+                const int r = sw[j];
+                pos = pos == j ? r : (pos == r ? j : pos);
+            }
+            mv_src[t] = pos;
+        }
+        __syncthreads();
+        if (c < m && !inpanel) {
+            double *col = Fm + jb + (int64_t)c * m;
+            for (int t0 = 0; t0 < n; t0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) v[t] = t0 + t < n ? col[mv_src[min(t0 + t, n - 1)]] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 16; t++) park[min(t0 + t, 2 * LU_NB - 1)][tid] = v[t];
+            }
+            for (int t = 0; t < n; t++)
+                if (mv_src[t] != mv_dst[t]) col[mv_dst[t]] = park[t][tid];
         }
     }
     if (c0 + 64 <= jb + nbk) return;                          // nothing right of the panel in this block of columns
@@ -1208,6 +1801,8 @@ static void allow_large_lds()
     done = true;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front<true, LU_NT_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front_tiled<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front_wp<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lu_front_wp<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lub_panel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
 }
@@ -1222,6 +1817,21 @@ void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, i
         static const bool legacy = getenv("KVX_LU_LDS_LEGACY") != nullptr;       // the LDS-resident elimination (debugging aid)
         if (legacy) {
             hipLaunchKernelGGL((k_lu_front<true, LU_NT_LDS>), dim3(cnt), dim3(LU_NT_LDS), sm, st, d, list, Ax, tol, stol, reuse, lds_m);
+            return;
+        }
+        static const bool wp = [] { const char *e = getenv("KVX_LU_WP"); return !e || e[0] != '0'; }();   // 0: the round-3 kernel (two barriers per pivot)
+        // ... where a launch is a level's few dozen fronts (its time is that of its slowest front); thousands of fronts per launch are
+        // bound by how many workgroups a CU holds, and the round-3 kernel is the smaller one (KVX_LU_WP_MAXCNT, default 512)
+        static const int wp_maxcnt = [] { const char *e = getenv("KVX_LU_WP_MAXCNT"); return e ? atoi(e) : 512; }();
+        if (wp && cnt <= wp_maxcnt) {
+            switch ((lds_m + 15) / 16) {
+            case 1: hipLaunchKernelGGL((k_lu_front_wp<1>), dim3(cnt), dim3(256), wp_lds_bytes(1), st, d, list, Ax, tol, stol, reuse); break;
+            case 2: hipLaunchKernelGGL((k_lu_front_wp<2>), dim3(cnt), dim3(256), wp_lds_bytes(2), st, d, list, Ax, tol, stol, reuse); break;
+            case 3: hipLaunchKernelGGL((k_lu_front_wp<3>), dim3(cnt), dim3(256), wp_lds_bytes(3), st, d, list, Ax, tol, stol, reuse); break;
+            case 4: hipLaunchKernelGGL((k_lu_front_wp<4>), dim3(cnt), dim3(256), wp_lds_bytes(4), st, d, list, Ax, tol, stol, reuse); break;
+            case 5: case 6: hipLaunchKernelGGL((k_lu_front_wp<6>), dim3(cnt), dim3(256), wp_lds_bytes(6), st, d, list, Ax, tol, stol, reuse); break;
+            default: hipLaunchKernelGGL((k_lu_front_wp<7>), dim3(cnt), dim3(256), wp_lds_bytes(7), st, d, list, Ax, tol, stol, reuse); break;
+            }
             return;
         }
         switch ((lds_m + 15) / 16) {
@@ -1251,11 +1861,17 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
         const int rows = max_m - jb;                          // tallest panel of this step
         const int nth = std::min(1024, (rows + 63) / 64 * 64);
         int nbs = LU_NB;
-        if (rows <= 1024) hipLaunchKernelGGL((k_lub_panel_reg<32, 1>), dim3(cnt), dim3(nth), 0, st, d, list, jb, tol, stol, reuse);
-        else if (rows <= 2048) { nbs = 16; hipLaunchKernelGGL((k_lub_panel_reg<16, 2>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol, reuse); }
-        else {
+        if (rows <= 1024) {
+            if (reuse) hipLaunchKernelGGL((k_lub_panel_reg<32, 1, true>), dim3(cnt), dim3(nth), 0, st, d, list, jb, tol, stol);
+            else hipLaunchKernelGGL((k_lub_panel_reg<32, 1, false>), dim3(cnt), dim3(nth), 0, st, d, list, jb, tol, stol);
+        } else if (rows <= 2048) {
+            nbs = 16;
+            if (reuse) hipLaunchKernelGGL((k_lub_panel_reg<16, 2, true>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol);
+            else hipLaunchKernelGGL((k_lub_panel_reg<16, 2, false>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol);
+        } else {
             nbs = 8;
-            hipLaunchKernelGGL((k_lub_panel_reg<8, 4>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol, reuse);
+            if (reuse) hipLaunchKernelGGL((k_lub_panel_reg<8, 4, true>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol);
+            else hipLaunchKernelGGL((k_lub_panel_reg<8, 4, false>), dim3(cnt), dim3(1024), 0, st, d, list, jb, tol, stol);
             if (rows > 4096)
                 hipLaunchKernelGGL(k_lub_panel, dim3(cnt), dim3(LU_NT_LDS), (size_t)LU_PANEL_LDS_DOUBLES * sizeof(double), st, d, list, jb, nbs,
                                    tol, stol, reuse);
