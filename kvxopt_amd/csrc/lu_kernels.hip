@@ -1125,7 +1125,19 @@ __global__ __launch_bounds__(256) void k_lub_assemble(const LuDev d, const int32
 
 // Panels of a factored big front, one workgroup per 64 front columns; the first workgroup also turns the interchange
 // sequence into the in-front permutation.
-__global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t *__restrict__ list)
+// first column right of the pivot block that pivot t belongs to (the caller caps it at the front's k: a front's last block is
+// shorter), for a level whose tallest front has max_m rows: the blocks
+// are those of launch_lu_big_level (8 pivots while more than 2048 rows remain, 16 down to 1024, then 32)
+__device__ __forceinline__ int lub_block_end(const int t, const int max_m)
+{
+    const int jb1 = max_m > 2048 ? (max_m - 2048 + 7) / 8 * 8 : 0;
+    const int jb2 = max_m - jb1 > 1024 ? jb1 + (max_m - jb1 - 1024 + 15) / 16 * 16 : jb1;
+    if (t < jb1) return t / 8 * 8 + 8;
+    if (t < jb2) return jb1 + (t - jb1) / 16 * 16 + 16;
+    return jb2 + (t - jb2) / 32 * 32 + 32;
+}
+
+__global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t *__restrict__ list, const int max_m)
 {
     extern __shared__ double smem[];
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -1143,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_lub_store(const LuDev d, const int32_t 
             tile[cc][tx] = (t0 + tx < k && c0 + cc < m) ? Fm[(t0 + tx) + (int64_t)(c0 + cc) * m] : 0.0;
         __syncthreads();
         for (int tt = ty; tt < 64; tt += 4)                   // Up[c + t m]: lanes along the columns
-            if (t0 + tt < k && c0 + tx < m) Up[(c0 + tx) + (int64_t)(t0 + tt) * m] = tile[tx][tt];
+            if (t0 + tt < k && c0 + tx < min(k, lub_block_end(t0 + tt, max_m))) Up[(c0 + tx) + (int64_t)(t0 + tt) * m] = tile[tx][tt];   // (right of the block: k_lub_gemm)
         __syncthreads();
     }
     for (int cc = c0 + ty; cc < min(k, c0 + 64); cc += 4)
@@ -1481,90 +1493,26 @@ __global__ __launch_bounds__(1024) void k_lub_panel_reg(const LuDev d, const int
         }
 }
 
+// The block's row interchanges, every column outside the panel (LAPACK's laswp; the panel itself was written back in order).
+// Most blocks of a refactorisation of a diagonally heavy matrix have none: the launch ends there.
 __global__ __launch_bounds__(64) void k_lub_trsm(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs)
 {
-    __shared__ double L11[LU_NB * LU_NB];
-    __shared__ double T[LU_NB][65];                           // 32 block rows x 64 columns, padded: conflict-free by column
-    __shared__ int sw[LU_NB];
     const int tid = threadIdx.x;
     const LuFrontD F = d.fr[list[blockIdx.y]];
     const int m = F.m, k = F.k;
     const int c0 = blockIdx.x * 64;
     if (jb >= k || c0 >= m) return;
     const int nbk = min(nbs, k - jb);
+    const int piv = tid < nbk ? d.ipiv[F.p0 + jb + tid] : 0;
+    if (__ballot(piv != 0) == 0ull) return;
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
-    for (int idx = tid; idx < LU_NB * LU_NB; idx += 64) {
-        const int i = idx % LU_NB, t = idx / LU_NB;
-        L11[idx] = (i < nbk && t < nbk && i > t) ? Fm[(jb + i) + (int64_t)(jb + t) * m] : 0.0;
-    }
-    if (tid < LU_NB) sw[tid] = tid < nbk ? tid + d.ipiv[F.p0 + jb + tid] : tid;
-    __syncthreads();
     const int c = c0 + tid;
-    const bool inpanel = c >= jb && c < jb + nbk;
-    // The block's row interchanges, every column outside the panel.  Applied one after the other they are a chain of dependent
-    // trips to memory (22 us a launch, rocprofv3); their net effect is a permutation of at most 2 nbk rows: the sequence is
-    // followed backwards once per touched position (src = the row whose entry ends there), then every column loads ALL its
-    // sources (parked in LDS) before it stores any.
-    __shared__ int mv_dst[2 * LU_NB], mv_src[2 * LU_NB], mv_n;
-    __shared__ double park[2 * LU_NB][65];
-    {
-        {                                                         // touched positions: the block rows and the partners outside the block, each once
-            const int r = tid < nbk ? sw[tid] : 0;
-            bool first = tid < nbk && r >= nbk;
-            for (int j = 0; j < nbk; j++) first = first && !(j < tid && sw[j] == r);
-            const unsigned long long mask = __ballot(first);
-            if (tid < nbk) mv_dst[tid] = tid;
-            if (first) mv_dst[nbk + __popcll(mask & ((1ull << tid) - 1ull))] = r;
-            if (tid == 0) mv_n = nbk + __popcll(mask);
+    if (c < m && !(c >= jb && c < jb + nbk)) {
+        double *col = Fm + jb + (int64_t)c * m;
+        for (int j = 0; j < nbk; j++) {
+            const int r = j + __builtin_amdgcn_readlane(piv, j);
+            if (r != j) { const double a = col[j], b = col[r]; col[j] = b; col[r] = a; }
         }
-        __syncthreads();
-        const int n = mv_n;
-        for (int t = tid; t < n; t += 64) {                     // undo the swaps last to first
-            int pos = mv_dst[t];
-            for (int j = nbk - 1; j >= 0; j--) {
-                const int r = sw[j];
-                pos = pos == j ? r : (pos == r ? j : pos);
-            }
-            mv_src[t] = pos;
-        }
-        __syncthreads();
-        if (c < m && !inpanel) {
-            double *col = Fm + jb + (int64_t)c * m;
-            for (int t0 = 0; t0 < n; t0 += 16) {
-                double v[16];
-#pragma unroll
-                for (int t = 0; t < 16; t++) v[t] = t0 + t < n ? col[mv_src[min(t0 + t, n - 1)]] : 0.0;
-#pragma unroll
-                for (int t = 0; t < 16; t++) park[min(t0 + t, 2 * LU_NB - 1)][tid] = v[t];
-            }
-            for (int t = 0; t < n; t++)
-                if (mv_src[t] != mv_dst[t]) col[mv_dst[t]] = park[t][tid];
-        }
-    }
-    if (c0 + 64 <= jb + nbk) return;                          // nothing right of the panel in this block of columns
-    __syncthreads();
-    const int lr = tid & 31, lc = tid >> 5;                   // coalesced tile load: 32 consecutive rows of two columns per instruction
-    for (int cc = 0; cc < 64; cc += 2) {
-        const int col = c0 + cc + lc;
-        T[lr][cc + lc] = (lr < nbk && col < m) ? Fm[(jb + lr) + (int64_t)col * m] : 0.0;
-    }
-    __syncthreads();
-    if (c < m && c >= jb + nbk) {                             // U12(:, c) = L11^-1 A12(:, c)
-        double v[LU_NB];
-#pragma unroll
-        for (int t = 0; t < LU_NB; t++) v[t] = T[t][tid];
-#pragma unroll
-        for (int t = 0; t < LU_NB; t++) {
-#pragma unroll
-            for (int s2 = t + 1; s2 < LU_NB; s2++) v[s2] -= L11[s2 + t * LU_NB] * v[t];
-        }
-#pragma unroll
-        for (int t = 0; t < LU_NB; t++) T[t][tid] = v[t];
-    }
-    __syncthreads();
-    for (int cc = 0; cc < 64; cc += 2) {
-        const int col = c0 + cc + lc;
-        if (lr < nbk && col < m && col >= jb + nbk) Fm[(jb + lr) + (int64_t)col * m] = T[lr][cc + lc];
     }
 }
 
@@ -1577,7 +1525,7 @@ constexpr int LU_GLD = 80;
 typedef double lu_d4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *__restrict__ list, const int jb, const int nbs)
 {
-    __shared__ double Ls[LU_NB * LU_GLD], Us[LU_NB * LU_GLD];
+    __shared__ double Ls[LU_NB * LU_GLD], Us[LU_NB * LU_GLD], L11[LU_NB * LU_NB];
     const int tid = threadIdx.x;
     const LuFrontD F = d.fr[list[blockIdx.z]];
     const int m = F.m, k = F.k;
@@ -1586,6 +1534,10 @@ __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *
     const int r0 = t0 + blockIdx.x * 64, c0 = t0 + blockIdx.y * 64;
     if (r0 >= m || c0 >= m) return;
     double *Fm = d.arena + (F.upd_off - k - (int64_t)k * m);
+    for (int idx = tid; idx < LU_NB * LU_NB; idx += 256) {    // the panel's unit triangle (strictly lower part, zero padding)
+        const int i = idx % LU_NB, t = idx / LU_NB;
+        L11[idx] = (i < nbk && t < nbk && i > t) ? Fm[(jb + i) + (int64_t)(jb + t) * m] : 0.0;
+    }
     for (int idx = tid; idx < LU_NB * 64; idx += 256) {
         const int i = idx & 63, t = idx >> 6;                 // L21 tile: rows r0.., block column t
         Ls[t * LU_GLD + i] = (t < nbk && r0 + i < m) ? Fm[(r0 + i) + (int64_t)(jb + t) * m] : 0.0;
@@ -1593,6 +1545,30 @@ __global__ __launch_bounds__(256) void k_lub_gemm(const LuDev d, const int32_t *
     for (int idx = tid; idx < LU_NB * 64; idx += 256) {
         const int t = idx % LU_NB, c = idx / LU_NB;           // U12 tile: block row t, columns c0..
         Us[t * LU_GLD + c] = (t < nbk && c0 + c < m) ? Fm[(jb + t) + (int64_t)(c0 + c) * m] : 0.0;
+    }
+    __syncthreads();
+    // U12 = L11^-1 A12 for the tile's 64 columns, here rather than in a launch of its own (k_lub_trsm: 20 us a step on the chain
+    // panel -> solve -> update; every tile row repeats the 32 x 64 solve -- 500 multiply-adds a thread of one wavefront -- and the
+    // first one writes it back)
+    if (tid < 64) {
+        double v[LU_NB];
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) v[t] = Us[t * LU_GLD + tid];
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) {
+#pragma unroll
+            for (int s2 = t + 1; s2 < LU_NB; s2++) v[s2] -= L11[s2 + t * LU_NB] * v[t];
+        }
+#pragma unroll
+        for (int t = 0; t < LU_NB; t++) Us[t * LU_GLD + tid] = v[t];
+        // (not into the front: the other tile rows of this launch read the unsolved block from there.  Nothing reads these rows of
+        //  the front again but k_lub_store, which leaves the entries right of a pivot's block alone: they go to their final place)
+        if (blockIdx.x == 0 && c0 + tid < m) {
+            double *__restrict__ Up = d.Ux + F.px;
+#pragma unroll
+            for (int t = 0; t < LU_NB; t++)
+                if (t < nbk) Up[(c0 + tid) + (int64_t)(jb + t) * m] = v[t];
+        }
     }
     __syncthreads();
     const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
@@ -1880,7 +1856,7 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
         hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb, nbs);
         jb += nbs;
     }
-    hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt, (max_m + 255) / 256), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list);
+    hipLaunchKernelGGL(k_lub_store, dim3(tiles, cnt, (max_m + 255) / 256), dim3(256), 2 * (size_t)max_k * sizeof(int32_t) + 16, st, d, list, max_m);
 }
 
 void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx, int nrhs,

@@ -260,6 +260,32 @@ def test_unsymmetric_grid_uses_the_blocked_big_front_path():
     assert rho < 1e-12
 
 
+def test_blocked_path_on_fronts_of_many_tiles_factor_and_refactor():
+    """Convection-diffusion on a 300 x 300 grid: fronts of ~580 rows, i.e. nine tile rows per update launch (the U12 block is solved
+    by every tile row of the launch and written once, never into the front the other rows read), 16- and 32-pivot panels.
+    Factor, then refactor with other values on the recorded pivot sequence (klu.c:296-308): residual and L U = R P A Q - F."""
+    from kvxopt_amd import workloads
+    n, cp, ri, v = workloads.convdiff_2d(300, seed=2)
+    A = spmatrix.from_ccs(n, n, cp, ri, v)
+    Fs = klu.symbolic(A)
+    Fn = klu.numeric(A, Fs)
+    assert Fn.num.info()["max_front"] > 512                              # nine or more tile rows
+    b = np.random.default_rng(9).standard_normal((n, 2))
+    v2 = v * (1.0 + 0.25 * np.random.default_rng(10).standard_normal(v.size))
+    for vals, fresh in ((v, True), (v2, False), (v, False)):
+        Av = spmatrix.from_ccs(n, n, cp, ri, vals)
+        As = to_sp(Av)
+        if not fresh:
+            klu.numeric(Av, Fs, Fn)                                      # refactorisation into the existing factor
+        x = np.asfortranarray(b.copy())
+        klu.solve(Av, Fs, Fn, x)
+        assert np.linalg.norm(As @ x - b) <= 1e-10 * np.linalg.norm(b)
+    L, U, P, Q, R, F, r = klu.get_numeric(A, Fs, Fn)
+    As = to_sp(A)
+    rho = abs(to_sp(R) @ to_sp(P) @ As @ to_sp(Q) - to_sp(L) @ to_sp(U) - to_sp(F)).sum(axis=0).max()
+    assert rho < 1e-11
+
+
 def test_ldb_offset_and_nrhs_arguments():
     """klu.c:619-628: nrhs / ldB / offsetB follow the BLAS conventions."""
     A = spmatrix(DOC_V, DOC_I, DOC_J)
