@@ -56,6 +56,9 @@ struct kvx_lu_num {
     std::vector<int32_t> lvl_maxm, lvl_maxk, lvl_smallm, lvl_smallk;   // per level: all fronts / those swept by one workgroup
     double tol = 1e-3, stol = 1e-3;
     int64_t attempts = 0;
+    // per level: does any big front of the level interchange rows in pivot block `step`?  Read from the recorded pivot sequence after
+    // a factorisation; a refactorisation (same sequence) leaves out the interchange launch of every block that has none
+    std::vector<std::vector<uint8_t>> swap_steps;
     bool unblocked = std::getenv("KVX_LU_UNBLOCKED") != nullptr;   // debugging aid: big fronts by one workgroup each
 };
 
@@ -288,7 +291,10 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
             int bm = 0, bk = 0;                                // big fronts of the level: blocked multi-launch path
             for (int64_t qq = b + nl; qq < e; qq++) { bm = std::max(bm, P.fr[P.levellist[qq]].m); bk = std::max(bk, P.fr[P.levellist[qq]].k); }
             if (N->unblocked) launch_lu_fronts(d, N->d_lists + b + nl, (int)(e - b - nl), 0, bk, Ax_dev, N->tol, N->stol, reuse, N->st2);
-            else launch_lu_big_level(d, N->d_lists + b + nl, (int)(e - b - nl), bm, bk, Ax_dev, N->tol, N->stol, reuse, N->st2);
+            else {
+                const uint8_t *sw = (reuse && (size_t)l < N->swap_steps.size() && !N->swap_steps[(size_t)l].empty()) ? N->swap_steps[(size_t)l].data() : nullptr;
+                launch_lu_big_level(d, N->d_lists + b + nl, (int)(e - b - nl), bm, bk, Ax_dev, N->tol, N->stol, reuse, N->st2, sw);
+            }
         }
         if (hasA) { HIPCHK(hipEventRecord(N->evA[l], N->st)); lastA = l; }
         if (hasB) { HIPCHK(hipEventRecord(N->evB[l], N->st2)); lastB = l; }
@@ -300,6 +306,38 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
     HIPCHK(hipMemcpyAsync(fail_host.data(), N->d_fail, (size_t)P.nfront * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
     HIPCHK(hipStreamSynchronize(N->st));
     N->attempts++;
+    return KVX_OK;
+}
+
+// After a factorisation that chose its pivots: which pivot blocks of the blocked fronts interchange rows at all (the blocks are
+// those of launch_lu_big_level: lu_big_block_width).
+int refresh_swap_steps(kvx_lu_num *N)
+{
+    const LuPlan &P = N->P;
+    N->swap_steps.assign((size_t)P.nlevels, {});
+    if (N->unblocked) return KVX_OK;
+    bool any_big = false;
+    for (int32_t l = 0; l < P.nlevels; l++) any_big = any_big || P.levelptr[l + 1] > P.levelptr[l] + P.nlds[l];
+    if (!any_big) return KVX_OK;
+    std::vector<int32_t> ipiv((size_t)N->n);
+    HIPCHK(hipMemcpy(ipiv.data(), N->d_ipiv, (size_t)N->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t l = 0; l < P.nlevels; l++) {
+        const int64_t b = P.levelptr[l] + P.nlds[l], e = P.levelptr[l + 1];
+        if (e <= b) continue;
+        int bm = 0, bk = 0;
+        for (int64_t q = b; q < e; q++) { bm = std::max(bm, P.fr[P.levellist[q]].m); bk = std::max(bk, P.fr[P.levellist[q]].k); }
+        std::vector<uint8_t> &fl = N->swap_steps[(size_t)l];
+        for (int jb = 0; jb < bk;) {
+            const int nbs = lu_big_block_width(bm - jb);
+            uint8_t any = 0;
+            for (int64_t q = b; q < e && !any; q++) {
+                const LuFrontH &f = P.fr[P.levellist[q]];
+                for (int t = jb; t < std::min(jb + nbs, (int)f.k) && !any; t++) any = ipiv[(size_t)f.p0 + t] != 0;
+            }
+            fl.push_back(any);
+            jb += nbs;
+        }
+    }
     return KVX_OK;
 }
 
@@ -325,7 +363,11 @@ int factor_loop(kvx_lu_num *N, const double *Ax_dev, int reuse)
             if (flagged && !below[f]) minimal.push_back((int32_t)f);
             if ((flagged || below[f]) && P.fr[f].parent >= 0) below[P.fr[f].parent] = 1;
         }
-        if (minimal.empty()) { N->factored = true; return KVX_OK; }
+        if (minimal.empty()) {
+            N->factored = true;
+            if (!reuse && (rc = refresh_swap_steps(N))) return rc;
+            return KVX_OK;
+        }
         if (reuse) { reuse = 0; continue; }                   // klu.c:296-303: a refactorisation that runs into numerical trouble becomes a full one
         if (!lu_merge_fronts(N->sym->Y, P, minimal)) {
             set_last_error("singular matrix");

@@ -37,7 +37,9 @@ void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, i
                       double tol, double stol, int reuse, hipStream_t st);
 // All fronts of a level that do not fit in LDS (blocked: lu_kernels.hip k_lub_*).
 void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, const double *Ax, double tol,
-                         double stol, int reuse, hipStream_t st);
+                         double stol, int reuse, hipStream_t st, const uint8_t *swap_steps = nullptr);
+// pivots per block while `rows` rows of the level's tallest front remain (the register budget of the panel's workgroup)
+inline int lu_big_block_width(int rows) { return rows <= 1024 ? 32 : (rows <= 2048 ? 16 : 8); }
 // Triangular sweeps over one level.  unit = 1: the L panels (unit diagonal, in-front row permutation);
 // unit = 0: the U' panels.  W: update vectors, wsize doubles per right-hand side.
 void launch_lu_fwd(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, int unit, double *X, int64_t ldx,

@@ -1826,14 +1826,14 @@ void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, i
 
 
 void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m, int max_k, const double *Ax, double tol,
-                         double stol, int reuse, hipStream_t st)
+                         double stol, int reuse, hipStream_t st, const uint8_t *swap_steps)
 {
     if (cnt <= 0) return;
     allow_large_lds();
     hipLaunchKernelGGL(k_lub_assemble, dim3((max_m + LU_ASM_COLS - 1) / LU_ASM_COLS, cnt, (max_m + LU_ASM_ROWS - 1) / LU_ASM_ROWS), dim3(256), 0, st,
                        d, list, Ax);
     const int tiles = (max_m + 63) / 64;
-    for (int jb = 0; jb < max_k;) {
+    for (int jb = 0, step = 0; jb < max_k; step++) {
         const int rows = max_m - jb;                          // tallest panel of this step
         const int nth = std::min(1024, (rows + 63) / 64 * 64);
         int nbs = LU_NB;
@@ -1852,7 +1852,8 @@ void launch_lu_big_level(const LuDev &d, const int32_t *list, int cnt, int max_m
                 hipLaunchKernelGGL(k_lub_panel, dim3(cnt), dim3(LU_NT_LDS), (size_t)LU_PANEL_LDS_DOUBLES * sizeof(double), st, d, list, jb, nbs,
                                    tol, stol, reuse);
         }
-        hipLaunchKernelGGL(k_lub_trsm, dim3(tiles, cnt), dim3(64), 0, st, d, list, jb, nbs);
+        // (a refactorisation knows from the recorded sequence which blocks interchange rows at all: lu_api.cpp, refresh_swap_steps)
+        if (!swap_steps || swap_steps[step]) hipLaunchKernelGGL(k_lub_trsm, dim3(tiles, cnt), dim3(64), 0, st, d, list, jb, nbs);
         hipLaunchKernelGGL(k_lub_gemm, dim3(tiles, tiles, cnt), dim3(256), 0, st, d, list, jb, nbs);
         jb += nbs;
     }
