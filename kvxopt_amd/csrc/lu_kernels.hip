@@ -5,9 +5,9 @@
 // One workgroup per front and one launch per (level, size class).  A front is a dense m x m matrix: k pivot rows /
 // columns first, then u = m - k update rows / columns.  Small fronts live in LDS for the whole assemble-factor-store
 // sequence; larger ones in their own m x m region of the arena in HBM (their update matrix is read from there by
-// the parent) and are factored by column blocks of 32 pivots with three launches per block (panel, row interchanges +
-// triangular solve, rank-32 update on 64 x 64 tiles).  Byte/latency-bound work on plain FP64 FMAs: fronts of circuit /
-// power-flow matrices are tens to hundreds of rows (an MFMA update for fronts of thousands of rows is future work).
+// the parent) and are factored by column blocks of 32 pivots with two or three launches per block (panel; row interchanges
+// where the block has any; rank-32 update on 64 x 64 FP64-MFMA tiles, which also solves its own columns of U12).
+// Latency-bound work: fronts of circuit / power-flow matrices are tens to hundreds of rows.
 #include "lu_device.hpp"
 #include <algorithm>
 #include <cstdlib>

@@ -78,6 +78,14 @@ if lu:
         f.write("kernel,calls,total_us,avg_us,pct\n")
         for r in rows:
             f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+lu2 = glob.glob(os.path.join(out, tag + "_lu2dstats", "**", "*kernel_stats.csv"), recursive=True)
+if lu2:
+    rows = list(csv.DictReader(open(lu2[0])))
+    with open(os.path.join(prof, tag + "_lu2d_kernel_stats.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python3 bench_extra.py --cases lu2d  (600 x 600 convection-diffusion: first factorisation with its merge passes, then the timed refactor + solve steps)\n")
+        f.write("kernel,calls,total_us,avg_us,pct\n")
+        for r in rows:
+            f.write("%s,%s,%.1f,%.2f,%s\n" % (clean(r["Name"]).replace(",", ";"), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, r["Percentage"]))
 lj = os.path.join(out, tag + "_lu.jsonl")
 if os.path.exists(lj):
     shutil.copy(lj, os.path.join(prof, tag + "_lu.jsonl"))
