@@ -188,6 +188,7 @@ _SIGS = {
     "kvx_lu_free_numeric": (None, [vp]),
     "kvx_lu_num_info": (ctypes.c_int, [vp, i64p]),
     "kvx_lu_num_work": (ctypes.c_int, [vp, f64p]),
+    "kvx_lu_num_graph_replays": (ctypes.c_int, [vp, i64p]),
     "kvx_lu_solve": (ctypes.c_int, [vp, ctypes.c_int, f64p, i64, i64]),
     "kvx_lu_solve_dev": (ctypes.c_int, [vp, ctypes.c_int, vp, i64, i64]),
     "kvx_lu_extract": (ctypes.c_int, [vp, i64p, ctypes.POINTER(i64p), ctypes.POINTER(i64p), ctypes.POINTER(f64p),

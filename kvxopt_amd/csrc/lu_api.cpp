@@ -59,6 +59,20 @@ struct kvx_lu_num {
     // per level: does any big front of the level interchange rows in pivot block `step`?  Read from the recorded pivot sequence after
     // a factorisation; a refactorisation (same sequence) leaves out the interchange launch of every block that has none
     std::vector<std::vector<uint8_t>> swap_steps;
+    // Launch graphs of the steady state (klu.c:296-308: refactorisation on the recorded pivot sequence, then solves): the launches of
+    // a pass / of a solve captured once per (buffer addresses, right-hand sides) and replayed.  `version` changes with everything
+    // a captured sequence depends on besides its key: the plan (front merges), the interchange flags, the work buffers.
+    struct Graph {
+        hipGraphExec_t exec = nullptr;
+        const void *ptr = nullptr;
+        int64_t a = 0, b = 0;
+        uint64_t version = 0;
+        void drop() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
+    };
+    Graph g_pass, g_solve[2];
+    uint64_t version = 1;
+    bool graphs_on = [] { const char *e = std::getenv("KVX_LU_GRAPH"); return !e || e[0] != '0'; }();
+    int64_t graph_replays = 0;
     bool unblocked = std::getenv("KVX_LU_UNBLOCKED") != nullptr;   // debugging aid: big fronts by one workgroup each
 };
 
@@ -130,6 +144,7 @@ void free_structure(kvx_lu_num *N)
 int upload_structure(kvx_lu_num *N)
 {
     LuLap tl;
+    N->version++;                                                 // (captured launch sequences belong to the old plan)
     free_structure(N);
     tl.lap("free structure");
     try {
@@ -224,24 +239,47 @@ int lu_wait_for_caller(kvx_lu_num *N)
     return KVX_OK;
 }
 
+// Run `body` (enqueues on N->st, forks to the side streams by events and joins them again) from a launch graph: replayed when
+// `g` was captured under the same key, captured now otherwise.  Whatever goes wrong with capture or instantiation turns the
+// graphs of this factor off; the launches then go out one by one as before.
+template <class Body>
+int run_graphed(kvx_lu_num *N, kvx_lu_num::Graph &g, const void *ptr, int64_t a, int64_t b, Body body)
+{
+    if (!N->graphs_on) return body();
+    if (g.exec && g.ptr == ptr && g.a == a && g.b == b && g.version == N->version) {
+        HIPCHK(hipGraphLaunch(g.exec, N->st));
+        N->graph_replays++;
+        return KVX_OK;
+    }
+    g.drop();
+    if (hipStreamBeginCapture(N->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); N->graphs_on = false; return body(); }
+    const int rc = body();
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(N->st, &graph);
+    if (rc || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        N->graphs_on = false;
+        return rc ? rc : body();
+    }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { (void)hipGetLastError(); g.exec = nullptr; N->graphs_on = false; return body(); }
+    g.ptr = ptr; g.a = a; g.b = b; g.version = N->version;
+    HIPCHK(hipGraphLaunch(g.exec, N->st));
+    return KVX_OK;
+}
+
 // One numeric pass over the current plan.  fail_host receives the per-front flags.
-int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int32_t> &fail_host)
+int enqueue_pass(kvx_lu_num *N, const double *Ax_dev, int reuse)
 {
     const LuPlan &P = N->P;
     const LuDev d = dev_view(N);
-    HIPCHK(hipMemsetAsync(N->d_rmax, 0, (size_t)N->n * sizeof(double), N->st));
+    launch_lu_zero(N->n, N->d_rmax, N->st);                       // (a kernel, not a memset node of the launch graph)
     launch_lu_rowmax(N->nnz, N->d_ai32, Ax_dev, N->d_rmax, N->st);
     launch_lu_rinv(N->n, N->d_rmax, N->d_rinv, N->st);
     launch_lu_fvals((int64_t)P.fcol.size(), N->d_fsrc_r, Ax_dev, N->d_rinv, N->d_ai32, N->d_fval_r, N->st);
     launch_lu_fvals((int64_t)P.fcol.size(), N->d_fsrc_c, Ax_dev, N->d_rinv, N->d_ai32, N->d_fval_c, N->st);
-    while ((int32_t)N->evA.size() < P.nlevels) {
-        hipEvent_t a, b2, c2, d2;
-        HIPCHK(pool_event_get(&a, false));
-        HIPCHK(pool_event_get(&b2, false));
-        HIPCHK(pool_event_get(&c2, false));
-        HIPCHK(pool_event_get(&d2, false));
-        N->evA.push_back(a); N->evB.push_back(b2); N->evC.push_back(c2); N->evD.push_back(d2);
-    }
     HIPCHK(hipEventRecord(N->ev0, N->st));
     HIPCHK(hipStreamWaitEvent(N->st2, N->ev0, 0));
     if (std::getenv("KVX_LU_DUMP_PLAN")) {                        // per level: fronts, LDS-resident, largest m / k / child count, children of the level
@@ -300,7 +338,30 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
         if (hasB) { HIPCHK(hipEventRecord(N->evB[l], N->st2)); lastB = l; }
     }
     if (lastB >= 0) HIPCHK(hipStreamWaitEvent(N->st, N->evB[lastB], 0));
+    else if (!N->evB.empty()) {                                   // st2 forked from st above: joined again whether or not it got work
+        HIPCHK(hipEventRecord(N->evB[0], N->st2));
+        HIPCHK(hipStreamWaitEvent(N->st, N->evB[0], 0));
+    }
     HIPCHK(hipGetLastError());
+    return KVX_OK;
+}
+
+int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int32_t> &fail_host)
+{
+    const LuPlan &P = N->P;
+    // the events of the level schedule exist before anything is captured
+    while ((int32_t)N->evA.size() < P.nlevels) {
+        hipEvent_t a, b2, c2, d2;
+        HIPCHK(pool_event_get(&a, false));
+        HIPCHK(pool_event_get(&b2, false));
+        HIPCHK(pool_event_get(&c2, false));
+        HIPCHK(pool_event_get(&d2, false));
+        N->evA.push_back(a); N->evB.push_back(b2); N->evC.push_back(c2); N->evD.push_back(d2);
+    }
+    int rc;
+    if (reuse) rc = run_graphed(N, N->g_pass, Ax_dev, 0, 0, [&] { return enqueue_pass(N, Ax_dev, reuse); });   // the steady state: replayed
+    else rc = enqueue_pass(N, Ax_dev, reuse);
+    if (rc) return rc;
     if (std::getenv("KVX_LU_TIMING")) fprintf(stderr, "  lu   (pass enqueued, %d levels)\n", (int)P.nlevels);
     fail_host.resize((size_t)P.nfront);
     HIPCHK(hipMemcpyAsync(fail_host.data(), N->d_fail, (size_t)P.nfront * sizeof(int32_t), hipMemcpyDeviceToHost, N->st));
@@ -314,6 +375,7 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
 int refresh_swap_steps(kvx_lu_num *N)
 {
     const LuPlan &P = N->P;
+    N->version++;                                                 // (the launches of a refactorisation depend on these flags)
     N->swap_steps.assign((size_t)P.nlevels, {});
     if (N->unblocked) return KVX_OK;
     bool any_big = false;
@@ -421,10 +483,16 @@ int ensure_rhs(kvx_lu_num *N, int64_t nrhs)
     if ((rc = dalloc(&N->d_X, N->n * nrhs))) return rc;
     if ((rc = dalloc(&N->d_B, N->n * nrhs))) return rc;
     N->cap_rhs = nrhs;
+    N->version++;                                                 // (new work buffers)
     return KVX_OK;
 }
 
+int enqueue_solve(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB);
 int solve_on_device(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
+{
+    return run_graphed(N, N->g_solve[trans ? 1 : 0], B_dev, nrhs, ldB, [&] { return enqueue_solve(N, trans, B_dev, nrhs, ldB); });
+}
+int enqueue_solve(kvx_lu_num *N, int trans, double *B_dev, int64_t nrhs, int64_t ldB)
 {
     const LuPlan &P = N->P;
     const LuDev d = dev_view(N);
@@ -518,6 +586,9 @@ void kvx_lu_free_numeric(kvx_lu_num *N)
 {
     if (!N) return;
     if (N->st) (void)hipDeviceSynchronize();       // streams and events go back to the pool idle
+    N->g_pass.drop();
+    N->g_solve[0].drop();
+    N->g_solve[1].drop();
     free_structure(N);
     if (N->d_base) (void)pool_free(N->d_base);    // d_ai32, d_rinv, d_rmax, d_Ax
     for (hipEvent_t e : N->evA) pool_event_put(e, false);
@@ -673,6 +744,13 @@ int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8])
     if (!N || !info) return KVX_EINVAL;
     info[0] = N->P.nfront; info[1] = N->P.nlevels; info[2] = N->P.max_m; info[3] = N->P.max_k;
     info[4] = N->P.lsize; info[5] = N->P.arena; info[6] = N->attempts; info[7] = N->factored ? 1 : 0;
+    return KVX_OK;
+}
+
+int kvx_lu_num_graph_replays(kvx_lu_num *N, int64_t *replays)
+{
+    if (!N || !replays) return KVX_EINVAL;
+    *replays = N->graph_replays;
     return KVX_OK;
 }
 

@@ -57,6 +57,7 @@ void launch_lu_fterm(int64_t cnt, int nrhs, const int32_t *poslist, const int64_
                      int64_t ldx, hipStream_t st);
 void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double *rmax, hipStream_t st);   // rmax zeroed by the caller
 void launch_lu_rinv(int64_t n, const double *rmax, double *rinv, hipStream_t st);
+void launch_lu_zero(int64_t n, double *x, hipStream_t st);          // x := 0 (a kernel: the numeric pass is captured into a launch graph)
 // X[p] = B[idx[p]] * (scale ? scale[idx[p]] : 1)   /   B[idx[p]] = X[p] * (scale ? scale[idx[p]] : 1)
 void launch_lu_gather(int64_t n, int nrhs, const int64_t *idx, const double *scale, const double *B, int64_t ldb, double *X,
                       int64_t ldx, hipStream_t st);

@@ -1921,6 +1921,15 @@ void launch_lu_rowmax(int64_t nnz, const int32_t *ai32, const double *Ax, double
     if (nnz <= 0) return;
     hipLaunchKernelGGL(k_lu_rowmax, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, ai32, Ax, (unsigned long long *)rmax);
 }
+__global__ void k_lu_zero(const int64_t n, double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = 0.0;
+}
+void launch_lu_zero(int64_t n, double *x, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_lu_zero, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, x);
+}
 void launch_lu_rinv(int64_t n, const double *rmax, double *rinv, hipStream_t st)
 {
     hipLaunchKernelGGL(k_lu_rinv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, rmax, rinv);

@@ -89,6 +89,12 @@ class LuNumeric:
         raise_for(lib().kvx_lu_num_work(self._h, pd(w)))
         return dict(zip(("flops", "panel_entries", "update_entries", "blocked_fronts", "blocked_flops"), (float(x) for x in w)))
 
+    def graph_replays(self):
+        """Replays of captured launch sequences (refactorisations and solves of the steady state) by this factor."""
+        a = np.zeros(1, dtype=np.int64)
+        raise_for(lib().kvx_lu_num_graph_replays(self._h, pi(a)))
+        return int(a[0])
+
     def solve(self, B, trans="N", nrhs=None, ldB=None, offset=0):
         """B: 1-D float64 buffer holding an n x nrhs column-major block at `offset` with leading dimension ldB."""
         n = self.n

@@ -284,6 +284,9 @@ def test_blocked_path_on_fronts_of_many_tiles_factor_and_refactor():
     As = to_sp(A)
     rho = abs(to_sp(R) @ to_sp(P) @ As @ to_sp(Q) - to_sp(L) @ to_sp(U) - to_sp(F)).sum(axis=0).max()
     assert rho < 1e-11
+    # the second refactorisation and the later solves were replays of captured launch graphs (unless turned off)
+    if os.environ.get("KVX_LU_GRAPH", "1") != "0":
+        assert Fn.num.graph_replays() >= 2
 
 
 def test_ldb_offset_and_nrhs_arguments():
