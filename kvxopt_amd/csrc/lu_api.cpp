@@ -70,7 +70,7 @@ struct kvx_lu_num {
         void drop() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
     };
     Graph g_pass, g_solve[2];
-    uint64_t version = 1;
+    uint64_t version = 1, swap_version = 0;                   // (swap_version: the interchange flags -- the passes depend on them, the solves do not)
     bool graphs_on = [] { const char *e = std::getenv("KVX_LU_GRAPH"); return !e || e[0] != '0'; }();
     int64_t graph_replays = 0;
     bool unblocked = std::getenv("KVX_LU_UNBLOCKED") != nullptr;   // debugging aid: big fronts by one workgroup each
@@ -359,7 +359,7 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
         N->evA.push_back(a); N->evB.push_back(b2); N->evC.push_back(c2); N->evD.push_back(d2);
     }
     int rc;
-    if (reuse) rc = run_graphed(N, N->g_pass, Ax_dev, 0, 0, [&] { return enqueue_pass(N, Ax_dev, reuse); });   // the steady state: replayed
+    if (reuse) rc = run_graphed(N, N->g_pass, Ax_dev, (int64_t)N->swap_version, 0, [&] { return enqueue_pass(N, Ax_dev, reuse); });   // the steady state: replayed
     else rc = enqueue_pass(N, Ax_dev, reuse);
     if (rc) return rc;
     if (std::getenv("KVX_LU_TIMING")) fprintf(stderr, "  lu   (pass enqueued, %d levels)\n", (int)P.nlevels);
@@ -375,7 +375,7 @@ int numeric_pass(kvx_lu_num *N, const double *Ax_dev, int reuse, std::vector<int
 int refresh_swap_steps(kvx_lu_num *N)
 {
     const LuPlan &P = N->P;
-    N->version++;                                                 // (the launches of a refactorisation depend on these flags)
+    N->swap_version++;                                            // (the launches of a refactorisation depend on these flags)
     N->swap_steps.assign((size_t)P.nlevels, {});
     if (N->unblocked) return KVX_OK;
     bool any_big = false;
