@@ -179,8 +179,10 @@ def linsolve(A, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
     buf, nrhs_, ldB_ = _rhs_args(n, B, trans, nrhs, ldB, offsetB, "z" if v.dtype.kind == "c" else "d")
     if nrhs_ == 0:
         return 0 if n == 0 or nrhs == 0 else None
-    key = (n, v.dtype.kind, cp.tobytes(), ri.tobytes(), _lib.current_device())     # the factors live on ONE device
+    key = (n, v.dtype.kind, _lib.pattern_digest(cp, ri), _lib.current_device())     # the factors live on ONE device
     hit = _LINSOLVE_CACHE.pop(key, None) if _LINSOLVE_CACHE_MAX > 0 else None
+    if hit is not None and not _same_pattern(hit[0], cp, ri):  # (a digest is not the pattern)
+        hit = None
     if hit is not None:
         Fs, Fn = hit
         try:
