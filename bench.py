@@ -702,9 +702,10 @@ def klu_leg(args):
     algorithmic bytes 8 (panel entries + 2 update entries) + 12 nnz(A) (kvx_lu_num_work) for the latency-bound small case, flops
     against the FP64 MFMA peak for the blocked one."""
     import bench_extra
-    from kvxopt_amd import klu as kvx_klu
+    from kvxopt_amd import klu as kvx_klu, _lib as kvx_lib
     from kvxopt_amd.base import spmatrix
     out = {}
+    kvx_lib.release_cached()        # (the 170 GB of the 200^3 factor sit in the pool's cache: handing them back took 4.6 s of this leg's first call)
     r = bench_extra.klu_case(20, 5)
     z = np.load(os.path.join(ROOT, "tests", "golden", "ACTIVSg2000.npz"))
     A = spmatrix.from_ccs(int(z["n"]), int(z["n"]), z["colptr"], z["rowind"], z["values"])

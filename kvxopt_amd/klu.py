@@ -186,7 +186,10 @@ def linsolve(A, B, trans="N", nrhs=-1, ldB=0, offsetB=0):
     if hit is not None:
         Fs, Fn = hit
         try:
-            Fn = numeric(A, Fs, Fn)
+            if v.dtype.kind == "c":
+                Fn = numeric(A, Fs, Fn)
+            else:
+                Fn.num.refactor(v)                        # (numeric(A, Fs, Fn) without its second comparison of the pattern)
         except ArithmeticError:
             hit = None                                    # (singular with these values: start over below and report from there)
     if hit is None:
