@@ -502,7 +502,8 @@ int kvx_lu_num_info(kvx_lu_num *N, int64_t info[8]);
 int kvx_lu_num_work(kvx_lu_num *N, double work[5]);
 /* Launch graphs of the steady state (klu.c:296-308 refactorisation on the recorded pivot sequence, klu.c:651-665 solves on the same
  * buffers): how many times a captured sequence of launches has been replayed by this factor (0: every pass went out launch by
- * launch -- first factorisations always do; KVX_LU_GRAPH=0 turns the graphs off). */
+ * launch -- first factorisations always do, and so does a call whose buffers differ from the previous call's: a sequence is
+ * captured when the same buffers come twice in a row; KVX_LU_GRAPH=0 turns the graphs off). */
 int kvx_lu_num_graph_replays(kvx_lu_num *N, int64_t *replays);
 
 /* solve(A, Fs, Fn, B, trans) -- klu.c:593-690 (klu_solve / klu_tsolve :651-665).  trans: 0 = 'N', 1 = 'T'.

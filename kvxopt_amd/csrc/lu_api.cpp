@@ -67,6 +67,9 @@ struct kvx_lu_num {
         const void *ptr = nullptr;
         int64_t a = 0, b = 0;
         uint64_t version = 0;
+        const void *seen_ptr = nullptr;                           // the key of the previous call (a sequence is captured when a key comes twice in a row)
+        int64_t seen_a = 0, seen_b = 0;
+        uint64_t seen_version = 0;
         void drop() { if (exec) (void)hipGraphExecDestroy(exec); exec = nullptr; }
     };
     Graph g_pass, g_solve[2];
@@ -240,7 +243,7 @@ int lu_wait_for_caller(kvx_lu_num *N)
 }
 
 // Run `body` (enqueues on N->st, forks to the side streams by events and joins them again) from a launch graph: replayed when
-// `g` was captured under the same key, captured now otherwise.  Whatever goes wrong with capture or instantiation turns the
+// `g` was captured under the same key, captured when the key of the previous call comes again, launch by launch otherwise.  Whatever goes wrong with capture or instantiation turns the
 // graphs of this factor off; the launches then go out one by one as before.
 template <class Body>
 int run_graphed(kvx_lu_num *N, kvx_lu_num::Graph &g, const void *ptr, int64_t a, int64_t b, Body body)
@@ -251,6 +254,11 @@ int run_graphed(kvx_lu_num *N, kvx_lu_num::Graph &g, const void *ptr, int64_t a,
         N->graph_replays++;
         return KVX_OK;
     }
+    // A capture and an instantiation cost milliseconds: a caller that hands over another buffer at every call must not pay them
+    // every time.  The launches go out one by one until the same key comes twice in a row.
+    const bool again = g.seen_ptr == ptr && g.seen_a == a && g.seen_b == b && g.seen_version == N->version && ptr != nullptr;
+    g.seen_ptr = ptr; g.seen_a = a; g.seen_b = b; g.seen_version = N->version;
+    if (!again) return body();
     g.drop();
     if (hipStreamBeginCapture(N->st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); N->graphs_on = false; return body(); }
     const int rc = body();
