@@ -38,9 +38,8 @@ DIST_COMM_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(Di
 def pattern_digest(*arrays):
     """128-bit digest of index arrays (dtype, length and bytes of each) for the keys of the host-side caches.  The caches are looked
     up at every call with the caller's whole pattern: hashed with xxh3 (10+ GB/s, zero-copy) where the module is there, else blake2b
-    (1 GB/s: 3 ms of a 33 ms conelp call on a known structure).  (cholmod keys its cache by the arrays' bytes themselves:
-    measured faster than either digest -- 8.2 against 9.2 ms per known-pattern linsolve with 10^6 columns; klu.linsolve, whose
-    patterns are small and whose call is 1 ms, uses the digest: 13 against 125 us for ACTIVSg2000's 267 KB.)"""
+    (1 GB/s: 3 ms of a 33 ms conelp call on a known structure).  Round 4: cholmod, klu and the S = G'DG plans key their caches by it too -- the bytes themselves as a key were copied and
+    hashed by Python at every call: 22 ms against 1.8 for config 2's 32 MB of pattern, 125 against 13 us for ACTIVSg2000's 267 KB.)"""
     try:
         import xxhash
         h = xxhash.xxh3_128()

@@ -265,7 +265,7 @@ _plans = {}
 
 
 def _atda_plan(ml, n, Gp, Gi):
-    key = (ml, n, Gp.tobytes(), Gi.tobytes())
+    key = (ml, n, _lib.pattern_digest(Gp, Gi))
     P = _plans.get(key)
     if P is None:
         h = ctypes.c_void_p()

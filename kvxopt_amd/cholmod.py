@@ -354,7 +354,9 @@ _lib.register_cache(clear_cache)
 
 def _cached_symbolic(A, p, uplo, n, cp, ri, v):
     q = _perm(p, n)
-    key = (n, uplo, v.dtype.kind, None if q is None else q.tobytes(), cp.tobytes(), ri.tobytes(),
+    # (a 128-bit digest of the index arrays, not their bytes: copying and hashing the 32 MB of config 2's pattern was 22 ms of
+    #  every call on a known pattern -- the whole call is 6 ms with the digest)
+    key = (n, uplo, v.dtype.kind, None if q is None else _lib.pattern_digest(q), _lib.pattern_digest(cp, ri),
            tuple(sorted((k, repr(val)) for k, val in options.items())), _lib.current_device())   # a factor lives on ONE device
     if _SYMBOLIC_CACHE_MAX <= 0:
         return symbolic(A, p, uplo)
