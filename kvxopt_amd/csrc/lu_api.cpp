@@ -222,6 +222,7 @@ LuDev dev_view(const kvx_lu_num *N)
     d.fr = N->d_fr; d.rowidx = N->d_rowidx; d.rel = N->d_rel; d.children = N->d_children;
     d.a_src = N->d_asrc; d.a_dst = N->d_adst; d.ai32 = N->d_ai32; d.rinv = N->d_rinv;
     d.Lx = N->d_Lx; d.Ux = N->d_Ux; d.arena = N->d_arena; d.ipiv = N->d_ipiv; d.lperm = N->d_lperm; d.fail = N->d_fail;
+    d.arena_size = N->P.arena;
     return d;
 }
 

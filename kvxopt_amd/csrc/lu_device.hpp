@@ -30,6 +30,7 @@ struct LuDev {           // all device pointers
     int32_t *ipiv;           // [n] swap partner (local index) chosen at each pivot step
     int32_t *lperm;          // [n] local index of the front row that ended in each pivot slot
     int32_t *fail;           // [nfront] 0 = ok, else 1 + first pivot step without an acceptable pivot
+    int64_t arena_size;      // doubles in `arena` (k_lu_front_wp keeps 32-bit offsets into it)
 };
 
 // Factor the fronts list[0..cnt) (one workgroup each).  lds_m > 0: fronts of order <= lds_m held in LDS; 0: in HBM.

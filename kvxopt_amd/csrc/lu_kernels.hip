@@ -661,24 +661,46 @@ __device__ __forceinline__ void wp_solve(double *Fm, const int ld, const int c, 
 // wavefront.  Wave w owns the target columns c with c % 4 == w and walks the children in their order: a target entry
 // receives its contributions in the order of lu_assemble_front whatever the waves' pace (reproducible sums), and no barrier
 // stands between two children.
-constexpr int WP_CH = 32, WP_REL = 2048, WP_Q = 16;
+constexpr int WP_CH = 32, WP_REL = 1024, WP_ITEMS = WP_REL + 4 * WP_CH;
+// A work item = one column of a child's update matrix that this wave owns: word 0 = offset of the column in the arena, word 1 =
+// target column | rows << 7 | offset of the child's index list in `rel` << 14 (rows <= 127, target < 128, list offset < 1024).
+// A wave's items are in child order, every child's run padded to a multiple of four (0 / 0 = nothing): four consecutive,
+// aligned items belong to ONE child, i.e. to four different target columns.
 struct WpAsmLds {
     int64_t ch_off[WP_CH], ch_relptr[WP_CH];
     int32_t ch_uc[WP_CH], ch_ldc[WP_CH], ch_rel[WP_CH];
     int32_t rel[WP_REL];
-    int64_t q_src[4][WP_Q];
-    int32_t q_rel[4][WP_Q], q_dst[4][WP_Q], q_n[4][WP_Q];
+    uint2 items[4][WP_ITEMS];
     int32_t cnt;
 };
 
-__device__ __forceinline__ void wp_run_batch(const LuDev &d, WpAsmLds &S, double *Fm, const int w, const int lane, const int n)
+// Sixteen items of wave w from position `it` on: the four 16-lane groups of the wave take four items at a time (group G the
+// item it + 4 s + G, its lanes the rows r16 + 16 rr + row0 of the column), all 16 loads of a lane are in flight before the
+// first of them is added into the front.
+__device__ __forceinline__ void wp_run_items(const LuDev &d, WpAsmLds &S, double *Fm, const int ld, const int w, const int lane, const int it,
+                                             const int cnt, const int row0)
 {
-    double v[WP_Q];
+    const int G = lane >> 4, r16 = lane & 15;
+    double v[4][4];
+    int dst[4][4];
 #pragma unroll
-    for (int t = 0; t < WP_Q; t++) v[t] = (t < n && lane < S.q_n[w][t]) ? d.arena[S.q_src[w][t] + lane] : 0.0;
+    for (int sl = 0; sl < 4; sl++) {
+        const int e = it + 4 * sl + G;
+        const uint2 item = e < cnt ? S.items[w][e] : make_uint2(0u, 0u);
+        const int tj = (int)(item.y & 127u), uc = (int)((item.y >> 7) & 127u), ro = (int)(item.y >> 14);
 #pragma unroll
-    for (int t = 0; t < WP_Q; t++)
-        if (t < n && lane < S.q_n[w][t]) Fm[S.rel[S.q_rel[w][t] + lane] + S.q_dst[w][t]] += v[t];
+        for (int rr = 0; rr < 4; rr++) {
+            const int i = row0 + r16 + 16 * rr;
+            const bool ok = i < uc;                               // (a padding item has no rows)
+            v[sl][rr] = ok ? d.arena[(int64_t)item.x + i] : 0.0;
+            dst[sl][rr] = ok ? S.rel[ro + i] + tj * ld : -1;
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++)
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++)
+            if (dst[sl][rr] >= 0) Fm[dst[sl][rr]] += v[sl][rr];
 }
 
 __device__ __forceinline__ void wp_assemble(const LuDev &d, const LuFrontD &F, double *Fm, const int ld, const double *__restrict__ Ax,
@@ -705,7 +727,7 @@ __device__ __forceinline__ void wp_assemble(const LuDev &d, const LuFrontD &F, d
         __syncthreads();
         if (tid == 0) {                                           // as many children as the index table holds (a child has <= 112 rows)
             int off = 0, n = 0;
-            while (n < nc && off + S.ch_uc[n] <= WP_REL) { S.ch_rel[n] = off; off += S.ch_uc[n]; n++; }
+            while (n < nc && off + S.ch_uc[n] <= WP_REL) { S.ch_rel[n] = off; off += S.ch_uc[n]; n++; }      // (and so <= WP_ITEMS items a wave)
             S.cnt = n;
         }
         __syncthreads();
@@ -716,30 +738,31 @@ __device__ __forceinline__ void wp_assemble(const LuDev &d, const LuFrontD &F, d
             for (int i = lane; i < uc; i += 64) S.rel[S.ch_rel[c] + i] = relc[i];
         }
         __syncthreads();
-        int nq = 0;
+        // this wave's items: the columns of every child whose target column it owns, compacted by ballot / prefix count
+        int cnt = 0;
+        bool tall = false;                                        // a child with more than 64 update rows (second pass over its rows)
         for (int c = 0; c < n; c++) {
             const int uc = S.ch_uc[c], ldc = S.ch_ldc[c], ro = S.ch_rel[c];
             const int64_t off = S.ch_off[c];
+            tall = tall || uc > 64;
             for (int base = 0; base < uc; base += 64) {
-                const int tj = base + lane < uc ? S.rel[ro + base + lane] : -1;
-                unsigned long long mask = __ballot(tj >= 0 && (tj & 3) == w);
-                while (mask) {
-                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
-                    mask &= mask - 1;
-                    const int tjv = __builtin_amdgcn_readlane(tj, b);
-                    for (int half = 0; half < uc; half += 64) {
-                        if (lane == 0) {
-                            S.q_src[w][nq] = off + (int64_t)(base + b) * ldc + half;
-                            S.q_rel[w][nq] = ro + half;
-                            S.q_dst[w][nq] = tjv * ld;
-                            S.q_n[w][nq] = min(64, uc - half);
-                        }
-                        if (++nq == WP_Q) { wp_wave_sync(); wp_run_batch(d, S, Fm, w, lane, WP_Q); wp_wave_sync(); nq = 0; }
-                    }
-                }
+                const int l = base + lane;
+                const int tj = l < uc ? S.rel[ro + l] : -1;
+                const bool own = tj >= 0 && (tj & 3) == w;
+                const unsigned long long mask = __ballot(own);
+                if (own) S.items[w][cnt + __popcll(mask & ((1ull << lane) - 1ull))] =
+                             make_uint2((unsigned)(off + (int64_t)l * ldc), (unsigned)tj | ((unsigned)uc << 7) | ((unsigned)ro << 14));
+                cnt += __popcll(mask);
             }
+            const int pad = (4 - (cnt & 3)) & 3;
+            if (lane < pad) S.items[w][cnt + lane] = make_uint2(0u, 0u);
+            cnt += pad;
         }
-        if (nq) { wp_wave_sync(); wp_run_batch(d, S, Fm, w, lane, nq); wp_wave_sync(); }
+        wp_wave_sync();
+        for (int it = 0; it < cnt; it += 16) wp_run_items(d, S, Fm, ld, w, lane, it, cnt, 0);
+        if (tall)
+            for (int it = 0; it < cnt; it += 16) wp_run_items(d, S, Fm, ld, w, lane, it, cnt, 64);
+        wp_wave_sync();
         c0 += n;
     }
     __syncthreads();
@@ -1799,7 +1822,7 @@ void launch_lu_fronts(const LuDev &d, const int32_t *list, int cnt, int lds_m, i
         // ... where a launch is a level's few dozen fronts (its time is that of its slowest front); thousands of fronts per launch are
         // bound by how many workgroups a CU holds, and the round-3 kernel is the smaller one (KVX_LU_WP_MAXCNT, default 512)
         static const int wp_maxcnt = [] { const char *e = getenv("KVX_LU_WP_MAXCNT"); return e ? atoi(e) : 512; }();
-        if (wp && cnt <= wp_maxcnt) {
+        if (wp && cnt <= wp_maxcnt && d.arena_size < (int64_t)1 << 32) {      // (its work items hold 32-bit offsets into the arena)
             switch ((lds_m + 15) / 16) {
             case 1: hipLaunchKernelGGL((k_lu_front_wp<1>), dim3(cnt), dim3(256), wp_lds_bytes(1), st, d, list, Ax, tol, stol, reuse); break;
             case 2: hipLaunchKernelGGL((k_lu_front_wp<2>), dim3(cnt), dim3(256), wp_lds_bytes(2), st, d, list, Ax, tol, stol, reuse); break;
